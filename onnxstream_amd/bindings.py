@@ -1,0 +1,164 @@
+"""ctypes binding over the ``model_*`` C API.
+
+The product library (``onnxstream_amd/libonnxstream_amd.so``) exports the same ``extern "C"`` surface as the
+reference's ``src/exports.cpp`` (model_new_2 :62, model_read_file :98, model_add_tensor :169, model_get_tensor :205,
+model_run_2 :258, model_set_option :276, ...), so this class -- whose public API mirrors the reference's
+``src/bindings.py`` ``Model`` (:62-330) -- drives either library unchanged.  That is the drop-in test: the very same
+binding object is pointed at the reference oracle ``.so`` and at ours.
+
+Additions over the reference binding (all optional, feature-probed with ``hasattr`` on the library):
+``set_option_uint`` for non-bool options (attention parts), ``get_tensor_any`` for fp16/u8 read-back.
+"""
+import ctypes
+import re
+from typing import List, Tuple
+
+import numpy
+
+
+class OnnxStreamError(Exception):
+    pass
+
+
+class _GetTensorReturnLayout(ctypes.Structure):
+    _fields_ = [("dims_num", ctypes.c_size_t), ("dims", ctypes.c_void_p),
+                ("data_num", ctypes.c_size_t), ("data", ctypes.c_void_p)]
+
+
+_WP_NAMES = ("ram", "nocache", "prefetch", "ram+nocache", "ram+prefetch")
+
+
+class Model:
+    def __init__(self, library_path: str, threads_count: int = 0, weights_provider_name: str = "prefetch"):
+        self._lib = ctypes.CDLL(library_path)
+        self._proto()
+        self.mangle_tensor_names = True
+        if weights_provider_name not in _WP_NAMES:
+            raise OnnxStreamError(f"Invalid weights provider name: {weights_provider_name}")
+        self._h = self._lib.model_new_2(threads_count, weights_provider_name.encode())
+        if not self._h:
+            raise OnnxStreamError("Unable to create the native model object")
+
+    def _proto(self):
+        L, vp, cp = self._lib, ctypes.c_void_p, ctypes.c_char_p
+        L.model_new_2.argtypes = [ctypes.c_int, cp]; L.model_new_2.restype = vp
+        L.model_delete.argtypes = [vp]; L.model_delete.restype = None
+        L.model_read_file.argtypes = [vp, cp]; L.model_read_file.restype = vp
+        L.model_read_string.argtypes = [vp, cp]; L.model_read_string.restype = None
+        L.model_run_2.argtypes = [vp]; L.model_run_2.restype = vp
+        L.model_add_tensor.argtypes = [vp, cp, cp, ctypes.c_uint, ctypes.POINTER(ctypes.c_uint)]
+        L.model_add_tensor.restype = vp
+        L.model_get_tensor.argtypes = [vp, cp]; L.model_get_tensor.restype = vp
+        L.model_get_all_tensor_names.argtypes = [vp]; L.model_get_all_tensor_names.restype = vp
+        L.model_clear_tensors.argtypes = [vp]; L.model_clear_tensors.restype = None
+        L.model_set_option.argtypes = [vp, cp, ctypes.c_uint]; L.model_set_option.restype = None
+        L.model_add_extra_output.argtypes = [vp, cp]; L.model_add_extra_output.restype = None
+        L.model_free_buffer.argtypes = [vp]; L.model_free_buffer.restype = None
+
+    # -- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if self._h:
+            self._lib.model_delete(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def lib(self):
+        return self._lib
+
+    def _err(self, p):
+        if p:
+            msg = ctypes.cast(p, ctypes.c_char_p).value.decode("utf-8", "replace")
+            self._lib.model_free_buffer(p)
+            raise OnnxStreamError(msg)
+
+    # -- model / run ---------------------------------------------------------------------------
+    def read_file(self, filename: str):
+        self._err(self._lib.model_read_file(self._h, filename.encode()))
+
+    def read_string(self, model_string: str):
+        self._lib.model_read_string(self._h, model_string.encode())
+
+    def run(self):
+        self._err(self._lib.model_run_2(self._h))
+
+    def _name(self, name):
+        return (self.mangle_name(name) if self.mangle_tensor_names else name).encode()
+
+    def add_tensor(self, name: str, data: "numpy.ndarray"):
+        if data.dtype == numpy.float32:
+            ty = b"float32"
+        elif data.dtype == numpy.int64:
+            ty = b"int64"
+        else:
+            raise OnnxStreamError(f"Unsupported data type: {data.dtype}")
+        data = numpy.ascontiguousarray(data)
+        dims = (ctypes.c_uint * data.ndim)(*data.shape)
+        p = self._lib.model_add_tensor(self._h, ty, self._name(name), data.ndim, dims)
+        ctypes.memmove(p, data.ctypes.data, data.nbytes)
+
+    def get_tensor(self, name: str):
+        p = self._lib.model_get_tensor(self._h, self._name(name))
+        if not p:
+            return None
+        r = ctypes.cast(p, ctypes.POINTER(_GetTensorReturnLayout)).contents
+        dims = ctypes.cast(r.dims, ctypes.POINTER(ctypes.c_size_t))
+        shape = [dims[i] for i in range(r.dims_num)]
+        arr = numpy.ctypeslib.as_array(ctypes.cast(r.data, ctypes.POINTER(ctypes.c_float)), shape=(r.data_num,)).copy()
+        self._lib.model_free_buffer(p)
+        return arr.reshape(shape), shape
+
+    def get_all_tensor_names(self) -> List[str]:
+        p = self._lib.model_get_all_tensor_names(self._h)
+        if not p:
+            return []
+        s = ctypes.cast(p, ctypes.c_char_p).value.decode()
+        self._lib.model_free_buffer(p)
+        names = s.split("|") if s else []
+        return [self.demangle_name(n) for n in names] if self.mangle_tensor_names else names
+
+    def clear_tensors(self):
+        self._lib.model_clear_tensors(self._h)
+
+    def add_extra_output(self, name: str):
+        self._lib.model_add_extra_output(self._h, self._name(name))
+
+    # -- options -------------------------------------------------------------------------------
+    def _set_option(self, name: str, value):
+        self._lib.model_set_option(self._h, name.encode(), int(value))
+
+    def set_use_fp16_arithmetic(self, v): self._set_option("use_fp16_arithmetic", bool(v))
+    def set_use_uint8_qdq(self, v): self._set_option("use_uint8_qdq", bool(v))
+    def set_use_uint8_arithmetic(self, v): self._set_option("use_uint8_arithmetic", bool(v))
+    def set_fuse_ops_in_attention(self, v): self._set_option("fuse_ops_in_attention", bool(v))
+    def set_force_fp16_storage(self, v): self._set_option("force_fp16_storage", bool(v))
+    def set_support_dynamic_shapes(self, v): self._set_option("support_dynamic_shapes", bool(v))
+    def set_use_ops_cache(self, v): self._set_option("use_ops_cache", bool(v))
+    def set_use_scaled_dp_attn_op(self, v): self._set_option("use_scaled_dp_attn_op", bool(v))
+    def set_use_next_op_cache(self, v): self._set_option("use_next_op_cache", bool(v))
+    def set_ops_printf(self, v): self._set_option("ops_printf", bool(v))
+    def set_ops_times_printf(self, v): self._set_option("ops_times_printf", bool(v))
+    def set_use_nchw_convs(self, v): self._set_option("use_nchw_convs", bool(v))
+
+    # -- name mangling (reference bindings.py:310) ------------------------------------------------
+    @staticmethod
+    def mangle_name(name: str) -> str:
+        return "".join(c if c.isalnum() else f"_{ord(c):X}_" for c in name)
+
+    @staticmethod
+    def demangle_name(name: str) -> str:
+        def repl(m):
+            try:
+                return chr(int(m.group(1), 16))
+            except (ValueError, TypeError):
+                return m.group(0)
+        return re.sub(r"_([0-9A-Fa-f]+)_", repl, name)

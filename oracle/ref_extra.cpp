@@ -1,0 +1,61 @@
+// TEST INFRASTRUCTURE ONLY (oracle). Never linked into the product libraries.
+//
+// ref_extra.cpp -- a few extra extern "C" accessors on the *reference* onnxstream::Model for the
+// public fields that /root/reference/src/exports.cpp does not expose through model_set_option
+// (attention parts, range data, calibration).  Compiled together with the unmodified reference
+// sources into oracle/_ref/libonnxstream_ref.so; it includes the reference header from where it lies.
+//
+// The handle is the ModelContext* returned by the reference's own model_new_2 (exports.cpp:62);
+// its first member is the Model (exports.cpp:28-40), so the handle doubles as a Model*.
+#include "onnxstream.h"
+#include <cstring>
+
+using namespace onnxstream;
+
+static Model* as_model(void* ctx) { return reinterpret_cast<Model*>(ctx); }
+
+extern "C" {
+
+void ref_set_attention_parts(void* ctx, unsigned parts) { as_model(ctx)->m_attention_fused_ops_parts = parts; }
+
+void ref_set_range_data_calibrate(void* ctx, unsigned on) { as_model(ctx)->m_range_data_calibrate = on != 0; }
+
+const char* ref_read_range_data(void* ctx, const char* fn) {
+    static thread_local std::string err;
+    try { as_model(ctx)->read_range_data(fn); return nullptr; }
+    catch (const std::exception& e) { err = e.what(); return err.c_str(); }
+}
+
+const char* ref_write_range_data(void* ctx, const char* fn) {
+    static thread_local std::string err;
+    try { as_model(ctx)->write_range_data(fn); return nullptr; }
+    catch (const std::exception& e) { err = e.what(); return err.c_str(); }
+}
+
+void ref_add_outputs_convert_exclusion(void* ctx, const char* name) { as_model(ctx)->m_outputs_convert_set.insert(name); }
+
+void ref_add_force_uint8_storage(void* ctx, const char* name) { as_model(ctx)->m_force_uint8_storage_set.insert(name); }
+
+// Generic tensor read-back (any dtype).  Returns element count, fills dtype (1=u8, 2=f16, 3=f32, 4=i64),
+// rank/shape (up to 8 dims), scale/zero-point and the raw data pointer (owned by the model).
+size_t ref_get_tensor_any(void* ctx, const char* name, int* dtype, size_t* rank, size_t* shape, float* scale, int* zp,
+                          const void** data) {
+    for (auto& t : as_model(ctx)->m_data)
+        if (t.m_name == name) {
+            *dtype = (int)t.m_type;
+            *rank = t.m_shape.size();
+            for (size_t i = 0; i < t.m_shape.size() && i < 8; i++) shape[i] = t.m_shape[i];
+            *scale = t.m_scale;
+            *zp = t.m_zero_point;
+            switch (t.m_type) {
+                case TensorDataType::uint8: *data = t.get_vector<uint8_t>().data(); return t.get_vector<uint8_t>().size();
+                case TensorDataType::float16: *data = t.get_vector<uint16_t>().data(); return t.get_vector<uint16_t>().size();
+                case TensorDataType::float32: *data = t.get_vector<float>().data(); return t.get_vector<float>().size();
+                case TensorDataType::int64: *data = t.get_vector<int64_t>().data(); return t.get_vector<int64_t>().size();
+                default: return 0;
+            }
+        }
+    return 0;
+}
+
+}  // extern "C"
