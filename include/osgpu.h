@@ -1,0 +1,165 @@
+/*
+ * osgpu.h -- C ABI of the MI355X (gfx950) operator backend that takes the seat of OnnxStream's `class XnnPack`
+ * (reference src/onnxstream.cpp:657-2150) and of the inline host kernels `Model::run` launches through
+ * `XnnPack::parallelize` (call sites :4130 Erf/Sqrt/Sin/Cos, :4293 Concat, :5046 InstanceNormalization,
+ * :5384 ReduceMean, :5595 Pow, :6110 Split, :6309 Resize, :6489 Gather, :6670 Slice).
+ *
+ * Conventions
+ *  - plain C: opaque context, raw DEVICE pointers (void*), sizes; no C++/torch types cross this boundary.
+ *  - every compute entry point is ASYNCHRONOUS on the context's compute stream (like the reference's
+ *    CublasOps precedent, onnxstream.cpp:308-352); `osg_download` / `osg_sync` are the sync points
+ *    (== CublasOps::ensure_is_ready, onnxstream.cpp:200-230).
+ *  - return value: 0 = success, non-zero = failure; the message is available from osg_last_error()
+ *    (the host Model turns it into the std::runtime_error/invalid_argument the reference throws).
+ *  - element types: OSG_F16 (IEEE half, the reference's uint16_t "fp16 bits"), OSG_F32, OSG_U8, OSG_I64.
+ *  - arithmetic contract (matches the XNNPACK CPU path the reference uses): f16 operands, f32 accumulation /
+ *    f32 intermediate math, ONE round-to-nearest-even to f16 on store of every entry point's output.
+ *  - tensors are dense row-major; 4-D activations around convolutions are NHWC exactly like the reference
+ *    (XnnPack::convolution returns [1,Ho,Wo,Cout], onnxstream.cpp:1292-1534).
+ *  - `batch`/N arguments generalise the reference's per-op batch loop (onnxstream.cpp:3847): N independent samples
+ *    that share one weight fetch are executed as one launch.
+ */
+#ifndef OSGPU_H
+#define OSGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct osg_ctx osg_ctx;
+typedef struct osg_graph osg_graph;
+
+typedef enum { OSG_U8 = 1, OSG_F16 = 2, OSG_F32 = 3, OSG_I64 = 4 } osg_dtype; /* == onnxstream::TensorDataType */
+
+typedef enum { OSG_ACT_NONE = 0, OSG_ACT_SILU = 1, OSG_ACT_SIGMOID = 2 } osg_act;
+
+typedef enum {
+  OSG_UN_SIGMOID = 0, /* XnnPack::sigmoid            onnxstream.cpp:1217 */
+  OSG_UN_ERF = 1,     /* Model::run Erf  (std::erf)  onnxstream.cpp:4001-4139 */
+  OSG_UN_SQRT = 2,    /* Model::run Sqrt             onnxstream.cpp:4001-4139 */
+  OSG_UN_SIN = 3,     /* Model::run Sin              onnxstream.cpp:4001-4139 */
+  OSG_UN_COS = 4,     /* Model::run Cos              onnxstream.cpp:4001-4139 */
+  OSG_UN_NEG = 5,     /* Model::run Neg              onnxstream.cpp:7475 */
+  OSG_UN_POW = 6,     /* Model::run Pow (scalar exponent in `param`) onnxstream.cpp:5478-5604 */
+  OSG_UN_SILU = 7,    /* fused Sigmoid+Mul (x*sigmoid(x)) */
+  OSG_UN_GELU_ERF = 8 /* fused Div,Erf,Add,Mul,Mul (0.5*x*(1+erf(x/sqrt2))) */
+} osg_unary_kind;
+
+typedef enum {
+  OSG_BIN_ADD = 0, /* XnnPack::add       onnxstream.cpp:1666 */
+  OSG_BIN_SUB = 1, /* XnnPack::subtract  onnxstream.cpp:1811 */
+  OSG_BIN_MUL = 2, /* XnnPack::multiply  onnxstream.cpp:846  */
+  OSG_BIN_DIV = 3  /* XnnPack::divide    onnxstream.cpp:1881 */
+} osg_binary_kind;
+
+/* ---- lifetime / device ---------------------------------------------------------------------------- */
+int osg_device_count(void);
+int osg_init(int device, osg_ctx** out);  /* replaces XnnPack::XnnPack(threads) onnxstream.cpp:678 */
+void osg_destroy(osg_ctx* ctx);           /* replaces XnnPack::~XnnPack          onnxstream.cpp:689 */
+const char* osg_last_error(const osg_ctx* ctx);
+const char* osg_device_name(const osg_ctx* ctx);
+void* osg_stream(const osg_ctx* ctx);     /* the compute hipStream_t (for callers that record their own events) */
+
+/* ---- memory / transfers (CublasOps buffer pool + cudaMemcpyAsync precedent, onnxstream.cpp:141-230,325,347) --- */
+int osg_malloc(osg_ctx* ctx, size_t bytes, void** dptr);
+int osg_free(osg_ctx* ctx, void* dptr);
+int osg_upload(osg_ctx* ctx, void* dst, const void* host_src, size_t bytes);         /* pinned staging + async H2D on the COPY stream; compute stream waits on it */
+int osg_upload_sync(osg_ctx* ctx, void* dst, const void* host_src, size_t bytes);    /* plain blocking H2D */
+int osg_download(osg_ctx* ctx, void* host_dst, const void* src, size_t bytes);       /* D2H + wait == ensure_is_ready */
+int osg_copy(osg_ctx* ctx, void* dst, const void* src, size_t bytes);                /* async D2D on compute stream */
+int osg_memset(osg_ctx* ctx, void* dst, int value, size_t bytes);
+int osg_sync(osg_ctx* ctx);
+
+/* ---- stream capture: a whole Model::run pass replayed as one hipGraph ------------------------------------ */
+int osg_graph_begin(osg_ctx* ctx);
+int osg_graph_end(osg_ctx* ctx, osg_graph** out);
+int osg_graph_launch(osg_ctx* ctx, osg_graph* g);
+void osg_graph_destroy(osg_graph* g);
+
+/* ---- timing on the compute stream (HIP events) ------------------------------------------------------------ */
+int osg_timer_start(osg_ctx* ctx);
+int osg_timer_stop(osg_ctx* ctx, float* ms); /* waits for the stop event */
+
+/* ---- dense contractions ------------------------------------------------------------------------------------ */
+/* Convolution, NHWC in / OHWI weights / NHWC out, group 1, dilation 1, f32 accumulate.
+ * Replaces XnnPack::convolution<T,U> (onnxstream.cpp:1292-1534).  `bias` (f16 or f32 per bias_dtype, may be NULL),
+ * optional fused `residual` (same shape as y, added in f32 before the single rounding) and activation. */
+int osg_conv2d_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* w_ohwi, const void* bias, osg_dtype bias_dtype,
+                    const void* residual, void* y, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride_h,
+                    int stride_w, int pad_top, int pad_left, int pad_bottom, int pad_right, osg_act act);
+
+/* C[b] = act(A[b] (MxK, row-major, lda) * B[b] + bias + residual).  B is [K,N] row-major (b_is_nk=0, the layout
+ * XNN_FLAG_TRANSPOSE_WEIGHTS gives the reference, onnxstream.cpp:977,1136) or pre-transposed [N,K] (b_is_nk=1, how
+ * resident weights are kept on the device).  stride_* are element strides between batch items (0 = broadcast).
+ * Replaces XnnPack::matrix_multiply / matrix_multiply_dynamic (onnxstream.cpp:929-1215) and the n-loop of
+ * Model::run MatMul (:5798).  bias: [N] (row broadcast) ; residual: [batch,M,N] like C. */
+int osg_gemm(osg_ctx* ctx, osg_dtype dtype, const void* A, const void* B, int b_is_nk, const void* bias, osg_dtype bias_dtype,
+             const void* residual, void* C, int M, int N, int K, int batch, long stride_a, long stride_b, long stride_c,
+             osg_act act);
+
+/* Re-layout a [K,N] row-major matrix into [N,K] (done once per resident weight). */
+int osg_transpose_kn_to_nk(osg_ctx* ctx, osg_dtype dtype, const void* src_kn, void* dst_nk, int K, int N);
+
+/* Fused attention == the reference's AttentionFusedOps pseudo-op (onnxstream.cpp:6696-6929):
+ * for each of `heads` items: O = softmax(scale * Q K^T) V, with Q:[heads,Tq,D], K given TRANSPOSED as the reference
+ * receives it (k_is_dt=1: [heads,D,Tkv], :6792,6814) or natural [heads,Tkv,D] (k_is_dt=0), V:[heads,Tkv,D], O:[heads,Tq,D].
+ * `scale` multiplies the f16-rounded scores (the reference's separate Mul); scores and probabilities are kept in
+ * f32 on chip (flash-style), i.e. FEWER roundings than the sliced reference path.  The strided variant reads Q/K/V
+ * directly out of [T, heads*D] projection outputs (token stride ld*, head stride D) so the head split/merge
+ * Reshape/Transpose ops vanish. */
+int osg_attention(osg_ctx* ctx, osg_dtype dtype, const void* q, const void* k, const void* v, void* o, int heads, int Tq, int Tkv,
+                  int D, float scale, int k_is_dt);
+int osg_attention_strided(osg_ctx* ctx, osg_dtype dtype, const void* q, long q_tok, long q_head, long q_batch, const void* k,
+                          long k_tok, long k_head, long k_batch, const void* v, long v_tok, long v_head, long v_batch, void* o,
+                          long o_tok, long o_head, long o_batch, int batch, int heads, int Tq, int Tkv, int D, float scale);
+
+/* ---- normalisation / reductions ---------------------------------------------------------------------------- */
+/* InstanceNormalization on [rows, L] (reference input [1,G,L], onnxstream.cpp:4788-5055): per row mean/var in f32,
+ * y = scale[row % n_scale]*(x-mean)/sqrt(var+eps)+bias[row % n_scale]; scale/bias are f32 (forced f32 at :4802). */
+int osg_instance_norm(osg_ctx* ctx, osg_dtype dtype, const void* x, const float* scale, const float* bias, void* y, int rows,
+                      long L, int n_scale, float eps);
+/* Fused GroupNorm on NHWC [N,HW,C] = Reshape->InstanceNorm->Reshape->Mul(gamma[C])->Add(beta[C]) (+SiLU). */
+int osg_group_norm_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* gamma, const void* beta, void* y, int N, long HW,
+                        int C, int groups, float eps, osg_act act);
+/* Fused LayerNorm over the last axis == ReduceMean,Sub,Pow,ReduceMean,Add,Sqrt,Div,Mul,Add (onnxstream.cpp:5237-5604). */
+int osg_layer_norm(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* gamma, const void* beta, void* y, long rows, int C,
+                   float eps);
+/* ReduceMean over the last axis, keepdims (onnxstream.cpp:5237-5393). */
+int osg_reduce_mean_last(osg_ctx* ctx, osg_dtype dtype, const void* x, void* y, long rows, long C);
+/* Softmax over the last axis (XnnPack::softmax, onnxstream.cpp:1958). */
+int osg_softmax_last(osg_ctx* ctx, osg_dtype dtype, const void* x, void* y, long rows, long C);
+
+/* ---- elementwise -------------------------------------------------------------------------------------------- */
+int osg_unary(osg_ctx* ctx, osg_dtype dtype, osg_unary_kind kind, const void* x, void* y, long n, float param);
+/* NumPy-style broadcasting binary op, shapes right-aligned to `rank` (<=6) dims (onnxstream.cpp:855-876). */
+int osg_binary(osg_ctx* ctx, osg_dtype dtype, osg_binary_kind kind, const void* a, const long* a_shape, const void* b,
+               const long* b_shape, void* y, int rank);
+/* GEGLU: x:[rows,2C] -> y:[rows,C] = x[:, :C] * gelu_erf(x[:, C:]) (Slice,Slice,Div,Erf,Add,Mul,Mul,Mul). */
+int osg_geglu(osg_ctx* ctx, osg_dtype dtype, const void* x, void* y, long rows, long C);
+
+/* ---- data movement ------------------------------------------------------------------------------------------ */
+/* N-d transpose (XnnPack::transpose, onnxstream.cpp:1748): out.shape[i] = shape[perm[i]]. elem_size in {1,2,4,8}. */
+int osg_transpose(osg_ctx* ctx, int elem_size, const void* x, void* y, int rank, const long* shape, const int* perm);
+/* 2-D strided block copy: for o<outer: dst[o*dst_pitch + dst_off .. +inner) = src[o*src_pitch + src_off .. +inner)
+ * (element units).  Implements Concat (:4140), Split (:5999), Slice (:6499) along any axis. */
+int osg_copy_2d(osg_ctx* ctx, int elem_size, const void* src, long src_pitch, long src_off, void* dst, long dst_pitch,
+                long dst_off, long outer, long inner);
+/* Nearest/asymmetric/floor resize of [N,H,W,C] (nhwc=1) or [N,C,H,W] (nhwc=0) by integer-or-not scales (onnxstream.cpp:6120-6315). */
+int osg_resize_nearest(osg_ctx* ctx, int elem_size, const void* x, void* y, int N, int C, int H, int W, int Ho, int Wo, int nhwc);
+/* Gather rows along axis 0: y[i,:] = x[idx[i],:] (onnxstream.cpp:6316). idx is a DEVICE int64 array. */
+int osg_gather_rows(osg_ctx* ctx, int elem_size, const void* x, const int64_t* idx, void* y, long n_idx, long row_elems, long n_rows);
+/* MaxPool NHWC (XnnPack::maxpool_nhwc, onnxstream.cpp:1536). */
+int osg_maxpool_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, void* y, int N, int H, int W, int C, int KH, int KW, int sh,
+                     int sw, int pt, int pl, int pb, int pr);
+
+/* ---- conversion / quantisation (XnnPack::convert :757, convert_qu8 :802, Model::dequantize :3353, quantize :3247) -- */
+/* f16<->f32 ; u8->f32/f16: (float)((int)q - zp) * scale ; f32/f16->u8: clamp(rne(x * (1.0f/scale)) + zp, 0, 255). */
+int osg_convert(osg_ctx* ctx, osg_dtype src_dtype, osg_dtype dst_dtype, const void* x, void* y, long n, float scale, int zero_point);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSGPU_H */

@@ -1,0 +1,256 @@
+// libosgpu: fused attention on the matrix cores (flash-style, online softmax), f16 operands / f32 accumulate.
+//
+// Replaces the reference's AttentionFusedOps pseudo-op (onnxstream.cpp:6696-6929), which runs, per head and per
+// Q row-chunk ("sliced attention"), 4 XNNPACK operators and round-trips the score slab through memory:
+//     S = Q K^T ; S *= scale ; P = softmax_rows(S) ; O = P V.
+// Here the [Tq x Tkv] scores never leave the chip, so slicing (m_attention_fused_ops_parts) is unnecessary and the
+// result is independent of it.
+//
+// Mapping (one workgroup = 4 waves = 64*QT query rows of one head; KV swept in tiles of 64):
+//   S^T[kv][q] = mfma_16x16x32(A = K rows from LDS, B = Q fragment held in registers)      (contraction over d)
+//   lane (q = lane&15, g = lane>>4) then owns scores kv = t*16 + g*4 + r: the row max / sum need only two
+//   cross-lane steps (xor 16, 32); P is converted to f16 IN PLACE as the B operand of
+//   O^T[d][q] += mfma_16x16x32(A = V^T fragment from LDS, B = P)                           (contraction over kv)
+//   -- the kv order inside a 32-wide contraction step is permuted identically for P and V^T, so P never moves
+//   between lanes.  The O^T layout gives each lane 4 consecutive d of one query row: 8-byte stores.
+// Head dims are zero-padded in LDS/registers to a multiple of 32 (QK^T) / 16 (PV): 40->64/48, 80->96/80, 160->160.
+#include "osg_common.h"
+
+namespace {
+
+struct AttnParams {
+    const f16 *q, *k, *v;
+    f16* o;
+    long q_tok, q_head, q_batch;
+    long k_tok, k_head, k_batch;
+    long v_tok, v_head, v_batch;
+    long o_tok, o_head, o_batch;
+    int heads, Tq, Tkv, D;
+    float scale_log2e;
+};
+
+constexpr int BKV = 64;
+
+template <int DP, int DT, int QT>
+__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+    constexpr int KLD = DP + 8;     // Ks row stride (halves): 16-byte aligned rows, conflict-free b128 reads
+    constexpr int VLD = BKV + 8;    // Vt row stride (halves): 8-byte aligned b64 reads
+    constexpr int DV = DT * 16;
+    constexpr int KS = DP / 32;
+    __shared__ __attribute__((aligned(16))) f16 Ks[BKV * KLD];
+    __shared__ __attribute__((aligned(16))) f16 Vt[DV * VLD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.y;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+    const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+    const int D = p.D;
+
+    const f16* __restrict__ Q = p.q + b * p.q_batch + h * p.q_head;
+    const f16* __restrict__ K = p.k + b * p.k_batch + h * p.k_head;
+    const f16* __restrict__ V = p.v + b * p.v_batch + h * p.v_head;
+    f16* __restrict__ O = p.o + b * p.o_batch + h * p.o_head;
+
+    // zero the LDS padding once (pad columns of Ks, pad rows of Vt) so no NaN bit patterns enter the MFMAs
+    for (int i = tid; i < BKV * KLD; i += 256) Ks[i] = (f16)0;
+    for (int i = tid; i < DV * VLD; i += 256) Vt[i] = (f16)0;
+
+    // Q fragments (operand B: lane holds Q[q][ks*32 + g*8 .. +7])
+    f16x8 qf[QT][KS];
+#pragma unroll
+    for (int qt = 0; qt < QT; qt++) {
+        const int q = q0 + qt * 16 + lq;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const int d = ks * 32 + g * 8;
+            f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (q < p.Tq && d < D) v = *reinterpret_cast<const f16x8*>(Q + (long)q * p.q_tok + d);
+            qf[qt][ks] = v;
+        }
+    }
+
+    f32x4 oacc[QT][DT];
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; qt++) {
+        m_run[qt] = -INFINITY;
+        l_run[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) oacc[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int dchunks = D / 8;
+    for (int kv0 = 0; kv0 < p.Tkv; kv0 += BKV) {
+        __syncthreads();  // previous tile fully consumed (also orders the initial zero fill)
+        // ---- stage K (natural [kv][d]) and V (transposed [d][kv]); lane = kv row, waves stride over d-chunks ----
+        {
+            const int kv = kv0 + lane;
+            const bool ok = kv < p.Tkv;
+            for (int dc = wave; dc < dchunks; dc += 4) {
+                f16x8 kvv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) {
+                    kvv = *reinterpret_cast<const f16x8*>(K + (long)kv * p.k_tok + dc * 8);
+                    vv = *reinterpret_cast<const f16x8*>(V + (long)kv * p.v_tok + dc * 8);
+                }
+                *reinterpret_cast<f16x8*>(&Ks[lane * KLD + dc * 8]) = kvv;
+#pragma unroll
+                for (int e = 0; e < 8; e++) Vt[(dc * 8 + e) * VLD + lane] = vv[e];
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T -------------------------------------------------------------------------------
+        f32x4 s[QT][4];
+#pragma unroll
+        for (int qt = 0; qt < QT; qt++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) s[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) {
+                f16x8 kf = *reinterpret_cast<const f16x8*>(&Ks[(t * 16 + lq) * KLD + ks * 32 + g * 8]);
+#pragma unroll
+                for (int qt = 0; qt < QT; qt++) s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][ks], s[qt][t], 0, 0, 0);
+            }
+        }
+
+        // ---- online softmax (log2 domain) ----------------------------------------------------------------
+        f16x8 pf[QT][2];
+#pragma unroll
+        for (int qt = 0; qt < QT; qt++) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int kv = kv0 + t * 16 + g * 4 + r;
+                    float x = kv < p.Tkv ? s[qt][t][r] * p.scale_log2e : -INFINITY;
+                    s[qt][t][r] = x;
+                    mx = fmaxf(mx, x);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx);
+            const float alpha = exp2f(m_run[qt] - m_new);
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float e = exp2f(s[qt][t][r] - m_new);
+                    s[qt][t][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            l_run[qt] = l_run[qt] * alpha + sum;
+            m_run[qt] = m_new;
+#pragma unroll
+            for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) oacc[qt][dt][r] *= alpha;
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                f16x8 pv;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    pv[r] = (f16)s[qt][2 * st][r];
+                    pv[4 + r] = (f16)s[qt][2 * st + 1][r];
+                }
+                pf[qt][st] = pv;
+            }
+        }
+
+        // ---- O^T += V^T P ------------------------------------------------------------------------------
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) {
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                const f16* vrow = &Vt[(dt * 16 + lq) * VLD + st * 32 + g * 4];
+                f16x4 lo = *reinterpret_cast<const f16x4*>(vrow);
+                f16x4 hi = *reinterpret_cast<const f16x4*>(vrow + 16);
+                f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int qt = 0; qt < QT; qt++)
+                    oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][st], oacc[qt][dt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: O[q][d..d+3] = O^T / l -----------------------------------------------------------------
+#pragma unroll
+    for (int qt = 0; qt < QT; qt++) {
+        const int q = q0 + qt * 16 + lq;
+        if (q >= p.Tq) continue;
+        const float inv = 1.0f / l_run[qt];
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) {
+            const int d = dt * 16 + g * 4;
+            if (d >= D) continue;
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r] = (f16)(oacc[qt][dt][r] * inv);
+            *reinterpret_cast<f16x4*>(O + (long)q * p.o_tok + d) = o;
+        }
+    }
+}
+
+template <int DP, int DT>
+int launch_attn(osg_ctx* ctx, const AttnParams& p, int batch) {
+    if (p.Tq >= 1024) {
+        dim3 grid((p.Tq + 127) / 128, batch * p.heads);
+        hipLaunchKernelGGL((attn_kernel<DP, DT, 2>), grid, dim3(256), 0, ctx->compute, p);
+    } else {
+        dim3 grid((p.Tq + 63) / 64, batch * p.heads);
+        hipLaunchKernelGGL((attn_kernel<DP, DT, 1>), grid, dim3(256), 0, ctx->compute, p);
+    }
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int osg_attention_strided(osg_ctx* ctx, osg_dtype dtype, const void* q, long q_tok, long q_head, long q_batch, const void* k, long k_tok,
+                          long k_head, long k_batch, const void* v, long v_tok, long v_head, long v_batch, void* o, long o_tok,
+                          long o_head, long o_batch, int batch, int heads, int Tq, int Tkv, int D, float scale) {
+    if (dtype != OSG_F16) OSG_FAIL(ctx, "osg_attention: only f16 arithmetic is implemented on the device");
+    if (batch <= 0 || heads <= 0 || Tq <= 0 || Tkv <= 0 || D <= 0) OSG_FAIL(ctx, "osg_attention: invalid shape(s) of q, k and/or v");
+    if (D % 8) OSG_FAIL(ctx, "osg_attention: head dim must be a multiple of 8");
+    if ((q_tok | q_head | q_batch | k_tok | k_head | k_batch | v_tok | v_head | v_batch) % 8 || (o_tok | o_head | o_batch) % 4)
+        OSG_FAIL(ctx, "osg_attention: strides must keep 16-byte (q,k,v) / 8-byte (o) alignment");
+    AttnParams p{(const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, q_tok, q_head, q_batch, k_tok, k_head, k_batch,
+                 v_tok, v_head, v_batch, o_tok, o_head, o_batch, heads, Tq, Tkv, D, scale * 1.4426950408889634f};
+    const int dt = (D + 15) / 16;
+    if (D <= 32) return launch_attn<32, 2>(ctx, p, batch);
+    if (D <= 48) return launch_attn<64, 3>(ctx, p, batch);
+    if (D <= 64) return launch_attn<64, 4>(ctx, p, batch);
+    if (D <= 80) return launch_attn<96, 5>(ctx, p, batch);
+    if (D <= 96) return launch_attn<96, 6>(ctx, p, batch);
+    if (D <= 128) return launch_attn<128, 8>(ctx, p, batch);
+    if (D <= 160) return launch_attn<160, 10>(ctx, p, batch);
+    (void)dt;
+    OSG_FAIL(ctx, "osg_attention: head dim > 160 not implemented");
+}
+
+int osg_attention(osg_ctx* ctx, osg_dtype dtype, const void* q, const void* k, const void* v, void* o, int heads, int Tq, int Tkv, int D,
+                  float scale, int k_is_dt) {
+    if (dtype != OSG_F16) OSG_FAIL(ctx, "osg_attention: only f16 arithmetic is implemented on the device");
+    const void* kk = k;
+    if (k_is_dt) {
+        // the reference hands K over already transposed ([heads, D, Tkv], onnxstream.cpp:6792): undo it into scratch
+        size_t bytes = (size_t)heads * D * Tkv * sizeof(f16);
+        if (osg_ensure_workspace2(ctx, bytes)) return 1;
+        long shape[3] = {heads, D, Tkv};
+        int perm[3] = {0, 2, 1};
+        if (osg_transpose(ctx, 2, k, ctx->ws2, 3, shape, perm)) return 1;
+        kk = ctx->ws2;
+    }
+    return osg_attention_strided(ctx, dtype, q, D, (long)Tq * D, 0, kk, D, (long)Tkv * D, 0, v, D, (long)Tkv * D, 0, o, D, (long)Tq * D, 0,
+                                 1, heads, Tq, Tkv, D, scale);
+}
+
+}  // extern "C"

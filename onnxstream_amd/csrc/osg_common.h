@@ -1,0 +1,96 @@
+// Internal definitions shared by the HIP translation units of libosgpu (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdio>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "osgpu.h"
+
+struct osg_ctx {
+    int device = 0;
+    hipStream_t compute = nullptr;
+    hipStream_t copy = nullptr;
+    hipEvent_t ev_copy = nullptr;       // copy stream -> compute stream dependency
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    // pinned double-buffered staging for host->device streaming (weights provider path)
+    static constexpr int kStages = 2;
+    void* stage[kStages] = {nullptr, nullptr};
+    hipEvent_t stage_free[kStages] = {nullptr, nullptr};
+    size_t stage_bytes = 0;
+    int stage_next = 0;
+    // split-K / reduction workspace (grown on demand, never inside a capture)
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    void* ws2 = nullptr;                // scratch for re-laid-out dynamic GEMM operands
+    size_t ws2_bytes = 0;
+    bool capturing = false;
+    std::string err;
+    std::string name;
+    int num_cu = 256;
+};
+
+struct osg_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+#define OSG_FAIL(ctx, msg)                 \
+    do {                                   \
+        (ctx)->err = (msg);                \
+        return 1;                          \
+    } while (0)
+
+#define OSG_HIP(ctx, call)                                                                        \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
+            return 1;                                                                             \
+        }                                                                                         \
+    } while (0)
+
+#define OSG_LAUNCH_CHECK(ctx)                                                                     \
+    do {                                                                                          \
+        hipError_t e__ = hipGetLastError();                                                       \
+        if (e__ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string("kernel launch: ") + hipGetErrorString(e__);                 \
+            return 1;                                                                             \
+        }                                                                                         \
+    } while (0)
+
+int osg_ensure_workspace(osg_ctx* ctx, size_t bytes);
+int osg_ensure_workspace2(osg_ctx* ctx, size_t bytes);
+
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float osg_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float osg_apply_act(float v, int act) {
+    if (act == OSG_ACT_SILU) return v * osg_sigmoid(v);
+    if (act == OSG_ACT_SIGMOID) return osg_sigmoid(v);
+    return v;
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<f16>(f16 v) { return (float)v; }
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)v; }  // v_cvt_f16_f32: RNE
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,199 @@
+// libosgpu: context, memory, transfers, graph capture, timing.  (C ABI: include/osgpu.h)
+#include "osg_common.h"
+#include <cstring>
+
+extern "C" {
+
+int osg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int osg_init(int device, osg_ctx** out) {
+    if (!out) return 1;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 2;  // no GPU: the product path fails loudly
+    if (device < 0 || device >= n) return 3;
+    if (hipSetDevice(device) != hipSuccess) return 4;
+    osg_ctx* c = new osg_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        c->name = prop.gcnArchName;
+        c->num_cu = prop.multiProcessorCount;
+    }
+    bool ok = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreate(&c->ev_t0) == hipSuccess && hipEventCreate(&c->ev_t1) == hipSuccess;
+    c->stage_bytes = 64u << 20;
+    for (int i = 0; ok && i < osg_ctx::kStages; i++) {
+        ok = hipHostMalloc(&c->stage[i], c->stage_bytes, hipHostMallocDefault) == hipSuccess &&
+             hipEventCreateWithFlags(&c->stage_free[i], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) {
+        delete c;
+        return 5;
+    }
+    *out = c;
+    return 0;
+}
+
+void osg_destroy(osg_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (int i = 0; i < osg_ctx::kStages; i++) {
+        if (c->stage[i]) hipHostFree(c->stage[i]);
+        if (c->stage_free[i]) hipEventDestroy(c->stage_free[i]);
+    }
+    if (c->ws) hipFree(c->ws);
+    if (c->ws2) hipFree(c->ws2);
+    if (c->ev_copy) hipEventDestroy(c->ev_copy);
+    if (c->ev_t0) hipEventDestroy(c->ev_t0);
+    if (c->ev_t1) hipEventDestroy(c->ev_t1);
+    if (c->compute) hipStreamDestroy(c->compute);
+    if (c->copy) hipStreamDestroy(c->copy);
+    delete c;
+}
+
+const char* osg_last_error(const osg_ctx* c) { return c ? c->err.c_str() : "null context"; }
+const char* osg_device_name(const osg_ctx* c) { return c ? c->name.c_str() : ""; }
+void* osg_stream(const osg_ctx* c) { return c ? (void*)c->compute : nullptr; }
+
+int osg_malloc(osg_ctx* c, size_t bytes, void** dptr) {
+    if (c->capturing) OSG_FAIL(c, "osg_malloc inside graph capture");
+    OSG_HIP(c, hipSetDevice(c->device));
+    OSG_HIP(c, hipMalloc(dptr, bytes ? bytes : 16));
+    return 0;
+}
+
+int osg_free(osg_ctx* c, void* dptr) {
+    if (!dptr) return 0;
+    OSG_HIP(c, hipFree(dptr));
+    return 0;
+}
+
+// Host->device through the pinned double-buffered ring on the COPY stream: chunk k+1 is memcpy'd into pinned memory
+// while chunk k's hipMemcpyAsync is in flight; the compute stream is made to wait for the last chunk.
+int osg_upload(osg_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (c->capturing) OSG_FAIL(c, "osg_upload inside graph capture");
+    const char* s = (const char*)src;
+    char* d = (char*)dst;
+    size_t off = 0;
+    while (off < bytes) {
+        size_t n = bytes - off < c->stage_bytes ? bytes - off : c->stage_bytes;
+        int i = c->stage_next;
+        c->stage_next = (i + 1) % osg_ctx::kStages;
+        OSG_HIP(c, hipEventSynchronize(c->stage_free[i]));  // previous DMA out of this pinned buffer finished
+        std::memcpy(c->stage[i], s + off, n);
+        OSG_HIP(c, hipMemcpyAsync(d + off, c->stage[i], n, hipMemcpyHostToDevice, c->copy));
+        OSG_HIP(c, hipEventRecord(c->stage_free[i], c->copy));
+        off += n;
+    }
+    OSG_HIP(c, hipEventRecord(c->ev_copy, c->copy));
+    OSG_HIP(c, hipStreamWaitEvent(c->compute, c->ev_copy, 0));
+    return 0;
+}
+
+int osg_upload_sync(osg_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (c->capturing) OSG_FAIL(c, "osg_upload_sync inside graph capture");
+    OSG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->compute));
+    OSG_HIP(c, hipStreamSynchronize(c->compute));
+    return 0;
+}
+
+int osg_download(osg_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (c->capturing) OSG_FAIL(c, "osg_download inside graph capture");
+    OSG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->compute));
+    OSG_HIP(c, hipStreamSynchronize(c->compute));
+    return 0;
+}
+
+int osg_copy(osg_ctx* c, void* dst, const void* src, size_t bytes) {
+    OSG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->compute));
+    return 0;
+}
+
+int osg_memset(osg_ctx* c, void* dst, int value, size_t bytes) {
+    OSG_HIP(c, hipMemsetAsync(dst, value, bytes, c->compute));
+    return 0;
+}
+
+int osg_sync(osg_ctx* c) {
+    OSG_HIP(c, hipStreamSynchronize(c->copy));
+    OSG_HIP(c, hipStreamSynchronize(c->compute));
+    return 0;
+}
+
+int osg_graph_begin(osg_ctx* c) {
+    if (c->capturing) OSG_FAIL(c, "already capturing");
+    OSG_HIP(c, hipStreamSynchronize(c->copy));
+    OSG_HIP(c, hipStreamBeginCapture(c->compute, hipStreamCaptureModeThreadLocal));
+    c->capturing = true;
+    return 0;
+}
+
+int osg_graph_end(osg_ctx* c, osg_graph** out) {
+    if (!c->capturing) OSG_FAIL(c, "not capturing");
+    c->capturing = false;
+    hipGraph_t g = nullptr;
+    OSG_HIP(c, hipStreamEndCapture(c->compute, &g));
+    hipGraphExec_t ex = nullptr;
+    hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        hipGraphDestroy(g);
+        OSG_FAIL(c, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    }
+    osg_graph* r = new osg_graph();
+    r->graph = g;
+    r->exec = ex;
+    *out = r;
+    return 0;
+}
+
+int osg_graph_launch(osg_ctx* c, osg_graph* g) {
+    OSG_HIP(c, hipGraphLaunch(g->exec, c->compute));
+    return 0;
+}
+
+void osg_graph_destroy(osg_graph* g) {
+    if (!g) return;
+    if (g->exec) hipGraphExecDestroy(g->exec);
+    if (g->graph) hipGraphDestroy(g->graph);
+    delete g;
+}
+
+int osg_timer_start(osg_ctx* c) {
+    OSG_HIP(c, hipEventRecord(c->ev_t0, c->compute));
+    return 0;
+}
+
+int osg_timer_stop(osg_ctx* c, float* ms) {
+    OSG_HIP(c, hipEventRecord(c->ev_t1, c->compute));
+    OSG_HIP(c, hipEventSynchronize(c->ev_t1));
+    OSG_HIP(c, hipEventElapsedTime(ms, c->ev_t0, c->ev_t1));
+    return 0;
+}
+
+}  // extern "C"
+
+static int ensure_buf(osg_ctx* c, void** ptr, size_t* cur, size_t bytes);
+
+int osg_ensure_workspace(osg_ctx* c, size_t bytes) { return ensure_buf(c, &c->ws, &c->ws_bytes, bytes); }
+int osg_ensure_workspace2(osg_ctx* c, size_t bytes) { return ensure_buf(c, &c->ws2, &c->ws2_bytes, bytes); }
+
+static int ensure_buf(osg_ctx* c, void** ptr, size_t* cur, size_t bytes) {
+    if (bytes <= *cur) return 0;
+    if (c->capturing) OSG_FAIL(c, "workspace growth inside graph capture (run the pass once eagerly first)");
+    OSG_HIP(c, hipStreamSynchronize(c->compute));
+    if (*ptr) OSG_HIP(c, hipFree(*ptr));
+    *ptr = nullptr;
+    *cur = 0;
+    size_t n = (bytes + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
+    OSG_HIP(c, hipMalloc(ptr, n));
+    *cur = n;
+    return 0;
+}

@@ -1,0 +1,456 @@
+// libosgpu: dense contractions on the gfx950 matrix cores.
+//
+// One implicit-GEMM kernel serves Conv (XnnPack::convolution, reference onnxstream.cpp:1292) and MatMul/Gemm
+// (XnnPack::matrix_multiply, :1035):   C[M,N] = A[M,K] * Bt[N,K]^T   (f16 operands, f32 accumulate on
+// v_mfma_f32_16x16x32_f16, one RNE rounding to f16 in the epilogue -- the numerics class of XNNPACK's f16_f32acc GEMMs).
+//   * A is either a plain row-major matrix or gathered on the fly from an NHWC activation (im2col never materialised):
+//     m -> (n,ho,wo), k -> (kh,kw,c); a 16-byte k-chunk never straddles a filter tap when Cin % 8 == 0.
+//   * Bt is K-contiguous: OHWI conv weights already are [Cout][KH*KW*Cin]; MatMul weights ([K,N] on disk) are
+//     re-laid out to [N,K] once when they become resident.
+//   * global -> registers -> LDS (padded rows: +16 B => conflict-free ds_read_b128), double-buffered, one barrier per
+//     k-tile, next tile's global loads in flight under the MFMAs.
+//   * operands are swapped (weights as MFMA "A") so each lane owns 4 consecutive output channels of one pixel:
+//     8-byte epilogue stores, bias/residual fused in f32 before the single rounding.
+//   * split-K (grid.z) with f32 partial slabs + a fused reduce epilogue for the small-M (8x8, 16x16 latent) layers.
+#include "osg_common.h"
+
+namespace {
+
+struct GemmParams {
+    const f16* A;
+    const f16* Bt;
+    f16* C;
+    const void* bias;
+    const f16* residual;
+    float* partial;
+    int M, N, K;
+    long lda;
+    long strideA, strideB, strideC;
+    int bias_f32, act;
+    int splits, k_per_split;
+    // conv geometry (CONV only)
+    int H, W, Cin, Ho, Wo, KW, sh, sw, pt, pl;
+};
+
+template <int BM, int BN, int BK, bool CONV, bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+    constexpr int LDS = BK + 8;               // padded row stride (halves)
+    constexpr int CPR = BK / 8;               // 16-byte chunks per tile row
+    constexpr int ROWS_PER_PASS = 256 / CPR;  // rows covered by one pass of the 256 threads
+    constexpr int A_IT = BM / ROWS_PER_PASS;
+    constexpr int B_IT = BN / ROWS_PER_PASS;
+    constexpr int WM = BM / 2, WN = BN / 2;   // 2x2 waves
+    constexpr int TM = WM / 16, TN = WN / 16;
+    static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for 256 threads");
+
+    extern __shared__ __attribute__((aligned(16))) f16 smem[];
+    f16* As0 = smem;
+    f16* Bs0 = smem + BM * LDS;
+    constexpr int STAGE = (BM + BN) * LDS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm0 = (wave >> 1) * WM;
+    const int wn0 = (wave & 1) * WN;
+
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int zb = blockIdx.z / p.splits;
+    const int zs = blockIdx.z - zb * p.splits;
+    const int kbeg = zs * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+
+    const f16* __restrict__ A = p.A + zb * p.strideA;
+    const f16* __restrict__ Bt = p.Bt + zb * p.strideB;
+
+    const int kc = tid % CPR;       // this thread's chunk column (same for all its chunks)
+    const int r0 = tid / CPR;
+
+    // per-chunk row state
+    long a_off[A_IT];
+    int a_hi0[A_IT], a_wi0[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; i++) {
+        int m = m0 + r0 + i * ROWS_PER_PASS;
+        a_ok[i] = m < p.M;
+        if (CONV) {
+            int mm = a_ok[i] ? m : 0;
+            int hw = p.Ho * p.Wo;
+            int n_img = mm / hw;
+            int rem = mm - n_img * hw;
+            int ho = rem / p.Wo;
+            int wo = rem - ho * p.Wo;
+            a_off[i] = (long)n_img * p.H * p.W * p.Cin;
+            a_hi0[i] = ho * p.sh - p.pt;
+            a_wi0[i] = wo * p.sw - p.pl;
+        } else {
+            a_off[i] = (long)(a_ok[i] ? m : 0) * p.lda;
+            a_hi0[i] = a_wi0[i] = 0;
+        }
+    }
+    long b_off[B_IT];
+    bool b_ok[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; i++) {
+        int n = n0 + r0 + i * ROWS_PER_PASS;
+        b_ok[i] = n < p.N;
+        b_off[i] = (long)(b_ok[i] ? n : 0) * p.K;
+    }
+
+    f16x8 areg[A_IT], breg[B_IT];
+
+    auto load_tile = [&](int k0) {
+        const int k = k0 + kc * 8;
+        if (VEC) {
+            const bool kok = k < kend;
+            int kh = 0, kw = 0, c = k;
+            if (CONV) {
+                int cell = k / p.Cin;
+                c = k - cell * p.Cin;
+                kh = cell / p.KW;
+                kw = cell - kh * p.KW;
+            }
+#pragma unroll
+            for (int i = 0; i < A_IT; i++) {
+                f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (CONV) {
+                    int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;
+                    if (a_ok[i] && kok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                        v = *reinterpret_cast<const f16x8*>(A + a_off[i] + ((long)hi * p.W + wi) * p.Cin + c);
+                } else {
+                    if (a_ok[i] && kok) v = *reinterpret_cast<const f16x8*>(A + a_off[i] + k);
+                }
+                areg[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < B_IT; i++) {
+                f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (b_ok[i] && kok) v = *reinterpret_cast<const f16x8*>(Bt + b_off[i] + k);
+                breg[i] = v;
+            }
+        } else {
+            // generic path: K or Cin not a multiple of 8 (e.g. conv_in with 4 input channels) -- element-wise gather
+#pragma unroll
+            for (int i = 0; i < A_IT; i++) {
+                f16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    int ke = k + e;
+                    f16 x = (f16)0;
+                    if (a_ok[i] && ke < kend) {
+                        if (CONV) {
+                            int cell = ke / p.Cin;
+                            int c = ke - cell * p.Cin;
+                            int kh = cell / p.KW;
+                            int kw = cell - kh * p.KW;
+                            int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;
+                            if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                                x = A[a_off[i] + ((long)hi * p.W + wi) * p.Cin + c];
+                        } else {
+                            x = A[a_off[i] + ke];
+                        }
+                    }
+                    v[e] = x;
+                }
+                areg[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < B_IT; i++) {
+                f16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    int ke = k + e;
+                    v[e] = (b_ok[i] && ke < kend) ? Bt[b_off[i] + ke] : (f16)0;
+                }
+                breg[i] = v;
+            }
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        f16* As = As0 + buf * STAGE;
+        f16* Bs = Bs0 + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_IT; i++)
+            *reinterpret_cast<f16x8*>(As + (r0 + i * ROWS_PER_PASS) * LDS + kc * 8) = areg[i];
+#pragma unroll
+        for (int i = 0; i < B_IT; i++)
+            *reinterpret_cast<f16x8*>(Bs + (r0 + i * ROWS_PER_PASS) * LDS + kc * 8) = breg[i];
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+    if (nkt > 0) {
+        load_tile(kbeg);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    const int frow = lane & 15;
+    const int fk = (lane >> 4) * 8;
+    for (int kt = 0; kt < nkt; kt++) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile(kbeg + (kt + 1) * BK);
+        const f16* As = As0 + cur * STAGE;
+        const f16* Bs = Bs0 + cur * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ks++) {
+            f16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+                a[i] = *reinterpret_cast<const f16x8*>(As + (wm0 + i * 16 + frow) * LDS + ks * 32 + fk);
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+                b[j] = *reinterpret_cast<const f16x8*>(Bs + (wn0 + j * 16 + frow) * LDS + ks * 32 + fk);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns C[m][n..n+3], m = tile_m + (lane&15), n = tile_n + (lane>>4)*4 -------------------
+    const int N = p.N;
+    if (p.splits == 1) {
+        f16* __restrict__ C = p.C + zb * p.strideC;
+        const f16* __restrict__ R = p.residual ? p.residual + zb * p.strideC : nullptr;
+        const bool vec_ok = (N & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int m = m0 + wm0 + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
+                if (n >= N) continue;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (vec_ok) {
+                    if (p.bias) {
+                        if (p.bias_f32) {
+                            f32x4 bv = *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
+#pragma unroll
+                            for (int r = 0; r < 4; r++) v[r] += bv[r];
+                        } else {
+                            f16x4 bv = *reinterpret_cast<const f16x4*>((const f16*)p.bias + n);
+#pragma unroll
+                            for (int r = 0; r < 4; r++) v[r] += (float)bv[r];
+                        }
+                    }
+                    if (R) {
+                        f16x4 rv = *reinterpret_cast<const f16x4*>(R + (long)m * N + n);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) v[r] += (float)rv[r];
+                    }
+                    f16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (f16)osg_apply_act(v[r], p.act);
+                    *reinterpret_cast<f16x4*>(C + (long)m * N + n) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        if (n + r >= N) break;
+                        float x = v[r];
+                        if (p.bias) x += p.bias_f32 ? ((const float*)p.bias)[n + r] : (float)((const f16*)p.bias)[n + r];
+                        if (R) x += (float)R[(long)m * N + n + r];
+                        C[(long)m * N + n + r] = (f16)osg_apply_act(x, p.act);
+                    }
+                }
+            }
+        }
+    } else {
+        float* __restrict__ P = p.partial + ((long)blockIdx.z) * p.M * N;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int m = m0 + wm0 + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
+                if (n >= N) continue;
+                if ((N & 3) == 0) {
+                    *reinterpret_cast<f32x4*>(P + (long)m * N + n) = acc[i][j];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (n + r < N) P[(long)m * N + n + r] = acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+// sum the split-K slabs, fuse bias/residual/activation, round once to f16
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, f16* __restrict__ C,
+                                                            const void* __restrict__ bias, int bias_f32,
+                                                            const f16* __restrict__ residual, long MN, int N, int splits, int batch,
+                                                            long strideC, int act) {
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    long total = MN * batch;
+    if (idx >= total) return;
+    int b = (int)(idx / MN);
+    long e = idx - (long)b * MN;
+    float v = 0.f;
+    for (int s = 0; s < splits; s++) v += partial[((long)(b * splits + s)) * MN + e];
+    int n = (int)(e % N);
+    if (bias) v += bias_f32 ? ((const float*)bias)[n] : (float)((const f16*)bias)[n];
+    if (residual) v += (float)residual[b * strideC + e];
+    C[b * strideC + e] = (f16)osg_apply_act(v, act);
+}
+
+template <int BM, int BN, int BK, bool CONV, bool VEC>
+int launch_cfg(osg_ctx* ctx, const GemmParams& p, int batch) {
+    constexpr int LDS = BK + 8;
+    size_t smem = (size_t)2 * (BM + BN) * LDS * sizeof(f16);
+    auto kern = gemm_kernel<BM, BN, BK, CONV, VEC>;
+    static bool attr_set = false;
+    if (!attr_set && smem > 48 * 1024) {
+        OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, batch * p.splits);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, ctx->compute, p);
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+template <bool CONV>
+int run_gemm(osg_ctx* ctx, GemmParams p, int batch) {
+    const bool vec = CONV ? (p.Cin % 8 == 0) : (p.K % 8 == 0 && p.lda % 8 == 0);
+    // ---- tile / split-K selection -------------------------------------------------------------------------
+    auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * batch; };
+    const long cu = ctx->num_cu;
+    int cfg;  // 0: 128x128x32, 1: 128x64x32, 2: 64x64x32
+    if (tiles(128, 128) >= cu && p.N % 128 == 0) cfg = 0;
+    else if (tiles(128, 64) >= cu && p.M >= 128) cfg = 1;
+    else cfg = 2;
+    const int bm = cfg == 2 ? 64 : 128, bn = cfg == 0 ? 128 : 64;
+    long t = tiles(bm, bn);
+    int splits = 1;
+    const int BK = 32;
+    if (t < cu && p.K >= 1024) {
+        splits = (int)((2 * cu + t - 1) / t);
+        int max_splits = p.K / 256;
+        if (splits > max_splits) splits = max_splits;
+        if (splits > 32) splits = 32;
+        if (splits < 1) splits = 1;
+    }
+    int ktiles = (p.K + BK - 1) / BK;
+    int kt_per = (ktiles + splits - 1) / splits;
+    splits = (ktiles + kt_per - 1) / kt_per;
+    p.splits = splits;
+    p.k_per_split = kt_per * BK;
+    if (splits > 1) {
+        size_t need = (size_t)batch * splits * p.M * p.N * sizeof(float);
+        if (osg_ensure_workspace(ctx, need)) return 1;
+        p.partial = (float*)ctx->ws;
+    }
+    int rc;
+#define OSG_DISPATCH(BM_, BN_)                                                   \
+    (vec ? launch_cfg<BM_, BN_, 32, CONV, true>(ctx, p, batch) : launch_cfg<BM_, BN_, 32, CONV, false>(ctx, p, batch))
+    if (cfg == 0) rc = OSG_DISPATCH(128, 128);
+    else if (cfg == 1) rc = OSG_DISPATCH(128, 64);
+    else rc = OSG_DISPATCH(64, 64);
+#undef OSG_DISPATCH
+    if (rc) return rc;
+    if (splits > 1) {
+        long MN = (long)p.M * p.N;
+        long total = MN * batch;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->compute, p.partial, p.C,
+                           p.bias, p.bias_f32, p.residual, MN, p.N, splits, batch, p.strideC, p.act);
+        OSG_LAUNCH_CHECK(ctx);
+    }
+    return 0;
+}
+
+// [K,N] -> [N,K] tiled transpose through LDS
+__global__ __launch_bounds__(256) void transpose_kn_nk_kernel(const f16* __restrict__ src, f16* __restrict__ dst, int K, int N) {
+    __shared__ f16 tile[32][33];
+    int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        int k = k0 + r, n = n0 + tx;
+        tile[r][tx] = (k < K && n < N) ? src[(long)k * N + n] : (f16)0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int n = n0 + r, k = k0 + tx;
+        if (n < N && k < K) dst[(long)n * K + k] = tile[tx][r];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int osg_transpose_kn_to_nk(osg_ctx* ctx, osg_dtype dtype, const void* src, void* dst, int K, int N) {
+    if (dtype != OSG_F16) OSG_FAIL(ctx, "osg_transpose_kn_to_nk: only f16 implemented");
+    dim3 grid((N + 31) / 32, (K + 31) / 32);
+    hipLaunchKernelGGL(transpose_kn_nk_kernel, grid, dim3(256), 0, ctx->compute, (const f16*)src, (f16*)dst, K, N);
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int osg_gemm(osg_ctx* ctx, osg_dtype dtype, const void* A, const void* B, int b_is_nk, const void* bias, osg_dtype bias_dtype,
+             const void* residual, void* C, int M, int N, int K, int batch, long stride_a, long stride_b, long stride_c,
+             osg_act act) {
+    if (dtype != OSG_F16) OSG_FAIL(ctx, "osg_gemm: only f16 arithmetic is implemented on the device");
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) OSG_FAIL(ctx, "osg_gemm: invalid shape of inputs");
+    if (bias && bias_dtype != OSG_F16 && bias_dtype != OSG_F32) OSG_FAIL(ctx, "osg_gemm: invalid bias dtype");
+    const f16* Bt = (const f16*)B;
+    long sb = stride_b;
+    if (!b_is_nk) {
+        // dynamic [K,N] operand: re-lay it out into scratch, then run the K-contiguous kernel
+        int nb = stride_b ? batch : 1;
+        size_t bytes = (size_t)nb * K * N * sizeof(f16);
+        if (osg_ensure_workspace2(ctx, bytes)) return 1;
+        f16* tmp = (f16*)ctx->ws2;
+        for (int b = 0; b < nb; b++) {
+            dim3 grid((N + 31) / 32, (K + 31) / 32);
+            hipLaunchKernelGGL(transpose_kn_nk_kernel, grid, dim3(256), 0, ctx->compute, (const f16*)B + (long)b * stride_b,
+                               tmp + (long)b * K * N, K, N);
+            OSG_LAUNCH_CHECK(ctx);
+        }
+        Bt = tmp;
+        sb = stride_b ? (long)K * N : 0;
+    }
+    GemmParams p{};
+    p.A = (const f16*)A; p.Bt = Bt; p.C = (f16*)C; p.bias = bias; p.residual = (const f16*)residual;
+    p.M = M; p.N = N; p.K = K; p.lda = K;
+    p.strideA = stride_a; p.strideB = sb; p.strideC = stride_c;
+    p.bias_f32 = bias_dtype == OSG_F32; p.act = act;
+    return run_gemm<false>(ctx, p, batch);
+}
+
+int osg_conv2d_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* w, const void* bias, osg_dtype bias_dtype,
+                    const void* residual, void* y, int N, int H, int W, int Cin, int Cout, int KH, int KW, int sh, int sw,
+                    int pt, int pl, int pb, int pr, osg_act act) {
+    if (dtype != OSG_F16) OSG_FAIL(ctx, "osg_conv2d_nhwc: only f16 arithmetic is implemented on the device");
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || sh <= 0 || sw <= 0)
+        OSG_FAIL(ctx, "osg_conv2d_nhwc: invalid argument");
+    int Ho = (H + pt + pb - KH) / sh + 1;
+    int Wo = (W + pl + pr - KW) / sw + 1;
+    if (Ho <= 0 || Wo <= 0) OSG_FAIL(ctx, "osg_conv2d_nhwc: empty output");
+    GemmParams p{};
+    p.A = (const f16*)x; p.Bt = (const f16*)w; p.C = (f16*)y; p.bias = bias; p.residual = (const f16*)residual;
+    p.M = N * Ho * Wo; p.N = Cout; p.K = KH * KW * Cin; p.lda = 0;
+    p.bias_f32 = bias_dtype == OSG_F32; p.act = act;
+    p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.KW = KW; p.sh = sh; p.sw = sw; p.pt = pt; p.pl = pl;
+    // a 1x1 / stride 1 / no-pad convolution IS a plain GEMM over the pixels
+    if (KH == 1 && KW == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0 && pb == 0 && pr == 0) {
+        p.lda = Cin;
+        return run_gemm<false>(ctx, p, 1);
+    }
+    return run_gemm<true>(ctx, p, 1);
+}
+
+}  // extern "C"

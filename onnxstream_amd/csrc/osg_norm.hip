@@ -1,0 +1,330 @@
+// libosgpu: normalisation / row reductions (HBM-bound; wavefront shuffle + LDS block reductions, f32 math).
+//   osg_instance_norm   <- Model::run InstanceNormalization (reference onnxstream.cpp:4788-5055): mean, then variance
+//                          of the deviations, y = scale*(x-mean)/sqrt(var+eps)+bias in f32, one rounding.
+//   osg_group_norm_nhwc <- the exported GroupNorm pattern Reshape/InstanceNorm/Reshape/Mul/Add(+Sigmoid,Mul) fused, NHWC.
+//   osg_layer_norm      <- the decomposed LayerNorm chain (ReduceMean :5237, Sub, Pow :5478, ReduceMean, Add, Sqrt, Div, Mul, Add).
+//   osg_reduce_mean_last, osg_softmax_last <- ReduceMean (:5237-5393), XnnPack::softmax (:1958).
+#include "osg_common.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; i++) t += red[i];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = red[0];
+    for (int i = 1; i < nw; i++) t = fmaxf(t, red[i]);
+    return t;
+}
+
+// ---- InstanceNormalization on [rows, L]: one block per row, three sweeps (the row stays in L2) ---------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void instance_norm_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ bias, T* __restrict__ y, long L, int n_scale,
+                                                             float eps) {
+    __shared__ float red[16];
+    const long row = blockIdx.x;
+    const T* xr = x + row * L;
+    T* yr = y + row * L;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < L; i += blockDim.x) s += to_f32<T>(xr[i]);
+    const float mean = block_sum(s, red) / (float)L;
+    float q = 0.f;
+    for (long i = threadIdx.x; i < L; i += blockDim.x) {
+        float d = to_f32<T>(xr[i]) - mean;
+        q += d * d;
+    }
+    const float var = block_sum(q, red) / (float)L;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float sc = scale ? scale[row % n_scale] : 1.f, bi = bias ? bias[row % n_scale] : 0.f;
+    for (long i = threadIdx.x; i < L; i += blockDim.x) yr[i] = from_f32<T>(sc * ((to_f32<T>(xr[i]) - mean) * rstd) + bi);
+}
+
+// ---- fused GroupNorm, NHWC --------------------------------------------------------------------------------------
+// pass 1: grid (N*G, S): block (n,g,s) sweeps its slice of the HW pixels of group g and emits (sum, sumsq)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ part, long HW, int C, int G, int S) {
+    __shared__ float red[8];
+    const int ng = blockIdx.x, s = blockIdx.y;
+    const int n = ng / G, g = ng - n * G;
+    const int cpg = C / G;
+    const long p0 = HW * s / S, p1 = HW * (s + 1) / S;
+    const T* base = x + (long)n * HW * C + (long)g * cpg;
+    const long cnt = (p1 - p0) * cpg;
+    float sum = 0.f, sq = 0.f;
+    for (long i = threadIdx.x; i < cnt; i += 256) {
+        long p = p0 + i / cpg;
+        int c = (int)(i % cpg);
+        float v = to_f32<T>(base[p * C + c]);
+        sum += v;
+        sq += v * v;
+    }
+    sum = block_sum(sum, red);
+    sq = block_sum(sq, red);
+    if (threadIdx.x == 0) {
+        part[((long)ng * S + s) * 2 + 0] = sum;
+        part[((long)ng * S + s) * 2 + 1] = sq;
+    }
+}
+
+// pass 2: normalise + affine (+SiLU); each block first folds the S partials of the G groups of its image into LDS
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ part, const T* __restrict__ gamma,
+                                                       const T* __restrict__ beta, T* __restrict__ y, long HW, int C, int G, int S,
+                                                       float eps, int act, int blocks_per_img) {
+    constexpr int V = 8 / (sizeof(T) / 2);  // f16: 8, f32: 4  (16-byte accesses)
+    extern __shared__ float stat[];         // [G][2] mean, rstd
+    const int n = blockIdx.x / blocks_per_img;
+    const int bi = blockIdx.x - n * blocks_per_img;
+    const int cpg = C / G;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        double s = 0, q = 0;
+        for (int k = 0; k < S; k++) {
+            s += part[(((long)n * G + g) * S + k) * 2 + 0];
+            q += part[(((long)n * G + g) * S + k) * 2 + 1];
+        }
+        double cnt = (double)HW * cpg;
+        double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0) var = 0;
+        stat[g * 2 + 0] = (float)mean;
+        stat[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const long cv = C / V;
+    const long total = HW * cv;
+    const T* xb = x + (long)n * HW * C;
+    T* yb = y + (long)n * HW * C;
+    for (long i = (long)bi * 256 + threadIdx.x; i < total; i += (long)blocks_per_img * 256) {
+        long p = i / cv;
+        int c0 = (int)(i - p * cv) * V;
+        T xv[V], gv[V], bv[V], ov[V];
+        *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(xb + p * C + c0);
+        *reinterpret_cast<uint4*>(gv) = *reinterpret_cast<const uint4*>(gamma + c0);
+        *reinterpret_cast<uint4*>(bv) = *reinterpret_cast<const uint4*>(beta + c0);
+#pragma unroll
+        for (int e = 0; e < V; e++) {
+            int g = (c0 + e) / cpg;
+            float v = (to_f32<T>(xv[e]) - stat[g * 2]) * stat[g * 2 + 1];
+            v = v * to_f32<T>(gv[e]) + to_f32<T>(bv[e]);
+            ov[e] = from_f32<T>(osg_apply_act(v, act));
+        }
+        *reinterpret_cast<uint4*>(yb + p * C + c0) = *reinterpret_cast<uint4*>(ov);
+    }
+}
+
+// ---- LayerNorm over the last axis: one wave per row, row cached in registers (C <= 64*8*MAXV) --------------------
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layer_norm_kernel(const T* __restrict__ x, const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                         T* __restrict__ y, long rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + row * C;
+    float v[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        int c = (j * 64 + lane) * 8;
+        if (c < C) {
+            f16x8 t = *reinterpret_cast<const f16x8*>(xr + c);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { v[j][e] = (float)t[e]; s += v[j][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[j][e] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        int c = (j * 64 + lane) * 8;
+        if (c < C) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) { float d = v[j][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        int c = (j * 64 + lane) * 8;
+        if (c < C) {
+            f16x8 g = *reinterpret_cast<const f16x8*>(gamma + c);
+            f16x8 b = *reinterpret_cast<const f16x8*>(beta + c);
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = (f16)((v[j][e] - mean) * rstd * (float)g[e] + (float)b[e]);
+            *reinterpret_cast<f16x8*>(y + row * C + c) = o;
+        }
+    }
+}
+
+// generic (any C / dtype): one block per row
+template <typename T>
+__global__ __launch_bounds__(256) void layer_norm_generic_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
+                                                                 const T* __restrict__ beta, T* __restrict__ y, int C, float eps) {
+    __shared__ float red[8];
+    const long row = blockIdx.x;
+    const T* xr = x + row * C;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < C; i += 256) s += to_f32<T>(xr[i]);
+    const float mean = block_sum(s, red) / (float)C;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < C; i += 256) { float d = to_f32<T>(xr[i]) - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(block_sum(q, red) / (float)C + eps);
+    for (int i = threadIdx.x; i < C; i += 256)
+        y[row * C + i] = from_f32<T>((to_f32<T>(xr[i]) - mean) * rstd * to_f32<T>(gamma[i]) + to_f32<T>(beta[i]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_mean_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, long C) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + row * C;
+    float s = 0.f;
+    for (long i = lane; i < C; i += 64) s += to_f32<T>(xr[i]);
+    s = wave_sum(s);
+    if (lane == 0) y[row] = from_f32<T>(s / (float)C);
+}
+
+// Softmax over the last axis; restates XNNPACK's three passes (rmax / raddstoreexpminusmax / vmulc):
+// e = exp(x-max) stored in T, sum from the un-rounded e, out = T(e) * T(1/sum).
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_kernel(const T* __restrict__ x, T* __restrict__ y, long C) {
+    __shared__ float red[8];
+    const long row = blockIdx.x;
+    const T* xr = x + row * C;
+    T* yr = y + row * C;
+    float mx = -INFINITY;
+    for (long i = threadIdx.x; i < C; i += 256) mx = fmaxf(mx, to_f32<T>(xr[i]));
+    mx = block_max(mx, red);
+    float s = 0.f;
+    for (long i = threadIdx.x; i < C; i += 256) s += expf(to_f32<T>(xr[i]) - mx);
+    s = block_sum(s, red);
+    const float rinv = to_f32<T>(from_f32<T>(1.0f / s));
+    for (long i = threadIdx.x; i < C; i += 256) {
+        float e = to_f32<T>(from_f32<T>(expf(to_f32<T>(xr[i]) - mx)));
+        yr[i] = from_f32<T>(e * rinv);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int osg_instance_norm(osg_ctx* ctx, osg_dtype dtype, const void* x, const float* scale, const float* bias, void* y, int rows, long L,
+                      int n_scale, float eps) {
+    if (rows <= 0 || L <= 0) return 0;
+    if (n_scale <= 0) n_scale = 1;
+    int threads = L >= 8192 ? 1024 : 256;
+    if (dtype == OSG_F16)
+        hipLaunchKernelGGL(instance_norm_kernel<f16>, dim3(rows), dim3(threads), 0, ctx->compute, (const f16*)x, scale, bias, (f16*)y, L,
+                           n_scale, eps);
+    else if (dtype == OSG_F32)
+        hipLaunchKernelGGL(instance_norm_kernel<float>, dim3(rows), dim3(threads), 0, ctx->compute, (const float*)x, scale, bias,
+                           (float*)y, L, n_scale, eps);
+    else
+        OSG_FAIL(ctx, "osg_instance_norm: unsupported dtype");
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int osg_group_norm_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* gamma, const void* beta, void* y, int N, long HW,
+                        int C, int G, float eps, osg_act act) {
+    if (N <= 0 || HW <= 0 || C <= 0) return 0;
+    if (G <= 0 || C % G) OSG_FAIL(ctx, "osg_group_norm_nhwc: C must be a multiple of groups");
+    const int V = dtype == OSG_F16 ? 8 : 4;
+    if (dtype != OSG_F16 && dtype != OSG_F32) OSG_FAIL(ctx, "osg_group_norm_nhwc: unsupported dtype");
+    if (C % V) OSG_FAIL(ctx, "osg_group_norm_nhwc: C must be a multiple of the 16-byte vector width");
+    long per_group = HW * (C / G);
+    int S = (int)((per_group + 8191) / 8192);
+    if (S < 1) S = 1;
+    if (S > 64) S = 64;
+    if ((long)S > HW) S = (int)HW;
+    size_t need = (size_t)N * G * S * 2 * sizeof(float);
+    if (osg_ensure_workspace(ctx, need)) return 1;
+    float* part = (float*)ctx->ws;
+    long total_v = HW * (C / V);
+    int bpi = (int)((total_v + 256 * 4 - 1) / (256 * 4));
+    if (bpi < 1) bpi = 1;
+    if (bpi > 1024) bpi = 1024;
+    if (dtype == OSG_F16) {
+        hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(N * G, S), dim3(256), 0, ctx->compute, (const f16*)x, part, HW, C, G, S);
+        OSG_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(N * bpi), dim3(256), G * 2 * sizeof(float), ctx->compute, (const f16*)x, part,
+                           (const f16*)gamma, (const f16*)beta, (f16*)y, HW, C, G, S, eps, (int)act, bpi);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(N * G, S), dim3(256), 0, ctx->compute, (const float*)x, part, HW, C, G, S);
+        OSG_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(N * bpi), dim3(256), G * 2 * sizeof(float), ctx->compute, (const float*)x, part,
+                           (const float*)gamma, (const float*)beta, (float*)y, HW, C, G, S, eps, (int)act, bpi);
+    }
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int osg_layer_norm(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* gamma, const void* beta, void* y, long rows, int C,
+                   float eps) {
+    if (rows <= 0 || C <= 0) return 0;
+    if (dtype == OSG_F16 && C % 8 == 0 && C <= 64 * 8 * 4) {
+        dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+        int nv = (C + 511) / 512;
+#define OSG_LN(NV) hipLaunchKernelGGL((layer_norm_kernel<f16, NV>), grid, block, 0, ctx->compute, (const f16*)x, (const f16*)gamma, \
+                                      (const f16*)beta, (f16*)y, rows, C, eps)
+        if (nv == 1) OSG_LN(1);
+        else if (nv == 2) OSG_LN(2);
+        else if (nv == 3) OSG_LN(3);
+        else OSG_LN(4);
+#undef OSG_LN
+    } else if (dtype == OSG_F16) {
+        hipLaunchKernelGGL(layer_norm_generic_kernel<f16>, dim3((unsigned)rows), dim3(256), 0, ctx->compute, (const f16*)x,
+                           (const f16*)gamma, (const f16*)beta, (f16*)y, C, eps);
+    } else if (dtype == OSG_F32) {
+        hipLaunchKernelGGL(layer_norm_generic_kernel<float>, dim3((unsigned)rows), dim3(256), 0, ctx->compute, (const float*)x,
+                           (const float*)gamma, (const float*)beta, (float*)y, C, eps);
+    } else
+        OSG_FAIL(ctx, "osg_layer_norm: unsupported dtype");
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int osg_reduce_mean_last(osg_ctx* ctx, osg_dtype dtype, const void* x, void* y, long rows, long C) {
+    if (rows <= 0 || C <= 0) return 0;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (dtype == OSG_F16)
+        hipLaunchKernelGGL(reduce_mean_kernel<f16>, grid, block, 0, ctx->compute, (const f16*)x, (f16*)y, rows, C);
+    else if (dtype == OSG_F32)
+        hipLaunchKernelGGL(reduce_mean_kernel<float>, grid, block, 0, ctx->compute, (const float*)x, (float*)y, rows, C);
+    else
+        OSG_FAIL(ctx, "osg_reduce_mean_last: unsupported dtype");
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int osg_softmax_last(osg_ctx* ctx, osg_dtype dtype, const void* x, void* y, long rows, long C) {
+    if (rows <= 0 || C <= 0) return 0;
+    if (dtype == OSG_F16)
+        hipLaunchKernelGGL(softmax_kernel<f16>, dim3((unsigned)rows), dim3(256), 0, ctx->compute, (const f16*)x, (f16*)y, C);
+    else if (dtype == OSG_F32)
+        hipLaunchKernelGGL(softmax_kernel<float>, dim3((unsigned)rows), dim3(256), 0, ctx->compute, (const float*)x, (float*)y, C);
+    else
+        OSG_FAIL(ctx, "osg_softmax_last: unsupported dtype");
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,315 @@
+"""ctypes binding over the C ABI of ``libosgpu.so`` (include/osgpu.h) -- one method per exported entry point.
+
+Only plumbing lives here: numpy <-> device buffers and argument marshalling.  There is deliberately NO CPU fallback:
+if the HIP library is missing or no GPU is visible, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libosgpu.so")
+
+U8, F16, F32, I64 = 1, 2, 3, 4
+_NP2DT = {np.dtype(np.uint8): U8, np.dtype(np.float16): F16, np.dtype(np.float32): F32, np.dtype(np.int64): I64}
+ACT_NONE, ACT_SILU, ACT_SIGMOID = 0, 1, 2
+UN = dict(sigmoid=0, erf=1, sqrt=2, sin=3, cos=4, neg=5, pow=6, silu=7, gelu_erf=8)
+BIN = dict(add=0, sub=1, mul=2, div=3)
+
+EXPORTS = [
+    "osg_device_count", "osg_init", "osg_destroy", "osg_last_error", "osg_device_name", "osg_stream",
+    "osg_malloc", "osg_free", "osg_upload", "osg_upload_sync", "osg_download", "osg_copy", "osg_memset", "osg_sync",
+    "osg_graph_begin", "osg_graph_end", "osg_graph_launch", "osg_graph_destroy", "osg_timer_start", "osg_timer_stop",
+    "osg_conv2d_nhwc", "osg_gemm", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided",
+    "osg_instance_norm", "osg_group_norm_nhwc", "osg_layer_norm", "osg_reduce_mean_last", "osg_softmax_last",
+    "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_resize_nearest", "osg_gather_rows",
+    "osg_maxpool_nhwc", "osg_convert",
+]
+
+
+class OsgError(RuntimeError):
+    pass
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise OsgError(f"{path} not found: build it with `python -m onnxstream_amd.build` (hipcc, gfx950)")
+    lib = ctypes.CDLL(path)
+    vp, ci, cl, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+    lib.osg_init.argtypes = [ci, ctypes.POINTER(vp)]
+    lib.osg_destroy.argtypes = [vp]
+    lib.osg_destroy.restype = None
+    lib.osg_last_error.argtypes = [vp]
+    lib.osg_last_error.restype = ctypes.c_char_p
+    lib.osg_device_name.argtypes = [vp]
+    lib.osg_device_name.restype = ctypes.c_char_p
+    lib.osg_stream.argtypes = [vp]
+    lib.osg_stream.restype = vp
+    lib.osg_malloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+    lib.osg_free.argtypes = [vp, vp]
+    for f in ("osg_upload", "osg_upload_sync", "osg_download", "osg_copy"):
+        getattr(lib, f).argtypes = [vp, vp, vp, ctypes.c_size_t]
+    lib.osg_memset.argtypes = [vp, vp, ci, ctypes.c_size_t]
+    lib.osg_sync.argtypes = [vp]
+    lib.osg_graph_begin.argtypes = [vp]
+    lib.osg_graph_end.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.osg_graph_launch.argtypes = [vp, vp]
+    lib.osg_graph_destroy.argtypes = [vp]
+    lib.osg_graph_destroy.restype = None
+    lib.osg_timer_start.argtypes = [vp]
+    lib.osg_timer_stop.argtypes = [vp, ctypes.POINTER(cf)]
+    lib.osg_conv2d_nhwc.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp] + [ci] * 14
+    lib.osg_gemm.argtypes = [vp, ci, vp, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, cl, cl, cl, ci]
+    lib.osg_transpose_kn_to_nk.argtypes = [vp, ci, vp, vp, ci, ci]
+    lib.osg_attention.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, cf, ci]
+    lib.osg_attention_strided.argtypes = [vp, ci, vp, cl, cl, cl, vp, cl, cl, cl, vp, cl, cl, cl, vp, cl, cl, cl, ci, ci, ci, ci,
+                                          ci, cf]
+    lib.osg_instance_norm.argtypes = [vp, ci, vp, vp, vp, vp, ci, cl, ci, cf]
+    lib.osg_group_norm_nhwc.argtypes = [vp, ci, vp, vp, vp, vp, ci, cl, ci, ci, cf, ci]
+    lib.osg_layer_norm.argtypes = [vp, ci, vp, vp, vp, vp, cl, ci, cf]
+    lib.osg_reduce_mean_last.argtypes = [vp, ci, vp, vp, cl, cl]
+    lib.osg_softmax_last.argtypes = [vp, ci, vp, vp, cl, cl]
+    lib.osg_unary.argtypes = [vp, ci, ci, vp, vp, cl, cf]
+    lib.osg_binary.argtypes = [vp, ci, ci, vp, ctypes.POINTER(cl), vp, ctypes.POINTER(cl), vp, ci]
+    lib.osg_geglu.argtypes = [vp, ci, vp, vp, cl, cl]
+    lib.osg_transpose.argtypes = [vp, ci, vp, vp, ci, ctypes.POINTER(cl), ctypes.POINTER(ci)]
+    lib.osg_copy_2d.argtypes = [vp, ci, vp, cl, cl, vp, cl, cl, cl, cl]
+    lib.osg_resize_nearest.argtypes = [vp, ci, vp, vp] + [ci] * 7
+    lib.osg_gather_rows.argtypes = [vp, ci, vp, vp, vp, cl, cl, cl]
+    lib.osg_maxpool_nhwc.argtypes = [vp, ci, vp, vp] + [ci] * 12
+    lib.osg_convert.argtypes = [vp, ci, ci, vp, vp, cl, cf, ci]
+    return lib
+
+
+class DevBuf:
+    """A device allocation with numpy-side shape/dtype metadata."""
+
+    def __init__(self, gpu: "Gpu", shape, dtype):
+        self.gpu = gpu
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = ctypes.c_void_p()
+        gpu._ck(gpu.lib.osg_malloc(gpu.ctx, max(self.nbytes, 16), ctypes.byref(p)))
+        self.ptr = p.value
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, self.dtype)
+        if self.nbytes:
+            self.gpu._ck(self.gpu.lib.osg_download(self.gpu.ctx, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.gpu.lib.osg_free(self.gpu.ctx, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Gpu:
+    def __init__(self, device: int = 0, lib_path: str = LIB_PATH):
+        self.lib = load_library(lib_path)
+        if self.lib.osg_device_count() <= 0:
+            raise OsgError("no HIP device visible: the osgpu backend has no CPU fallback")
+        c = ctypes.c_void_p()
+        rc = self.lib.osg_init(device, ctypes.byref(c))
+        if rc:
+            raise OsgError(f"osg_init failed with code {rc}")
+        self.ctx = c
+
+    def close(self):
+        if self.ctx:
+            self.lib.osg_destroy(self.ctx)
+            self.ctx = None
+
+    def _ck(self, rc):
+        if rc:
+            raise OsgError(self.lib.osg_last_error(self.ctx).decode())
+
+    @property
+    def name(self):
+        return self.lib.osg_device_name(self.ctx).decode()
+
+    # ---- memory ----
+    def empty(self, shape, dtype=np.float16) -> DevBuf:
+        return DevBuf(self, shape, dtype)
+
+    def to_dev(self, arr: np.ndarray, staged: bool = False) -> DevBuf:
+        arr = np.ascontiguousarray(arr)
+        b = DevBuf(self, arr.shape, arr.dtype)
+        if arr.nbytes:
+            fn = self.lib.osg_upload if staged else self.lib.osg_upload_sync
+            self._ck(fn(self.ctx, b.ptr, arr.ctypes.data, arr.nbytes))
+        return b
+
+    def sync(self):
+        self._ck(self.lib.osg_sync(self.ctx))
+
+    def timer_start(self):
+        self._ck(self.lib.osg_timer_start(self.ctx))
+
+    def timer_stop(self) -> float:
+        ms = ctypes.c_float()
+        self._ck(self.lib.osg_timer_stop(self.ctx, ctypes.byref(ms)))
+        return ms.value
+
+    # ---- compute ----
+    @staticmethod
+    def _p(b: Optional[DevBuf]):
+        return b.ptr if b is not None else None
+
+    def conv2d_nhwc(self, x: DevBuf, w: DevBuf, bias: Optional[DevBuf], stride=1, pads=(1, 1, 1, 1), residual=None, act=ACT_NONE):
+        n, h, wd, cin = x.shape
+        cout, kh, kw, cin2 = w.shape
+        assert cin == cin2
+        sh, sw = (stride, stride) if isinstance(stride, int) else stride
+        pt, pl, pb, pr = pads
+        ho, wo = (h + pt + pb - kh) // sh + 1, (wd + pl + pr - kw) // sw + 1
+        y = self.empty((n, ho, wo, cout), x.dtype)
+        bdt = _NP2DT[bias.dtype] if bias is not None else F16
+        self._ck(self.lib.osg_conv2d_nhwc(self.ctx, _NP2DT[x.dtype], x.ptr, w.ptr, self._p(bias), bdt, self._p(residual), y.ptr, n, h,
+                                          wd, cin, cout, kh, kw, sh, sw, pt, pl, pb, pr, act))
+        return y
+
+    def gemm(self, a: DevBuf, b: DevBuf, bias=None, residual=None, b_is_nk=False, act=ACT_NONE):
+        """a:[(batch,)M,K]; b:[(batch,)K,N] (or [(batch,)N,K] when b_is_nk)."""
+        batch = a.shape[0] if len(a.shape) == 3 else 1
+        m, k = a.shape[-2:]
+        n = b.shape[-2] if b_is_nk else b.shape[-1]
+        sb = 0 if len(b.shape) == 2 else k * n
+        c = self.empty(a.shape[:-1] + (n,), a.dtype)
+        bdt = _NP2DT[bias.dtype] if bias is not None else F16
+        self._ck(self.lib.osg_gemm(self.ctx, _NP2DT[a.dtype], a.ptr, b.ptr, int(b_is_nk), self._p(bias), bdt, self._p(residual), c.ptr, m,
+                                   n, k, batch, m * k if batch > 1 else 0, sb, m * n if batch > 1 else 0, act))
+        return c
+
+    def transpose_kn_to_nk(self, w: DevBuf):
+        k, n = w.shape
+        o = self.empty((n, k), w.dtype)
+        self._ck(self.lib.osg_transpose_kn_to_nk(self.ctx, _NP2DT[w.dtype], w.ptr, o.ptr, k, n))
+        return o
+
+    def attention(self, q: DevBuf, k: DevBuf, v: DevBuf, scale: float, k_is_dt: bool):
+        heads, tq, d = q.shape
+        tkv = v.shape[1]
+        o = self.empty(q.shape, q.dtype)
+        self._ck(self.lib.osg_attention(self.ctx, _NP2DT[q.dtype], q.ptr, k.ptr, v.ptr, o.ptr, heads, tq, tkv, d, scale, int(k_is_dt)))
+        return o
+
+    def attention_tokens(self, q: DevBuf, k: DevBuf, v: DevBuf, heads: int, scale: float):
+        """q:[B,Tq,heads*D], k,v:[B,Tkv,heads*D] straight out of the projections -> o:[B,Tq,heads*D]."""
+        bsz, tq, c = q.shape
+        tkv = k.shape[1]
+        d = c // heads
+        o = self.empty(q.shape, q.dtype)
+        self._ck(self.lib.osg_attention_strided(self.ctx, F16, q.ptr, c, d, tq * c, k.ptr, c, d, tkv * c, v.ptr, c, d, tkv * c, o.ptr, c, d,
+                                                tq * c, bsz, heads, tq, tkv, d, scale))
+        return o
+
+    def instance_norm(self, x: DevBuf, scale: Optional[DevBuf], bias: Optional[DevBuf], eps: float):
+        rows, L = int(np.prod(x.shape[:-1])), x.shape[-1]
+        y = self.empty(x.shape, x.dtype)
+        ns = scale.size if scale is not None else 1
+        self._ck(self.lib.osg_instance_norm(self.ctx, _NP2DT[x.dtype], x.ptr, self._p(scale), self._p(bias), y.ptr, rows, L, ns, eps))
+        return y
+
+    def group_norm_nhwc(self, x: DevBuf, gamma: DevBuf, beta: DevBuf, groups: int, eps: float, act=ACT_NONE):
+        n, h, w, c = x.shape
+        y = self.empty(x.shape, x.dtype)
+        self._ck(self.lib.osg_group_norm_nhwc(self.ctx, _NP2DT[x.dtype], x.ptr, gamma.ptr, beta.ptr, y.ptr, n, h * w, c, groups, eps, act))
+        return y
+
+    def layer_norm(self, x: DevBuf, gamma: DevBuf, beta: DevBuf, eps: float):
+        rows, c = int(np.prod(x.shape[:-1])), x.shape[-1]
+        y = self.empty(x.shape, x.dtype)
+        self._ck(self.lib.osg_layer_norm(self.ctx, _NP2DT[x.dtype], x.ptr, gamma.ptr, beta.ptr, y.ptr, rows, c, eps))
+        return y
+
+    def reduce_mean_last(self, x: DevBuf):
+        rows, c = int(np.prod(x.shape[:-1])), x.shape[-1]
+        y = self.empty(x.shape[:-1] + (1,), x.dtype)
+        self._ck(self.lib.osg_reduce_mean_last(self.ctx, _NP2DT[x.dtype], x.ptr, y.ptr, rows, c))
+        return y
+
+    def softmax_last(self, x: DevBuf):
+        rows, c = int(np.prod(x.shape[:-1])), x.shape[-1]
+        y = self.empty(x.shape, x.dtype)
+        self._ck(self.lib.osg_softmax_last(self.ctx, _NP2DT[x.dtype], x.ptr, y.ptr, rows, c))
+        return y
+
+    def unary(self, kind: str, x: DevBuf, param: float = 0.0):
+        y = self.empty(x.shape, x.dtype)
+        self._ck(self.lib.osg_unary(self.ctx, _NP2DT[x.dtype], UN[kind], x.ptr, y.ptr, x.size, param))
+        return y
+
+    def binary(self, kind: str, a: DevBuf, b: DevBuf):
+        rank = max(len(a.shape), len(b.shape))
+        ash = (1,) * (rank - len(a.shape)) + a.shape
+        bsh = (1,) * (rank - len(b.shape)) + b.shape
+        osh = tuple(np.broadcast_shapes(ash, bsh))
+        y = self.empty(osh, a.dtype)
+        A = (ctypes.c_long * rank)(*ash)
+        B = (ctypes.c_long * rank)(*bsh)
+        self._ck(self.lib.osg_binary(self.ctx, _NP2DT[a.dtype], BIN[kind], a.ptr, A, b.ptr, B, y.ptr, rank))
+        return y
+
+    def geglu(self, x: DevBuf):
+        rows, c2 = int(np.prod(x.shape[:-1])), x.shape[-1]
+        y = self.empty(x.shape[:-1] + (c2 // 2,), x.dtype)
+        self._ck(self.lib.osg_geglu(self.ctx, _NP2DT[x.dtype], x.ptr, y.ptr, rows, c2 // 2))
+        return y
+
+    def transpose(self, x: DevBuf, perm: Sequence[int]):
+        rank = len(x.shape)
+        y = self.empty(tuple(x.shape[p] for p in perm), x.dtype)
+        S = (ctypes.c_long * rank)(*x.shape)
+        P = (ctypes.c_int * rank)(*perm)
+        self._ck(self.lib.osg_transpose(self.ctx, x.dtype.itemsize, x.ptr, y.ptr, rank, S, P))
+        return y
+
+    def copy_2d(self, src: DevBuf, src_pitch, src_off, dst: DevBuf, dst_pitch, dst_off, outer, inner):
+        self._ck(self.lib.osg_copy_2d(self.ctx, src.dtype.itemsize, src.ptr, src_pitch, src_off, dst.ptr, dst_pitch, dst_off, outer, inner))
+
+    def resize_nearest(self, x: DevBuf, ho: int, wo: int, nhwc: bool):
+        if nhwc:
+            n, h, w, c = x.shape
+            y = self.empty((n, ho, wo, c), x.dtype)
+        else:
+            n, c, h, w = x.shape
+            y = self.empty((n, c, ho, wo), x.dtype)
+        self._ck(self.lib.osg_resize_nearest(self.ctx, x.dtype.itemsize, x.ptr, y.ptr, n, c, h, w, ho, wo, int(nhwc)))
+        return y
+
+    def gather_rows(self, x: DevBuf, idx: DevBuf):
+        n_rows = x.shape[0]
+        row = int(np.prod(x.shape[1:]))
+        y = self.empty((idx.size,) + x.shape[1:], x.dtype)
+        self._ck(self.lib.osg_gather_rows(self.ctx, x.dtype.itemsize, x.ptr, idx.ptr, y.ptr, idx.size, row, n_rows))
+        return y
+
+    def maxpool_nhwc(self, x: DevBuf, k, stride, pads):
+        n, h, w, c = x.shape
+        pt, pl, pb, pr = pads
+        ho, wo = (h + pt + pb - k[0]) // stride[0] + 1, (w + pl + pr - k[1]) // stride[1] + 1
+        y = self.empty((n, ho, wo, c), x.dtype)
+        self._ck(self.lib.osg_maxpool_nhwc(self.ctx, _NP2DT[x.dtype], x.ptr, y.ptr, n, h, w, c, k[0], k[1], stride[0], stride[1], pt, pl,
+                                           pb, pr))
+        return y
+
+    def convert(self, x: DevBuf, dtype, scale: float = 1.0, zero_point: int = 0):
+        y = self.empty(x.shape, dtype)
+        self._ck(self.lib.osg_convert(self.ctx, _NP2DT[x.dtype], _NP2DT[np.dtype(dtype)], x.ptr, y.ptr, x.size, scale, zero_point))
+        return y

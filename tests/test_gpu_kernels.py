@@ -1,0 +1,282 @@
+"""-m gpu: every C-ABI entry point of libosgpu vs the numpy restatement of the reference arithmetic (oracle/np_ops.py).
+
+Tolerances (written per test): integer/byte work bit-exact; f16 outputs within a few f16 ulps of the restatement
+(summation order / polynomial-vs-libm exp), quoted relative to max|reference| as north_star asks (<= 1e-3).
+"""
+import numpy as np
+import pytest
+
+from oracle import np_ops as ref
+
+pytestmark = pytest.mark.gpu
+f16, f32 = np.float16, np.float32
+
+
+def rel_max(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def rnd(rng, shape, std=1.0, dtype=f16):
+    return (rng.standard_normal(shape, dtype=f32) * std).astype(dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (4096, 320, 320), (77, 320, 768), (1, 1280, 320), (256, 1280, 1280),
+                                   (64, 1280, 5120), (130, 72, 40), (33, 7, 36)])
+def test_gemm(gpu, M, N, K):
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    a, b = rnd(rng, (M, K)), rnd(rng, (K, N), K ** -0.5)
+    bias = rnd(rng, (N,), 0.1)
+    res = rnd(rng, (M, N))
+    want = ref.matmul(a, b, bias, res)
+    da, db = gpu.to_dev(a), gpu.to_dev(b)
+    got = gpu.gemm(da, db, gpu.to_dev(bias), gpu.to_dev(res)).numpy()
+    assert rel_max(got, want) <= 1e-3
+    # resident-weight layout [N,K]
+    dbt = gpu.transpose_kn_to_nk(db)
+    assert np.array_equal(dbt.numpy(), b.T)
+    got2 = gpu.gemm(da, dbt, gpu.to_dev(bias.astype(f32)), gpu.to_dev(res), b_is_nk=True).numpy()
+    assert rel_max(got2, want) <= 1e-3
+    # asymmetric-operand transpose check: A = I must reproduce B exactly
+    if M == K:
+        eye = np.eye(M, dtype=f16)
+        assert np.array_equal(gpu.gemm(gpu.to_dev(eye), db).numpy(), b)
+
+
+def test_gemm_batched(gpu):
+    rng = np.random.default_rng(5)
+    a, b = rnd(rng, (8, 256, 160)), rnd(rng, (8, 160, 77), 0.1)
+    want = np.stack([ref.matmul(a[i], b[i]) for i in range(8)])
+    got = gpu.gemm(gpu.to_dev(a), gpu.to_dev(b)).numpy()
+    assert rel_max(got, want) <= 1e-3
+    # shared weight across the batch (the reference's per-op batch loop)
+    w = rnd(rng, (160, 96), 0.1)
+    want = np.stack([ref.matmul(a[i], w) for i in range(8)])
+    assert rel_max(gpu.gemm(gpu.to_dev(a), gpu.to_dev(w)).numpy(), want) <= 1e-3
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,pad", [
+    (1, 16, 16, 32, 64, 3, 1, 1), (2, 64, 64, 320, 320, 3, 1, 1), (1, 64, 64, 4, 320, 3, 1, 1), (1, 64, 64, 320, 4, 3, 1, 1),
+    (1, 32, 32, 640, 640, 3, 2, 1), (1, 8, 8, 1280, 1280, 3, 1, 1), (1, 16, 16, 640, 1280, 1, 1, 0), (1, 9, 7, 24, 40, 3, 2, 1),
+    (2, 8, 8, 2560, 1280, 3, 1, 1)])
+def test_conv2d(gpu, N, H, W, Cin, Cout, k, stride, pad):
+    rng = np.random.default_rng(H * 31 + Cin + Cout)
+    x = rnd(rng, (N, H, W, Cin))
+    w = rnd(rng, (Cout, k, k, Cin), (Cin * k * k) ** -0.5)
+    b = rnd(rng, (Cout,), 0.1)
+    want = ref.conv2d_nhwc(x, w, b, (stride, stride), (pad,) * 4)
+    got = gpu.conv2d_nhwc(gpu.to_dev(x), gpu.to_dev(w), gpu.to_dev(b), stride, (pad,) * 4).numpy()
+    assert got.shape == want.shape
+    assert rel_max(got, want) <= 1e-3
+    res = rnd(rng, want.shape)
+    want2 = ref.conv2d_nhwc(x, w, b.astype(f32), (stride, stride), (pad,) * 4, residual=res)
+    got2 = gpu.conv2d_nhwc(gpu.to_dev(x), gpu.to_dev(w), gpu.to_dev(b.astype(f32)), stride, (pad,) * 4, residual=gpu.to_dev(res)).numpy()
+    assert rel_max(got2, want2) <= 1e-3
+
+
+def test_conv_linearity_full_size(gpu):
+    """Size-independent property at SD1.5 full size: conv(a*x) + conv(b*y) == conv(a*x + b*y) up to f16 rounding."""
+    rng = np.random.default_rng(11)
+    x, y = rnd(rng, (2, 64, 64, 320)), rnd(rng, (2, 64, 64, 320))
+    w = rnd(rng, (320, 3, 3, 320), 2880 ** -0.5)
+    dw = gpu.to_dev(w)
+    cx = gpu.conv2d_nhwc(gpu.to_dev(x), dw, None).numpy().astype(f32)
+    cy = gpu.conv2d_nhwc(gpu.to_dev(y), dw, None).numpy().astype(f32)
+    cxy = gpu.conv2d_nhwc(gpu.to_dev((x.astype(f32) + y.astype(f32)).astype(f16)), dw, None).numpy().astype(f32)
+    assert rel_max(cx + cy, cxy) <= 4e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("heads,Tq,Tkv,D", [(8, 64, 64, 160), (8, 256, 77, 160), (8, 1024, 1024, 80), (4, 2048, 77, 40),
+                                            (2, 4096, 4096, 40), (10, 256, 256, 64), (3, 50, 11, 16), (2, 130, 200, 24)])
+def test_attention(gpu, heads, Tq, Tkv, D):
+    rng = np.random.default_rng(Tq + Tkv + D)
+    q, k, v = rnd(rng, (heads, Tq, D)), rnd(rng, (heads, Tkv, D)), rnd(rng, (heads, Tkv, D))
+    scale = D ** -0.5
+    want = ref.attention_exact(q, k, v, scale)
+    got = gpu.attention(gpu.to_dev(q), gpu.to_dev(k), gpu.to_dev(v), scale, k_is_dt=False).numpy()
+    assert rel_max(got, want) <= 2e-3
+    kdt = np.ascontiguousarray(k.transpose(0, 2, 1))
+    got2 = gpu.attention(gpu.to_dev(q), gpu.to_dev(kdt), gpu.to_dev(v), scale, k_is_dt=True).numpy()
+    assert np.array_equal(got, got2)
+    if Tq * Tkv <= 256 * 256:
+        # the reference's sliced path (f16 scores / probabilities) agrees within its own rounding noise
+        sliced = ref.attention_fused_ops(q, kdt, v, f16(scale), parts=2)
+        assert rel_max(got, sliced) <= 6e-3
+
+
+def test_attention_spike_rows(gpu):
+    """Force the online-softmax rescale branch: one key dominates a late tile for some query rows."""
+    rng = np.random.default_rng(3)
+    heads, T, D = 2, 512, 64
+    q, k, v = rnd(rng, (heads, T, D)), rnd(rng, (heads, T, D)), rnd(rng, (heads, T, D))
+    k[:, 300] = q[:, 7] * 4
+    k[:, 450] = q[:, 100] * 6
+    want = ref.attention_exact(q, k, v, D ** -0.5)
+    got = gpu.attention(gpu.to_dev(q), gpu.to_dev(k), gpu.to_dev(v), D ** -0.5, k_is_dt=False).numpy()
+    assert rel_max(got, want) <= 2e-3
+
+
+def test_attention_token_layout(gpu):
+    rng = np.random.default_rng(4)
+    B, heads, Tq, Tkv, D = 2, 8, 256, 77, 40
+    q, k, v = rnd(rng, (B, Tq, heads * D)), rnd(rng, (B, Tkv, heads * D)), rnd(rng, (B, Tkv, heads * D))
+    got = gpu.attention_tokens(gpu.to_dev(q), gpu.to_dev(k), gpu.to_dev(v), heads, D ** -0.5).numpy()
+    sp = lambda t, T: t.reshape(B, T, heads, D).transpose(0, 2, 1, 3).reshape(B * heads, T, D)
+    want = ref.attention_exact(sp(q, Tq), sp(k, Tkv), sp(v, Tkv), D ** -0.5)
+    want = want.reshape(B, heads, Tq, D).transpose(0, 2, 1, 3).reshape(B, Tq, heads * D)
+    assert rel_max(got, want) <= 2e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,L", [(32, 40960), (32, 5120), (64, 640), (3, 17)])
+def test_instance_norm(gpu, rows, L):
+    rng = np.random.default_rng(rows + L)
+    x = rnd(rng, (1, rows, L), 2.0) + f16(0.5)
+    sc, bi = rnd(rng, (rows,), 1.0, f32), rnd(rng, (rows,), 1.0, f32)
+    want = ref.instance_norm(x, sc, bi, 1e-5)
+    got = gpu.instance_norm(gpu.to_dev(x), gpu.to_dev(sc), gpu.to_dev(bi), 1e-5).numpy()
+    assert rel_max(got, want) <= 1e-3
+
+
+@pytest.mark.parametrize("N,H,W,C,act", [(2, 64, 64, 320, 1), (1, 8, 8, 2560, 0), (2, 16, 16, 1280, 1), (1, 5, 3, 64, 0)])
+def test_group_norm_nhwc(gpu, N, H, W, C, act):
+    rng = np.random.default_rng(C + H)
+    x = rnd(rng, (N, H, W, C), 1.5) + f16(0.3)
+    g, b = (1 + rnd(rng, (C,), 0.1).astype(f32)).astype(f16), rnd(rng, (C,), 0.1)
+    want = ref.group_norm_nhwc_exact(x, g, b, 32, 1e-5, bool(act))
+    got = gpu.group_norm_nhwc(gpu.to_dev(x), gpu.to_dev(g), gpu.to_dev(b), 32, 1e-5, act).numpy()
+    assert rel_max(got, want) <= 1e-3
+    if N == 1 and not act:
+        # the decomposed reference chain (Reshape/InstanceNorm/Reshape/Mul/Add on NCHW) agrees within its extra roundings
+        dec = ref.group_norm_decomposed_nchw(x.transpose(0, 3, 1, 2), g, b, 32, 1e-5).transpose(0, 2, 3, 1)
+        assert rel_max(got, dec) <= 2e-3
+
+
+@pytest.mark.parametrize("rows,C", [(4096, 320), (1024, 640), (256, 1280), (7, 48), (5, 30)])
+def test_layer_norm(gpu, rows, C):
+    rng = np.random.default_rng(rows + C)
+    x = rnd(rng, (1, rows, C), 1.5) + f16(0.2)
+    g, b = (1 + rnd(rng, (C,), 0.1).astype(f32)).astype(f16), rnd(rng, (C,), 0.1)
+    got = gpu.layer_norm(gpu.to_dev(x), gpu.to_dev(g), gpu.to_dev(b), 1e-5).numpy()
+    assert rel_max(got, ref.layer_norm_exact(x, g, b, 1e-5)) <= 1e-3
+    assert rel_max(got, ref.layer_norm_decomposed(x, g, b, 1e-5)) <= 4e-3
+
+
+def test_reduce_mean_softmax(gpu):
+    rng = np.random.default_rng(9)
+    x = rnd(rng, (3, 77, 333), 2.0)
+    assert rel_max(gpu.reduce_mean_last(gpu.to_dev(x)).numpy(), ref.reduce_mean_last(x)) <= 1e-3
+    want = ref.softmax_last(x)
+    got = gpu.softmax_last(gpu.to_dev(x)).numpy()
+    assert rel_max(got, want) <= 2e-3
+    xl = rnd(rng, (16, 4096), 3.0)
+    assert rel_max(gpu.softmax_last(gpu.to_dev(xl)).numpy(), ref.softmax_last(xl)) <= 2e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["sigmoid", "erf", "sqrt", "sin", "cos", "neg", "pow", "silu", "gelu_erf"])
+def test_unary(gpu, kind):
+    rng = np.random.default_rng(1)
+    x = rnd(rng, (1000, 37), 3.0)
+    if kind == "sqrt":
+        x = np.abs(x)
+    got = gpu.unary(kind, gpu.to_dev(x), 2.0).numpy()
+    want = ref.unary(kind, x, 2.0)
+    if kind == "neg":
+        assert np.array_equal(got, want)
+    else:
+        # <= 1 f16 ulp of the correctly rounded value
+        assert np.abs(got.astype(f32) - want.astype(f32)).max() <= np.abs(want.astype(f32)).max() * 1e-3
+
+
+@pytest.mark.parametrize("kind", ["add", "sub", "mul", "div"])
+@pytest.mark.parametrize("ash,bsh", [((1, 4096, 320), (1, 4096, 320)), ((1, 4096, 320), (320,)), ((1, 320, 64, 64), (320, 1, 1)),
+                                     ((1, 64, 64, 320), (1, 1, 1, 320)), ((2, 77, 5), ()), ((1, 1280, 1, 1), (1, 1280, 8, 8)),
+                                     ((3, 1, 5), (1, 4, 1)), ((7,), (7,))])
+def test_binary(gpu, kind, ash, bsh):
+    rng = np.random.default_rng(len(ash) * 10 + len(bsh))
+    a, b = rnd(rng, ash, 2.0), rnd(rng, bsh, 2.0)
+    if kind == "div":
+        b = (np.abs(b.astype(f32)) + 0.5).astype(f16)
+    got = gpu.binary(kind, gpu.to_dev(a), gpu.to_dev(b)).numpy()
+    want = ref.binary(kind, a, b)
+    assert got.shape == want.shape
+    # f32 math + one rounding on both sides: bit-exact except f32->f16 double rounding in div
+    assert np.array_equal(got, want) or (kind == "div" and rel_max(got, want) <= 1e-3)
+
+
+def test_geglu(gpu):
+    rng = np.random.default_rng(2)
+    x = rnd(rng, (1, 256, 2 * 1280), 1.5)
+    want = ref.r16(x[..., :1280].astype(f32) * ref.unary("gelu_erf", x[..., 1280:]).astype(f32))
+    assert rel_max(gpu.geglu(gpu.to_dev(x)).numpy(), want) <= 2e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,perm", [((1, 320, 64, 64), (0, 2, 3, 1)), ((1, 64, 64, 320), (0, 3, 1, 2)), ((1, 4096, 8, 40), (0, 2, 1, 3)),
+                                        ((8, 77, 160), (0, 2, 1)), ((2, 3, 4, 5, 6), (4, 0, 3, 1, 2)), ((5, 1, 7), (2, 1, 0)), ((6, 9), (1, 0)),
+                                        ((3, 4, 5), (0, 1, 2))])
+@pytest.mark.parametrize("dtype", [np.uint8, np.float16, np.float32])
+def test_transpose(gpu, shape, perm, dtype):
+    rng = np.random.default_rng(sum(shape))
+    x = rng.integers(0, 255, size=shape).astype(dtype)
+    assert np.array_equal(gpu.transpose(gpu.to_dev(x), perm).numpy(), x.transpose(perm))
+
+
+def test_copy2d_concat_slice(gpu):
+    rng = np.random.default_rng(8)
+    a, b = rnd(rng, (4096, 320)), rnd(rng, (4096, 640))
+    out = gpu.empty((4096, 960), f16)
+    gpu.copy_2d(gpu.to_dev(a), 320, 0, out, 960, 0, 4096, 320)
+    gpu.copy_2d(gpu.to_dev(b), 640, 0, out, 960, 320, 4096, 640)
+    assert np.array_equal(out.numpy(), np.concatenate([a, b], 1))
+    sl = gpu.empty((4096, 100), f16)
+    gpu.copy_2d(out, 960, 33, sl, 100, 0, 4096, 100)
+    assert np.array_equal(sl.numpy(), out.numpy()[:, 33:133])
+
+
+@pytest.mark.parametrize("nhwc", [True, False])
+def test_resize_nearest(gpu, nhwc):
+    rng = np.random.default_rng(6)
+    x = rnd(rng, (1, 16, 16, 64) if nhwc else (1, 64, 16, 16))
+    got = gpu.resize_nearest(gpu.to_dev(x), 32, 32, nhwc).numpy()
+    want = x.repeat(2, axis=1 if nhwc else 2).repeat(2, axis=2 if nhwc else 3)
+    assert np.array_equal(got, want)
+
+
+def test_gather_maxpool(gpu):
+    rng = np.random.default_rng(7)
+    x = rnd(rng, (100, 33))
+    idx = np.array([5, 99, 0, -1, 42], np.int64)
+    assert np.array_equal(gpu.gather_rows(gpu.to_dev(x), gpu.to_dev(idx)).numpy(), x[idx])
+    img = rnd(rng, (1, 20, 20, 128))
+    got = gpu.maxpool_nhwc(gpu.to_dev(img), (5, 5), (1, 1), (2, 2, 2, 2)).numpy()
+    pad = np.full((1, 24, 24, 128), -np.inf, f32)
+    pad[:, 2:22, 2:22] = img
+    want = np.max([pad[:, i:i + 20, j:j + 20] for i in range(5) for j in range(5)], axis=0).astype(f16)
+    assert np.array_equal(got, want)
+
+
+def test_convert_quant_bit_exact(gpu):
+    """Integer path: u8 codes and dequantised values must be BIT-EXACT (SURVEY A13 formulas)."""
+    rng = np.random.default_rng(10)
+    x = (rng.standard_normal(1 << 20, dtype=f32) * 3).astype(f32)
+    scale, zp = ref.range_to_scale(float(x.min()) * 0.7, float(x.max()) * 0.7)
+    q = gpu.convert(gpu.to_dev(x), np.uint8, scale, zp).numpy()
+    assert np.array_equal(q, ref.quantize_u8(x, scale, zp))
+    dq = gpu.convert(gpu.to_dev(q), np.float32, scale, zp).numpy()
+    assert np.array_equal(dq, ref.dequantize_u8(q, scale, zp))
+    dq16 = gpu.convert(gpu.to_dev(q), np.float16, scale, zp).numpy()
+    assert np.array_equal(dq16, ref.dequantize_u8(q, scale, zp, f16))
+    h = x.astype(f16)
+    assert np.array_equal(gpu.convert(gpu.to_dev(h), np.float32).numpy(), h.astype(f32))
+    assert np.array_equal(gpu.convert(gpu.to_dev(x), np.float16).numpy(), h)
+
+
+def test_upload_staged_roundtrip(gpu):
+    rng = np.random.default_rng(12)
+    x = rng.integers(0, 255, size=(150 << 20) + 13, dtype=np.uint8)   # > 2 staging chunks, ragged tail
+    d = gpu.to_dev(x, staged=True)
+    assert np.array_equal(d.numpy(), x)
