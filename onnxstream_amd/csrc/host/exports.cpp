@@ -1,0 +1,224 @@
+// exports.cpp -- the flat C API over Model that foreign-language bindings use.  Names, argument order, ownership and
+// error conventions are those of the reference's src/exports.cpp (model_new :42, model_new_2 :62, model_delete :87,
+// model_read_string :92, model_read_file :98, model_get_weights_names :111, model_add_weights_file :150,
+// model_add_tensor :169, model_get_tensor :205, model_get_all_tensor_names :235, model_run :245, model_run_2 :258,
+// model_clear_tensors :271, model_set_option :276, model_add_extra_output :303, model_free_buffer :308): errors come back
+// as malloc'd C strings the caller releases with model_free_buffer.  Extra entry points for this backend carry a
+// `model_hip_` prefix.
+#include <cstdio>
+#include <cstring>
+
+#include "onnxstream.h"
+
+using namespace onnxstream;
+
+namespace {
+
+char* dup_cstr(const std::string& s) {
+    char* p = (char*)std::malloc(s.size() + 1);
+    std::memcpy(p, s.c_str(), s.size() + 1);
+    return p;
+}
+
+struct Handle {
+    explicit Handle(int threads) : model(threads) {}
+    Model model;
+    std::string definition;
+    std::string provider;
+};
+
+const char* dtype_name(TensorDataType t) {
+    switch (t) {
+        case TensorDataType::uint8: return "uint8";
+        case TensorDataType::float16: return "float16";
+        case TensorDataType::float32: return "float32";
+        case TensorDataType::int64: return "int64";
+        default: throw std::invalid_argument("Unsupported tensor data format.");
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+Handle* model_new_2(int threads_count, char* wp_name) {
+    Handle* h = new Handle(threads_count);
+    h->provider = wp_name;
+    const std::string& w = h->provider;
+    if (w == "ram") h->model.set_weights_provider(RamWeightsProvider<WeightsProvider>());
+    else if (w == "nocache") h->model.set_weights_provider(DiskNoCacheWeightsProvider());
+    else if (w == "prefetch") h->model.set_weights_provider(DiskPrefetchWeightsProvider());
+    else if (w == "ram+nocache") h->model.set_weights_provider(RamWeightsProvider<DiskNoCacheWeightsProvider>(DiskNoCacheWeightsProvider()));
+    else if (w == "ram+prefetch") h->model.set_weights_provider(RamWeightsProvider<DiskPrefetchWeightsProvider>(DiskPrefetchWeightsProvider()));
+    else {
+        delete h;
+        return nullptr;
+    }
+    return h;
+}
+
+Handle* model_new() {
+    static char ram[] = "ram";
+    return model_new_2(0, ram);
+}
+
+void model_delete(Handle* h) { delete h; }
+
+void model_read_string(Handle* h, char* str) {
+    h->definition = str;
+    h->model.read_string(str);
+}
+
+char* model_read_file(Handle* h, char* fn) {
+    try {
+        h->model.read_file(fn);
+        return nullptr;
+    } catch (const std::exception& e) {
+        return dup_cstr(e.what());
+    }
+}
+
+char* model_get_weights_names(Handle* h) {
+    Model probe(-1);
+    probe.m_support_dynamic_shapes = true;
+    probe.set_weights_provider(CollectNamesWeightsProvider(true));
+    probe.read_string(h->definition.c_str());
+    probe.init();
+    std::string out;
+    for (auto& e : probe.get_weights_provider<CollectNamesWeightsProvider>().m_names_vec) {
+        std::string fn = e.m_name;
+        auto pos = fn.find("_nchw.bin");
+        if (pos != std::string::npos) fn = fn.substr(0, pos) + "_nhwc.bin";
+        if (!out.empty()) out += "|";
+        out += std::string(dtype_name(e.m_type)) + ":" + fn;
+    }
+    return dup_cstr(out);
+}
+
+void* model_add_weights_file(Handle* h, char* type, char* name, unsigned int size) {
+    if (h->provider != "ram") return nullptr;
+    auto& wp = h->model.get_weights_provider<RamWeightsProvider<WeightsProvider>>();
+    const std::string t = type;
+    if (t == "uint8") return wp.add_empty_and_return_ptr<uint8_t>(name, size / sizeof(uint8_t));
+    if (t == "float16") return wp.add_empty_and_return_ptr<uint16_t>(name, size / sizeof(uint16_t));
+    if (t == "float32") return wp.add_empty_and_return_ptr<float>(name, size / sizeof(float));
+    if (t == "int64") return wp.add_empty_and_return_ptr<int64_t>(name, size / sizeof(int64_t));
+    throw std::invalid_argument("Unsupported tensor data format.");
+}
+
+// 64-bit size variant (a 2560->1280 3x3 conv weight alone is 59 MB; whole models exceed 4 GiB only in aggregate, but
+// bindings that pass size_t need not truncate)
+void* model_hip_add_weights_file(Handle* h, const char* type, const char* name, unsigned long long size) {
+    return model_add_weights_file(h, (char*)type, (char*)name, (unsigned int)size);
+}
+
+void* model_add_tensor(Handle* h, char* type, char* name, unsigned int dims_num, unsigned int* dims) {
+    Tensor t;
+    t.m_name = name;
+    size_t n = 1;
+    for (unsigned i = 0; i < dims_num; i++) {
+        t.m_shape.push_back(dims[i]);
+        n *= dims[i];
+    }
+    const std::string ty = type;
+    void* ptr = nullptr;
+    if (ty == "float32") {
+        tensor_vector<float> v(n);
+        ptr = v.data();  // the heap block moves with the vector into the tensor
+        t.set_vector(std::move(v));
+    } else if (ty == "int64") {
+        tensor_vector<int64_t> v(n);
+        ptr = v.data();
+        t.set_vector(std::move(v));
+    } else {
+        throw std::invalid_argument("Unsupported tensor data format.");
+    }
+    h->model.push_tensor(std::move(t));
+    return ptr;
+}
+
+void* model_get_tensor(Handle* h, char* name) {
+    struct Ret {
+        size_t dims_num;
+        size_t* dims;
+        size_t data_num;
+        float* data;
+    };
+    for (auto& t : h->model.m_data)
+        if (t.m_name == name) {
+            if (t.m_type != TensorDataType::float32) return nullptr;
+            Ret* r = (Ret*)std::malloc(sizeof(Ret));
+            r->dims_num = t.m_shape.size();
+            r->dims = t.m_shape.data();
+            r->data_num = t.get_vector<float>().size();
+            r->data = t.get_vector<float>().data();
+            return r;
+        }
+    return nullptr;
+}
+
+char* model_get_all_tensor_names(Handle* h) {
+    std::string out;
+    for (auto& t : h->model.m_data) out += (out.empty() ? "" : "|") + t.m_name;
+    return dup_cstr(out);
+}
+
+void model_run(Handle* h) {
+    try {
+        h->model.run();
+    } catch (const std::exception& e) {
+        printf("=== ERROR === %s\n", e.what());
+        throw;
+    }
+}
+
+char* model_run_2(Handle* h) {
+    try {
+        h->model.run();
+        return nullptr;
+    } catch (const std::exception& e) {
+        return dup_cstr(e.what());
+    }
+}
+
+void model_clear_tensors(Handle* h) { h->model.m_data.clear(); }
+
+void model_set_option(Handle* h, char* name, unsigned int value) {
+    Model& m = h->model;
+    const std::string n = name;
+    const bool b = value != 0;
+    if (n == "use_fp16_arithmetic") m.m_use_fp16_arithmetic = b;
+    else if (n == "use_uint8_qdq") m.m_use_uint8_qdq = b;
+    else if (n == "use_uint8_arithmetic") m.m_use_uint8_arithmetic = b;
+    else if (n == "fuse_ops_in_attention") m.m_fuse_ops_in_attention = b;
+    else if (n == "force_fp16_storage") m.m_force_fp16_storage = b;
+    else if (n == "support_dynamic_shapes") m.m_support_dynamic_shapes = b;
+    else if (n == "use_ops_cache") m.m_use_ops_cache = b;
+    else if (n == "use_scaled_dp_attn_op") m.m_use_scaled_dp_attn_op = b;
+    else if (n == "use_next_op_cache") m.m_use_next_op_cache = b;
+    else if (n == "ops_printf") m.m_ops_printf = b;
+    else if (n == "ops_times_printf") m.m_ops_times_printf = b;
+    else if (n == "use_nchw_convs") m.m_use_nchw_convs = b;
+    // ---- backend additions ----
+    else if (n == "attention_fused_ops_parts") m.m_attention_fused_ops_parts = value;
+    else if (n == "hip_device") m.m_hip_device = (int)value;
+    else if (n == "hip_fusion_level") m.m_hip_fusion_level = (int)value;
+    else if (n == "hip_use_graph") m.m_hip_use_graph = b;
+    else if (n == "hip_stream_weights") m.m_hip_stream_weights = b;
+    else {
+        const char* err = "model_set_option: 'name' not found.";
+        printf("=== ERROR === %s\n", err);
+        throw std::invalid_argument(err);
+    }
+}
+
+void model_add_extra_output(Handle* h, char* name) { h->model.m_extra_outputs.emplace_back(name); }
+
+void model_free_buffer(void* ptr) { std::free(ptr); }
+
+// ---- backend additions -------------------------------------------------------------------------------------------
+double model_hip_last_pass_ms(Handle* h) { return h->model.hip_last_pass_ms(); }
+unsigned long long model_hip_last_kernel_count(Handle* h) { return h->model.hip_last_kernel_count(); }
+void model_hip_invalidate_plan(Handle* h) { h->model.hip_invalidate_plan(); }
+
+}  // extern "C"

@@ -1,0 +1,1626 @@
+// plan.cpp -- lowering of an OnnxStream graph onto the HIP operator layer (see plan.h for the pipeline).
+// Per-op semantics follow the reference's Model::run branches (cited per function as reference src/onnxstream.cpp:LINE);
+// the error strings mirror the reference's so that callers matching on them keep working.
+#include "plan.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace onnxstream {
+
+namespace {
+
+using Shape = std::vector<long>;
+
+long prod(const Shape& s, size_t from = 0, size_t to = (size_t)-1) {
+    long n = 1;
+    for (size_t i = from; i < std::min(to, s.size()); i++) n *= s[i];
+    return n;
+}
+
+Shape to_shape(const std::vector<size_t>& s) { return Shape(s.begin(), s.end()); }
+
+std::string shape_str(const Shape& s) {
+    std::string r = "(";
+    for (size_t i = 0; i < s.size(); i++) r += (i ? "," : "") + std::to_string(s[i]);
+    return r + ")";
+}
+
+std::vector<int> int_list(const std::string& s) {
+    std::vector<int> out;
+    size_t b = 0;
+    while (b <= s.size()) {
+        size_t e = s.find(',', b);
+        if (e == std::string::npos) e = s.size();
+        if (e > b) out.push_back(std::stoi(s.substr(b, e - b)));
+        b = e + 1;
+    }
+    return out;
+}
+
+const std::string* attr(const Operation& op, const char* key) {
+    for (auto& a : op.m_attributes)
+        if (a.first == key) return &a.second;
+    return nullptr;
+}
+
+size_t esize(osg_dtype d) { return d == OSG_U8 ? 1 : d == OSG_F16 ? 2 : d == OSG_F32 ? 4 : 8; }
+
+float half_to_float(uint16_t h) {
+    uint32_t sign = (h >> 15) & 1, exp = (h >> 10) & 0x1f, man = h & 0x3ff;
+    float v;
+    if (exp == 0) v = std::ldexp((float)man, -24);
+    else if (exp == 31) v = man ? NAN : INFINITY;
+    else v = std::ldexp((float)(man | 0x400), (int)exp - 25);
+    return sign ? -v : v;
+}
+
+bool is_const_tensor(const Tensor& t) { return !t.m_name.empty() && t.m_type != TensorDataType::none; }
+
+}  // namespace
+
+// ======================================================================================================================
+Plan::Plan(Model& model, HipBackend& backend, size_t batch) : m(model), be(backend), N((long)batch) {
+    fp16 = m.m_use_fp16_arithmetic;
+    fusion = m.m_hip_fusion_level;
+    extra_outputs = m.m_extra_outputs;
+}
+
+bool Plan::compatible(Model& mm, size_t batch) const {
+    return (long)batch == N && mm.m_use_fp16_arithmetic == fp16 && mm.m_hip_fusion_level == fusion && mm.m_extra_outputs == extra_outputs;
+}
+
+int Plan::new_val(const std::string& name, const Shape& shape, osg_dtype dt, Lay lay, bool batched) {
+    Val v;
+    v.name = name;
+    v.shape = shape;
+    v.dtype = dt;
+    v.lay = lay;
+    v.batched = batched;
+    vals.push_back(std::move(v));
+    int id = (int)vals.size() - 1;
+    if (!name.empty()) by_name[name] = id;
+    return id;
+}
+
+int Plan::root_of(int v) const {
+    while (vals[v].root >= 0) v = vals[v].root;
+    return v;
+}
+
+int Plan::alias(int v, const Shape& shape, Lay lay, const std::string& name) {
+    Val a;
+    a.name = name;
+    a.shape = shape;
+    a.dtype = vals[v].dtype;
+    a.lay = lay;
+    a.batched = vals[v].batched;
+    a.is_const = vals[v].is_const;
+    a.root = v;
+    a.host_f = vals[v].host_f;
+    a.host_i = vals[v].host_i;
+    a.host_valid = vals[v].host_valid;
+    vals.push_back(std::move(a));
+    int id = (int)vals.size() - 1;
+    if (!name.empty()) by_name[name] = id;
+    return id;
+}
+
+long Plan::total_elems(int v) const { return vals[v].numel() * (vals[v].batched ? N : 1); }
+size_t Plan::val_bytes(int v) const { return (size_t)total_elems(v) * esize(vals[v].dtype); }
+
+void* Plan::ptr(int v) const {
+    const Val& r = vals[root_of(v)];
+    if (r.dptr) return r.dptr;
+    return (char*)arena + r.offset;
+}
+
+void Plan::add_step(const std::string& what, std::vector<int> reads, std::vector<int> writes, std::function<void()> fn) {
+    Step s;
+    s.what = what;
+    s.run = std::move(fn);
+    s.reads = std::move(reads);
+    s.writes = std::move(writes);
+    steps.push_back(std::move(s));
+}
+
+// NHWC -> logical (NCHW) row-major copy (the reference does this transpose on the host, :2922-2928)
+int Plan::ensure_plain(int v) {
+    if (vals[v].lay == Lay::plain) return v;
+    if (vals[v].as_plain >= 0) return vals[v].as_plain;
+    const Shape& s = vals[v].shape;  // [n,C,H,W]
+    int o = new_val("", s, vals[v].dtype, Lay::plain, vals[v].batched);
+    long b = (vals[v].batched ? N : 1) * s[0], C = s[1], HW = s[2] * s[3];
+    int es = (int)esize(vals[v].dtype);
+    add_step("to_nchw " + vals[v].name, {v}, {o}, [this, v, o, b, C, HW, es] {
+        long shape[3] = {b, HW, C};
+        int perm[3] = {0, 2, 1};
+        be.check(be.api.osg_transpose(be.ctx, es, ptr(v), ptr(o), 3, shape, perm), "osg_transpose");
+    });
+    vals[v].as_plain = o;
+    return o;
+}
+
+int Plan::ensure_nhwc(int v) {
+    if (vals[v].lay == Lay::nhwc) return v;
+    if (vals[v].as_nhwc >= 0) return vals[v].as_nhwc;
+    const Shape& s = vals[v].shape;
+    if (s.size() != 4) throw std::invalid_argument("Model::get_tensor_data: layout is nhwc but invalid shape.");
+    long b = (vals[v].batched ? N : 1) * s[0], C = s[1], HW = s[2] * s[3];
+    if (C == 1 || HW == 1) {  // identical memory image
+        int o = alias(v, s, Lay::nhwc);
+        vals[v].as_nhwc = o;
+        return o;
+    }
+    int o = new_val("", s, vals[v].dtype, Lay::nhwc, vals[v].batched);
+    int es = (int)esize(vals[v].dtype);
+    add_step("to_nhwc " + vals[v].name, {v}, {o}, [this, v, o, b, C, HW, es] {
+        long shape[3] = {b, C, HW};
+        int perm[3] = {0, 2, 1};
+        be.check(be.api.osg_transpose(be.ctx, es, ptr(v), ptr(o), 3, shape, perm), "osg_transpose");
+    });
+    vals[v].as_nhwc = o;
+    return o;
+}
+
+// ======================================================================================================================
+// The lowering proper lives in a helper class so the per-op functions can share state tersely.
+// ======================================================================================================================
+struct Lowering {
+    Plan& P;
+    Model& m;
+    HipBackend& be;
+    long N;
+    std::map<std::string, int> uses;                    // activation name -> number of consumer ops
+    std::map<std::string, int> producer;                // activation name -> op index
+    std::map<std::string, std::vector<int>> consumers;  // activation name -> consumer op indices
+    std::vector<char> dead;
+    std::map<std::string, int> const_cache;             // file name + dtype -> val
+
+    explicit Lowering(Plan& p) : P(p), m(p.m), be(p.be), N(p.N) {}
+
+    std::vector<Operation>& ops() { return P.ops; }
+    Val& V(int v) { return P.vals[v]; }
+    osg_dtype act_dtype() const { return OSG_F16; }
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // Phase B: pull every weight occurrence through the WeightsProvider in model order and make it resident.
+    // dtype policy (reference get_tensor_data :2885-2909): u8 -> dequantised; f16/f32 -> the arithmetic type, except
+    // operands the reference forces to float (InstanceNormalization scale/bias :4802, Pow exponent :5485, Resize scales).
+    // ------------------------------------------------------------------------------------------------------------------
+    static bool wants_f32(const Operation& op, size_t idx) {
+        if (op.m_type == "InstanceNormalization" && (idx == 1 || idx == 2)) return true;
+        if (op.m_type == "Resize") return true;
+        if (op.m_type == "Pow" && idx == 1) return true;
+        return false;
+    }
+
+    template <typename T>
+    tensor_vector<T> fetch(WeightsProvider* wp, const std::string& fn) {
+        if constexpr (std::is_same_v<T, uint8_t>) return wp->get_uint8(fn);
+        else if constexpr (std::is_same_v<T, uint16_t>) return wp->get_float16(fn);
+        else if constexpr (std::is_same_v<T, float>) return wp->get_float32(fn);
+        else return wp->get_int64(fn);
+    }
+
+    void load_weights() {
+        WeightsProvider* wp = m.get_wp();
+        for (auto& op : ops())
+            for (size_t i = 0; i < op.m_input.size(); i++) {
+                Tensor& t = op.m_input[i];
+                if (!is_const_tensor(t)) continue;
+                std::string fn = t.m_name;
+                Shape shape = to_shape(t.m_shape);
+                Lay lay = Lay::plain;
+                auto pos = fn.find("_nchw.bin");
+                if (pos != std::string::npos) {
+                    // conv weight: model.txt names the OIHW file, the runtime loads the OHWI twin (reference :2666-2692)
+                    if (shape.size() == 3) shape.push_back(1);  // Conv1D lifted to 2-D
+                    if (shape.size() != 4) throw std::invalid_argument("Model::get_tensor_data: layout is nhwc but invalid shape.");
+                    fn = fn.substr(0, pos) + "_nhwc.bin";
+                    lay = Lay::nhwc;
+                }
+                TensorDataType ty = t.m_type;
+                TensorDataType nt = wp->get_type_of_next();
+                if (nt != TensorDataType::none) ty = nt;
+                const bool f32 = wants_f32(op, i) || !P.fp16;
+                const osg_dtype want = ty == TensorDataType::int64 ? OSG_I64 : (f32 ? OSG_F32 : OSG_F16);
+                const std::string key = fn + (want == OSG_F32 ? "|f32" : want == OSG_F16 ? "|f16" : "|i64");
+                const long count = prod(shape);
+                int v = -1;
+                auto it = const_cache.find(key);
+                detail::dispatch_dtype(ty, [&](auto tag) {
+                    using T = typename decltype(tag)::type;
+                    tensor_vector<T> data = fetch<T>(wp, fn);  // always fetched: providers serve strictly in order
+                    if ((long)data.size() != count) throw std::invalid_argument("Model::get_tensor_data: mismatch between tensor shape and data size.");
+                    if (it != const_cache.end()) {
+                        v = it->second;
+                        return;
+                    }
+                    v = P.new_val("", shape, want, lay, false);
+                    Val& val = V(v);
+                    val.is_const = true;
+                    val.name = fn;
+                    size_t bytes = (size_t)count * esize(want);
+                    val.dptr = be.malloc(bytes);
+                    P.owned.push_back(val.dptr);
+                    P.weight_bytes += bytes;
+                    constexpr osg_dtype have = std::is_same_v<T, uint8_t> ? OSG_U8 : std::is_same_v<T, uint16_t> ? OSG_F16
+                                               : std::is_same_v<T, float> ? OSG_F32 : OSG_I64;
+                    if (have == want) {
+                        be.check(be.api.osg_upload(be.ctx, val.dptr, data.data(), bytes), "osg_upload");
+                    } else {
+                        if (have == OSG_I64 || want == OSG_I64) throw std::invalid_argument("Model::get_tensor_data: unsupported tensor data format.");
+                        void* tmp = be.malloc((size_t)count * sizeof(T));
+                        be.check(be.api.osg_upload(be.ctx, tmp, data.data(), (size_t)count * sizeof(T)), "osg_upload");
+                        be.check(be.api.osg_convert(be.ctx, have, want, tmp, val.dptr, count, t.m_scale, (int)t.m_zero_point), "osg_convert");
+                        be.check(be.api.osg_sync(be.ctx), "osg_sync");
+                        be.free(tmp);
+                    }
+                    // small constants stay readable on the host for the planner (shapes, axes, eps, scales ...)
+                    if (have == OSG_I64) {
+                        val.host_i.assign((const int64_t*)data.data(), (const int64_t*)data.data() + count);
+                        val.host_valid = true;
+                    } else if (count <= 4096) {
+                        val.host_f.resize(count);
+                        for (long k = 0; k < count; k++) {
+                            if constexpr (std::is_same_v<T, uint8_t>) val.host_f[k] = (float)((int)data[k] - (int)t.m_zero_point) * t.m_scale;
+                            else if constexpr (std::is_same_v<T, uint16_t>) val.host_f[k] = half_to_float(data[k]);
+                            else if constexpr (std::is_same_v<T, float>) val.host_f[k] = data[k];
+                        }
+                        val.host_valid = true;
+                    }
+                    const_cache[key] = v;
+                });
+                if (m.m_use_ops_cache && !m.m_weights_exclusion_set.count(fn)) {
+                    // resident from now on: drop the provider's host copy, like the reference's ops cache does (:4556-4569)
+                    try { wp->remove(fn); } catch (const std::exception&) {}
+                    m.m_weights_exclusion_set.insert(fn);
+                }
+                t.m_name = "#" + std::to_string(v);  // from here on the tensor names its resident val
+            }
+        be.check(be.api.osg_sync(be.ctx), "osg_sync");
+    }
+
+    int const_val(const Tensor& t) const { return std::stoi(t.m_name.substr(1)); }
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // graph indices for the fusion passes
+    // ------------------------------------------------------------------------------------------------------------------
+    void index_graph() {
+        uses.clear(); producer.clear(); consumers.clear();
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (dead[i]) continue;
+            for (auto& in : ops()[i].m_input)
+                if (!in.m_name.empty() && in.m_type == TensorDataType::none) {
+                    uses[in.m_name]++;
+                    consumers[in.m_name].push_back((int)i);
+                }
+            for (auto& out : ops()[i].m_output) producer[out.m_name] = (int)i;
+        }
+        for (auto& n : P.extra_outputs) uses[n] += 1000;  // never fuse away something the caller wants to read
+    }
+    bool act(const Tensor& t) const { return !t.m_name.empty() && t.m_type == TensorDataType::none; }
+    int prod_of(const Tensor& t) const {
+        if (!act(t)) return -1;
+        auto it = producer.find(t.m_name);
+        return it == producer.end() ? -1 : it->second;
+    }
+    int use_count(const std::string& n) const { auto it = uses.find(n); return it == uses.end() ? 0 : it->second; }
+    int sole_consumer(const Tensor& t) const {
+        if (use_count(t.m_name) != 1) return -1;
+        auto it = consumers.find(t.m_name);
+        return it == consumers.end() || it->second.size() != 1 ? -1 : it->second[0];
+    }
+    bool is(int i, const char* type) const { return i >= 0 && !dead[i] && P.ops[i].m_type == type; }
+    const Val* cval(const Tensor& t) const { return is_const_tensor(t) ? &P.vals[const_val(t)] : nullptr; }
+    bool const_scalar(const Tensor& t, float* out) const {
+        const Val* v = cval(t);
+        if (!v || v->numel() != 1 || !v->host_valid || v->host_f.empty()) return false;
+        *out = v->host_f[0];
+        return true;
+    }
+    // the other operand of a commutative binary op
+    int other(const Operation& op, const std::string& name) const { return op.m_input[0].m_name == name ? 1 : 0; }
+
+    void run_fusions() {
+        dead.assign(ops().size(), 0);
+        if (P.fusion >= 1) {
+            index_graph(); fuse_silu();
+            index_graph(); fuse_group_norm();
+            index_graph(); fuse_layer_norm();
+            index_graph(); fuse_geglu();
+        }
+        if (P.fusion >= 2) {
+            index_graph(); fuse_attention(true);
+            index_graph(); fuse_linear();
+            index_graph(); fuse_residual();
+        } else if (m.m_fuse_ops_in_attention) {
+            index_graph(); fuse_attention(false);
+        }
+        std::vector<Operation> live;
+        for (size_t i = 0; i < ops().size(); i++)
+            if (!dead[i]) live.push_back(std::move(ops()[i]));
+        ops() = std::move(live);
+    }
+
+    // Sigmoid(x) -> Mul(x, .)   ==> osg.SiLU
+    void fuse_silu() {
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (!is((int)i, "Sigmoid")) continue;
+            Operation& sg = ops()[i];
+            if (sg.m_input.size() != 1 || sg.m_output.size() != 1 || !act(sg.m_input[0])) continue;
+            int j = sole_consumer(sg.m_output[0]);
+            if (!is(j, "Mul")) continue;
+            Operation& mul = ops()[j];
+            if (mul.m_input.size() != 2) continue;
+            const std::string& s = sg.m_output[0].m_name;
+            int o = other(mul, s);
+            if (mul.m_input[o].m_name != sg.m_input[0].m_name || mul.m_input[1 - o].m_name != s) continue;
+            mul.m_type = "osg.SiLU";
+            Tensor x = mul.m_input[o];
+            mul.m_input.clear();
+            mul.m_input.push_back(x);
+            dead[i] = 1;
+        }
+    }
+
+    // Reshape[1,G,-1] -> InstanceNormalization(1,0) -> Reshape[n,C,H,W] -> Mul(gamma[C,1,1]) -> Add(beta[C,1,1]) [-> SiLU]
+    void fuse_group_norm() {
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (!is((int)i, "InstanceNormalization")) continue;
+            Operation& in = ops()[i];
+            if (in.m_input.size() != 3 || in.m_output.size() != 1) continue;
+            const Val* sc = cval(in.m_input[1]);
+            const Val* bi = cval(in.m_input[2]);
+            if (!sc || !bi || !sc->host_valid || !bi->host_valid) continue;
+            bool unit = true;
+            for (float f : sc->host_f) unit &= f == 1.0f;
+            for (float f : bi->host_f) unit &= f == 0.0f;
+            if (!unit) continue;
+            int r0 = prod_of(in.m_input[0]);
+            if (!is(r0, "Reshape") || use_count(in.m_input[0].m_name) != 1) continue;
+            const Tensor& x = ops()[r0].m_input[0];
+            if (!act(x) || x.m_shape.size() != 4) continue;
+            if (in.m_input[0].m_shape.size() != 3 || in.m_input[0].m_shape[0] != 1) continue;
+            long G = (long)in.m_input[0].m_shape[1];
+            int r1 = sole_consumer(in.m_output[0]);
+            if (!is(r1, "Reshape") || ops()[r1].m_output[0].m_shape != x.m_shape) continue;
+            int mu = sole_consumer(ops()[r1].m_output[0]);
+            if (!is(mu, "Mul")) continue;
+            int gi = other(ops()[mu], ops()[r1].m_output[0].m_name);
+            const Val* gam = cval(ops()[mu].m_input[gi]);
+            long C = (long)x.m_shape[1];
+            auto chan_shape = [&](const Val* v) {
+                if (!v || v->numel() != C) return false;
+                const Shape& s = v->shape;
+                return (s.size() == 3 && s[0] == C) || (s.size() == 4 && s[1] == C);
+            };
+            if (!chan_shape(gam)) continue;
+            int ad = sole_consumer(ops()[mu].m_output[0]);
+            if (!is(ad, "Add")) continue;
+            int bidx = other(ops()[ad], ops()[mu].m_output[0].m_name);
+            if (!chan_shape(cval(ops()[ad].m_input[bidx]))) continue;
+            if (C % G || x.m_shape[0] != 1) continue;
+            float eps = 1e-5f;
+            if (auto* e = attr(in, "epsilon")) eps = std::stof(*e);
+            int last = ad;
+            bool silu = false;
+            int sl = sole_consumer(ops()[ad].m_output[0]);
+            if (is(sl, "osg.SiLU")) { silu = true; last = sl; }
+            Operation f;
+            f.m_name = in.m_name + "_GroupNorm";
+            f.m_type = "osg.GroupNorm";
+            f.m_input = {x, ops()[mu].m_input[gi], ops()[ad].m_input[bidx]};
+            f.m_output = {ops()[last].m_output[0]};
+            f.m_attributes = {{"groups", std::to_string(G)}, {"epsilon", std::to_string(eps)}, {"silu", silu ? "1" : "0"}};
+            char buf[64];
+            snprintf(buf, sizeof buf, "%.9g", eps);
+            f.m_attributes[1].second = buf;
+            for (int k : {r0, (int)i, r1, mu, ad}) dead[k] = 1;
+            if (silu) dead[sl] = 1;
+            dead[last] = 0;
+            ops()[last] = std::move(f);
+        }
+    }
+
+    // ReduceMean -> Sub -> Pow(2) -> ReduceMean -> Add(eps) -> Sqrt -> Div -> Mul(gamma) -> Add(beta)
+    void fuse_layer_norm() {
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (!is((int)i, "ReduceMean")) continue;
+            Operation& rm = ops()[i];
+            if (rm.m_input.size() != 1 || !act(rm.m_input[0])) continue;
+            const Tensor x = rm.m_input[0];
+            int sub = sole_consumer(rm.m_output[0]);
+            if (!is(sub, "Sub") || ops()[sub].m_input[0].m_name != x.m_name || ops()[sub].m_input[1].m_name != rm.m_output[0].m_name) continue;
+            const std::string d = ops()[sub].m_output[0].m_name;
+            if (use_count(d) != 2) continue;
+            auto& dc = consumers[d];
+            int pw = -1, dv = -1;
+            for (int c : dc) { if (is(c, "Pow")) pw = c; if (is(c, "Div")) dv = c; }
+            if (pw < 0 || dv < 0 || ops()[pw].m_input[0].m_name != d || ops()[dv].m_input[0].m_name != d) continue;
+            float p = 0;
+            if (!const_scalar(ops()[pw].m_input[1], &p) || p != 2.0f) continue;
+            int rm2 = sole_consumer(ops()[pw].m_output[0]);
+            if (!is(rm2, "ReduceMean")) continue;
+            int ae = sole_consumer(ops()[rm2].m_output[0]);
+            if (!is(ae, "Add")) continue;
+            float eps = 0;
+            if (!const_scalar(ops()[ae].m_input[other(ops()[ae], ops()[rm2].m_output[0].m_name)], &eps)) continue;
+            int sq = sole_consumer(ops()[ae].m_output[0]);
+            if (!is(sq, "Sqrt")) continue;
+            if (sole_consumer(ops()[sq].m_output[0]) != dv || ops()[dv].m_input[1].m_name != ops()[sq].m_output[0].m_name) continue;
+            int mu = sole_consumer(ops()[dv].m_output[0]);
+            if (!is(mu, "Mul")) continue;
+            int gi = other(ops()[mu], ops()[dv].m_output[0].m_name);
+            const Val* gam = cval(ops()[mu].m_input[gi]);
+            long C = (long)x.m_shape.back();
+            if (!gam || gam->numel() != C || gam->shape.back() != C) continue;
+            int ad = sole_consumer(ops()[mu].m_output[0]);
+            if (!is(ad, "Add")) continue;
+            int bidx = other(ops()[ad], ops()[mu].m_output[0].m_name);
+            const Val* bet = cval(ops()[ad].m_input[bidx]);
+            if (!bet || bet->numel() != C || bet->shape.back() != C) continue;
+            Operation f;
+            f.m_name = rm.m_name + "_LayerNorm";
+            f.m_type = "osg.LayerNorm";
+            f.m_input = {x, ops()[mu].m_input[gi], ops()[ad].m_input[bidx]};
+            f.m_output = {ops()[ad].m_output[0]};
+            char buf[64];
+            snprintf(buf, sizeof buf, "%.9g", eps);
+            f.m_attributes = {{"epsilon", buf}};
+            for (int k : {(int)i, sub, pw, rm2, ae, sq, dv, mu}) dead[k] = 1;
+            ops()[ad] = std::move(f);
+        }
+    }
+
+    bool slice_last_range(const Operation& sl, long* b, long* e) const {
+        if (sl.m_input.size() < 3) return false;
+        const Val* s = cval(sl.m_input[1]);
+        const Val* en = cval(sl.m_input[2]);
+        if (!s || !en || s->host_i.size() != 1 || en->host_i.size() != 1) return false;
+        long rank = (long)sl.m_input[0].m_shape.size(), dim = (long)sl.m_input[0].m_shape.back();
+        if (sl.m_input.size() > 3) {
+            const Val* ax = cval(sl.m_input[3]);
+            if (!ax || ax->host_i.size() != 1) return false;
+            long a = ax->host_i[0];
+            if (a < 0) a += rank;
+            if (a != rank - 1) return false;
+        } else if (rank != 1) return false;
+        if (sl.m_input.size() > 4) {
+            const Val* st = cval(sl.m_input[4]);
+            if (!st || st->host_i.size() != 1 || st->host_i[0] != 1) return false;
+        }
+        long bb = s->host_i[0], ee = en->host_i[0];
+        if (bb < 0) bb += dim;
+        if (ee < 0) ee += dim;
+        if (ee > dim) ee = dim;
+        *b = bb; *e = ee;
+        return true;
+    }
+
+    // p -> Slice(0:C)=val, Slice(C:2C)=gate ; gate -> Div(sqrt2) -> Erf -> Add(1) -> Mul(gate,.) -> Mul(.,0.5) -> Mul(val,.)
+    void fuse_geglu() {
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (!is((int)i, "Erf")) continue;
+            int dv = prod_of(ops()[i].m_input[0]);
+            if (!is(dv, "Div") || use_count(ops()[i].m_input[0].m_name) != 1) continue;
+            float c = 0;
+            if (!const_scalar(ops()[dv].m_input[1], &c) || std::fabs(c - 1.41421356f) > 2e-3f) continue;
+            const Tensor gate = ops()[dv].m_input[0];
+            int gs = prod_of(gate);
+            if (!is(gs, "Slice") || use_count(gate.m_name) != 2) continue;
+            int a1 = sole_consumer(ops()[i].m_output[0]);
+            if (!is(a1, "Add")) continue;
+            float one = 0;
+            if (!const_scalar(ops()[a1].m_input[other(ops()[a1], ops()[i].m_output[0].m_name)], &one) || one != 1.0f) continue;
+            int m1 = sole_consumer(ops()[a1].m_output[0]);
+            if (!is(m1, "Mul") || ops()[m1].m_input[other(ops()[m1], ops()[a1].m_output[0].m_name)].m_name != gate.m_name) continue;
+            int m2 = sole_consumer(ops()[m1].m_output[0]);
+            if (!is(m2, "Mul")) continue;
+            float half = 0;
+            if (!const_scalar(ops()[m2].m_input[other(ops()[m2], ops()[m1].m_output[0].m_name)], &half) || half != 0.5f) continue;
+            int m3 = sole_consumer(ops()[m2].m_output[0]);
+            if (!is(m3, "Mul")) continue;
+            const Tensor& val = ops()[m3].m_input[other(ops()[m3], ops()[m2].m_output[0].m_name)];
+            int vs = prod_of(val);
+            if (!is(vs, "Slice") || use_count(val.m_name) != 1) continue;
+            const Tensor p = ops()[gs].m_input[0];
+            if (!act(p) || ops()[vs].m_input[0].m_name != p.m_name || use_count(p.m_name) != 2) continue;
+            long C2 = (long)p.m_shape.back(), b0, e0, b1, e1;
+            if (C2 % 2 || !slice_last_range(ops()[vs], &b0, &e0) || !slice_last_range(ops()[gs], &b1, &e1)) continue;
+            if (b0 != 0 || e0 != C2 / 2 || b1 != C2 / 2 || e1 != C2) continue;
+            Operation f;
+            f.m_name = ops()[i].m_name + "_GEGLU";
+            f.m_type = "osg.GEGLU";
+            f.m_input = {p};
+            f.m_output = {ops()[m3].m_output[0]};
+            for (int k : {(int)i, dv, gs, vs, a1, m1, m2}) dead[k] = 1;
+            ops()[m3] = std::move(f);
+        }
+    }
+
+    // follows Reshape[1,T,h,d] -> Transpose(0,2,1,3) -> Reshape[h,T,d] backwards from `t`; returns the projection tensor
+    bool head_split_source(const Tensor& t, Tensor* src, long* h, long* d, std::vector<int>* chain) {
+        int r1 = prod_of(t);
+        if (!is(r1, "Reshape") || use_count(t.m_name) != 1 || t.m_shape.size() != 3) return false;
+        const Tensor& a = ops()[r1].m_input[0];
+        int tp = prod_of(a);
+        if (!is(tp, "Transpose") || use_count(a.m_name) != 1) return false;
+        auto* pm = attr(ops()[tp], "perm");
+        if (!pm || int_list(*pm) != std::vector<int>{0, 2, 1, 3}) return false;
+        const Tensor& b = ops()[tp].m_input[0];
+        int r0 = prod_of(b);
+        if (!is(r0, "Reshape") || use_count(b.m_name) != 1 || b.m_shape.size() != 4 || b.m_shape[0] != 1) return false;
+        const Tensor& s = ops()[r0].m_input[0];
+        if (!act(s) || s.m_shape.size() != 3 || s.m_shape[0] != 1) return false;
+        long T = (long)b.m_shape[1];
+        *h = (long)b.m_shape[2];
+        *d = (long)b.m_shape[3];
+        if ((long)s.m_shape[1] != T || (long)s.m_shape[2] != *h * *d) return false;
+        if ((long)t.m_shape[0] != *h || (long)t.m_shape[1] != T || (long)t.m_shape[2] != *d) return false;
+        *src = s;
+        chain->insert(chain->end(), {r1, tp, r0});
+        return true;
+    }
+
+    // MatMul(q,kT) -> [Mul(scale)] -> Softmax(-1) -> MatMul(.,v)
+    //   full=false: the reference's own AttentionFusedOps rewrite (:3576-3633) -- operands stay [h,T,d]/[h,d,Tk]
+    //   full=true : additionally folds the head split / merge Reshape+Transpose chains: reads Q,K,V straight from the
+    //               [1,T,h*d] projection outputs and writes [1,T,h*d]
+    void fuse_attention(bool full) {
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (!is((int)i, "Softmax")) continue;
+            Operation& sm = ops()[i];
+            auto* ax = attr(sm, "axis");
+            if (!ax || *ax != "-1" || sm.m_attributes.size() != 1 || sm.m_input.size() != 1) continue;
+            int pre = prod_of(sm.m_input[0]);
+            if (pre < 0 || use_count(sm.m_input[0].m_name) != 1) continue;
+            int mul = -1, mm0 = pre;
+            Tensor scale_t;
+            if (is(pre, "Mul")) {
+                mul = pre;
+                if (ops()[mul].m_input.size() != 2) continue;
+                mm0 = prod_of(ops()[mul].m_input[0]);
+                if (mm0 < 0 || use_count(ops()[mul].m_input[0].m_name) != 1) continue;
+                scale_t = ops()[mul].m_input[1];
+            }
+            if (!is(mm0, "MatMul")) continue;
+            int mm1 = sole_consumer(sm.m_output[0]);
+            if (!is(mm1, "MatMul") || ops()[mm1].m_input[0].m_name != sm.m_output[0].m_name) continue;
+            const Tensor q = ops()[mm0].m_input[0], kt = ops()[mm0].m_input[1], v = ops()[mm1].m_input[1];
+            if (!act(q) || !act(kt) || !act(v)) continue;
+            float scale = 1.0f;
+            if (mul >= 0) {
+                const Val* sv = cval(scale_t);
+                if (!sv || !sv->shape.empty() || !const_scalar(scale_t, &scale)) continue;  // "s must be a scalar" (:6723)
+            }
+            std::vector<int> chain = {mm0, (int)i};
+            if (mul >= 0) chain.push_back(mul);
+            if (full) {
+                Tensor qs, ks, vs;
+                long h, d, h2, d2, h3, d3;
+                int ktp = prod_of(kt);
+                auto* pm = ktp >= 0 ? attr(ops()[ktp], "perm") : nullptr;
+                if (!is(ktp, "Transpose") || !pm || int_list(*pm) != std::vector<int>{0, 2, 1} || use_count(kt.m_name) != 1) goto plain;
+                {
+                    std::vector<int> c2 = chain;
+                    c2.push_back(ktp);
+                    if (!head_split_source(q, &qs, &h, &d, &c2) || !head_split_source(ops()[ktp].m_input[0], &ks, &h2, &d2, &c2) ||
+                        !head_split_source(v, &vs, &h3, &d3, &c2) || h != h2 || h != h3 || d != d2 || d != d3)
+                        goto plain;
+                    // merge: Reshape[1,h,T,d] -> Transpose(0,2,1,3) -> Reshape[1,T,h*d]
+                    int o0 = sole_consumer(ops()[mm1].m_output[0]);
+                    if (!is(o0, "Reshape")) goto plain;
+                    int o1 = sole_consumer(ops()[o0].m_output[0]);
+                    auto* pm2 = o1 >= 0 ? attr(ops()[o1], "perm") : nullptr;
+                    if (!is(o1, "Transpose") || !pm2 || int_list(*pm2) != std::vector<int>{0, 2, 1, 3}) goto plain;
+                    int o2 = sole_consumer(ops()[o1].m_output[0]);
+                    if (!is(o2, "Reshape")) goto plain;
+                    const auto& os = ops()[o2].m_output[0].m_shape;
+                    if (os.size() != 3 || os[0] != 1 || (long)os[1] != (long)q.m_shape[1] || (long)os[2] != h * d) goto plain;
+                    Operation f;
+                    f.m_name = ops()[mm0].m_name + "_Attention";
+                    f.m_type = "osg.Attention";
+                    f.m_input = {qs, ks, vs};
+                    f.m_output = {ops()[o2].m_output[0]};
+                    char buf[64];
+                    snprintf(buf, sizeof buf, "%.9g", scale);
+                    f.m_attributes = {{"heads", std::to_string(h)}, {"scale", buf}};
+                    for (int k : c2) dead[k] = 1;
+                    for (int k : {mm1, o0, o1}) dead[k] = 1;
+                    ops()[o2] = std::move(f);
+                    continue;
+                }
+            }
+        plain:
+            {
+                Operation f;
+                f.m_name = ops()[mm0].m_name + "_AttentionFusedOps";
+                f.m_type = "AttentionFusedOps";
+                f.m_input = {q, kt, mul >= 0 ? scale_t : Tensor(), v};
+                f.m_output = {ops()[mm1].m_output[0]};
+                for (int k : chain) dead[k] = 1;
+                ops()[mm1] = std::move(f);
+            }
+        }
+    }
+
+    // MatMul(x, W) -> Add(., b[N])  ==> osg.Linear(x, W, b)
+    void fuse_linear() {
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (!is((int)i, "MatMul")) continue;
+            Operation& mm = ops()[i];
+            const Val* w = cval(mm.m_input[1]);
+            if (!act(mm.m_input[0]) || !w || w->shape.size() != 2) continue;
+            mm.m_type = "osg.Linear";
+            int ad = sole_consumer(mm.m_output[0]);
+            if (!is(ad, "Add")) continue;
+            int bi = other(ops()[ad], mm.m_output[0].m_name);
+            const Val* b = cval(ops()[ad].m_input[bi]);
+            if (!b || b->shape.size() != 1 || b->shape[0] != w->shape[1]) continue;
+            Operation f = mm;
+            f.m_input.push_back(ops()[ad].m_input[bi]);
+            f.m_output = {ops()[ad].m_output[0]};
+            dead[i] = 1;
+            ops()[ad] = std::move(f);
+        }
+    }
+
+    // {Conv | osg.Linear}(..) -> Add(., r)  with r an activation of the same shape  ==> residual fused in the epilogue
+    void fuse_residual() {
+        for (size_t i = 0; i < ops().size(); i++) {
+            const bool conv = is((int)i, "Conv"), lin = is((int)i, "osg.Linear");
+            if (!conv && !lin) continue;
+            Operation& op = ops()[i];
+            if (op.m_output.size() != 1) continue;
+            int ad = sole_consumer(op.m_output[0]);
+            if (!is(ad, "Add")) continue;
+            int ri = other(ops()[ad], op.m_output[0].m_name);
+            const Tensor& r = ops()[ad].m_input[ri];
+            if (!act(r) || r.m_shape != op.m_output[0].m_shape || r.m_name == op.m_output[0].m_name) continue;
+            // the residual must already exist when the fused op runs: its producer has to precede `ad` (always true in a
+            // topologically sorted file) -- the fused op takes the place of the Add.
+            Operation f = op;
+            if (conv && f.m_input.size() == 2) f.m_input.push_back(Tensor());  // no bias
+            if (lin && f.m_input.size() == 2) f.m_input.push_back(Tensor());
+            f.m_input.push_back(r);
+            f.m_attributes.emplace_back("osg_residual", "1");
+            f.m_output = {ops()[ad].m_output[0]};
+            dead[i] = 1;
+            ops()[ad] = std::move(f);
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------------------------------
+    // lowering
+    // ------------------------------------------------------------------------------------------------------------------
+    int in_val(const Tensor& t) {
+        if (is_const_tensor(t)) return const_val(t);
+        auto it = P.by_name.find(t.m_name);
+        if (it == P.by_name.end()) throw std::invalid_argument("Model::get_tensor_data: input tensor not found: " + t.m_name);
+        return it->second;
+    }
+
+    void check_out(const Operation& op, const Shape& got, size_t idx = 0) {
+        // the reference's per-op self check (check_output_shape, :3070)
+        const auto& want = op.m_output[idx].m_shape;
+        bool ok = want.size() == got.size();
+        for (size_t i = 0; ok && i < got.size(); i++) ok = (long)want[i] == got[i] || (m.m_support_dynamic_shapes && want[i] == 0);
+        if (!ok && !(m.m_support_dynamic_shapes && want.empty()))
+            throw std::invalid_argument(op.m_type + ": unexpected shape of output. (" + op.m_name + ": computed " + shape_str(got) + ")");
+    }
+
+    int out_val(const Operation& op, const Shape& shape, Lay lay, bool batched, osg_dtype dt = OSG_F16, size_t idx = 0) {
+        check_out(op, shape, idx);
+        return P.new_val(op.m_output[idx].m_name, shape, dt, lay, batched);
+    }
+
+    long B(int v) { return V(v).batched ? N : 1; }
+
+    void lower_all() {
+        for (auto& op : ops()) lower(op);
+    }
+
+    void lower(const Operation& op) {
+        const std::string& t = op.m_type;
+        if (t == "Conv") return lower_conv(op);
+        if (t == "MatMul") return lower_matmul(op);
+        if (t == "osg.Linear") return lower_linear(op);
+        if (t == "Gemm") return lower_gemm(op);
+        if (t == "Add" || t == "Sub" || t == "Mul" || t == "Div") return lower_binary(op);
+        if (t == "Sigmoid" || t == "Erf" || t == "Sqrt" || t == "Sin" || t == "Cos" || t == "Neg" || t == "osg.SiLU") return lower_unary(op);
+        if (t == "Pow") return lower_pow(op);
+        if (t == "InstanceNormalization") return lower_instance_norm(op);
+        if (t == "osg.GroupNorm") return lower_group_norm(op);
+        if (t == "osg.LayerNorm") return lower_layer_norm(op);
+        if (t == "osg.GEGLU") return lower_geglu(op);
+        if (t == "osg.Attention") return lower_attention(op);
+        if (t == "AttentionFusedOps") return lower_attention_fused_ops(op);
+        if (t == "ReduceMean") return lower_reduce_mean(op);
+        if (t == "Softmax") return lower_softmax(op);
+        if (t == "Reshape") return lower_reshape(op);
+        if (t == "Flatten") return lower_flatten(op);
+        if (t == "Unsqueeze" || t == "Squeeze") return lower_squeeze(op, t == "Unsqueeze");
+        if (t == "Transpose") return lower_transpose(op);
+        if (t == "Concat") return lower_concat(op);
+        if (t == "Split") return lower_split(op);
+        if (t == "Slice") return lower_slice(op);
+        if (t == "Resize") return lower_resize(op);
+        if (t == "MaxPool") return lower_maxpool(op);
+        throw std::invalid_argument("Model::run: operation not implemented on the HIP backend: " + t);
+    }
+
+    static void need(const Operation& op, bool cond, const char* msg) {
+        if (!cond) throw std::invalid_argument(op.m_type + ": " + msg);
+    }
+
+    // Conv (reference :4494-4707 -> XnnPack::convolution :1292): group 1, dilation 1, pads re-centred (:1315-1329)
+    void lower_conv(const Operation& op) {
+        const bool has_res = attr(op, "osg_residual") != nullptr;
+        const size_t nin = op.m_input.size();
+        need(op, nin == 2 || nin == 3 || (has_res && nin == 4), "wrong number of inputs.");
+        need(op, op.m_output.size() == 1, "wrong number of outputs.");
+        std::vector<int> dil = {1, 1}, ks, pads = {0, 0, 0, 0}, strides = {1, 1};
+        int group = 1;
+        for (auto& a : op.m_attributes) {
+            if (a.first == "dilations") dil = int_list(a.second);
+            else if (a.first == "group") group = std::stoi(a.second);
+            else if (a.first == "kernel_shape") ks = int_list(a.second);
+            else if (a.first == "pads") pads = int_list(a.second);
+            else if (a.first == "strides") strides = int_list(a.second);
+            else if (a.first == "osg_residual") {}
+            else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
+        }
+        int x = in_val(op.m_input[0]);
+        need(op, V(x).shape.size() == 4, "Conv1D / non 4-D input not implemented on the HIP backend.");
+        for (int d : dil) need(op, d == 1, "dilations != 1 not supported (not implemented).");
+        need(op, group == 1, "group != 1 not supported (not implemented).");
+        need(op, pads.size() == 4 && strides.size() == 2, "invalid pads/strides.");
+        x = P.ensure_nhwc(x);
+        int w = in_val(op.m_input[1]);
+        const Shape& ws = V(w).shape;  // [O, I, kh, kw] as named in model.txt; data is OHWI
+        need(op, V(w).is_const && V(w).lay == Lay::nhwc && ws.size() == 4, "weights must be a static *_nchw.bin tensor.");
+        const Shape& xs = V(x).shape;
+        need(op, xs[0] == 1, "batch size must be 1 (push several samples instead).");
+        const long Cin = xs[1], H = xs[2], W = xs[3], Cout = ws[0], KH = ws[2], KW = ws[3];
+        need(op, ws[1] == Cin, "invalid shape of weights.");
+        if (!ks.empty()) need(op, ks.size() == 2 && ks[0] == KH && ks[1] == KW, "kernel_shape does not match the weights.");
+        const int ph = pads[0] + pads[2], pw = pads[1] + pads[3];
+        const int pt = ph / 2, pb = ph - pt, pl = pw / 2, pr = pw - pl;
+        const long Ho = (H + ph - KH) / strides[0] + 1, Wo = (W + pw - KW) / strides[1] + 1;
+        int bias = -1;
+        if (nin >= 3 && !op.m_input[2].m_name.empty()) {
+            bias = in_val(op.m_input[2]);
+            need(op, V(bias).numel() == Cout, "invalid shape of bias.");
+        }
+        int res = -1;
+        if (has_res) res = P.ensure_nhwc(in_val(op.m_input[3]));
+        int y = out_val(op, {1, Cout, Ho, Wo}, Lay::nhwc, V(x).batched);
+        const long nb = B(x);
+        const int sh = strides[0], sw = strides[1];
+        std::vector<int> reads = {x, w};
+        if (bias >= 0) reads.push_back(bias);
+        if (res >= 0) reads.push_back(res);
+        P.add_step("Conv " + op.m_name, reads, {y}, [=, this] {
+            be.check(be.api.osg_conv2d_nhwc(be.ctx, OSG_F16, P.ptr(x), P.ptr(w), bias >= 0 ? P.ptr(bias) : nullptr,
+                                            bias >= 0 ? P.vals[bias].dtype : OSG_F16, res >= 0 ? P.ptr(res) : nullptr, P.ptr(y), (int)nb,
+                                            (int)H, (int)W, (int)Cin, (int)Cout, (int)KH, (int)KW, sh, sw, pt, pl, pb, pr, OSG_ACT_NONE),
+                     "Conv");
+        });
+    }
+
+    // resident [K,N] weight -> [N,K] (done once, at plan time)
+    int weight_nk(int w) {
+        Val& wv = V(w);
+        if (wv.as_nhwc >= 0) return wv.as_nhwc;  // reuse the slot: "K-contiguous twin"
+        const long K = wv.shape[0], Nn = wv.shape[1];
+        int t = P.new_val("", {Nn, K}, OSG_F16, Lay::plain, false);
+        Val& tv = V(t);
+        tv.is_const = true;
+        tv.name = V(w).name + "|nk";
+        size_t bytes = (size_t)K * Nn * 2;
+        tv.dptr = be.malloc(bytes);
+        P.owned.push_back(tv.dptr);
+        be.check(be.api.osg_transpose_kn_to_nk(be.ctx, OSG_F16, P.ptr(w), tv.dptr, (int)K, (int)Nn), "osg_transpose_kn_to_nk");
+        V(w).as_nhwc = t;
+        return t;
+    }
+
+    void emit_gemm(const std::string& what, int a, int wnk, int bias, int res, int y, long M, long Nn, long K, long batch, long sa, long sb,
+                   long sc, int b_is_nk) {
+        std::vector<int> reads = {a, wnk};
+        if (bias >= 0) reads.push_back(bias);
+        if (res >= 0) reads.push_back(res);
+        P.add_step(what, reads, {y}, [=, this] {
+            be.check(be.api.osg_gemm(be.ctx, OSG_F16, P.ptr(a), P.ptr(wnk), b_is_nk, bias >= 0 ? P.ptr(bias) : nullptr,
+                                     bias >= 0 ? P.vals[bias].dtype : OSG_F16, res >= 0 ? P.ptr(res) : nullptr, P.ptr(y), (int)M, (int)Nn,
+                                     (int)K, (int)batch, sa, sb, sc, OSG_ACT_NONE),
+                     what.c_str());
+        });
+    }
+
+    // MatMul with a static 2-D weight, optional fused bias / residual
+    void lower_linear(const Operation& op) {
+        const bool has_res = attr(op, "osg_residual") != nullptr;
+        int a = P.ensure_plain(in_val(op.m_input[0]));
+        int w = in_val(op.m_input[1]);
+        const Shape as = V(a).shape;
+        const long K = V(w).shape[0], Nn = V(w).shape[1];
+        need(op, !as.empty() && as.back() == K, "invalid shape of inputs.");
+        int bias = op.m_input.size() > 2 && !op.m_input[2].m_name.empty() ? in_val(op.m_input[2]) : -1;
+        int res = has_res ? P.ensure_plain(in_val(op.m_input[3])) : -1;
+        Shape os = as;
+        os.back() = Nn;
+        int y = out_val(op, os, Lay::plain, V(a).batched);
+        const long M = prod(as) / K * B(a);
+        emit_gemm("Linear " + op.m_name, a, weight_nk(w), bias, res, y, M, Nn, K, 1, 0, 0, 0, 1);
+    }
+
+    // MatMul (reference :5669-5861): [.., M,K] x [K,N] (static weight, broadcast) or batched [n,M,K] x [n,K,N]
+    void lower_matmul(const Operation& op) {
+        need(op, op.m_input.size() == 2, "wrong number of inputs.");
+        need(op, op.m_output.size() == 1, "wrong number of outputs.");
+        int b = in_val(op.m_input[1]);
+        if (V(b).is_const && V(b).shape.size() == 2) return lower_linear(op);
+        int a = P.ensure_plain(in_val(op.m_input[0]));
+        b = P.ensure_plain(b);
+        Shape as = V(a).shape, bs = V(b).shape;
+        bool lead1 = false;
+        if (as.size() == 4 && as[0] == 1) { as.erase(as.begin()); lead1 = true; }
+        if (bs.size() == 4 && bs[0] == 1) bs.erase(bs.begin());
+        need(op, as.size() == 3 && bs.size() == 3 && as[0] == bs[0] && as[2] == bs[1], "invalid shape of inputs.");
+        const long n = as[0], M = as[1], K = as[2], Nn = bs[2];
+        Shape os = {n, M, Nn};
+        if (lead1) os.insert(os.begin(), 1);
+        const bool batched = V(a).batched || V(b).batched;
+        int y = out_val(op, os, Lay::plain, batched);
+        const long batch = n * (batched ? N : 1);
+        // an operand that is not batched is re-read for every sample: stride 0 across samples is not expressible with one
+        // stride, so require both or neither when N > 1
+        need(op, N == 1 || (V(a).batched == V(b).batched), "mixing per-sample and shared dynamic operands is not implemented.");
+        emit_gemm("MatMul " + op.m_name, a, b, -1, -1, y, M, Nn, K, batch, M * K, K * Nn, M * Nn, 0);
+    }
+
+    // Gemm (reference :4300-4375): A[1,K] x B[K,N] + bias, no alpha/beta/trans
+    void lower_gemm(const Operation& op) {
+        need(op, op.m_input.size() == 3, "wrong number of inputs. 2 inputs case not implemented.");
+        need(op, op.m_output.size() == 1, "wrong number of outputs.");
+        for (auto& a : op.m_attributes) {
+            if (a.first == "alpha" || a.first == "beta") need(op, std::stof(a.second) == 1.0f, (a.first + " != 1 case not implemented.").c_str());
+            else if (a.first == "transA" || a.first == "transB") need(op, std::stoi(a.second) == 0, (a.first + " != 0 case not implemented.").c_str());
+            else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
+        }
+        int a = P.ensure_plain(in_val(op.m_input[0]));
+        int w = in_val(op.m_input[1]);
+        int bias = in_val(op.m_input[2]);
+        need(op, V(w).is_const && V(w).shape.size() == 2 && V(a).shape.size() == 2, "not implemented (shape of inputs).");
+        const long M = V(a).shape[0], K = V(a).shape[1], Nn = V(w).shape[1];
+        need(op, V(w).shape[0] == K, "invalid shape of inputs.");
+        need(op, M == 1 && V(bias).numel() == Nn, "invalid shape of bias.");
+        int y = out_val(op, {M, Nn}, Lay::plain, V(a).batched);
+        emit_gemm("Gemm " + op.m_name, a, weight_nk(w), bias, -1, y, M * B(a), Nn, K, 1, 0, 0, 0, 1);
+    }
+
+    // Add/Sub/Mul/Div with NumPy broadcasting (reference :3906-4000, :5056-5175, :5394-5477, :5605-5668)
+    void lower_binary(const Operation& op) {
+        need(op, op.m_input.size() == 2, "wrong number of inputs.");
+        need(op, op.m_output.size() == 1, "wrong number of outputs.");
+        int a = in_val(op.m_input[0]), b = in_val(op.m_input[1]);
+        need(op, V(a).dtype == OSG_F16 && V(b).dtype == OSG_F16, "wrong data type of inputs (only the arithmetic type is supported on the device).");
+        const osg_binary_kind kind = op.m_type == "Add" ? OSG_BIN_ADD : op.m_type == "Sub" ? OSG_BIN_SUB : op.m_type == "Mul" ? OSG_BIN_MUL : OSG_BIN_DIV;
+        // logical output shape (right-aligned broadcast, :855-876)
+        const Shape as = V(a).shape, bs = V(b).shape;
+        const size_t rank = std::max(as.size(), bs.size());
+        Shape os(rank);
+        for (size_t i = 0; i < rank; i++) {
+            long da = i + as.size() >= rank ? as[i + as.size() - rank] : 1;
+            long db = i + bs.size() >= rank ? bs[i + bs.size() - rank] : 1;
+            need(op, da == db || da == 1 || db == 1, "shapes are not broadcastable.");
+            os[i] = std::max(da, db);
+        }
+        const bool batched = V(a).batched || V(b).batched;
+        // ---- NHWC-aware fast paths: keep the conv layout when the other operand is per-channel / same-layout ----
+        auto per_channel = [&](int v, long C) {  // logical [C,1,1] / [1,C,1,1] / scalar
+            const Shape& s = V(v).shape;
+            if (V(v).lay == Lay::nhwc) return false;
+            if (V(v).numel() == 1) return true;
+            if (V(v).numel() != C) return false;
+            return (s.size() == 3 && s[0] == C) || (s.size() == 4 && s[1] == C);
+        };
+        Lay olay = Lay::plain;
+        Shape pa, pb;  // physical shapes handed to the kernel (without the batch dim)
+        if (V(a).lay == Lay::nhwc || V(b).lay == Lay::nhwc) {
+            int x = V(a).lay == Lay::nhwc ? a : b, o = x == a ? b : a;
+            const Shape& xs = V(x).shape;
+            const long C = xs[1], HW = xs[2] * xs[3];
+            if (V(o).lay == Lay::nhwc && V(o).shape == xs) {
+                olay = Lay::nhwc;
+                pa = pb = {HW, C};
+            } else if (per_channel(o, C) && os == xs) {
+                olay = Lay::nhwc;
+                Shape px = {HW, C}, po = {1, V(o).numel() == 1 ? 1 : C};
+                pa = x == a ? px : po;
+                pb = x == a ? po : px;
+            } else {
+                a = P.ensure_plain(a);
+                b = P.ensure_plain(b);
+            }
+        }
+        if (olay == Lay::plain) { pa = V(a).shape; pb = V(b).shape; }
+        int y = out_val(op, os, olay, batched);
+        // prepend the sample dim
+        const size_t prank = std::max(pa.size(), pb.size()) + 1;
+        need(op, prank <= 6, "rank too large for the device broadcast kernel.");
+        std::vector<long> sa(prank, 1), sb(prank, 1);
+        for (size_t i = 0; i < pa.size(); i++) sa[prank - pa.size() + i] = pa[i];
+        for (size_t i = 0; i < pb.size(); i++) sb[prank - pb.size() + i] = pb[i];
+        sa[0] = B(a);
+        sb[0] = B(b);
+        P.add_step(op.m_type + " " + op.m_name, {a, b}, {y}, [=, this] {
+            be.check(be.api.osg_binary(be.ctx, OSG_F16, kind, P.ptr(a), sa.data(), P.ptr(b), sb.data(), P.ptr(y), (int)prank), op.m_type.c_str());
+        });
+    }
+
+    void lower_unary(const Operation& op) {
+        need(op, op.m_input.size() == 1, "wrong number of inputs.");
+        need(op, op.m_output.size() == 1, "wrong number of outputs.");
+        int x = in_val(op.m_input[0]);
+        need(op, V(x).dtype == OSG_F16, "wrong data type of input.");
+        const std::string& t = op.m_type;
+        const osg_unary_kind k = t == "Sigmoid" ? OSG_UN_SIGMOID : t == "Erf" ? OSG_UN_ERF : t == "Sqrt" ? OSG_UN_SQRT : t == "Sin" ? OSG_UN_SIN
+                                 : t == "Cos" ? OSG_UN_COS : t == "Neg" ? OSG_UN_NEG : OSG_UN_SILU;
+        int y = out_val(op, V(x).shape, V(x).lay, V(x).batched);
+        const long n = P.total_elems(x);
+        P.add_step(t + " " + op.m_name, {x}, {y}, [=, this] { be.check(be.api.osg_unary(be.ctx, OSG_F16, k, P.ptr(x), P.ptr(y), n, 0.f), t.c_str()); });
+    }
+
+    // Pow (reference :5478-5604): scalar exponent only
+    void lower_pow(const Operation& op) {
+        need(op, op.m_input.size() == 2, "wrong number of inputs.");
+        int x = in_val(op.m_input[0]);
+        float p = 0;
+        need(op, const_scalar(op.m_input[1], &p) && cval(op.m_input[1])->shape.empty(), "power must be a scalar (not implemented).");
+        int y = out_val(op, V(x).shape, V(x).lay, V(x).batched);
+        const long n = P.total_elems(x);
+        P.add_step("Pow " + op.m_name, {x}, {y}, [=, this] { be.check(be.api.osg_unary(be.ctx, OSG_F16, OSG_UN_POW, P.ptr(x), P.ptr(y), n, p), "Pow"); });
+    }
+
+    // InstanceNormalization (reference :4788-5055): input [1,G,L]
+    void lower_instance_norm(const Operation& op) {
+        need(op, op.m_input.size() == 3, "wrong number of inputs.");
+        int x = P.ensure_plain(in_val(op.m_input[0]));
+        int sc = in_val(op.m_input[1]), bi = in_val(op.m_input[2]);
+        const Shape& s = V(x).shape;
+        need(op, s.size() == 3 && s[0] == 1, "input shape must be [1,G,L] (not implemented).");
+        need(op, V(sc).numel() == s[1] && V(bi).numel() == s[1] && V(sc).dtype == OSG_F32 && V(bi).dtype == OSG_F32, "invalid scale/bias.");
+        float eps = 1e-5f;
+        for (auto& a : op.m_attributes) {
+            if (a.first == "epsilon") eps = std::stof(a.second);
+            else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
+        }
+        int y = out_val(op, s, Lay::plain, V(x).batched);
+        const long rows = s[1] * B(x), L = s[2], G = s[1];
+        P.add_step("InstanceNorm " + op.m_name, {x, sc, bi}, {y}, [=, this] {
+            be.check(be.api.osg_instance_norm(be.ctx, OSG_F16, P.ptr(x), (const float*)P.ptr(sc), (const float*)P.ptr(bi), P.ptr(y), (int)rows, L,
+                                              (int)G, eps),
+                     "InstanceNormalization");
+        });
+    }
+
+    void lower_group_norm(const Operation& op) {
+        int x = P.ensure_nhwc(in_val(op.m_input[0]));
+        int g = in_val(op.m_input[1]), b = in_val(op.m_input[2]);
+        const Shape& s = V(x).shape;
+        const long G = std::stol(*attr(op, "groups"));
+        const float eps = std::stof(*attr(op, "epsilon"));
+        const int act = *attr(op, "silu") == "1" ? OSG_ACT_SILU : OSG_ACT_NONE;
+        int y = out_val(op, s, Lay::nhwc, V(x).batched);
+        const long nb = B(x), HW = s[2] * s[3], C = s[1];
+        P.add_step("GroupNorm " + op.m_name, {x, g, b}, {y}, [=, this] {
+            be.check(be.api.osg_group_norm_nhwc(be.ctx, OSG_F16, P.ptr(x), P.ptr(g), P.ptr(b), P.ptr(y), (int)nb, HW, (int)C, (int)G, eps, (osg_act)act),
+                     "GroupNorm");
+        });
+    }
+
+    void lower_layer_norm(const Operation& op) {
+        int x = P.ensure_plain(in_val(op.m_input[0]));
+        int g = in_val(op.m_input[1]), b = in_val(op.m_input[2]);
+        const Shape& s = V(x).shape;
+        const float eps = std::stof(*attr(op, "epsilon"));
+        int y = out_val(op, s, Lay::plain, V(x).batched);
+        const long C = s.back(), rows = P.total_elems(x) / C;
+        P.add_step("LayerNorm " + op.m_name, {x, g, b}, {y}, [=, this] {
+            be.check(be.api.osg_layer_norm(be.ctx, OSG_F16, P.ptr(x), P.ptr(g), P.ptr(b), P.ptr(y), rows, (int)C, eps), "LayerNorm");
+        });
+    }
+
+    void lower_geglu(const Operation& op) {
+        int x = P.ensure_plain(in_val(op.m_input[0]));
+        Shape s = V(x).shape;
+        const long C = s.back() / 2, rows = P.total_elems(x) / s.back();
+        s.back() = C;
+        int y = out_val(op, s, Lay::plain, V(x).batched);
+        P.add_step("GEGLU " + op.m_name, {x}, {y}, [=, this] { be.check(be.api.osg_geglu(be.ctx, OSG_F16, P.ptr(x), P.ptr(y), rows, C), "GEGLU"); });
+    }
+
+    void lower_attention(const Operation& op) {
+        int q = P.ensure_plain(in_val(op.m_input[0])), k = P.ensure_plain(in_val(op.m_input[1])), v = P.ensure_plain(in_val(op.m_input[2]));
+        const long h = std::stol(*attr(op, "heads"));
+        const float scale = std::stof(*attr(op, "scale"));
+        const Shape& qs = V(q).shape;
+        const long Tq = qs[1], C = qs[2], Tk = V(k).shape[1], d = C / h;
+        int y = out_val(op, qs, Lay::plain, V(q).batched);
+        need(op, V(q).batched == V(k).batched && V(k).batched == V(v).batched, "q/k/v batching mismatch.");
+        const long nb = B(q);
+        P.add_step("Attention " + op.m_name, {q, k, v}, {y}, [=, this] {
+            be.check(be.api.osg_attention_strided(be.ctx, OSG_F16, P.ptr(q), C, d, Tq * C, P.ptr(k), C, d, Tk * C, P.ptr(v), C, d, Tk * C, P.ptr(y), C, d,
+                                                  Tq * C, (int)nb, (int)h, (int)Tq, (int)Tk, (int)d, scale),
+                     "Attention");
+        });
+    }
+
+    // AttentionFusedOps (reference :6696-6929): q [n,Tq,d], k [n,d,Tk] (already transposed), optional scalar s, v [n,Tk,d]
+    void lower_attention_fused_ops(const Operation& op) {
+        need(op, op.m_input.size() == 4, "wrong number of inputs.");
+        int q = P.ensure_plain(in_val(op.m_input[0])), k = P.ensure_plain(in_val(op.m_input[1])), v = P.ensure_plain(in_val(op.m_input[3]));
+        Shape qs = V(q).shape, ks = V(k).shape, vs = V(v).shape;
+        bool lead1 = false;
+        if (qs.size() == 4 && qs[0] == 1 && ks.size() == 4 && ks[0] == 1 && vs.size() == 4 && vs[0] == 1) {
+            qs.erase(qs.begin()); ks.erase(ks.begin()); vs.erase(vs.begin());
+            lead1 = true;
+        }
+        need(op, qs.size() == 3 && ks.size() == 3 && vs.size() == 3, "shapes of q, k and v must have 3 dimensions.");
+        need(op, qs[0] == ks[0] && qs[0] == vs[0] && ks[1] == qs[2] && vs[1] == ks[2] && vs[2] == qs[2], "invalid shape(s) of q, k and/or v.");
+        float scale = 1.0f;
+        if (!op.m_input[2].m_name.empty()) {
+            need(op, cval(op.m_input[2]) && cval(op.m_input[2])->shape.empty() && const_scalar(op.m_input[2], &scale), "s must be a scalar.");
+        }
+        need(op, (size_t)qs[1] >= m.m_attention_fused_ops_parts, "m_attention_fused_ops_parts is not valid.");
+        Shape os = qs;
+        if (lead1) os.insert(os.begin(), 1);
+        int y = out_val(op, os, Lay::plain, V(q).batched);
+        need(op, V(q).batched == V(k).batched && V(k).batched == V(v).batched, "q/k/v batching mismatch.");
+        const long heads = qs[0] * B(q), Tq = qs[1], d = qs[2], Tk = ks[2];
+        P.add_step("AttentionFusedOps " + op.m_name, {q, k, v}, {y}, [=, this] {
+            be.check(be.api.osg_attention(be.ctx, OSG_F16, P.ptr(q), P.ptr(k), P.ptr(v), P.ptr(y), (int)heads, (int)Tq, (int)Tk, (int)d, scale, 1),
+                     "AttentionFusedOps");
+        });
+    }
+
+    // ReduceMean (reference :5237-5393): last axis, keepdims
+    void lower_reduce_mean(const Operation& op) {
+        need(op, op.m_input.size() == 1, "wrong number of inputs.");
+        int x = P.ensure_plain(in_val(op.m_input[0]));
+        const Shape& s = V(x).shape;
+        for (auto& a : op.m_attributes) {
+            if (a.first == "axes") {
+                auto ax = int_list(a.second);
+                need(op, ax.size() == 1 && (ax[0] == -1 || ax[0] == (int)s.size() - 1), "reduction supported on the last axis only (not implemented).");
+            } else if (a.first == "keepdims") need(op, std::stoi(a.second) == 1, "keepdims must be 1 (not implemented).");
+            else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
+        }
+        Shape os = s;
+        os.back() = 1;
+        int y = out_val(op, os, Lay::plain, V(x).batched);
+        const long C = s.back(), rows = P.total_elems(x) / C;
+        P.add_step("ReduceMean " + op.m_name, {x}, {y}, [=, this] { be.check(be.api.osg_reduce_mean_last(be.ctx, OSG_F16, P.ptr(x), P.ptr(y), rows, C), "ReduceMean"); });
+    }
+
+    // Softmax (reference :5862-5998): any axis via transpose-in / softmax / transpose-out (:5883-5923)
+    void lower_softmax(const Operation& op) {
+        need(op, op.m_input.size() == 1, "wrong number of inputs.");
+        int x = P.ensure_plain(in_val(op.m_input[0]));
+        const Shape s = V(x).shape;
+        int axis = -1;
+        for (auto& a : op.m_attributes) {
+            if (a.first == "axis") axis = std::stoi(a.second);
+            else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
+        }
+        const int rank = (int)s.size();
+        if (axis < 0) axis += rank;
+        need(op, axis >= 0 && axis < rank, "invalid axis.");
+        int y = out_val(op, s, Lay::plain, V(x).batched);
+        const long nb = B(x);
+        if (axis == rank - 1) {
+            const long C = s.back(), rows = P.total_elems(x) / C;
+            P.add_step("Softmax " + op.m_name, {x}, {y}, [=, this] { be.check(be.api.osg_softmax_last(be.ctx, OSG_F16, P.ptr(x), P.ptr(y), rows, C), "Softmax"); });
+            return;
+        }
+        // [outer, A, inner] -> [outer, inner, A] -> softmax -> back
+        const long outer = prod(s, 0, axis) * nb, A = s[axis], inner = prod(s, axis + 1);
+        int t0 = P.new_val("", s, OSG_F16, Lay::plain, V(x).batched), t1 = P.new_val("", s, OSG_F16, Lay::plain, V(x).batched);
+        P.add_step("Softmax/T0 " + op.m_name, {x}, {t0}, [=, this] {
+            long sh[3] = {outer, A, inner}; int pm[3] = {0, 2, 1};
+            be.check(be.api.osg_transpose(be.ctx, 2, P.ptr(x), P.ptr(t0), 3, sh, pm), "Softmax");
+        });
+        P.add_step("Softmax " + op.m_name, {t0}, {t1}, [=, this] { be.check(be.api.osg_softmax_last(be.ctx, OSG_F16, P.ptr(t0), P.ptr(t1), outer * inner, A), "Softmax"); });
+        P.add_step("Softmax/T1 " + op.m_name, {t1}, {y}, [=, this] {
+            long sh[3] = {outer, inner, A}; int pm[3] = {0, 2, 1};
+            be.check(be.api.osg_transpose(be.ctx, 2, P.ptr(t1), P.ptr(y), 3, sh, pm), "Softmax");
+        });
+    }
+
+    // Reshape (reference :4708-4787): zero-copy; an NHWC producer is brought back to the logical layout first (:4724)
+    void lower_reshape(const Operation& op) {
+        need(op, op.m_input.size() == 2, "wrong number of inputs.");
+        for (auto& a : op.m_attributes) {
+            if (a.first == "allowzero") need(op, std::stoi(a.second) == 0, "allowzero != 0 not supported (not implemented).");
+            else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
+        }
+        int x = in_val(op.m_input[0]);
+        const Val* sv = cval(op.m_input[1]);
+        need(op, sv && sv->dtype == OSG_I64 && sv->host_valid, "wrong data type of shape.");
+        const long total = V(x).numel();
+        Shape os;
+        long known = 1;
+        int infer = -1;
+        for (size_t i = 0; i < sv->host_i.size(); i++) {
+            long d = sv->host_i[i];
+            if (d == 0) { need(op, i < V(x).shape.size(), "invalid 0 in shape."); d = V(x).shape[i]; }
+            if (d == -1) { need(op, infer < 0, "more than one -1 in shape."); infer = (int)i; os.push_back(1); continue; }
+            os.push_back(d);
+            known *= d;
+        }
+        if (infer >= 0) { need(op, known && total % known == 0, "invalid shape."); os[infer] = total / known; }
+        need(op, prod(os) == total, "invalid shape.");
+        // layout-preserving special case: an NHWC [1,C,H,W] tensor reshaped to [1,C,H*W]... is NOT a no-op; go plain.
+        x = P.ensure_plain(x);
+        check_out(op, os);
+        P.alias(x, os, Lay::plain, op.m_output[0].m_name);
+    }
+
+    void lower_flatten(const Operation& op) {
+        int x = P.ensure_plain(in_val(op.m_input[0]));
+        int axis = 1;
+        if (auto* a = attr(op, "axis")) axis = std::stoi(*a);
+        const Shape& s = V(x).shape;
+        if (axis < 0) axis += (int)s.size();
+        Shape os = {prod(s, 0, axis), prod(s, axis)};
+        check_out(op, os);
+        P.alias(x, os, Lay::plain, op.m_output[0].m_name);
+    }
+
+    // Unsqueeze (reference :3859-3905) / Squeeze (:7425): axes from a static int64 tensor
+    void lower_squeeze(const Operation& op, bool unsq) {
+        need(op, op.m_input.size() == 2, "wrong number of inputs.");
+        int x = P.ensure_plain(in_val(op.m_input[0]));
+        const Val* ax = cval(op.m_input[1]);
+        need(op, ax && ax->dtype == OSG_I64 && ax->host_valid, "wrong data type of axes.");
+        Shape os = V(x).shape;
+        std::vector<long> axes(ax->host_i.begin(), ax->host_i.end());
+        if (unsq) {
+            const long orank = (long)os.size() + (long)axes.size();
+            for (auto& a : axes) if (a < 0) a += orank;
+            std::sort(axes.begin(), axes.end());
+            for (long a : axes) { need(op, a >= 0 && a <= (long)os.size(), "invalid axis."); os.insert(os.begin() + a, 1); }
+        } else {
+            for (auto& a : axes) if (a < 0) a += (long)os.size();
+            std::sort(axes.rbegin(), axes.rend());
+            for (long a : axes) { need(op, a >= 0 && a < (long)os.size() && os[a] == 1, "invalid axis."); os.erase(os.begin() + a); }
+        }
+        check_out(op, os);
+        P.alias(x, os, Lay::plain, op.m_output[0].m_name);
+    }
+
+    // Transpose (reference :5176-5236).  (0,2,3,1) of an NHWC tensor and (0,3,1,2) into an NHWC tensor are relabelings.
+    void lower_transpose(const Operation& op) {
+        need(op, op.m_input.size() == 1, "wrong number of inputs.");
+        auto* pm = attr(op, "perm");
+        need(op, pm != nullptr, "perm attribute not found.");
+        std::vector<int> perm = int_list(*pm);
+        int x = in_val(op.m_input[0]);
+        const Shape s = V(x).shape;
+        need(op, perm.size() == s.size(), "invalid perm.");
+        Shape os(s.size());
+        for (size_t i = 0; i < s.size(); i++) { need(op, perm[i] >= 0 && perm[i] < (int)s.size(), "invalid index in perm."); os[i] = s[perm[i]]; }
+        check_out(op, os);
+        if (V(x).lay == Lay::nhwc && perm == std::vector<int>{0, 2, 3, 1}) {
+            P.alias(x, os, Lay::plain, op.m_output[0].m_name);
+            return;
+        }
+        if (V(x).lay == Lay::plain && s.size() == 4 && perm == std::vector<int>{0, 3, 1, 2}) {
+            P.alias(x, os, Lay::nhwc, op.m_output[0].m_name);
+            return;
+        }
+        x = P.ensure_plain(x);
+        int y = P.new_val(op.m_output[0].m_name, os, V(x).dtype, Lay::plain, V(x).batched);
+        const int rank = (int)s.size() + 1;
+        need(op, rank <= 6, "rank too large.");
+        std::vector<long> sh(rank);
+        std::vector<int> pp(rank);
+        sh[0] = B(x); pp[0] = 0;
+        for (int i = 1; i < rank; i++) { sh[i] = s[i - 1]; pp[i] = perm[i - 1] + 1; }
+        const int es = (int)esize(V(x).dtype);
+        P.add_step("Transpose " + op.m_name, {x}, {y}, [=, this] { be.check(be.api.osg_transpose(be.ctx, es, P.ptr(x), P.ptr(y), rank, sh.data(), pp.data()), "Transpose"); });
+    }
+
+    // Concat (reference :4140-4299)
+    void lower_concat(const Operation& op) {
+        need(op, !op.m_input.empty(), "wrong number of inputs.");
+        auto* ax = attr(op, "axis");
+        need(op, ax != nullptr, "axis attribute not found.");
+        int axis = std::stoi(*ax);
+        std::vector<int> xs;
+        for (auto& t : op.m_input) xs.push_back(in_val(t));
+        const int rank = (int)V(xs[0]).shape.size();
+        if (axis < 0) axis += rank;
+        need(op, axis >= 0 && axis < rank, "invalid axis.");
+        bool all_nhwc = rank == 4 && axis == 1;
+        for (int x : xs) all_nhwc &= V(x).lay == Lay::nhwc;
+        bool batched = false;
+        for (int& x : xs) { if (!all_nhwc) x = P.ensure_plain(x); batched |= V(x).batched; }
+        for (int x : xs) need(op, V(x).batched == batched || N == 1, "mixing per-sample and shared operands is not implemented.");
+        Shape os = V(xs[0]).shape;
+        os[axis] = 0;
+        for (int x : xs) {
+            const Shape& s = V(x).shape;
+            need(op, (int)s.size() == rank, "invalid shape of inputs.");
+            for (int d = 0; d < rank; d++) need(op, d == axis || s[d] == V(xs[0]).shape[d], "invalid shape of inputs.");
+            os[axis] += s[axis];
+        }
+        int y = out_val(op, os, all_nhwc ? Lay::nhwc : Lay::plain, batched);
+        const int es = (int)esize(V(y).dtype);
+        long outer, dst_pitch, off = 0;
+        if (all_nhwc) { outer = os[2] * os[3] * (batched ? N : 1); dst_pitch = os[1]; }
+        else { outer = prod(os, 0, axis) * (batched ? N : 1); dst_pitch = prod(os, axis); }
+        for (int x : xs) {
+            const long inner = all_nhwc ? V(x).shape[1] : prod(V(x).shape, axis);
+            const long o = off;
+            P.add_step("Concat " + op.m_name, {x}, {y}, [=, this] { be.check(be.api.osg_copy_2d(be.ctx, es, P.ptr(x), inner, 0, P.ptr(y), dst_pitch, o, outer, inner), "Concat"); });
+            off += inner;
+        }
+    }
+
+    // Split (reference :5999-6119): sizes from a static int64 tensor
+    void lower_split(const Operation& op) {
+        need(op, op.m_input.size() == 2, "wrong number of inputs.");
+        int x = in_val(op.m_input[0]);
+        const Val* sz = cval(op.m_input[1]);
+        need(op, sz && sz->dtype == OSG_I64 && sz->host_valid && sz->host_i.size() == op.m_output.size(), "invalid split tensor.");
+        int axis = 0;
+        if (auto* a = attr(op, "axis")) axis = std::stoi(*a);
+        const int rank = (int)V(x).shape.size();
+        if (axis < 0) axis += rank;
+        const bool nhwc = V(x).lay == Lay::nhwc && axis == 1;
+        if (!nhwc) x = P.ensure_plain(x);
+        const Shape s = V(x).shape;
+        long sum = 0;
+        for (auto v : sz->host_i) sum += v;
+        need(op, sum == s[axis], "invalid split sizes.");
+        const int es = (int)esize(V(x).dtype);
+        const long outer = (nhwc ? s[2] * s[3] : prod(s, 0, axis)) * B(x), src_pitch = nhwc ? s[1] : prod(s, axis);
+        const long unit = nhwc ? 1 : prod(s, axis + 1);
+        long off = 0;
+        for (size_t i = 0; i < op.m_output.size(); i++) {
+            Shape os = s;
+            os[axis] = sz->host_i[i];
+            int y = out_val(op, os, nhwc ? Lay::nhwc : Lay::plain, V(x).batched, V(x).dtype, i);
+            const long inner = sz->host_i[i] * unit, o = off;
+            P.add_step("Split " + op.m_name, {x}, {y}, [=, this] { be.check(be.api.osg_copy_2d(be.ctx, es, P.ptr(x), src_pitch, o, P.ptr(y), inner, 0, outer, inner), "Split"); });
+            off += inner;
+        }
+    }
+
+    // Slice (reference :6499-6695): last or last-but-one axis, step 1, one or two axes
+    void lower_slice(const Operation& op) {
+        need(op, op.m_input.size() >= 3 && op.m_input.size() <= 5, "wrong number of inputs.");
+        need(op, op.m_attributes.empty(), "unrecognized attribute (not implemented).");
+        int x = P.ensure_plain(in_val(op.m_input[0]));
+        const Val* st = cval(op.m_input[1]);
+        const Val* en = cval(op.m_input[2]);
+        const Val* ax = op.m_input.size() > 3 ? cval(op.m_input[3]) : nullptr;
+        const Val* sp = op.m_input.size() > 4 ? cval(op.m_input[4]) : nullptr;
+        need(op, st && en && st->dtype == OSG_I64 && en->dtype == OSG_I64, "wrong data type of starts.");
+        const size_t na = st->host_i.size();
+        need(op, (na == 1 || na == 2) && en->host_i.size() == na, "unsupported shape of starts (not implemented).");
+        int cur = x;
+        for (size_t k = 0; k < na; k++) {
+            const Shape s = V(cur).shape;
+            const int rank = (int)s.size();
+            int axis = rank - 1;
+            if (ax) { need(op, ax->host_i.size() == na, "unsupported shape of axes (not implemented)."); axis = (int)ax->host_i[k]; if (axis < 0) axis += rank; }
+            else if (na == 2) axis = rank - 2 + (int)k;
+            need(op, axis == rank - 1 || axis == rank - 2, "unsupported axes value(s): slice supported on last or last but one axis only (not implemented).");
+            if (sp) need(op, sp->host_i.size() == na && sp->host_i[k] == 1, "unsupported steps value(s) (not implemented).");
+            long dim = s[axis], b = st->host_i[k], e = en->host_i[k];
+            if (b < 0) b += dim;
+            if (b > dim - 1) b = dim - 1;
+            if (e < 0) e += dim;
+            if (e > dim) e = dim;
+            need(op, b >= 0 && e >= 0 && b < e, "invalid value(s) in starts and/or ends.");
+            Shape os = s;
+            os[axis] = e - b;
+            const bool last = k + 1 == na;
+            int y = last ? out_val(op, os, Lay::plain, V(cur).batched, V(cur).dtype) : P.new_val("", os, V(cur).dtype, Lay::plain, V(cur).batched);
+            const int es = (int)esize(V(cur).dtype);
+            const long unit = prod(s, axis + 1), outer = prod(s, 0, axis) * B(cur), src_pitch = dim * unit, inner = (e - b) * unit, off = b * unit;
+            const int src = cur;
+            P.add_step("Slice " + op.m_name, {src}, {y}, [=, this] { be.check(be.api.osg_copy_2d(be.ctx, es, P.ptr(src), src_pitch, off, P.ptr(y), inner, 0, outer, inner), "Slice"); });
+            cur = y;
+        }
+    }
+
+    // Resize (reference :6120-6315): nearest / asymmetric / floor, scales or sizes
+    void lower_resize(const Operation& op) {
+        need(op, op.m_input.size() == 3 || op.m_input.size() == 4, "wrong number of inputs.");
+        for (auto& a : op.m_attributes) {
+            if (a.first == "coordinate_transformation_mode") need(op, a.second == "asymmetric", "coordinate_transformation_mode must be asymmetric (not implemented).");
+            else if (a.first == "mode") need(op, a.second == "nearest", "mode must be nearest (not implemented).");
+            else if (a.first == "nearest_mode") need(op, a.second == "floor", "nearest_mode must be floor (not implemented).");
+            else if (a.first == "cubic_coeff_a") {}
+            else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
+        }
+        int x = in_val(op.m_input[0]);
+        const Shape s = V(x).shape;
+        need(op, s.size() == 4 && s[0] == 1, "input must be [1,C,H,W] (not implemented).");
+        Shape os = s;
+        if (op.m_input.size() == 4 && !op.m_input[3].m_name.empty()) {
+            const Val* sz = cval(op.m_input[3]);
+            need(op, sz && sz->host_i.size() == 4, "invalid sizes.");
+            for (int i = 0; i < 4; i++) os[i] = sz->host_i[i];
+        } else {
+            const Val* sc = cval(op.m_input[2]);
+            need(op, sc && sc->host_valid && sc->host_f.size() == 4, "invalid scales.");
+            need(op, sc->host_f[0] == 1.f && sc->host_f[1] == 1.f, "scales for N and C must be 1 (not implemented).");
+            for (int i = 2; i < 4; i++) os[i] = (long)std::floor((float)s[i] * sc->host_f[i]);
+        }
+        need(op, os[0] == s[0] && os[1] == s[1], "resize of N/C not supported.");
+        const bool nhwc = V(x).lay == Lay::nhwc;
+        int y = out_val(op, os, V(x).lay, V(x).batched);
+        const int es = (int)esize(V(x).dtype);
+        const long nb = B(x);
+        P.add_step("Resize " + op.m_name, {x}, {y}, [=, this] {
+            be.check(be.api.osg_resize_nearest(be.ctx, es, P.ptr(x), P.ptr(y), (int)nb, (int)s[1], (int)s[2], (int)s[3], (int)os[2], (int)os[3], nhwc ? 1 : 0), "Resize");
+        });
+    }
+
+    // MaxPool (reference :8075-8148 -> XnnPack::maxpool_nhwc :1536)
+    void lower_maxpool(const Operation& op) {
+        need(op, op.m_input.size() == 1, "wrong number of inputs.");
+        std::vector<int> ks, pads = {0, 0, 0, 0}, strides = {1, 1};
+        for (auto& a : op.m_attributes) {
+            if (a.first == "kernel_shape") ks = int_list(a.second);
+            else if (a.first == "pads") pads = int_list(a.second);
+            else if (a.first == "strides") strides = int_list(a.second);
+            else if (a.first == "ceil_mode") need(op, std::stoi(a.second) == 0, "ceil_mode != 0 not supported.");
+            else if (a.first == "dilations") { for (int d : int_list(a.second)) need(op, d == 1, "dilations != 1 not supported."); }
+            else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
+        }
+        need(op, ks.size() == 2 && pads.size() == 4 && strides.size() == 2, "invalid attributes.");
+        int x = P.ensure_nhwc(in_val(op.m_input[0]));
+        const Shape s = V(x).shape;
+        const long Ho = (s[2] + pads[0] + pads[2] - ks[0]) / strides[0] + 1, Wo = (s[3] + pads[1] + pads[3] - ks[1]) / strides[1] + 1;
+        int y = out_val(op, {s[0], s[1], Ho, Wo}, Lay::nhwc, V(x).batched);
+        const long nb = B(x);
+        P.add_step("MaxPool " + op.m_name, {x}, {y}, [=, this] {
+            be.check(be.api.osg_maxpool_nhwc(be.ctx, OSG_F16, P.ptr(x), P.ptr(y), (int)nb, (int)s[2], (int)s[3], (int)s[1], ks[0], ks[1], strides[0], strides[1],
+                                             pads[0], pads[1], pads[2], pads[3]),
+                     "MaxPool");
+        });
+    }
+};
+
+// ======================================================================================================================
+Plan::~Plan() {
+    be.api.osg_sync(be.ctx);
+    if (graph) be.api.osg_graph_destroy(graph);
+    delete lowering;
+    for (void* p : owned) be.free(p);
+    if (arena) be.free(arena);
+}
+
+void Plan::build() {
+    if (!fp16)
+        throw std::runtime_error("Model::run: the HIP backend implements f16 arithmetic only; set m_use_fp16_arithmetic "
+                                 "(the configuration the reference uses for the SD UNet, src/sd.cpp:1633).");
+    if (m.m_use_uint8_arithmetic || m.m_use_uint8_qdq)
+        throw std::runtime_error("Model::run: uint8 activations (m_use_uint8_arithmetic / m_use_uint8_qdq) are not implemented on the HIP backend yet.");
+    ops = m.m_ops;
+    lowering = new Lowering(*this);
+    Lowering& L = *lowering;
+    L.load_weights();
+
+    // ---- graph inputs: every activation name that is consumed but never produced --------------------------------
+    {
+        std::map<std::string, bool> produced;
+        for (auto& op : ops)
+            for (auto& o : op.m_output) produced[o.m_name] = true;
+        std::map<std::string, bool> seen;
+        for (auto& op : ops)
+            for (auto& in : op.m_input) {
+                if (in.m_name.empty() || in.m_type != TensorDataType::none || produced.count(in.m_name) || seen.count(in.m_name)) continue;
+                seen[in.m_name] = true;
+                Tensor* src = nullptr;
+                for (auto& t : m.m_data)
+                    if (t.m_name == in.m_name) { src = &t; break; }
+                if (!src) throw std::invalid_argument("Model::get_tensor_data: input tensor not found: " + in.m_name);
+                if (src->m_type != TensorDataType::float32)
+                    throw std::invalid_argument("Model::run: graph inputs must be float32 host tensors on the HIP backend (" + in.m_name + ").");
+                Shape shape = to_shape(src->m_shape);
+                In inp;
+                inp.name = in.m_name;
+                inp.host_type = src->m_type;
+                inp.shape = src->m_shape;
+                inp.staging = new_val("", shape, OSG_F32, Lay::plain, true);
+                vals[inp.staging].dptr = be.malloc(val_bytes(inp.staging));
+                owned.push_back(vals[inp.staging].dptr);
+                vals[inp.staging].pinned = true;
+                // fp32 inputs are rounded to f16 when pushed with fp16 arithmetic on (reference push_tensor :3029-3034)
+                inp.val = new_val(in.m_name, shape, OSG_F16, Lay::plain, true);
+                const int s = inp.staging, d = inp.val;
+                const long n = total_elems(d);
+                add_step("input " + in.m_name, {s}, {d}, [this, s, d, n] {
+                    be.check(be.api.osg_convert(be.ctx, OSG_F32, OSG_F16, ptr(s), ptr(d), n, 1.f, 0), "osg_convert");
+                });
+                inputs.push_back(std::move(inp));
+            }
+    }
+
+    L.run_fusions();
+    L.lower_all();
+
+    // ---- graph outputs: produced but never consumed, plus the caller's extra outputs -> fp32, logical layout --------
+    {
+        std::map<std::string, int> consumed;
+        for (auto& op : ops)
+            for (auto& in : op.m_input)
+                if (!in.m_name.empty() && in.m_type == TensorDataType::none) consumed[in.m_name]++;
+        std::vector<std::string> names;
+        for (auto& op : ops)
+            for (auto& o : op.m_output)
+                if (!consumed.count(o.m_name)) names.push_back(o.m_name);
+        for (auto& e : extra_outputs)
+            if (by_name.count(e) && std::find(names.begin(), names.end(), e) == names.end()) names.push_back(e);
+        for (auto& nme : names) {
+            int v = ensure_plain(by_name.at(nme));
+            Out o;
+            o.name = nme;
+            o.val = v;
+            for (long d : vals[v].shape) o.shape.push_back((size_t)d);
+            o.f32val = new_val("", vals[v].shape, OSG_F32, Lay::plain, vals[v].batched);
+            vals[o.f32val].dptr = be.malloc(val_bytes(o.f32val));
+            owned.push_back(vals[o.f32val].dptr);
+            vals[o.f32val].pinned = true;
+            const int s = v, d = o.f32val;
+            const long n = total_elems(v);
+            const osg_dtype sd = vals[v].dtype;
+            add_step("output " + nme, {s}, {d}, [this, s, d, n, sd] { be.check(be.api.osg_convert(be.ctx, sd, OSG_F32, ptr(s), ptr(d), n, 1.f, 0), "osg_convert"); });
+            outputs.push_back(std::move(o));
+        }
+    }
+
+    // ---- liveness + arena packing -----------------------------------------------------------------------------------
+    for (size_t si = 0; si < steps.size(); si++)
+        for (auto* lst : {&steps[si].reads, &steps[si].writes})
+            for (int v : *lst) {
+                Val& r = vals[root_of(v)];
+                r.first = std::min(r.first, (int)si);
+                r.last = std::max(r.last, (int)si);
+            }
+    struct Block { size_t off, size; };
+    std::vector<Block> free_list;
+    size_t top = 0;
+    auto take = [&](size_t size) {
+        for (size_t i = 0; i < free_list.size(); i++)
+            if (free_list[i].size >= size) {
+                size_t off = free_list[i].off;
+                free_list[i].off += size;
+                free_list[i].size -= size;
+                if (!free_list[i].size) free_list.erase(free_list.begin() + i);
+                return off;
+            }
+        if (!free_list.empty() && free_list.back().off + free_list.back().size == top) {  // grow the trailing hole
+            size_t off = free_list.back().off;
+            top = off + size;
+            free_list.pop_back();
+            return off;
+        }
+        size_t off = top;
+        top += size;
+        return off;
+    };
+    auto give = [&](size_t off, size_t size) {
+        free_list.push_back({off, size});
+        std::sort(free_list.begin(), free_list.end(), [](const Block& a, const Block& b) { return a.off < b.off; });
+        for (size_t i = 0; i + 1 < free_list.size();)
+            if (free_list[i].off + free_list[i].size == free_list[i + 1].off) {
+                free_list[i].size += free_list[i + 1].size;
+                free_list.erase(free_list.begin() + i + 1);
+            } else i++;
+    };
+    std::vector<std::vector<int>> born(steps.size()), dies(steps.size());
+    for (size_t v = 0; v < vals.size(); v++) {
+        Val& r = vals[v];
+        if (r.root >= 0 || r.dptr || r.is_const || r.last < 0) continue;
+        born[r.first].push_back((int)v);
+        dies[r.last].push_back((int)v);
+    }
+    auto aligned = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    for (size_t si = 0; si < steps.size(); si++) {
+        for (int v : born[si]) vals[v].offset = take(aligned(val_bytes(v)));
+        for (int v : dies[si]) give(vals[v].offset, aligned(val_bytes(v)));
+    }
+    arena_bytes = top ? top : 256;
+    arena = be.malloc(arena_bytes);
+    be.check(be.api.osg_sync(be.ctx), "osg_sync");
+}
+
+void Plan::execute() {
+    // ---- stage the inputs (host fp32, N samples stacked) -------------------------------------------------------------
+    for (auto& in : inputs) {
+        Tensor* src = nullptr;
+        for (auto& t : m.m_data)
+            if (t.m_name == in.name) { src = &t; break; }
+        if (!src) throw std::invalid_argument("Model::get_tensor_data: input tensor not found: " + in.name);
+        if (src->m_type != in.host_type || src->m_shape != in.shape)
+            throw std::invalid_argument("Model::run: input '" + in.name + "' changed type or shape since the plan was built.");
+        const size_t per = vals[in.staging].numel() * sizeof(float);
+        auto upload = [&](Tensor& t, long idx) {
+            auto& vec = t.get_vector<float>();
+            if (vec.size() * sizeof(float) != per) throw std::invalid_argument("Model::get_tensor_data: mismatch between tensor shape and data size.");
+            be.check(be.api.osg_upload(be.ctx, (char*)ptr(in.staging) + idx * per, vec.data(), per), "osg_upload");
+        };
+        upload(*src, 0);
+        const long extra = src->m_batch ? (long)src->m_batch->size() : 0;
+        if (extra + 1 != N) throw std::invalid_argument("Model::run: inconsistent m_batch.size() across two or more tensors.");
+        for (long i = 0; i < extra; i++) upload((*src->m_batch)[i], i + 1);
+    }
+    // ---- run the pass -------------------------------------------------------------------------------------------------
+    be.check(be.api.osg_timer_start(be.ctx), "osg_timer_start");
+    const bool print = m.m_ops_printf;
+    if (graph && !print) {
+        be.check(be.api.osg_graph_launch(be.ctx, graph), "osg_graph_launch");
+    } else if (runs >= 1 && m.m_hip_use_graph && !print && !graph) {
+        be.check(be.api.osg_graph_begin(be.ctx), "osg_graph_begin");
+        try {
+            for (auto& s : steps) s.run();
+        } catch (...) {
+            osg_graph* g = nullptr;
+            be.api.osg_graph_end(be.ctx, &g);
+            if (g) be.api.osg_graph_destroy(g);
+            throw;
+        }
+        be.check(be.api.osg_graph_end(be.ctx, &graph), "osg_graph_end");
+        be.check(be.api.osg_graph_launch(be.ctx, graph), "osg_graph_launch");
+    } else {
+        int idx = 0;
+        for (auto& s : steps) {
+            if (print) printf("#%i) %s\n", idx++, s.what.c_str());
+            s.run();
+        }
+    }
+    float ms = 0;
+    be.check(be.api.osg_timer_stop(be.ctx, &ms), "osg_timer_stop");
+    m_last_ms = ms;
+    runs++;
+    // ---- consume the inputs, publish the outputs as fp32 host tensors in the logical (NCHW) layout (reference :8217-8263) --
+    for (auto& in : inputs)
+        for (size_t i = 0; i < m.m_data.size(); i++)
+            if (m.m_data[i].m_name == in.name) { m.m_data.erase(m.m_data.begin() + i); break; }
+    for (auto& o : outputs) {
+        const size_t per_elems = (size_t)vals[o.f32val].numel();
+        const long nb = vals[o.f32val].batched ? N : 1;
+        Tensor first;
+        for (long i = 0; i < nb; i++) {
+            tensor_vector<float> host(per_elems);
+            be.check(be.api.osg_download(be.ctx, host.data(), (char*)ptr(o.f32val) + i * per_elems * sizeof(float), per_elems * sizeof(float)), "osg_download");
+            Tensor t;
+            t.m_name = o.name;
+            t.m_shape = o.shape;
+            t.set_vector(std::move(host));
+            if (i == 0) first = std::move(t);
+            else {
+                if (!first.m_batch) first.m_batch = std::make_shared<std::vector<Tensor>>();
+                first.m_batch->push_back(std::move(t));
+            }
+        }
+        for (size_t i = 0; i < m.m_data.size(); i++)
+            if (m.m_data[i].m_name == o.name) { m.m_data.erase(m.m_data.begin() + i); break; }
+        m.m_data.push_back(std::move(first));
+    }
+}
+
+}  // namespace onnxstream

@@ -1,0 +1,99 @@
+// plan.h -- the device execution plan behind Model::run().
+//
+// The reference interprets the graph op by op on the host, allocating every output and converting layouts/dtypes
+// around each call (reference src/onnxstream.cpp:3550-8269).  On MI355X that shape of execution is launch- and
+// PCIe-bound, so this backend lowers the WHOLE graph once:
+//   parse (model.cpp) -> fetch weights through the WeightsProvider in model order and make them resident in HBM
+//   -> graph-level fusion (SiLU, GroupNorm, LayerNorm, GEGLU, Linear+bias+residual, attention incl. head split/merge)
+//   -> lowering to a list of kernel launches over device-resident f16 activations (NHWC around convolutions)
+//   -> liveness-based packing of all activations into one HBM arena
+//   -> eager first pass, then capture into a hipGraph that later passes replay.
+#pragma once
+
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "backend.h"
+#include "onnxstream.h"
+
+namespace onnxstream {
+
+enum class Lay { plain, nhwc };
+
+struct Val {
+    std::string name;
+    std::vector<long> shape;      // logical (ONNX) shape of ONE sample
+    osg_dtype dtype = OSG_F16;
+    Lay lay = Lay::plain;         // nhwc: 4-D logical [n,C,H,W] stored as [n,H,W,C]
+    bool batched = false;         // one copy per pushed sample, stacked contiguously
+    bool is_const = false;        // resident weight / constant
+    int root = -1;                // >=0: alias sharing the storage of another val
+    void* dptr = nullptr;         // constants & pinned buffers: own allocation
+    size_t offset = 0;            // activations: offset inside the arena
+    bool pinned = false;          // graph input/output staging: never recycled
+    int first = 1 << 30, last = -1;
+    std::vector<float> host_f;    // small constants, available at plan time
+    std::vector<int64_t> host_i;
+    bool host_valid = false;
+    int as_plain = -1, as_nhwc = -1;
+    long numel() const { long n = 1; for (auto d : shape) n *= d; return n; }
+};
+
+struct Step {
+    std::string what;
+    std::function<void()> run;
+    std::vector<int> reads, writes;
+};
+
+struct Lowering;
+
+struct Plan {
+    Plan(Model& m, HipBackend& be, size_t batch);
+    ~Plan();
+    void build();
+    void execute();
+    bool compatible(Model& m, size_t batch) const;
+    size_t kernel_count() const { return steps.size(); }
+    double last_ms() const { return m_last_ms; }
+
+    Model& m;
+    HipBackend& be;
+    long N;  // batch (number of samples pushed under each input name)
+
+    std::vector<Operation> ops;  // working copy of the graph (mutated by the fusion passes)
+    std::vector<Val> vals;
+    std::map<std::string, int> by_name;
+    std::vector<Step> steps;
+    std::vector<void*> owned;     // device allocations owned by the plan (weights, staging, outputs)
+    void* arena = nullptr;
+    size_t arena_bytes = 0, weight_bytes = 0;
+
+    struct In { std::string name; int val; int staging; TensorDataType host_type; std::vector<size_t> shape; };
+    struct Out { std::string name; int val; int f32val; std::vector<size_t> shape; };
+    std::vector<In> inputs;
+    std::vector<Out> outputs;
+
+    osg_graph* graph = nullptr;
+    Lowering* lowering = nullptr;  // kept alive: the launch closures capture it
+    int runs = 0;
+    double m_last_ms = 0;
+    // options the plan was built with
+    bool fp16 = true;
+    int fusion = 2;
+    std::vector<std::string> extra_outputs;
+
+    // ---- helpers used by the lowering code (plan.cpp) ----
+    int new_val(const std::string& name, const std::vector<long>& shape, osg_dtype dt, Lay lay, bool batched);
+    int alias(int v, const std::vector<long>& shape, Lay lay, const std::string& name = "");
+    int root_of(int v) const;
+    void* ptr(int v) const;
+    size_t val_bytes(int v) const;
+    long total_elems(int v) const;
+    void add_step(const std::string& what, std::vector<int> reads, std::vector<int> writes, std::function<void()> fn);
+    int ensure_plain(int v);
+    int ensure_nhwc(int v);
+};
+
+}  // namespace onnxstream
