@@ -130,7 +130,7 @@ void Plan::add_step(const std::string& what, std::vector<int> reads, std::vector
 int Plan::ensure_plain(int v) {
     if (vals[v].lay == Lay::plain) return v;
     if (vals[v].as_plain >= 0) return vals[v].as_plain;
-    const Shape& s = vals[v].shape;  // [n,C,H,W]
+    const Shape s = vals[v].shape;  // [n,C,H,W]
     int o = new_val("", s, vals[v].dtype, Lay::plain, vals[v].batched);
     long b = (vals[v].batched ? N : 1) * s[0], C = s[1], HW = s[2] * s[3];
     int es = (int)esize(vals[v].dtype);
@@ -146,7 +146,7 @@ int Plan::ensure_plain(int v) {
 int Plan::ensure_nhwc(int v) {
     if (vals[v].lay == Lay::nhwc) return v;
     if (vals[v].as_nhwc >= 0) return vals[v].as_nhwc;
-    const Shape& s = vals[v].shape;
+    const Shape s = vals[v].shape;
     if (s.size() != 4) throw std::invalid_argument("Model::get_tensor_data: layout is nhwc but invalid shape.");
     long b = (vals[v].batched ? N : 1) * s[0], C = s[1], HW = s[2] * s[3];
     if (C == 1 || HW == 1) {  // identical memory image
@@ -781,9 +781,9 @@ struct Lowering {
         need(op, pads.size() == 4 && strides.size() == 2, "invalid pads/strides.");
         x = P.ensure_nhwc(x);
         int w = in_val(op.m_input[1]);
-        const Shape& ws = V(w).shape;  // [O, I, kh, kw] as named in model.txt; data is OHWI
+        const Shape ws = V(w).shape;  // [O, I, kh, kw] as named in model.txt; data is OHWI
         need(op, V(w).is_const && V(w).lay == Lay::nhwc && ws.size() == 4, "weights must be a static *_nchw.bin tensor.");
-        const Shape& xs = V(x).shape;
+        const Shape xs = V(x).shape;
         need(op, xs[0] == 1, "batch size must be 1 (push several samples instead).");
         const long Cin = xs[1], H = xs[2], W = xs[3], Cout = ws[0], KH = ws[2], KW = ws[3];
         need(op, ws[1] == Cin, "invalid shape of weights.");
@@ -934,7 +934,7 @@ struct Lowering {
         Shape pa, pb;  // physical shapes handed to the kernel (without the batch dim)
         if (V(a).lay == Lay::nhwc || V(b).lay == Lay::nhwc) {
             int x = V(a).lay == Lay::nhwc ? a : b, o = x == a ? b : a;
-            const Shape& xs = V(x).shape;
+            const Shape xs = V(x).shape;
             const long C = xs[1], HW = xs[2] * xs[3];
             if (V(o).lay == Lay::nhwc && V(o).shape == xs) {
                 olay = Lay::nhwc;
@@ -993,7 +993,7 @@ struct Lowering {
         need(op, op.m_input.size() == 3, "wrong number of inputs.");
         int x = P.ensure_plain(in_val(op.m_input[0]));
         int sc = in_val(op.m_input[1]), bi = in_val(op.m_input[2]);
-        const Shape& s = V(x).shape;
+        const Shape s = V(x).shape;
         need(op, s.size() == 3 && s[0] == 1, "input shape must be [1,G,L] (not implemented).");
         need(op, V(sc).numel() == s[1] && V(bi).numel() == s[1] && V(sc).dtype == OSG_F32 && V(bi).dtype == OSG_F32, "invalid scale/bias.");
         float eps = 1e-5f;
@@ -1013,7 +1013,7 @@ struct Lowering {
     void lower_group_norm(const Operation& op) {
         int x = P.ensure_nhwc(in_val(op.m_input[0]));
         int g = in_val(op.m_input[1]), b = in_val(op.m_input[2]);
-        const Shape& s = V(x).shape;
+        const Shape s = V(x).shape;
         const long G = std::stol(*attr(op, "groups"));
         const float eps = std::stof(*attr(op, "epsilon"));
         const int act = *attr(op, "silu") == "1" ? OSG_ACT_SILU : OSG_ACT_NONE;
@@ -1028,7 +1028,7 @@ struct Lowering {
     void lower_layer_norm(const Operation& op) {
         int x = P.ensure_plain(in_val(op.m_input[0]));
         int g = in_val(op.m_input[1]), b = in_val(op.m_input[2]);
-        const Shape& s = V(x).shape;
+        const Shape s = V(x).shape;
         const float eps = std::stof(*attr(op, "epsilon"));
         int y = out_val(op, s, Lay::plain, V(x).batched);
         const long C = s.back(), rows = P.total_elems(x) / C;
@@ -1050,7 +1050,7 @@ struct Lowering {
         int q = P.ensure_plain(in_val(op.m_input[0])), k = P.ensure_plain(in_val(op.m_input[1])), v = P.ensure_plain(in_val(op.m_input[2]));
         const long h = std::stol(*attr(op, "heads"));
         const float scale = std::stof(*attr(op, "scale"));
-        const Shape& qs = V(q).shape;
+        const Shape qs = V(q).shape;
         const long Tq = qs[1], C = qs[2], Tk = V(k).shape[1], d = C / h;
         int y = out_val(op, qs, Lay::plain, V(q).batched);
         need(op, V(q).batched == V(k).batched && V(k).batched == V(v).batched, "q/k/v batching mismatch.");
@@ -1094,7 +1094,7 @@ struct Lowering {
     void lower_reduce_mean(const Operation& op) {
         need(op, op.m_input.size() == 1, "wrong number of inputs.");
         int x = P.ensure_plain(in_val(op.m_input[0]));
-        const Shape& s = V(x).shape;
+        const Shape s = V(x).shape;
         for (auto& a : op.m_attributes) {
             if (a.first == "axes") {
                 auto ax = int_list(a.second);
@@ -1176,7 +1176,7 @@ struct Lowering {
         int x = P.ensure_plain(in_val(op.m_input[0]));
         int axis = 1;
         if (auto* a = attr(op, "axis")) axis = std::stoi(*a);
-        const Shape& s = V(x).shape;
+        const Shape s = V(x).shape;
         if (axis < 0) axis += (int)s.size();
         Shape os = {prod(s, 0, axis), prod(s, axis)};
         check_out(op, os);
@@ -1256,7 +1256,7 @@ struct Lowering {
         Shape os = V(xs[0]).shape;
         os[axis] = 0;
         for (int x : xs) {
-            const Shape& s = V(x).shape;
+            const Shape s = V(x).shape;
             need(op, (int)s.size() == rank, "invalid shape of inputs.");
             for (int d = 0; d < rank; d++) need(op, d == axis || s[d] == V(xs[0]).shape[d], "invalid shape of inputs.");
             os[axis] += s[axis];
@@ -1419,6 +1419,7 @@ void Plan::build() {
     if (m.m_use_uint8_arithmetic || m.m_use_uint8_qdq)
         throw std::runtime_error("Model::run: uint8 activations (m_use_uint8_arithmetic / m_use_uint8_qdq) are not implemented on the HIP backend yet.");
     ops = m.m_ops;
+    vals.reserve(ops.size() * 12 + 1024);  // belt and braces: lowering code copies shapes, never holds Val& across new_val
     lowering = new Lowering(*this);
     Lowering& L = *lowering;
     L.load_weights();
