@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline measurement (BASELINE.json): SD 1.5 UNet step latency (ms) + images/sec, 512x512 20-step.
+
+A "step" is ONE denoising step of the reference's txt2img loop (src/sd.cpp:1537-1543): the UNet over the cond and the
+uncond sample -- two [1,4,64,64] latents pushed under the same input names (== the reference's m_batch loop,
+src/onnxstream.cpp:3847), executed here as one batch-2 pass of the captured hipGraph on inputs that are already resident
+in HBM.  W16A16 (fp16 weights, fp16 activations, fp32 accumulation), synthetic graph + seeded random weights of the exact
+SD 1.5 topology (no checkpoints offline).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+N>1: one process per GPU; every rank owns one prompt (its own cond+uncond pass per step) -> weak scaling, no collective on
+the data path; RCCL (torch.distributed "nccl") only broadcasts the latents/contexts from rank 0 before the timed region
+and gathers the result after it.  Timing: barrier + device sync on both sides of EXACTLY K steps,
+MAX over ranks, one JSON line from rank 0.
+
+Extra objects in the JSON line:
+  roofline      dominant kernel = the MFMA implicit-GEMM kernel (osg_gemm.hip: Conv + Linear/MatMul/Gemm launches);
+                achieved = sum(algorithmic FLOP of its launches in one step) / sum(their HIP-event durations), measured live
+                on the backend's compute stream (Model.hip_profile), peak = 2500 TFLOP/s dense fp16 MFMA.
+  cpu_baseline  the UNMODIFIED reference (oracle/_ref = reference sources + XNNPACK from libtorch_cpu) timed on this host's
+                cores on a bounded sample of the same workload (same model dir, same inputs), rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+STEPS_PER_IMAGE = 20                 # BASELINE.json: 512x512 20-step
+PEAK_F16_TFLOPS = 2500.0             # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+GEMM_KINDS = ("Conv", "Linear", "MatMul", "Gemm")
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def ensure_model_dir(cfg, local_rank, barrier):
+    from onnxstream_amd.synth import sd_unet
+    from onnxstream_amd.synth.graph import DirSink
+    d = os.path.join(os.environ.get("OSA_SYNTH_DIR", "/tmp/onnxstream_amd_synth"), cfg.name) + "/"
+    if local_rank == 0 and not os.path.exists(d + ".complete"):
+        t0 = time.time()
+        os.makedirs(d, exist_ok=True)
+        g, _ = sd_unet.build_unet(DirSink(d), cfg)
+        open(d + ".complete", "w").write("ok")
+        log(f"[bench] emitted synthetic {cfg.name} UNet: {len(g.lines)} ops, {g.n_params/1e6:.1f} M params in {time.time()-t0:.1f} s")
+    barrier()
+    return d
+
+
+def cpu_baseline(model_dir, inputs_cond, inputs_uncond, passes):
+    """Reference CPU path on a bounded sample: `passes` UNet passes (cond/uncond alternating) after one cache-filling run,
+    with the reference's --ram plumbing (Ram WP + ops cache + next-op cache, src/sd.cpp:1622-1627)."""
+    from oracle import ref as oref
+    if not oref.available():
+        return None
+    from onnxstream_amd.bindings import Model
+    cores = oref.usable_cores()
+    m = Model(oref.REF_LIB, cores, "ram+nocache")
+    m.read_file(model_dir + "model.txt")
+    m.set_use_ops_cache(True)
+    m.set_use_next_op_cache(True)
+    times = []
+    for i in range(passes + 1):
+        ins = inputs_cond if i % 2 == 0 else inputs_uncond
+        m.set_use_fp16_arithmetic(False)
+        for k, v in ins.items():
+            m.add_tensor(k, v)
+        m.set_use_fp16_arithmetic(True)
+        m.set_fuse_ops_in_attention(True)
+        t0 = time.perf_counter()
+        m.run()
+        times.append(time.perf_counter() - t0)
+        m.clear_tensors()
+    m.close()
+    timed = times[1:]
+    pass_s = float(np.mean(timed))
+    step_s = 2.0 * pass_s
+    return {"value": 1.0 / (STEPS_PER_IMAGE * step_s), "unit": "images/s", "cores": cores, "kind": "reference",
+            "ms_per_step": step_s * 1e3,
+            "sample": f"{passes} UNet passes (cond/uncond alternating; 2 passes = 1 step) after 1 cache-filling pass "
+                      f"({times[0]:.2f} s), W16A16, reference --ram plumbing, images/s = 1/(20 x 2 x {pass_s:.3f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="SD15", help="SD15 (headline) | SDXL | TINY | TINY_XL")
+    ap.add_argument("--fusion", type=int, default=2)
+    ap.add_argument("--cpu-passes", type=int, default=4, help="reference CPU passes in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--profile-reps", type=int, default=3)
+    ap.add_argument("--breakdown", default="", help="write the per-step HIP-event profile to this file")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N`")
+        args.gpus = world
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    from onnxstream_amd import build as b
+    from onnxstream_amd.bindings import Model
+    from onnxstream_amd.synth import sd_unet
+    if not (os.path.exists(b.LIB_GPU) and os.path.exists(b.LIB_HOST)):
+        raise SystemExit("native libraries missing: run `python __graft_entry__.py` (build()) first")
+
+    cfg = getattr(sd_unet, args.config)
+    model_dir = ensure_model_dir(cfg, local_rank, barrier)
+
+    # ---- inputs: rank 0 draws every prompt's latents/contexts, RCCL-broadcasts them over xGMI, each rank keeps its own ------
+    def draw(seed):
+        return sd_unet.unet_inputs(cfg, seed)
+    names = list(draw(0).keys())
+    if dist is not None:
+        packs = []
+        for nme in names:
+            full = np.stack([np.stack([draw(42 + 2 * r)[nme], draw(43 + 2 * r)[nme]]) for r in range(world)]) if rank == 0 else None
+            shape = (world, 2) + draw(0)[nme].shape
+            t = torch.from_numpy(full).cuda() if rank == 0 else torch.empty(shape, dtype=torch.float32, device="cuda")
+            dist.broadcast(t, src=0)
+            packs.append(t[rank].cpu().numpy())
+        cond = {n: p[0] for n, p in zip(names, packs)}
+        uncond = {n: p[1] for n, p in zip(names, packs)}
+    else:
+        cond, uncond = draw(42), draw(43)
+
+    # ---- the product path: model_* C API -> host planner -> libosgpu HIP kernels -------------------------------------------
+    m = Model(b.LIB_HOST, 0, "ram+nocache")
+    m._set_option("hip_device", local_rank)
+    m.read_file(model_dir + "model.txt")
+    t_build = time.time()
+    for r in range(2):                       # run 1: plan + eager pass (weights become resident); run 2: hipGraph capture
+        for ins in (cond, uncond):
+            for k, v in ins.items():
+                m.add_tensor(k, v)
+        if r == 0:
+            m.set_use_fp16_arithmetic(True)
+            m.set_fuse_ops_in_attention(True)
+            m._set_option("hip_fusion_level", args.fusion)
+        m.run()
+        if r == 0:
+            m.clear_tensors()
+    all_names = m.get_all_tensor_names()
+    out_name = "out_sample" if "out_sample" in all_names else all_names[0]
+    out, out_shape = m.get_tensor(out_name)
+    assert np.isfinite(out).all()
+    kernels = m.hip_last_kernel_count()
+    log(f"[bench r{rank}] plan+capture {time.time()-t_build:.1f} s, {kernels} launches/pass, eager pass {m.hip_last_pass_ms():.3f} ms")
+
+    # ---- warmup, then EXACTLY K timed steps ---------------------------------------------------------------------------
+    if args.warmup > 0:
+        m.hip_replay(args.warmup)
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    dev_ms = m.hip_replay(args.steps)        # K back-to-back launches; returns after the stop event (device idle)
+    torch.cuda.synchronize()
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+        # gather every prompt's predicted noise on rank 0 (what the sampler on rank 0 would consume)
+        res = torch.from_numpy(out).cuda()
+        gathered = [torch.empty_like(res) for _ in range(world)] if rank == 0 else None
+        dist.gather(res, gathered, dst=0)
+    ms_per_step = wall * 1e3 / args.steps
+    images_per_s = world / (STEPS_PER_IMAGE * ms_per_step * 1e-3)
+
+    line = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel, live (HIP events on the backend's compute stream) ---------------------------
+        rows = m.hip_profile(args.profile_reps)
+        by_kind = {}
+        for ms, fl, by, what in rows:
+            k = what.split(" ", 1)[0]
+            e = by_kind.setdefault(k, [0.0, 0.0, 0.0, 0])
+            e[0] += ms; e[1] += fl; e[2] += by; e[3] += 1
+        g_ms = sum(by_kind[k][0] for k in GEMM_KINDS if k in by_kind)
+        g_fl = sum(by_kind[k][1] for k in GEMM_KINDS if k in by_kind)
+        g_n = sum(by_kind[k][3] for k in GEMM_KINDS if k in by_kind)
+        tot_fl = sum(r[1] for r in rows)
+        tot_ms = sum(r[0] for r in rows)
+        achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "gemm_kernel (implicit-GEMM Conv + Linear/MatMul/Gemm)", "achieved": round(achieved, 2),
+                    "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": g_n, "flop_per_launch": g_fl / max(g_n, 1), "avg_launch_us": g_ms * 1e3 / max(g_n, 1),
+                    "step_flop": tot_fl, "step_frac": round(tot_fl / (ms_per_step * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
+                    "sum_of_kernels_ms": round(tot_ms, 4)}
+        if args.breakdown:
+            with open(args.breakdown, "w") as f:
+                f.write("# kind\tlaunches\tms\tGFLOP\tTFLOP/s\tGB(read+write of operands)\tGB/s\n")
+                for k, e in sorted(by_kind.items(), key=lambda kv: -kv[1][0]):
+                    f.write(f"{k}\t{e[3]}\t{e[0]:.4f}\t{e[1]/1e9:.2f}\t{(e[1]/(e[0]*1e-3)/1e12 if e[0] else 0):.1f}\t{e[2]/1e9:.4f}\t{(e[2]/(e[0]*1e-3)/1e9 if e[0] else 0):.1f}\n")
+                f.write("# per step: ms\tflops\tbytes\twhat\n")
+                for ms, fl, by, what in rows:
+                    f.write(f"{ms:.5f}\t{fl:.0f}\t{by:.0f}\t{what}\n")
+        cpu = None
+        if world == 1 and args.cpu_passes > 0:
+            m.close()
+            m = None
+            try:
+                cpu = cpu_baseline(model_dir, cond, uncond, args.cpu_passes)
+            except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
+                log(f"[bench] cpu_baseline failed: {e!r}")
+        line = {
+            "metric": "sd15_unet_step_latency_ms+images_per_sec_512x512_20step", "value": round(images_per_s, 4), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{cfg.name} UNet denoising step: cond+uncond 2x4x{cfg.latent}x{cfg.latent} latents, ctx 77x{cfg.ctx_dim}, "
+                                   f"W16A16, weights resident, images/s = gpus/(20 x step); VAE decode not included",
+                       "prompts_per_gpu": 1, "unet_passes_per_step": 2, "steps_per_image": STEPS_PER_IMAGE, "launches_per_step": kernels,
+                       "fusion_level": args.fusion, "device_ms_per_step": round(dev_ms, 4), "parallelism": f"replica x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+    if m is not None:
+        m.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -149,6 +149,44 @@ class Model:
     def set_ops_times_printf(self, v): self._set_option("ops_times_printf", bool(v))
     def set_use_nchw_convs(self, v): self._set_option("use_nchw_convs", bool(v))
 
+    # -- backend additions of libonnxstream_amd.so (absent from the reference library: feature-probed) -----------------
+    def hip_replay(self, n: int, per_launch: bool = False):
+        """Relaunch the captured pass n times on the inputs already resident in HBM.  Returns per-launch device ms
+        (HIP events) when per_launch, else the mean ms over n back-to-back launches."""
+        f = self._lib.model_hip_replay
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]; f.restype = ctypes.c_void_p
+        if per_launch:
+            buf = (ctypes.c_float * n)()
+            self._err(f(self._h, n, buf))
+            return list(buf)
+        self._err(f(self._h, n, None))
+        return self.hip_last_pass_ms()
+
+    def hip_profile(self, reps: int = 1):
+        """Eager pass with HIP events around every step -> list of (ms, flops, bytes, what)."""
+        f = self._lib.model_hip_profile
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int]; f.restype = ctypes.c_void_p
+        p = f(self._h, reps)
+        text = ctypes.cast(p, ctypes.c_char_p).value.decode("utf-8", "replace")
+        self._lib.model_free_buffer(p)
+        if text.startswith("ERROR: "):
+            raise OnnxStreamError(text[7:])
+        rows = []
+        for line in text.splitlines():
+            ms, fl, by, what = line.split("\t", 3)
+            rows.append((float(ms), float(fl), float(by), what))
+        return rows
+
+    def hip_last_pass_ms(self) -> float:
+        f = self._lib.model_hip_last_pass_ms
+        f.argtypes = [ctypes.c_void_p]; f.restype = ctypes.c_double
+        return f(self._h)
+
+    def hip_last_kernel_count(self) -> int:
+        f = self._lib.model_hip_last_kernel_count
+        f.argtypes = [ctypes.c_void_p]; f.restype = ctypes.c_ulonglong
+        return int(f(self._h))
+
     # -- name mangling (reference bindings.py:310) ------------------------------------------------
     @staticmethod
     def mangle_name(name: str) -> str:

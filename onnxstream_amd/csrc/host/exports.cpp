@@ -220,5 +220,22 @@ void model_free_buffer(void* ptr) { std::free(ptr); }
 double model_hip_last_pass_ms(Handle* h) { return h->model.hip_last_pass_ms(); }
 unsigned long long model_hip_last_kernel_count(Handle* h) { return h->model.hip_last_kernel_count(); }
 void model_hip_invalidate_plan(Handle* h) { h->model.hip_invalidate_plan(); }
+// relaunch the captured pass n times on the resident inputs; ms_each (may be NULL) receives per-launch device times
+char* model_hip_replay(Handle* h, int n, float* ms_each) {
+    try {
+        h->model.hip_replay(n, ms_each);
+        return nullptr;
+    } catch (const std::exception& e) {
+        return dup_cstr(e.what());
+    }
+}
+// per-step timing report (malloc'ed text, free with model_free_buffer); on error the text starts with "ERROR: "
+char* model_hip_profile(Handle* h, int reps) {
+    try {
+        return dup_cstr(h->model.hip_profile(reps));
+    } catch (const std::exception& e) {
+        return dup_cstr(std::string("ERROR: ") + e.what());
+    }
+}
 
 }  // extern "C"

@@ -212,6 +212,17 @@ void Model::hip_invalidate_plan() {
     m_plan = nullptr;
 }
 
+void Model::hip_replay(int n, float* ms_each) {
+    if (!m_plan) throw std::runtime_error("Model::hip_replay: no plan (call run() first).");
+    m_plan->replay(n, ms_each);
+    m_last_ms = m_plan->last_ms();
+}
+
+std::string Model::hip_profile(int reps) {
+    if (!m_plan) throw std::runtime_error("Model::hip_profile: no plan (call run() first).");
+    return m_plan->profile(reps);
+}
+
 size_t Model::hip_last_kernel_count() const { return m_last_kernels; }
 double Model::hip_last_pass_ms() const { return m_last_ms; }
 

@@ -810,6 +810,7 @@ struct Lowering {
                                             (int)H, (int)W, (int)Cin, (int)Cout, (int)KH, (int)KW, sh, sw, pt, pl, pb, pr, OSG_ACT_NONE),
                      "Conv");
         });
+        P.steps.back().flops = 2.0 * nb * Ho * Wo * Cout * KH * KW * Cin;
     }
 
     // resident [K,N] weight -> [N,K] (done once, at plan time)
@@ -840,6 +841,7 @@ struct Lowering {
                                      (int)K, (int)batch, sa, sb, sc, OSG_ACT_NONE),
                      what.c_str());
         });
+        P.steps.back().flops = 2.0 * M * Nn * K * batch;
     }
 
     // MatMul with a static 2-D weight, optional fused bias / residual
@@ -1060,6 +1062,7 @@ struct Lowering {
                                                   Tq * C, (int)nb, (int)h, (int)Tq, (int)Tk, (int)d, scale),
                      "Attention");
         });
+        P.steps.back().flops = 4.0 * nb * h * Tq * Tk * d;
     }
 
     // AttentionFusedOps (reference :6696-6929): q [n,Tq,d], k [n,d,Tk] (already transposed), optional scalar s, v [n,Tk,d]
@@ -1088,6 +1091,7 @@ struct Lowering {
             be.check(be.api.osg_attention(be.ctx, OSG_F16, P.ptr(q), P.ptr(k), P.ptr(v), P.ptr(y), (int)heads, (int)Tq, (int)Tk, (int)d, scale, 1),
                      "AttentionFusedOps");
         });
+        P.steps.back().flops = 4.0 * heads * Tq * Tk * d;
     }
 
     // ReduceMean (reference :5237-5393): last axis, keepdims
@@ -1622,6 +1626,51 @@ void Plan::execute() {
             if (m.m_data[i].m_name == o.name) { m.m_data.erase(m.m_data.begin() + i); break; }
         m.m_data.push_back(std::move(first));
     }
+}
+
+void Plan::replay(int n, float* ms_each) {
+    if (!graph) throw std::runtime_error("Model::hip_replay: no captured pass yet (run() at least twice with hip_use_graph on).");
+    if (!ms_each) {  // back-to-back launches, one event pair around all of them
+        be.check(be.api.osg_timer_start(be.ctx), "osg_timer_start");
+        for (int i = 0; i < n; i++) be.check(be.api.osg_graph_launch(be.ctx, graph), "osg_graph_launch");
+        float ms = 0;
+        be.check(be.api.osg_timer_stop(be.ctx, &ms), "osg_timer_stop");
+        m_last_ms = n > 0 ? ms / n : 0;
+        return;
+    }
+    for (int i = 0; i < n; i++) {
+        be.check(be.api.osg_timer_start(be.ctx), "osg_timer_start");
+        be.check(be.api.osg_graph_launch(be.ctx, graph), "osg_graph_launch");
+        float ms = 0;
+        be.check(be.api.osg_timer_stop(be.ctx, &ms), "osg_timer_stop");
+        ms_each[i] = ms;
+        m_last_ms = ms;
+    }
+}
+
+std::string Plan::profile(int reps) {
+    if (runs < 1) throw std::runtime_error("Model::hip_profile: run() once first (inputs must be resident).");
+    std::vector<double> acc(steps.size(), 0.0);
+    for (int r = 0; r < reps; r++)
+        for (size_t i = 0; i < steps.size(); i++) {
+            be.check(be.api.osg_timer_start(be.ctx), "osg_timer_start");
+            steps[i].run();
+            float ms = 0;
+            be.check(be.api.osg_timer_stop(be.ctx, &ms), "osg_timer_stop");
+            acc[i] += ms;
+        }
+    std::string out;
+    char buf[256];
+    for (size_t i = 0; i < steps.size(); i++) {
+        double bytes = 0;
+        for (int v : steps[i].reads) bytes += (double)val_bytes(v);
+        for (int v : steps[i].writes) bytes += (double)val_bytes(v);
+        snprintf(buf, sizeof buf, "%.6f\t%.0f\t%.0f\t", acc[i] / reps, steps[i].flops, bytes);
+        out += buf;
+        out += steps[i].what;
+        out += "\n";
+    }
+    return out;
 }
 
 }  // namespace onnxstream

@@ -45,6 +45,7 @@ struct Step {
     std::string what;
     std::function<void()> run;
     std::vector<int> reads, writes;
+    double flops = 0;             // algorithmic 2*MAC count of a contraction step (0 for memory-bound steps)
 };
 
 struct Lowering;
@@ -54,6 +55,10 @@ struct Plan {
     ~Plan();
     void build();
     void execute();
+    // relaunch the captured pass `n` times on the inputs already resident in HBM; per-launch device ms (HIP events)
+    void replay(int n, float* ms_each);
+    // eager pass with HIP events around every step, `reps` times; "ms<TAB>flops<TAB>bytes<TAB>what" per line (ms = mean)
+    std::string profile(int reps);
     bool compatible(Model& m, size_t batch) const;
     size_t kernel_count() const { return steps.size(); }
     double last_ms() const { return m_last_ms; }
