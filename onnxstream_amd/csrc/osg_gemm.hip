@@ -13,6 +13,9 @@
 //     8-byte epilogue stores, bias/residual fused in f32 before the single rounding.
 //   * split-K (grid.z) with f32 partial slabs + a fused reduce epilogue for the small-M (8x8, 16x16 latent) layers.
 #include "osg_common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -30,7 +33,86 @@ struct GemmParams {
     int splits, k_per_split;
     // conv geometry (CONV only)
     int H, W, Cin, Ho, Wo, KW, sh, sw, pt, pl;
+    // v2 (direct-to-LDS) kernel only
+    unsigned a_bytes, b_bytes;   // buffer-descriptor extents of one batch item of A / Bt
+    long a_bytes_l;              // conv: byte size of the whole NHWC input (host side, before the 2 GiB check)
+    int mt, nt, n_major;         // tile grid and the order tiles are walked inside an XCD's contiguous chunk
 };
+
+// ---- epilogue shared by both kernels: lane owns C[m][n..n+3], m = tile_m + (lane&15), n = tile_n + (lane>>4)*4 --------
+// (operands are swapped -- weights feed the MFMA "A" port -- so the 4 accumulator registers of a lane are 4 consecutive
+// output channels of one pixel); bias/residual/activation fused in f32 before the single RNE rounding to f16.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane,
+                                              int zb, int zslab) {
+    const int N = p.N;
+    if (p.splits == 1) {
+        f16* __restrict__ C = p.C + zb * p.strideC;
+        const f16* __restrict__ R = p.residual ? p.residual + zb * p.strideC : nullptr;
+        const bool vec_ok = (N & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int m = m0 + wm0 + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
+                if (n >= N) continue;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (vec_ok) {
+                    if (p.bias) {
+                        if (p.bias_f32) {
+                            f32x4 bv = *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
+#pragma unroll
+                            for (int r = 0; r < 4; r++) v[r] += bv[r];
+                        } else {
+                            f16x4 bv = *reinterpret_cast<const f16x4*>((const f16*)p.bias + n);
+#pragma unroll
+                            for (int r = 0; r < 4; r++) v[r] += (float)bv[r];
+                        }
+                    }
+                    if (R) {
+                        f16x4 rv = *reinterpret_cast<const f16x4*>(R + (long)m * N + n);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) v[r] += (float)rv[r];
+                    }
+                    f16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (f16)osg_apply_act(v[r], p.act);
+                    *reinterpret_cast<f16x4*>(C + (long)m * N + n) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        if (n + r >= N) break;
+                        float x = v[r];
+                        if (p.bias) x += p.bias_f32 ? ((const float*)p.bias)[n + r] : (float)((const f16*)p.bias)[n + r];
+                        if (R) x += (float)R[(long)m * N + n + r];
+                        C[(long)m * N + n + r] = (f16)osg_apply_act(x, p.act);
+                    }
+                }
+            }
+        }
+    } else {
+        float* __restrict__ P = p.partial + ((long)zslab) * p.M * N;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int m = m0 + wm0 + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
+                if (n >= N) continue;
+                if ((N & 3) == 0) {
+                    *reinterpret_cast<f32x4*>(P + (long)m * N + n) = acc[i][j];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (n + r < N) P[(long)m * N + n + r] = acc[i][j][r];
+                }
+            }
+        }
+    }
+}
 
 template <int BM, int BN, int BK, bool CONV, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
@@ -219,74 +301,185 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane owns C[m][n..n+3], m = tile_m + (lane&15), n = tile_n + (lane>>4)*4 -------------------
-    const int N = p.N;
-    if (p.splits == 1) {
-        f16* __restrict__ C = p.C + zb * p.strideC;
-        const f16* __restrict__ R = p.residual ? p.residual + zb * p.strideC : nullptr;
-        const bool vec_ok = (N & 3) == 0;
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-            const int m = m0 + wm0 + i * 16 + (lane & 15);
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < TN; j++) {
-                const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
-                if (n >= N) continue;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (vec_ok) {
-                    if (p.bias) {
-                        if (p.bias_f32) {
-                            f32x4 bv = *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
-#pragma unroll
-                            for (int r = 0; r < 4; r++) v[r] += bv[r];
-                        } else {
-                            f16x4 bv = *reinterpret_cast<const f16x4*>((const f16*)p.bias + n);
-#pragma unroll
-                            for (int r = 0; r < 4; r++) v[r] += (float)bv[r];
-                        }
-                    }
-                    if (R) {
-                        f16x4 rv = *reinterpret_cast<const f16x4*>(R + (long)m * N + n);
-#pragma unroll
-                        for (int r = 0; r < 4; r++) v[r] += (float)rv[r];
-                    }
-                    f16x4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) o[r] = (f16)osg_apply_act(v[r], p.act);
-                    *reinterpret_cast<f16x4*>(C + (long)m * N + n) = o;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        if (n + r >= N) break;
-                        float x = v[r];
-                        if (p.bias) x += p.bias_f32 ? ((const float*)p.bias)[n + r] : (float)((const f16*)p.bias)[n + r];
-                        if (R) x += (float)R[(long)m * N + n + r];
-                        C[(long)m * N + n + r] = (f16)osg_apply_act(x, p.act);
-                    }
-                }
-            }
-        }
+    gemm_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0, lane, zb, (int)blockIdx.z);
+}
+
+// =====================================================================================================================
+// v2: direct-to-LDS pipelined kernel (the hot one).  Requirements: K % 64 == 0 (conv: Cin % 64 == 0), 16-byte aligned rows.
+//   * both operands stream HBM/L2 -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR staging, no ds_write pass); the
+//     buffer descriptor's bounds check zero-fills M/N tails AND the convolution halo (out-of-image taps get an
+//     out-of-range offset), so the inner loop has no predication at all.
+//   * BK = 64: one tile row = 128 B = 8 x 16-B chunks; chunk c of row r lives at slot c ^ (r & 7) (XOR swizzle applied
+//     on the per-lane SOURCE address, LDS image stays lane-linear as the DMA requires) => conflict-free ds_read_b128.
+//   * NST-deep LDS ring, counted `s_waitcnt vmcnt(N)` (never 0 in the loop), ONE raw s_barrier per k-tile; one workgroup
+//     per CU owns up to 128 KiB of the 160 KiB LDS: with grids of ~1 tile per CU the latency hiding has to come from the
+//     depth of the ring, not from co-resident blocks.
+//   * XCD-aware tile walk: the 1-D grid is remapped so each of the 8 XCDs (private L2) gets a CONTIGUOUS run of tiles,
+//     ordered so that the operand with more unique bytes is split across XCDs and read from HBM once.
+template <int BM, int BN, int NST, bool CONV, int MODE = 0>
+__global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
+    constexpr int ROWB = 128;                       // bytes per tile row (BK = 64 halves)
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_LD = BM / 32, B_LD = BN / 32;   // 1-KiB wave-loads per wave per k-tile
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+    constexpr int INFLIGHT = (NST - 2) * (A_LD + B_LD);
+    constexpr unsigned OOB = 0x80000000u;
+    static_assert(INFLIGHT <= 63, "vmcnt is a 6-bit counter");
+
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * WM;
+    const int wn0 = (wave & 1) * WN;
+
+    // ---- XCD-aware bijective remap of the flat grid -------------------------------------------------------------------
+    const int total = gridDim.x;
+    int L;
+    {
+        const int bid = blockIdx.x, x = bid & 7, i = bid >> 3, q = total >> 3, r = total & 7;
+        L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int per_batch = p.mt * p.nt * p.splits;
+    const int zb = L / per_batch;
+    int rem = L - zb * per_batch;
+    int m_tile, n_tile, zs;
+    if (p.n_major) {
+        n_tile = rem / (p.splits * p.mt); rem -= n_tile * p.splits * p.mt;
+        zs = rem / p.mt; m_tile = rem - zs * p.mt;
     } else {
-        float* __restrict__ P = p.partial + ((long)blockIdx.z) * p.M * N;
+        m_tile = rem / (p.splits * p.nt); rem -= m_tile * p.splits * p.nt;
+        zs = rem / p.nt; n_tile = rem - zs * p.nt;
+    }
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int kbeg = zs * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nkt = (kend - kbeg) >> 6;
+
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long)zb * p.strideA), 0, p.a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Bt + (long)zb * p.strideB), 0, p.b_bytes, 0x00020000);
+
+    // ---- per-lane source addressing (constant over the k loop) -------------------------------------------------------------
+    const int rsub = lane >> 3;                     // row inside the 8-row group one wave-load covers
+    const int gch = (lane & 7) ^ rsub;              // global chunk this lane fetches into LDS slot (lane & 7)
+    int a_base[A_LD];                               // byte offset (conv: of tap (0,0); may be negative)
+    int a_hi0[A_LD], a_wi0[A_LD];
 #pragma unroll
-        for (int i = 0; i < TM; i++) {
-            const int m = m0 + wm0 + i * 16 + (lane & 15);
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < TN; j++) {
-                const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
-                if (n >= N) continue;
-                if ((N & 3) == 0) {
-                    *reinterpret_cast<f32x4*>(P + (long)m * N + n) = acc[i][j];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        if (n + r < N) P[(long)m * N + n + r] = acc[i][j][r];
-                }
-            }
+    for (int j = 0; j < A_LD; j++) {
+        const int m = m0 + (j * 4 + wave) * 8 + rsub;
+        if (CONV) {
+            const int mm = m < p.M ? m : 0;
+            const int hw = p.Ho * p.Wo;
+            const int n_img = mm / hw;
+            const int r2 = mm - n_img * hw;
+            const int ho = r2 / p.Wo, wo = r2 - ho * p.Wo;
+            a_hi0[j] = m < p.M ? ho * p.sh - p.pt : -0x40000000;
+            a_wi0[j] = wo * p.sw - p.pl;
+            a_base[j] = (((n_img * p.H + (ho * p.sh - p.pt)) * p.W + (wo * p.sw - p.pl)) * p.Cin + gch * 8) * 2;
+        } else {
+            a_base[j] = m < p.M ? (int)(((long)m * p.lda + gch * 8) * 2) : (int)OOB;
+            a_hi0[j] = a_wi0[j] = 0;
         }
     }
+    int b_base[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; j++) {
+        const int n = n0 + (j * 4 + wave) * 8 + rsub;
+        b_base[j] = n < p.N ? (int)(((long)n * p.K + gch * 8) * 2) : (int)OOB;
+    }
+
+    // running position of the NEXT tile to issue (conv: decomposed into tap + channel offset, updated incrementally)
+    int ik = kbeg, i_c0 = 0, i_kh = 0, i_kw = 0;
+    if (CONV) {
+        const int cell = kbeg / p.Cin;
+        i_c0 = kbeg - cell * p.Cin;
+        i_kh = cell / p.KW;
+        i_kw = cell - i_kh * p.KW;
+    }
+    auto issue_tile = [&](int stage) {
+        char* As = smem2 + stage * STAGE;
+        char* Bs = As + A_BYTES;
+        const bool live = ik < kend;
+        const unsigned kill = live ? 0u : OOB;      // past the last k-tile: dummy (zero-filling) loads keep vmcnt uniform
+        if (CONV) {
+            const int tap_off = ((i_kh * p.W + i_kw) * p.Cin + i_c0) * 2;
+#pragma unroll
+            for (int j = 0; j < A_LD; j++) {
+                const int hi = a_hi0[j] + i_kh, wi = a_wi0[j] + i_kw;
+                const bool ok = live && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                const unsigned off = ok ? (unsigned)(a_base[j] + tap_off) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(As + (j * 4 + wave) * 1024), 16, off, 0, 0, 0);
+            }
+            i_c0 += 64;
+            if (i_c0 >= p.Cin) { i_c0 = 0; if (++i_kw == p.KW) { i_kw = 0; ++i_kh; } }
+        } else {
+#pragma unroll
+            for (int j = 0; j < A_LD; j++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(As + (j * 4 + wave) * 1024), 16, (unsigned)a_base[j] | kill, ik * 2, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; j++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(Bs + (j * 4 + wave) * 1024), 16, (unsigned)b_base[j] | kill, ik * 2, 0, 0);
+        ik += 64;
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read addressing: row = lane & 15, k-chunk = (lane >> 4) (+4 for the second 32-deep half)
+    const int frow = lane & 15;
+    const int fsw = (((lane >> 4) ^ (frow & 7)) << 4);
+    const int a_rd = (wm0 + frow) * ROWB + fsw;
+    const int b_rd = A_BYTES + (wn0 + frow) * ROWB + fsw;
+
+#pragma unroll
+    for (int s2 = 0; s2 < NST - 1; s2++) issue_tile(s2);
+
+    int cur = 0, nxt = NST - 1;
+    for (int kt = 0; kt < nkt; kt++) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");   // my share of tile kt has landed
+        __builtin_amdgcn_s_barrier();                                      // everyone's has; tile kt-1's buffer is free
+        issue_tile(nxt);
+        const char* St = smem2 + cur * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < (MODE == 1 ? 0 : 2); ks++) {
+            f16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) a[i] = *reinterpret_cast<const f16x8*>(St + ((a_rd + i * 16 * ROWB) ^ (ks << 6)));
+#pragma unroll
+            for (int j = 0; j < TN; j++) b[j] = *reinterpret_cast<const f16x8*>(St + ((b_rd + j * 16 * ROWB) ^ (ks << 6)));
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+        cur = cur + 1 == NST ? 0 : cur + 1;
+        nxt = nxt + 1 == NST ? 0 : nxt + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the dummy tail loads before the LDS is released
+    gemm_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0, lane, zb, zb * p.splits + zs);
+}
+
+template <int BM, int BN, int NST, bool CONV, int MODE = 0>
+int launch_v2(osg_ctx* ctx, GemmParams& p, int batch) {
+    constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
+    auto kern = gemm2_kernel<BM, BN, NST, CONV, MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    p.mt = (p.M + BM - 1) / BM;
+    p.nt = (p.N + BN - 1) / BN;
+    dim3 grid((unsigned)(p.mt * p.nt * p.splits * batch));
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, ctx->compute, p);
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
 }
 
 // sum the split-K slabs, fuse bias/residual/activation, round once to f16
@@ -323,8 +516,89 @@ int launch_cfg(osg_ctx* ctx, const GemmParams& p, int batch) {
     return 0;
 }
 
+static int launch_splitk_reduce(osg_ctx* ctx, const GemmParams& p, int batch);
+
+// v2 tile / ring / split-K choice.  Measured on MI355X (tools/gemm_probe.py): the L2->LDS DMA path sustains ~23 B/clk per CU
+// and bounds every configuration (a 128x128x64 k-tile moves 32 KiB for 515 MFMA cycles), so the model is: k-tile time =
+// max(MFMA, bytes / 23) (+ ~450 exposed cycles when a block is alone on its CU), whole rounds of tiles over the CU slots,
+// a fixed fill + epilogue per round, and the extra pass of a split-K reduce.
+struct V2Choice { int cfg, nst, splits; };
+static const int kV2BM[3] = {128, 128, 64}, kV2BN[3] = {128, 64, 64};
+static V2Choice choose_v2(const osg_ctx* ctx, int M, int N, int K, int batch) {
+    const double cus = ctx->num_cu;
+    const int kt = K / 64;
+    V2Choice best{0, 4, 1};
+    double best_cost = 1e300;
+    for (int c = 0; c < 3; c++)
+        for (int nst = 4; nst >= 2; nst -= 2) {
+            const double tiles = (double)((M + kV2BM[c] - 1) / kV2BM[c]) * ((N + kV2BN[c] - 1) / kV2BN[c]) * batch;
+            const double mfma = kV2BM[c] * kV2BN[c] * 128.0 / 4069.0;
+            const double tload = (kV2BM[c] + kV2BN[c]) * 128.0 / 23.0;
+            const int smem = nst * (kV2BM[c] + kV2BN[c]) * 128;
+            const int bpc = std::min(4, 163840 / smem);
+            for (int s = 1; s <= 16; s++) {
+                if (s > 1 && (kt / s < 8)) break;
+                const int kts = (kt + s - 1) / s;
+                if (s > 1 && (kts * (s - 1) >= kt)) continue;   // an empty split
+                const double blocks = tiles * s;
+                const double rounds = std::ceil(blocks / (cus * bpc));
+                const double conc = std::min((double)bpc, std::ceil(blocks / cus));
+                const double tk = conc <= 1.0 ? std::max(mfma, tload) + 450.0 : conc * std::max(mfma, tload);
+                double cost = rounds * (kts * tk + 3500.0);
+                if (s > 1) cost += 4500.0 + (double)M * N * batch * s * 4.0 / 2000.0;   // reduce launch + slab traffic
+                if (cost < best_cost) { best_cost = cost; best = {c, nst, s}; }
+            }
+        }
+    return best;
+}
+
+template <bool CONV>
+int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch) {
+    V2Choice ch = choose_v2(ctx, p.M, p.N, p.K, batch);
+    if (const char* e = getenv("OSG_GEMM_CFG")) ch.cfg = atoi(e);
+    if (const char* e = getenv("OSG_GEMM_SPLITS")) ch.splits = atoi(e);
+    if (const char* e = getenv("OSG_GEMM_NST")) ch.nst = atoi(e);
+    const int ktiles = p.K / 64;
+    int kt_per = (ktiles + ch.splits - 1) / ch.splits;
+    p.splits = (ktiles + kt_per - 1) / kt_per;
+    p.k_per_split = kt_per * 64;
+    if (p.splits > 1) {
+        size_t need = (size_t)batch * p.splits * p.M * p.N * sizeof(float);
+        if (osg_ensure_workspace(ctx, need)) return 1;
+        p.partial = (float*)ctx->ws;
+    }
+    // split the operand with more unique bytes across the XCDs (each private L2 then streams its slice from HBM once)
+    const double a_unique = CONV ? (double)p.a_bytes : (double)p.M * p.K * 2.0;
+    p.n_major = (double)p.N * p.K * 2.0 > a_unique;
+    int rc;
+    static const int dbg = getenv("OSG_GEMM_DBG") ? atoi(getenv("OSG_GEMM_DBG")) : 0;   // experiments (tools/gemm_probe.py)
+    if (dbg == 1) rc = launch_v2<128, 128, 4, CONV, 1>(ctx, p, batch);        // loads only
+    else if (dbg == 2) rc = launch_v2<128, 128, 3, CONV>(ctx, p, batch);
+    else if (dbg == 3) rc = launch_v2<128, 128, 5, CONV>(ctx, p, batch);
+    else if (dbg == 4) rc = launch_v2<128, 128, 5, CONV, 1>(ctx, p, batch);
+    else if (dbg == 5) rc = launch_v2<128, 128, 2, CONV>(ctx, p, batch);
+    else if (ch.cfg == 0) rc = ch.nst == 4 ? launch_v2<128, 128, 4, CONV>(ctx, p, batch) : launch_v2<128, 128, 2, CONV>(ctx, p, batch);
+    else if (ch.cfg == 1) rc = ch.nst == 4 ? launch_v2<128, 64, 4, CONV>(ctx, p, batch) : launch_v2<128, 64, 2, CONV>(ctx, p, batch);
+    else rc = ch.nst == 4 ? launch_v2<64, 64, 4, CONV>(ctx, p, batch) : launch_v2<64, 64, 2, CONV>(ctx, p, batch);
+    if (rc) return rc;
+    if (p.splits > 1) return launch_splitk_reduce(ctx, p, batch);
+    return 0;
+}
+
 template <bool CONV>
 int run_gemm(osg_ctx* ctx, GemmParams p, int batch) {
+    {
+        static const bool force_v1 = getenv("OSG_GEMM_V1") != nullptr;
+        const bool shape_ok = p.K % 64 == 0 && (CONV ? p.Cin % 64 == 0 : p.lda % 8 == 0);
+        const bool align_ok = (((uintptr_t)p.A | (uintptr_t)p.Bt) & 15) == 0 && (p.strideA % 8 == 0) && (p.strideB % 8 == 0);
+        const double a_ext = CONV ? (double)p.a_bytes_l : ((double)(p.M - 1) * p.lda + p.K) * 2.0;
+        const double b_ext = (double)p.N * p.K * 2.0;
+        if (!force_v1 && shape_ok && align_ok && a_ext < 2147483648.0 && b_ext < 2147483648.0) {
+            p.a_bytes = (unsigned)a_ext;
+            p.b_bytes = (unsigned)b_ext;
+            return run_gemm_v2<CONV>(ctx, p, batch);
+        }
+    }
     const bool vec = CONV ? (p.Cin % 8 == 0) : (p.K % 8 == 0 && p.lda % 8 == 0);
     // ---- tile / split-K selection -------------------------------------------------------------------------
     auto tiles = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * batch; };
@@ -362,13 +636,16 @@ int run_gemm(osg_ctx* ctx, GemmParams p, int batch) {
     else rc = OSG_DISPATCH(64, 64);
 #undef OSG_DISPATCH
     if (rc) return rc;
-    if (splits > 1) {
-        long MN = (long)p.M * p.N;
-        long total = MN * batch;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->compute, p.partial, p.C,
-                           p.bias, p.bias_f32, p.residual, MN, p.N, splits, batch, p.strideC, p.act);
-        OSG_LAUNCH_CHECK(ctx);
-    }
+    if (splits > 1) return launch_splitk_reduce(ctx, p, batch);
+    return 0;
+}
+
+static int launch_splitk_reduce(osg_ctx* ctx, const GemmParams& p, int batch) {
+    long MN = (long)p.M * p.N;
+    long total = MN * batch;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->compute, p.partial, p.C,
+                       p.bias, p.bias_f32, p.residual, MN, p.N, p.splits, batch, p.strideC, p.act);
+    OSG_LAUNCH_CHECK(ctx);
     return 0;
 }
 
@@ -444,6 +721,7 @@ int osg_conv2d_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* w,
     p.A = (const f16*)x; p.Bt = (const f16*)w; p.C = (f16*)y; p.bias = bias; p.residual = (const f16*)residual;
     p.M = N * Ho * Wo; p.N = Cout; p.K = KH * KW * Cin; p.lda = 0;
     p.bias_f32 = bias_dtype == OSG_F32; p.act = act;
+    p.a_bytes_l = (long)N * H * W * Cin * 2;
     p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.KW = KW; p.sh = sh; p.sw = sw; p.pt = pt; p.pl = pl;
     // a 1x1 / stride 1 / no-pad convolution IS a plain GEMM over the pixels
     if (KH == 1 && KW == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0 && pb == 0 && pr == 0) {

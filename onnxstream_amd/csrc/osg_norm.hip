@@ -53,29 +53,60 @@ __global__ __launch_bounds__(1024) void instance_norm_kernel(const T* __restrict
 }
 
 // ---- fused GroupNorm, NHWC --------------------------------------------------------------------------------------
-// pass 1: grid (N*G, S): block (n,g,s) sweeps its slice of the HW pixels of group g and emits (sum, sumsq)
+// pass 1: grid (S, N): block (s, n) sweeps its slab of the HW pixels over ALL channels with 16-byte coalesced loads; a
+// thread keeps one fixed vector column (so each of its V elements belongs to a fixed group), accumulates (sum, sumsq)
+// per element in registers, then folds them per group through LDS atomics and emits one (sum, sumsq) pair per group.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ part, long HW, int C, int G, int S) {
-    __shared__ float red[8];
-    const int ng = blockIdx.x, s = blockIdx.y;
-    const int n = ng / G, g = ng - n * G;
-    const int cpg = C / G;
+    constexpr int V = 8 / (sizeof(T) / 2);
+    extern __shared__ float gsum[];  // [G][2]
+    const int s = blockIdx.x, n = blockIdx.y;
+    const int cpg = C / G, cv = C / V;
+    for (int i = threadIdx.x; i < G * 2; i += 256) gsum[i] = 0.f;
+    __syncthreads();
     const long p0 = HW * s / S, p1 = HW * (s + 1) / S;
-    const T* base = x + (long)n * HW * C + (long)g * cpg;
-    const long cnt = (p1 - p0) * cpg;
-    float sum = 0.f, sq = 0.f;
-    for (long i = threadIdx.x; i < cnt; i += 256) {
-        long p = p0 + i / cpg;
-        int c = (int)(i % cpg);
-        float v = to_f32<T>(base[p * C + c]);
-        sum += v;
-        sq += v * v;
+    const T* base = x + (long)n * HW * C;
+    const int cols = cv < 256 ? cv : 256;          // vector columns covered per sweep
+    const int R = 256 / cols;                      // pixel rows covered per sweep
+    const int tr = threadIdx.x / cols, tc = threadIdx.x - tr * cols;
+    if (tr < R) {
+        for (int c = tc; c < cv; c += cols) {
+            float sm[V], sq[V];
+#pragma unroll
+            for (int e = 0; e < V; e++) sm[e] = sq[e] = 0.f;
+            for (long p = p0 + tr; p < p1; p += R) {
+                T xv[V];
+                *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(base + p * C + (long)c * V);
+#pragma unroll
+                for (int e = 0; e < V; e++) {
+                    float v = to_f32<T>(xv[e]);
+                    sm[e] += v;
+                    sq[e] += v * v;
+                }
+            }
+            // elements of one vector span at most 2 groups when cpg >= V/2 ... fold runs of equal group first
+            int g_prev = (c * V) / cpg;
+            float as = 0.f, aq = 0.f;
+#pragma unroll
+            for (int e = 0; e < V; e++) {
+                int g = (c * V + e) / cpg;
+                if (g != g_prev) {
+                    atomicAdd(&gsum[g_prev * 2], as);
+                    atomicAdd(&gsum[g_prev * 2 + 1], aq);
+                    as = aq = 0.f;
+                    g_prev = g;
+                }
+                as += sm[e];
+                aq += sq[e];
+            }
+            atomicAdd(&gsum[g_prev * 2], as);
+            atomicAdd(&gsum[g_prev * 2 + 1], aq);
+        }
     }
-    sum = block_sum(sum, red);
-    sq = block_sum(sq, red);
-    if (threadIdx.x == 0) {
-        part[((long)ng * S + s) * 2 + 0] = sum;
-        part[((long)ng * S + s) * 2 + 1] = sq;
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += 256) {
+        part[(((long)n * G + g) * S + s) * 2 + 0] = gsum[g * 2];
+        part[(((long)n * G + g) * S + s) * 2 + 1] = gsum[g * 2 + 1];
     }
 }
 
@@ -250,11 +281,12 @@ int osg_group_norm_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void
     const int V = dtype == OSG_F16 ? 8 : 4;
     if (dtype != OSG_F16 && dtype != OSG_F32) OSG_FAIL(ctx, "osg_group_norm_nhwc: unsupported dtype");
     if (C % V) OSG_FAIL(ctx, "osg_group_norm_nhwc: C must be a multiple of the 16-byte vector width");
-    long per_group = HW * (C / G);
-    int S = (int)((per_group + 8191) / 8192);
-    if (S < 1) S = 1;
+    // slabs of >= ~8 pixel rows per sweep-row, at most 64 per image (the apply pass folds S partials per group)
+    const int cols = C / V < 256 ? C / V : 256;
+    const int Rr = 256 / cols;
+    int S = (int)(HW / ((long)Rr * 4));
     if (S > 64) S = 64;
-    if ((long)S > HW) S = (int)HW;
+    if (S < 1) S = 1;
     size_t need = (size_t)N * G * S * 2 * sizeof(float);
     if (osg_ensure_workspace(ctx, need)) return 1;
     float* part = (float*)ctx->ws;
@@ -263,12 +295,12 @@ int osg_group_norm_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void
     if (bpi < 1) bpi = 1;
     if (bpi > 1024) bpi = 1024;
     if (dtype == OSG_F16) {
-        hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(N * G, S), dim3(256), 0, ctx->compute, (const f16*)x, part, HW, C, G, S);
+        hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(S, N), dim3(256), G * 2 * sizeof(float), ctx->compute, (const f16*)x, part, HW, C, G, S);
         OSG_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(N * bpi), dim3(256), G * 2 * sizeof(float), ctx->compute, (const f16*)x, part,
                            (const f16*)gamma, (const f16*)beta, (f16*)y, HW, C, G, S, eps, (int)act, bpi);
     } else {
-        hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(N * G, S), dim3(256), 0, ctx->compute, (const float*)x, part, HW, C, G, S);
+        hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(S, N), dim3(256), G * 2 * sizeof(float), ctx->compute, (const float*)x, part, HW, C, G, S);
         OSG_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(N * bpi), dim3(256), G * 2 * sizeof(float), ctx->compute, (const float*)x, part,
                            (const float*)gamma, (const float*)beta, (float*)y, HW, C, G, S, eps, (int)act, bpi);
