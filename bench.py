@@ -138,21 +138,16 @@ def main():
     model_dir = ensure_model_dir(cfg, local_rank, barrier)
 
     # ---- inputs: rank 0 draws every prompt's latents/contexts, RCCL-broadcasts them over xGMI, each rank keeps its own ------
-    def draw(seed):
-        return sd_unet.unet_inputs(cfg, seed)
-    names = list(draw(0).keys())
-    if dist is not None:
-        packs = []
-        for nme in names:
-            full = np.stack([np.stack([draw(42 + 2 * r)[nme], draw(43 + 2 * r)[nme]]) for r in range(world)]) if rank == 0 else None
-            shape = (world, 2) + draw(0)[nme].shape
-            t = torch.from_numpy(full).cuda() if rank == 0 else torch.empty(shape, dtype=torch.float32, device="cuda")
-            dist.broadcast(t, src=0)
-            packs.append(t[rank].cpu().numpy())
-        cond = {n: p[0] for n, p in zip(names, packs)}
-        uncond = {n: p[1] for n, p in zip(names, packs)}
-    else:
-        cond, uncond = draw(42), draw(43)
+    # (one prompt per rank; a prompt = its cond and its uncond sample, stacked on a leading axis of 2)
+    from onnxstream_amd import shard
+
+    def draw(i):
+        c, u = sd_unet.unet_inputs(cfg, 42 + 2 * i), sd_unet.unet_inputs(cfg, 43 + 2 * i)
+        return {k: np.stack([c[k], u[k]]) for k in c}
+    mine = shard.scatter_prompts(dist, rank, world, world, draw, device="cuda" if dist is not None else "cpu")
+    (my_prompt, pack), = mine.items()
+    cond = {k: v[0] for k, v in pack.items()}
+    uncond = {k: v[1] for k, v in pack.items()}
 
     # ---- the product path: model_* C API -> host planner -> libosgpu HIP kernels -------------------------------------------
     m = Model(b.LIB_HOST, 0, "ram+nocache")
@@ -191,10 +186,9 @@ def main():
         tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
-        # gather every prompt's predicted noise on rank 0 (what the sampler on rank 0 would consume)
-        res = torch.from_numpy(out).cuda()
-        gathered = [torch.empty_like(res) for _ in range(world)] if rank == 0 else None
-        dist.gather(res, gathered, dst=0)
+        # gather every prompt's predicted noise on rank 0 (what the samplers on rank 0 would consume)
+        allr = shard.gather_results(dist, rank, world, world, {my_prompt: out}, device="cuda")
+        assert rank != 0 or (allr.shape[0] == world and np.isfinite(allr).all())
     ms_per_step = wall * 1e3 / args.steps
     images_per_s = world / (STEPS_PER_IMAGE * ms_per_step * 1e-3)
 

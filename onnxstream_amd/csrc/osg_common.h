@@ -25,6 +25,8 @@ struct osg_ctx {
     size_t ws_bytes = 0;
     void* ws2 = nullptr;                // scratch for re-laid-out dynamic GEMM operands
     size_t ws2_bytes = 0;
+    static constexpr long kTickets = 1 << 16;
+    int* tickets = nullptr;             // split-K arrival counters (zeroed once; the last arriver of a tile resets its counter)
     bool capturing = false;
     std::string err;
     std::string name;

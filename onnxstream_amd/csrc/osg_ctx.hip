@@ -33,6 +33,8 @@ int osg_init(int device, osg_ctx** out) {
         ok = hipHostMalloc(&c->stage[i], c->stage_bytes, hipHostMallocDefault) == hipSuccess &&
              hipEventCreateWithFlags(&c->stage_free[i], hipEventDisableTiming) == hipSuccess;
     }
+    ok = ok && hipMalloc((void**)&c->tickets, osg_ctx::kTickets * sizeof(int)) == hipSuccess &&
+         hipMemset(c->tickets, 0, osg_ctx::kTickets * sizeof(int)) == hipSuccess;
     if (!ok) {
         delete c;
         return 5;
@@ -49,6 +51,7 @@ void osg_destroy(osg_ctx* c) {
         if (c->stage[i]) hipHostFree(c->stage[i]);
         if (c->stage_free[i]) hipEventDestroy(c->stage_free[i]);
     }
+    if (c->tickets) hipFree(c->tickets);
     if (c->ws) hipFree(c->ws);
     if (c->ws2) hipFree(c->ws2);
     if (c->ev_copy) hipEventDestroy(c->ev_copy);

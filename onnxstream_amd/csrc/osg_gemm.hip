@@ -37,6 +37,7 @@ struct GemmParams {
     unsigned a_bytes, b_bytes;   // buffer-descriptor extents of one batch item of A / Bt
     long a_bytes_l;              // conv: byte size of the whole NHWC input (host side, before the 2 GiB check)
     int mt, nt, n_major;         // tile grid and the order tiles are walked inside an XCD's contiguous chunk
+    int* tickets;                // split-K arrival counters (one per output tile), zero between launches
 };
 
 // ---- epilogue shared by both kernels: lane owns C[m][n..n+3], m = tile_m + (lane&15), n = tile_n + (lane>>4)*4 --------
@@ -463,6 +464,57 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the dummy tail loads before the LDS is released
     gemm_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0, lane, zb, zb * p.splits + zs);
+
+    // ---- split-K: the LAST k-slice block to arrive at this tile folds the f32 slabs (fixed order => deterministic) and writes
+    // the f16 tile -- no separate reduce launch.  Hand-off = agent-scope release (writer) / acquire (reducer), relaxed ticket.
+    if (p.splits > 1 && p.tickets) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem2);
+        const int tile_id = (zb * p.mt + m_tile) * p.nt + n_tile;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *flag = __hip_atomic_fetch_add(&p.tickets[tile_id], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (*flag != p.splits - 1) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(&p.tickets[tile_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        constexpr int VPR = BN / 4;
+        const long MN = (long)p.M * p.N;
+        const float* __restrict__ P0 = p.partial + (long)zb * p.splits * MN;
+        f16* __restrict__ C = p.C + zb * p.strideC;
+        const f16* __restrict__ R = p.residual ? p.residual + zb * p.strideC : nullptr;
+        for (int v = tid; v < BM * VPR; v += 256) {
+            const int r = v / VPR, m = m0 + r, n = n0 + (v - r * VPR) * 4;
+            if (m >= p.M || n >= p.N) continue;
+            const float* src = P0 + (long)m * p.N + n;
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int s2 = 0; s2 < p.splits; s2++) sum += *reinterpret_cast<const f32x4*>(src + s2 * MN);
+            if (p.bias) {
+                if (p.bias_f32) sum += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
+                else {
+                    f16x4 bv = *reinterpret_cast<const f16x4*>((const f16*)p.bias + n);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) sum[e] += (float)bv[e];
+                }
+            }
+            if (R) {
+                f16x4 rv = *reinterpret_cast<const f16x4*>(R + (long)m * p.N + n);
+#pragma unroll
+                for (int e = 0; e < 4; e++) sum[e] += (float)rv[e];
+            }
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = (f16)osg_apply_act(sum[e], p.act);
+            *reinterpret_cast<f16x4*>(C + (long)m * p.N + n) = o;
+        }
+    }
 }
 
 template <int BM, int BN, int NST, bool CONV, int MODE = 0>
@@ -480,6 +532,53 @@ int launch_v2(osg_ctx* ctx, GemmParams& p, int batch) {
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, ctx->compute, p);
     OSG_LAUNCH_CHECK(ctx);
     return 0;
+}
+
+// ---- first-layer convolution (tiny Cin, e.g. conv_in 4 -> 320): K = KH*KW*Cin is a few dozen, far below one MFMA k-tile, so it
+// runs on the vector ALUs: the OHWI filter bank sits in LDS as [K][Cout], a thread owns 8 output channels of one pixel.
+__global__ __launch_bounds__(256) void conv_small_cin_kernel(GemmParams p, int KH, int pix_per_block) {
+    extern __shared__ __attribute__((aligned(16))) f16 wsm[];   // [K][N]
+    const int K = p.K, N = p.N;
+    for (int i = threadIdx.x; i < K * N; i += 256) {
+        const int n = i / K, k = i - n * K;
+        wsm[k * N + n] = p.Bt[i];
+    }
+    __syncthreads();
+    const int tc = N / 8;
+    const int pl_ = threadIdx.x / tc, cc = threadIdx.x - pl_ * tc;
+    if (pl_ >= pix_per_block) return;
+    const int hw = p.Ho * p.Wo;
+    for (int it = 0; it < 4; it++) {
+    const int m = (blockIdx.x * 4 + it) * pix_per_block + pl_;
+    if (m >= p.M) return;
+    const int n_img = m / hw, r2 = m - n_img * hw, ho = r2 / p.Wo, wo = r2 - ho * p.Wo;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const f16* xin = p.A + (long)n_img * p.H * p.W * p.Cin;
+    int k = 0;
+    for (int kh = 0; kh < KH; kh++) {
+        const int hi = ho * p.sh - p.pt + kh;
+        for (int kw = 0; kw < p.KW; kw++) {
+            const int wi = wo * p.sw - p.pl + kw;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            for (int c = 0; c < p.Cin; c++, k++) {
+                const float xv = ok ? (float)xin[((long)hi * p.W + wi) * p.Cin + c] : 0.f;
+                const f16x8 wv = *reinterpret_cast<const f16x8*>(wsm + k * N + cc * 8);
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[e] += xv * (float)wv[e];
+            }
+        }
+    }
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        float v = acc[e];
+        const int n = cc * 8 + e;
+        if (p.bias) v += p.bias_f32 ? ((const float*)p.bias)[n] : (float)((const f16*)p.bias)[n];
+        if (p.residual) v += (float)p.residual[(long)m * N + n];
+        o[e] = (f16)osg_apply_act(v, p.act);
+    }
+    *reinterpret_cast<f16x8*>(p.C + (long)m * N + cc * 8) = o;
+    }
 }
 
 // sum the split-K slabs, fuse bias/residual/activation, round once to f16
@@ -545,7 +644,7 @@ static V2Choice choose_v2(const osg_ctx* ctx, int M, int N, int K, int batch) {
                 const double conc = std::min((double)bpc, std::ceil(blocks / cus));
                 const double tk = conc <= 1.0 ? std::max(mfma, tload) + 450.0 : conc * std::max(mfma, tload);
                 double cost = rounds * (kts * tk + 3500.0);
-                if (s > 1) cost += 4500.0 + (double)M * N * batch * s * 4.0 / 2000.0;   // reduce launch + slab traffic
+                if (s > 1) cost += 9000.0 + (double)M * N * batch * s * 4.0 / 2000.0;   // reduce launch (measured ~4-7 us) + slab traffic
                 if (cost < best_cost) { best_cost = cost; best = {c, nst, s}; }
             }
         }
@@ -562,10 +661,16 @@ int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch) {
     int kt_per = (ktiles + ch.splits - 1) / ch.splits;
     p.splits = (ktiles + kt_per - 1) / kt_per;
     p.k_per_split = kt_per * 64;
+    p.tickets = nullptr;
     if (p.splits > 1) {
         size_t need = (size_t)batch * p.splits * p.M * p.N * sizeof(float);
         if (osg_ensure_workspace(ctx, need)) return 1;
         p.partial = (float*)ctx->ws;
+        const long n_tiles = (long)batch * ((p.M + kV2BM[ch.cfg] - 1) / kV2BM[ch.cfg]) * ((p.N + kV2BN[ch.cfg] - 1) / kV2BN[ch.cfg]);
+        // in-kernel last-arriver reduction: measured SLOWER than the reduce launch (the agent-scope release of freshly written
+        // slabs costs ~6 us per block, MI355X_MICROARCH.md 'publish-large'); kept for experiments only
+        static const bool use_tickets = getenv("OSG_GEMM_TICKET") != nullptr;
+        if (use_tickets && p.N % 4 == 0 && ctx->tickets && n_tiles <= osg_ctx::kTickets) p.tickets = ctx->tickets;
     }
     // split the operand with more unique bytes across the XCDs (each private L2 then streams its slice from HBM once)
     const double a_unique = CONV ? (double)p.a_bytes : (double)p.M * p.K * 2.0;
@@ -581,7 +686,7 @@ int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch) {
     else if (ch.cfg == 1) rc = ch.nst == 4 ? launch_v2<128, 64, 4, CONV>(ctx, p, batch) : launch_v2<128, 64, 2, CONV>(ctx, p, batch);
     else rc = ch.nst == 4 ? launch_v2<64, 64, 4, CONV>(ctx, p, batch) : launch_v2<64, 64, 2, CONV>(ctx, p, batch);
     if (rc) return rc;
-    if (p.splits > 1) return launch_splitk_reduce(ctx, p, batch);
+    if (p.splits > 1 && !p.tickets) return launch_splitk_reduce(ctx, p, batch);
     return 0;
 }
 
@@ -723,6 +828,12 @@ int osg_conv2d_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* w,
     p.bias_f32 = bias_dtype == OSG_F32; p.act = act;
     p.a_bytes_l = (long)N * H * W * Cin * 2;
     p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.KW = KW; p.sh = sh; p.sw = sw; p.pt = pt; p.pl = pl;
+    if (Cin < 8 && Cout % 8 == 0 && Cout / 8 <= 256 && (size_t)p.K * Cout * 2 <= 64 * 1024) {
+        const int ppb = 256 / (Cout / 8);
+        hipLaunchKernelGGL(conv_small_cin_kernel, dim3((p.M + 4 * ppb - 1) / (4 * ppb)), dim3(256), (size_t)p.K * Cout * 2, ctx->compute, p, KH, ppb);
+        OSG_LAUNCH_CHECK(ctx);
+        return 0;
+    }
     // a 1x1 / stride 1 / no-pad convolution IS a plain GEMM over the pixels
     if (KH == 1 && KW == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0 && pb == 0 && pr == 0) {
         p.lda = Cin;

@@ -120,39 +120,57 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     const int n = blockIdx.x / blocks_per_img;
     const int bi = blockIdx.x - n * blocks_per_img;
     const int cpg = C / G;
-    for (int g = threadIdx.x; g < G; g += 256) {
-        double s = 0, q = 0;
-        for (int k = 0; k < S; k++) {
-            s += part[(((long)n * G + g) * S + k) * 2 + 0];
-            q += part[(((long)n * G + g) * S + k) * 2 + 1];
+    // fold the S partials of every group: `tpg` lanes per group load independent partials, shuffle-reduce in f64
+    {
+        int tpg = 1;
+        while (tpg * 2 * G <= 256 && tpg < 64) tpg *= 2;
+        const double cnt = (double)HW * cpg;
+        for (int g0 = 0; g0 < G; g0 += 256 / tpg) {
+            const int g = g0 + threadIdx.x / tpg, l = threadIdx.x % tpg;
+            double sm = 0, q = 0;
+            if (g < G)
+                for (int k = l; k < S; k += tpg) {
+                    sm += part[(((long)n * G + g) * S + k) * 2 + 0];
+                    q += part[(((long)n * G + g) * S + k) * 2 + 1];
+                }
+            for (int o = tpg >> 1; o > 0; o >>= 1) {
+                sm += __shfl_xor(sm, o, 64);
+                q += __shfl_xor(q, o, 64);
+            }
+            if (g < G && l == 0) {
+                double mean = sm / cnt;
+                double var = q / cnt - mean * mean;
+                if (var < 0) var = 0;
+                stat[g * 2 + 0] = (float)mean;
+                stat[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+            }
         }
-        double cnt = (double)HW * cpg;
-        double mean = s / cnt;
-        double var = q / cnt - mean * mean;
-        if (var < 0) var = 0;
-        stat[g * 2 + 0] = (float)mean;
-        stat[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
     __syncthreads();
-    const long cv = C / V;
+    // per-channel affine table: y = x * ca[c] + cb[c]   (ca = rstd*gamma, cb = beta - mean*rstd*gamma)
+    float* ca = stat + 2 * G;
+    float* cb = ca + C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c / cpg;
+        const float a = stat[g * 2 + 1] * to_f32<T>(gamma[c]);
+        ca[c] = a;
+        cb[c] = to_f32<T>(beta[c]) - stat[g * 2] * a;
+    }
+    __syncthreads();
+    const int cv = C / V;
     const long total = HW * cv;
     const T* xb = x + (long)n * HW * C;
     T* yb = y + (long)n * HW * C;
     for (long i = (long)bi * 256 + threadIdx.x; i < total; i += (long)blocks_per_img * 256) {
-        long p = i / cv;
-        int c0 = (int)(i - p * cv) * V;
-        T xv[V], gv[V], bv[V], ov[V];
-        *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(xb + p * C + c0);
-        *reinterpret_cast<uint4*>(gv) = *reinterpret_cast<const uint4*>(gamma + c0);
-        *reinterpret_cast<uint4*>(bv) = *reinterpret_cast<const uint4*>(beta + c0);
+        const int c0 = (int)(i % cv) * V;
+        T xv[V], ov[V];
+        *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(xb + i * V);
 #pragma unroll
         for (int e = 0; e < V; e++) {
-            int g = (c0 + e) / cpg;
-            float v = (to_f32<T>(xv[e]) - stat[g * 2]) * stat[g * 2 + 1];
-            v = v * to_f32<T>(gv[e]) + to_f32<T>(bv[e]);
+            float v = to_f32<T>(xv[e]) * ca[c0 + e] + cb[c0 + e];
             ov[e] = from_f32<T>(osg_apply_act(v, act));
         }
-        *reinterpret_cast<uint4*>(yb + p * C + c0) = *reinterpret_cast<uint4*>(ov);
+        *reinterpret_cast<uint4*>(yb + i * V) = *reinterpret_cast<uint4*>(ov);
     }
 }
 
@@ -291,18 +309,18 @@ int osg_group_norm_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void
     if (osg_ensure_workspace(ctx, need)) return 1;
     float* part = (float*)ctx->ws;
     long total_v = HW * (C / V);
-    int bpi = (int)((total_v + 256 * 4 - 1) / (256 * 4));
+    int bpi = (int)((total_v + 256 * 8 - 1) / (256 * 8));
     if (bpi < 1) bpi = 1;
     if (bpi > 1024) bpi = 1024;
     if (dtype == OSG_F16) {
         hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(S, N), dim3(256), G * 2 * sizeof(float), ctx->compute, (const f16*)x, part, HW, C, G, S);
         OSG_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(N * bpi), dim3(256), G * 2 * sizeof(float), ctx->compute, (const f16*)x, part,
+        hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(N * bpi), dim3(256), (G * 2 + 2 * C) * sizeof(float), ctx->compute, (const f16*)x, part,
                            (const f16*)gamma, (const f16*)beta, (f16*)y, HW, C, G, S, eps, (int)act, bpi);
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(S, N), dim3(256), G * 2 * sizeof(float), ctx->compute, (const float*)x, part, HW, C, G, S);
         OSG_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(N * bpi), dim3(256), G * 2 * sizeof(float), ctx->compute, (const float*)x, part,
+        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(N * bpi), dim3(256), (G * 2 + 2 * C) * sizeof(float), ctx->compute, (const float*)x, part,
                            (const float*)gamma, (const float*)beta, (float*)y, HW, C, G, S, eps, (int)act, bpi);
     }
     OSG_LAUNCH_CHECK(ctx);

@@ -1,0 +1,74 @@
+"""Multi-GPU sharding of independent denoising passes.
+
+The path shards embarrassingly: every (prompt, cond|uncond) UNet pass is independent (reference src/sd.cpp:1537-1543,
+:2319-2321), so each rank (one process per GPU) owns whole prompts and runs its own cond+uncond batch-2 pass per step with
+replicated weights -- there is NO collective on the data path.  torch.distributed (backend "nccl" = RCCL over xGMI on the
+GPU box, "gloo" in the CPU tests) only moves the tiny tensors either side of it:
+
+    scatter_prompts   rank 0 draws/holds every prompt's inputs and broadcasts them; each rank keeps its own slice
+    gather_results    every rank's predicted noise back to rank 0 (what the samplers on rank 0 would consume)
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+
+
+def prompts_of_rank(n_prompts: int, rank: int, world: int) -> List[int]:
+    """Contiguous block partition of prompt indices; ragged tails go to the low ranks (|sizes| differ by at most 1)."""
+    q, r = divmod(n_prompts, world)
+    start = rank * q + min(rank, r)
+    return list(range(start, start + q + (1 if rank < r else 0)))
+
+
+def scatter_prompts(dist, rank: int, world: int, n_prompts: int, draw: Callable[[int], Dict[str, np.ndarray]], device="cpu"):
+    """draw(i) -> dict of fp32 arrays for prompt i (called on rank 0 only, plus once anywhere for the shapes).
+    Returns {prompt_index: inputs} for the prompts this rank owns."""
+    import torch
+    mine = prompts_of_rank(n_prompts, rank, world)
+    if dist is None or world == 1:
+        return {i: draw(i) for i in mine}
+    proto = draw(0)
+    out: Dict[int, Dict[str, np.ndarray]] = {i: {} for i in mine}
+    for name in sorted(proto):
+        shape = (n_prompts,) + proto[name].shape
+        if rank == 0:
+            t = torch.from_numpy(np.stack([draw(i)[name] for i in range(n_prompts)]).astype(np.float32)).to(device)
+        else:
+            t = torch.empty(shape, dtype=torch.float32, device=device)
+        dist.broadcast(t, src=0)
+        host = t.cpu().numpy()
+        for i in mine:
+            out[i][name] = host[i].copy()
+    return out
+
+
+def gather_results(dist, rank: int, world: int, n_prompts: int, results: Dict[int, np.ndarray], device="cpu") -> Optional[np.ndarray]:
+    """results: {prompt_index: array} of this rank.  Rank 0 returns the stacked [n_prompts, ...] array, other ranks None."""
+    import torch
+    if dist is None or world == 1:
+        return np.stack([results[i] for i in range(n_prompts)])
+    proto = next(iter(results.values())) if results else None
+    # ragged ownership: all_gather needs equal sizes, so pad every rank to the maximum share and drop the padding
+    share = max(len(prompts_of_rank(n_prompts, r, world)) for r in range(world))
+    shp = torch.tensor(list(proto.shape) if proto is not None else [], dtype=torch.int64, device=device)
+    ndim = torch.tensor([shp.numel()], dtype=torch.int64, device=device)
+    dist.all_reduce(ndim, op=dist.ReduceOp.MAX)
+    if shp.numel() == 0:
+        shp = torch.zeros(int(ndim.item()), dtype=torch.int64, device=device)
+    dist.all_reduce(shp, op=dist.ReduceOp.MAX)
+    item_shape = tuple(int(x) for x in shp.cpu().tolist())
+    buf = np.zeros((share,) + item_shape, np.float32)
+    for j, i in enumerate(prompts_of_rank(n_prompts, rank, world)):
+        buf[j] = results[i]
+    t = torch.from_numpy(buf).to(device)
+    gathered = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    if rank != 0:
+        return None
+    out = np.zeros((n_prompts,) + item_shape, np.float32)
+    for r in range(world):
+        for j, i in enumerate(prompts_of_rank(n_prompts, r, world)):
+            out[i] = gathered[r][j].cpu().numpy()
+    return out

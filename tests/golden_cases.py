@@ -1,0 +1,165 @@
+"""Hot-path golden cases: small graphs, each one a pattern of the SD UNet as the reference's exporter writes it.
+
+The reference ships no tests and no expected outputs, so the golden vectors are OUTPUTS OF THE REFERENCE
+ITSELF: tools/make_golden.py runs every case through oracle/_ref (the unmodified /root/reference sources + XNNPACK) in fp16
+and fp32 arithmetic and commits inputs + outputs as tests/golden/<case>.npz.  Graph + weights are NOT stored: they are
+re-emitted deterministically from the seeds below (numpy Generator streams are stable), so fixtures stay a few KB each.
+
+Used by: tools/make_golden.py (generator), tests/test_golden.py (CPU: oracle/_ref and the numpy restatement against the
+fixtures; GPU: the HIP backend against the fixtures -- works where /root/reference does not exist).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from onnxstream_amd.synth import sd_unet
+from onnxstream_amd.synth.graph import GraphBuilder
+
+f32 = np.float32
+
+
+def _rn(seed, shape, std=1.0):
+    return (np.random.default_rng(seed).standard_normal(shape, dtype=f32) * f32(std)).astype(f32)
+
+
+def _unet(g, **kw):
+    cfg = sd_unet.UNetConfig(block_out=(32, 64), heads=2, ctx_dim=48, ctx_len=11, latent=8, groups=8, name="case", **kw)
+    return sd_unet._UNet(g, cfg)
+
+
+# every builder: (GraphBuilder) -> dict of fp32 inputs.  The graph output is the single unconsumed tensor.
+def conv3x3(g):
+    x = g.input("x", (1, 64, 12, 12))
+    g.conv("/c", x, 128, 3)
+    return {"x": _rn(1, (1, 64, 12, 12))}
+
+
+def conv3x3_stride2(g):
+    x = g.input("x", (1, 64, 12, 12))
+    g.conv("/c", x, 64, 3, stride=2, pad=1)
+    return {"x": _rn(2, (1, 64, 12, 12))}
+
+
+def conv1x1_nobias(g):
+    x = g.input("x", (1, 64, 8, 8))
+    g.conv("/c", x, 32, 1, bias=False)
+    return {"x": _rn(3, (1, 64, 8, 8))}
+
+
+def conv_in_4ch(g):
+    x = g.input("x", (1, 4, 16, 16))
+    g.conv("/c", x, 32, 3)
+    return {"x": _rn(4, (1, 4, 16, 16))}
+
+
+def conv_ragged(g):   # Cin not a multiple of 8, odd spatial size, Cout not a multiple of 4
+    x = g.input("x", (1, 20, 7, 5))
+    g.conv("/c", x, 30, 3)
+    return {"x": _rn(5, (1, 20, 7, 5))}
+
+
+def linear_bias(g):
+    x = g.input("x", (1, 77, 64))
+    g.linear("/l", x, 128)
+    return {"x": _rn(6, (1, 77, 64))}
+
+
+def gemm_temb(g):
+    x = g.input("x", (1, 128))
+    g.gemm("/g", g.silu("/act", x), 64)
+    return {"x": _rn(7, (1, 128))}
+
+
+def group_norm_silu(g):
+    x = g.input("x", (1, 64, 8, 8))
+    g.silu("/act", g.group_norm("/gn", x, 8, 1e-5))
+    return {"x": _rn(8, (1, 64, 8, 8), 2.0) + f32(0.5)}
+
+
+def layer_norm(g):
+    x = g.input("x", (1, 64, 96))
+    g.layer_norm("/ln", x)
+    return {"x": _rn(9, (1, 64, 96), 1.5) - f32(0.3)}
+
+
+def self_attention(g):
+    x = g.input("x", (1, 64, 64))
+    _unet(g).attention("/attn1", x, x)
+    return {"x": _rn(10, (1, 64, 64))}
+
+
+def cross_attention(g):
+    x = g.input("x", (1, 64, 64))
+    c = g.input("ctx", (1, 11, 48))
+    _unet(g).attention("/attn2", x, c)
+    return {"x": _rn(11, (1, 64, 64)), "ctx": _rn(12, (1, 11, 48))}
+
+
+def geglu_ff(g):
+    x = g.input("x", (1, 64, 32))
+    _unet(g).feed_forward("/ff", x)
+    return {"x": _rn(13, (1, 64, 32))}
+
+
+def resnet_block(g):
+    x = g.input("x", (1, 32, 8, 8))
+    t = g.input("temb", (1, 128))
+    _unet(g).resnet("/res", x, t, 64)
+    return {"x": _rn(14, (1, 32, 8, 8)), "temb": _rn(15, (1, 128))}
+
+
+def transformer_block(g):
+    x = g.input("x", (1, 64, 8, 8))
+    c = g.input("ctx", (1, 11, 48))
+    _unet(g).transformer2d("/tr", x, c, 1)
+    return {"x": _rn(16, (1, 64, 8, 8)), "ctx": _rn(17, (1, 11, 48))}
+
+
+def upsample_concat(g):
+    x = g.input("x", (1, 32, 6, 6))
+    s = g.input("skip", (1, 32, 12, 12))
+    u = _unet(g).upsample("/up", x)
+    cat = g.concat("/cat", [u, s], 1)
+    g.conv("/c", cat, 32, 3)
+    return {"x": _rn(18, (1, 32, 6, 6)), "skip": _rn(19, (1, 32, 12, 12))}
+
+
+def time_embedding(g):
+    t = g.input("timestep", (1,))
+    _unet(g).time_embedding(t)
+    return {"timestep": np.asarray([999.0], f32)}
+
+
+CASES = [conv3x3, conv3x3_stride2, conv1x1_nobias, conv_in_4ch, conv_ragged, linear_bias, gemm_temb, group_norm_silu, layer_norm,
+         self_attention, cross_attention, geglu_ff, resnet_block, transformer_block, upsample_concat, time_embedding]
+# whole (miniature) UNets: SD1.5-shaped and SDXL-shaped
+UNETS = {"unet_tiny": sd_unet.TINY, "unet_tinyxl": sd_unet.TINY_XL}
+
+
+def emit(case, sink, seed=1234):
+    """Emit a case's graph + weights into `sink`; returns the fp32 input dict."""
+    if isinstance(case, str):
+        cfg = UNETS[case]
+        sd_unet.build_unet(sink, cfg, seed=seed)
+        return sd_unet.unet_inputs(cfg, 42)
+    g = GraphBuilder(sink, seed=seed)
+    ins = case(g)
+    # give the graph output (the last op's single output) the stable name "out"
+    head, outp = g.lines[-1].split("*output:", 1)
+    tok, _, rest = outp.partition("*")
+    g.lines[-1] = head + "*output:out" + tok[tok.index("("):] + (("*" + rest) if rest else "")
+    g.finish()
+    return ins
+
+
+def all_case_names():
+    return [c.__name__ for c in CASES] + list(UNETS)
+
+
+def by_name(name):
+    for c in CASES:
+        if c.__name__ == name:
+            return c
+    if name in UNETS:
+        return name
+    raise KeyError(name)

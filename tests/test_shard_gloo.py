@@ -1,0 +1,67 @@
+"""world_size-2 `gloo` test (CPU) of the N>1 path bench.py uses on the GPU box with RCCL: rank 0 draws every prompt's inputs,
+broadcast, each rank keeps its slice; results gathered back on rank 0.  Also the ragged case (3 prompts on 2 ranks)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from onnxstream_amd import shard
+
+
+def _draw(i):
+    rng = np.random.default_rng(1000 + i)
+    return {"sample": rng.standard_normal((1, 4, 8, 8), dtype=np.float32), "ctx": rng.standard_normal((1, 7, 16), dtype=np.float32)}
+
+
+def _worker(rank, world, port, n_prompts, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = shard.scatter_prompts(dist, rank, world, n_prompts, _draw)
+        ok = sorted(mine) == shard.prompts_of_rank(n_prompts, rank, world)
+        for i, ins in mine.items():
+            want = _draw(i)
+            ok = ok and all(np.array_equal(ins[k], want[k]) for k in want)
+        # the "pass": something rank- and prompt-specific computed from the inputs
+        res = {i: (ins["sample"] * 2.0 + float(i)).astype(np.float32) for i, ins in mine.items()}
+        allr = shard.gather_results(dist, rank, world, n_prompts, res)
+        if rank == 0:
+            for i in range(n_prompts):
+                ok = ok and np.array_equal(allr[i], _draw(i)["sample"] * 2.0 + float(i))
+        else:
+            ok = ok and allr is None
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_prompts", [2, 3])
+def test_scatter_gather_world2(n_prompts):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_prompts, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got == {0: True, 1: True}
+
+
+def test_partition_properties():
+    for n in range(0, 20):
+        for w in range(1, 9):
+            parts = [shard.prompts_of_rank(n, r, w) for r in range(w)]
+            assert sorted(sum(parts, [])) == list(range(n))                     # a partition: every prompt exactly once
+            assert max(map(len, parts)) - min(map(len, parts)) <= 1             # balanced
+    assert np.array_equal(shard.gather_results(None, 0, 1, 2, {0: np.ones(3, np.float32), 1: np.zeros(3, np.float32)}),
+                          np.stack([np.ones(3, np.float32), np.zeros(3, np.float32)]))

@@ -1,0 +1,35 @@
+"""Generate tests/golden/*.npz from the REFERENCE (oracle/_ref = unmodified /root/reference sources + XNNPACK).
+
+    python tools/make_golden.py            # needs oracle/_ref/libonnxstream_ref.so (make -C oracle ref)
+
+Each fixture holds: the fp32 inputs, the reference output with fp16 arithmetic (`ref16`, the parity target) and with fp32
+arithmetic (`ref32`, used to triangulate: being closer to fp32 than the fp16 reference is not an error)."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import golden_cases as gc  # noqa: E402
+from onnxstream_amd.synth.graph import DirSink  # noqa: E402
+from oracle import ref as oref  # noqa: E402
+
+out_dir = os.path.join(REPO, "tests", "golden")
+os.makedirs(out_dir, exist_ok=True)
+assert oref.available(), "build the oracle first: make -C oracle ref"
+for name in gc.all_case_names():
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        ins = gc.emit(gc.by_name(name), DirSink(d))
+        o16 = oref.run_model(d, ins, fp16=True, threads=1)
+        o32 = oref.run_model(d, ins, fp16=False, threads=1)
+        assert len(o16) == 1, (name, list(o16))
+        (oname, v16), = o16.items()
+        v32 = o32[oname]
+        mx = float(np.abs(v32).max())
+        print(f"{name:20s} out={oname} shape={v16.shape} max|ref32|={mx:.3f} |ref16-ref32|/max={np.abs(v16 - v32).max() / mx:.2e}")
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), out_name=np.asarray(oname), ref16=v16, ref32=v32,
+                            **{"in_" + k: v for k, v in ins.items()})
