@@ -91,6 +91,12 @@ int osg_conv2d_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* w_
                     const void* residual, void* y, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride_h,
                     int stride_w, int pad_top, int pad_left, int pad_bottom, int pad_right, osg_act act);
 
+/* Same, plus a per-IMAGE channel bias image_bias[n*image_bias_ld + c] (f16) added in f32 before the single rounding: the fused form
+ * of the resnet block's `Conv -> Add(Unsqueeze(Unsqueeze(time_emb_proj)))` (reference: XnnPack::add with a [1,C,1,1] operand, :1666). */
+int osg_conv2d_nhwc_rb(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* w_ohwi, const void* bias, osg_dtype bias_dtype,
+                       const void* image_bias, long image_bias_ld, const void* residual, void* y, int N, int H, int W, int Cin, int Cout,
+                       int KH, int KW, int stride_h, int stride_w, int pad_top, int pad_left, int pad_bottom, int pad_right, osg_act act);
+
 /* C[b] = act(A[b] (MxK, row-major, lda) * B[b] + bias + residual).  B is [K,N] row-major (b_is_nk=0, the layout
  * XNN_FLAG_TRANSPOSE_WEIGHTS gives the reference, onnxstream.cpp:977,1136) or pre-transposed [N,K] (b_is_nk=1, how
  * resident weights are kept on the device).  stride_* are element strides between batch items (0 = broadcast).

@@ -112,9 +112,28 @@ long Plan::total_elems(int v) const { return vals[v].numel() * (vals[v].batched 
 size_t Plan::val_bytes(int v) const { return (size_t)total_elems(v) * esize(vals[v].dtype); }
 
 void* Plan::ptr(int v) const {
-    const Val& r = vals[root_of(v)];
-    if (r.dptr) return r.dptr;
-    return (char*)arena + r.offset;
+    size_t off = 0;
+    while (vals[v].root >= 0) {
+        off += vals[v].view_off;
+        v = vals[v].root;
+    }
+    const Val& r = vals[v];
+    if (r.dptr) return (char*)r.dptr + off;
+    return (char*)arena + r.offset + off;
+}
+
+int Plan::ensure_dense(int v) {
+    if (vals[v].ld == 0) return v;
+    if (vals[v].as_dense >= 0) return vals[v].as_dense;
+    const Shape s = vals[v].shape;
+    int o = new_val("", s, vals[v].dtype, vals[v].lay, vals[v].batched);
+    const long cols = s.back(), rows = total_elems(v) / cols, ld = vals[v].ld;
+    const int es = (int)esize(vals[v].dtype);
+    add_step("dense " + vals[v].name, {v}, {o}, [this, v, o, rows, cols, ld, es] {
+        be.check(be.api.osg_copy_2d(be.ctx, es, ptr(v), ld, 0, ptr(o), cols, 0, rows, cols), "osg_copy_2d");
+    });
+    vals[v].as_dense = o;
+    return o;
 }
 
 void Plan::add_step(const std::string& what, std::vector<int> reads, std::vector<int> writes, std::function<void()> fn) {
@@ -337,6 +356,8 @@ struct Lowering {
             index_graph(); fuse_attention(true);
             index_graph(); fuse_linear();
             index_graph(); fuse_residual();
+            index_graph(); cse_silu();
+            index_graph(); fuse_image_bias();
         } else if (m.m_fuse_ops_in_attention) {
             index_graph(); fuse_attention(false);
         }
@@ -648,6 +669,60 @@ struct Lowering {
         }
     }
 
+    // identical osg.SiLU(x) ops (the 22 resnet blocks each re-activate the SAME time embedding) ==> one
+    void cse_silu() {
+        std::map<std::string, std::string> first;   // input name -> surviving output name
+        std::map<std::string, std::string> rename;
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (!is((int)i, "osg.SiLU")) continue;
+            Operation& op = ops()[i];
+            if (op.m_input.size() != 1 || op.m_output.size() != 1 || !act(op.m_input[0])) continue;
+            if (use_count(op.m_output[0].m_name) >= 1000) continue;  // an extra output the caller reads
+            auto it = first.find(op.m_input[0].m_name);
+            if (it == first.end()) first[op.m_input[0].m_name] = op.m_output[0].m_name;
+            else {
+                rename[op.m_output[0].m_name] = it->second;
+                dead[i] = 1;
+            }
+        }
+        if (rename.empty()) return;
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (dead[i]) continue;
+            for (auto& in : ops()[i].m_input) {
+                auto it = rename.find(in.m_name);
+                if (it != rename.end() && in.m_type == TensorDataType::none) in.m_name = it->second;
+            }
+        }
+    }
+
+    // Conv(x) -> Add(., Unsqueeze(Unsqueeze(g[1,C])))  ==> the per-image channel bias g rides in the conv epilogue
+    void fuse_image_bias() {
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (!is((int)i, "Conv")) continue;
+            Operation& op = ops()[i];
+            if (op.m_output.size() != 1 || attr(op, "osg_residual")) continue;
+            int ad = sole_consumer(op.m_output[0]);
+            if (!is(ad, "Add")) continue;
+            int ti = other(ops()[ad], op.m_output[0].m_name);
+            const Tensor& t = ops()[ad].m_input[ti];
+            const auto& os = op.m_output[0].m_shape;
+            if (!act(t) || os.size() != 4 || t.m_shape != std::vector<size_t>{1, os[1], 1, 1}) continue;
+            int u1 = prod_of(t);
+            if (!is(u1, "Unsqueeze") || use_count(t.m_name) != 1) continue;
+            int u0 = prod_of(ops()[u1].m_input[0]);
+            if (!is(u0, "Unsqueeze") || use_count(ops()[u1].m_input[0].m_name) != 1) continue;
+            const Tensor g = ops()[u0].m_input[0];
+            if (!act(g) || g.m_shape != std::vector<size_t>{1, os[1]} || use_count(g.m_name) != 1) continue;
+            Operation f = op;
+            while (f.m_input.size() < 4) f.m_input.push_back(Tensor());
+            f.m_input.push_back(g);
+            f.m_attributes.emplace_back("osg_image_bias", "1");
+            f.m_output = {ops()[ad].m_output[0]};
+            dead[i] = dead[u0] = dead[u1] = 1;
+            ops()[ad] = std::move(f);
+        }
+    }
+
     // MatMul(x, W) -> Add(., b[N])  ==> osg.Linear(x, W, b)
     void fuse_linear() {
         for (size_t i = 0; i < ops().size(); i++) {
@@ -697,12 +772,13 @@ struct Lowering {
     // ------------------------------------------------------------------------------------------------------------------
     // lowering
     // ------------------------------------------------------------------------------------------------------------------
-    int in_val(const Tensor& t) {
+    int in_val_raw(const Tensor& t) {   // may return a strided column view (Val::ld != 0)
         if (is_const_tensor(t)) return const_val(t);
         auto it = P.by_name.find(t.m_name);
         if (it == P.by_name.end()) throw std::invalid_argument("Model::get_tensor_data: input tensor not found: " + t.m_name);
         return it->second;
     }
+    int in_val(const Tensor& t) { return P.ensure_dense(in_val_raw(t)); }
 
     void check_out(const Operation& op, const Shape& got, size_t idx = 0) {
         // the reference's per-op self check (check_output_shape, :3070)
@@ -721,7 +797,11 @@ struct Lowering {
     long B(int v) { return V(v).batched ? N : 1; }
 
     void lower_all() {
-        for (auto& op : ops()) lower(op);
+        plan_linear_groups();
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (group_of.count((int)i)) lower_group_member(ops()[i], (int)i);
+            else lower(ops()[i]);
+        }
     }
 
     void lower(const Operation& op) {
@@ -760,8 +840,9 @@ struct Lowering {
     // Conv (reference :4494-4707 -> XnnPack::convolution :1292): group 1, dilation 1, pads re-centred (:1315-1329)
     void lower_conv(const Operation& op) {
         const bool has_res = attr(op, "osg_residual") != nullptr;
+        const bool has_ib = attr(op, "osg_image_bias") != nullptr;
         const size_t nin = op.m_input.size();
-        need(op, nin == 2 || nin == 3 || (has_res && nin == 4), "wrong number of inputs.");
+        need(op, nin == 2 || nin == 3 || (has_res && nin == 4) || (has_ib && nin == 5), "wrong number of inputs.");
         need(op, op.m_output.size() == 1, "wrong number of outputs.");
         std::vector<int> dil = {1, 1}, ks, pads = {0, 0, 0, 0}, strides = {1, 1};
         int group = 1;
@@ -771,7 +852,7 @@ struct Lowering {
             else if (a.first == "kernel_shape") ks = int_list(a.second);
             else if (a.first == "pads") pads = int_list(a.second);
             else if (a.first == "strides") strides = int_list(a.second);
-            else if (a.first == "osg_residual") {}
+            else if (a.first == "osg_residual" || a.first == "osg_image_bias") {}
             else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
         }
         int x = in_val(op.m_input[0]);
@@ -798,16 +879,25 @@ struct Lowering {
         }
         int res = -1;
         if (has_res) res = P.ensure_nhwc(in_val(op.m_input[3]));
+        int ib = -1;      // per-image channel bias [1,Cout] (may be a column view of the merged time-embedding projection)
+        long ib_ld = 0;
+        if (has_ib) {
+            ib = in_val_raw(op.m_input[4]);
+            need(op, V(ib).numel() == Cout && V(ib).dtype == OSG_F16 && V(ib).batched == V(x).batched, "invalid image bias.");
+            ib_ld = V(ib).ld ? V(ib).ld : Cout;
+        }
         int y = out_val(op, {1, Cout, Ho, Wo}, Lay::nhwc, V(x).batched);
         const long nb = B(x);
         const int sh = strides[0], sw = strides[1];
         std::vector<int> reads = {x, w};
         if (bias >= 0) reads.push_back(bias);
         if (res >= 0) reads.push_back(res);
+        if (ib >= 0) reads.push_back(ib);
         P.add_step("Conv " + op.m_name, reads, {y}, [=, this] {
-            be.check(be.api.osg_conv2d_nhwc(be.ctx, OSG_F16, P.ptr(x), P.ptr(w), bias >= 0 ? P.ptr(bias) : nullptr,
-                                            bias >= 0 ? P.vals[bias].dtype : OSG_F16, res >= 0 ? P.ptr(res) : nullptr, P.ptr(y), (int)nb,
-                                            (int)H, (int)W, (int)Cin, (int)Cout, (int)KH, (int)KW, sh, sw, pt, pl, pb, pr, OSG_ACT_NONE),
+            be.check(be.api.osg_conv2d_nhwc_rb(be.ctx, OSG_F16, P.ptr(x), P.ptr(w), bias >= 0 ? P.ptr(bias) : nullptr,
+                                               bias >= 0 ? P.vals[bias].dtype : OSG_F16, ib >= 0 ? P.ptr(ib) : nullptr, ib_ld,
+                                               res >= 0 ? P.ptr(res) : nullptr, P.ptr(y), (int)nb, (int)H, (int)W, (int)Cin, (int)Cout,
+                                               (int)KH, (int)KW, sh, sw, pt, pl, pb, pr, OSG_ACT_NONE),
                      "Conv");
         });
         P.steps.back().flops = 2.0 * nb * Ho * Wo * Cout * KH * KW * Cin;
@@ -842,6 +932,113 @@ struct Lowering {
                      what.c_str());
         });
         P.steps.back().flops = 2.0 * M * Nn * K * batch;
+    }
+
+    // ---- merged projections: osg.Linear / Gemm ops that read the SAME activation and whose results are only consumed through
+    // strided views (attention Q/K/V operands, conv image bias) run as ONE GEMM over the concatenated [sum N_i, K] weight:
+    // self-attention Q|K|V (3 launches -> 1), every cross-attention K|V of the net (they all read the text context: 32 -> 1),
+    // the 22 time-embedding projections of the resnet blocks (22 -> 1).
+    struct LinGroup {
+        std::vector<int> members;   // op indices, file order
+        std::vector<long> off;      // column offset of each member inside the merged output
+        long ntot = 0;
+        int y = -1;                 // merged output val [rows, ntot]
+    };
+    std::vector<LinGroup> groups;
+    std::map<int, std::pair<int, int>> group_of;   // op index -> (group, slot)
+
+    void plan_linear_groups() {
+        if (P.fusion < 2) return;
+        dead.assign(ops().size(), 0);
+        index_graph();
+        std::map<std::string, std::vector<int>> by_key;
+        for (size_t i = 0; i < ops().size(); i++) {
+            const Operation& op = ops()[i];
+            const bool lin = op.m_type == "osg.Linear", gemm = op.m_type == "Gemm";
+            if (!lin && !gemm) continue;
+            if (attr(op, "osg_residual") || op.m_output.size() != 1 || !act(op.m_input[0])) continue;
+            const Val* w = cval(op.m_input[1]);
+            if (!w || w->shape.size() != 2 || w->dtype != OSG_F16) continue;
+            const bool has_bias = op.m_input.size() > 2 && !op.m_input[2].m_name.empty();
+            if (gemm && (!has_bias || !op.m_attributes.empty())) continue;
+            if (has_bias && cval(op.m_input[2]) && cval(op.m_input[2])->dtype != OSG_F16) continue;
+            // every consumer must understand a leading dimension
+            bool ok = use_count(op.m_output[0].m_name) < 1000;
+            auto cit = consumers.find(op.m_output[0].m_name);
+            if (cit == consumers.end() || cit->second.empty()) ok = false;
+            else
+                for (int c : cit->second) {
+                    const Operation& co = ops()[c];
+                    if (co.m_type == "osg.Attention") continue;
+                    if (co.m_type == "Conv" && attr(co, "osg_image_bias") && co.m_input.size() == 5 && co.m_input[4].m_name == op.m_output[0].m_name) continue;
+                    ok = false;
+                }
+            if (!ok) continue;
+            by_key[op.m_type + "|" + op.m_input[0].m_name + "|" + std::to_string(w->shape[0]) + (has_bias ? "|b" : "|-")].push_back((int)i);
+        }
+        for (auto& kv : by_key) {
+            if (kv.second.size() < 2) continue;
+            LinGroup g;
+            for (int i : kv.second) {
+                g.members.push_back(i);
+                g.off.push_back(g.ntot);
+                g.ntot += cval(ops()[i].m_input[1])->shape[1];
+            }
+            for (size_t s2 = 0; s2 < g.members.size(); s2++) group_of[g.members[s2]] = {(int)groups.size(), (int)s2};
+            groups.push_back(std::move(g));
+        }
+    }
+
+    // emits the merged GEMM the first time one of its members is lowered; returns the member's column view
+    int lower_group_member(const Operation& op, int op_index) {
+        auto [gi, slot] = group_of.at(op_index);
+        LinGroup& g = groups[gi];
+        const Val* w0 = cval(op.m_input[1]);
+        const long K = w0->shape[0];
+        if (g.y < 0) {
+            int a = P.ensure_plain(in_val(op.m_input[0]));
+            const Shape as = V(a).shape;
+            need(op, !as.empty() && as.back() == K, "invalid shape of inputs.");
+            // concatenated [ntot, K] weight and [ntot] bias, built once from the resident per-op tensors
+            int wcat = P.new_val("", {g.ntot, K}, OSG_F16, Lay::plain, false);
+            V(wcat).is_const = true;
+            V(wcat).name = "merged|" + op.m_input[0].m_name;
+            V(wcat).dptr = be.malloc((size_t)g.ntot * K * 2);
+            P.owned.push_back(V(wcat).dptr);
+            const bool has_bias = op.m_input.size() > 2 && !op.m_input[2].m_name.empty();
+            int bcat = -1;
+            if (has_bias) {
+                bcat = P.new_val("", {g.ntot}, OSG_F16, Lay::plain, false);
+                V(bcat).is_const = true;
+                V(bcat).dptr = be.malloc((size_t)g.ntot * 2);
+                P.owned.push_back(V(bcat).dptr);
+            }
+            for (size_t s2 = 0; s2 < g.members.size(); s2++) {
+                const Operation& mo = ops()[g.members[s2]];
+                int wnk = weight_nk(in_val(mo.m_input[1]));
+                const long Ni = V(wnk).shape[0];
+                be.check(be.api.osg_copy(be.ctx, (char*)V(wcat).dptr + (size_t)g.off[s2] * K * 2, P.ptr(wnk), (size_t)Ni * K * 2), "osg_copy");
+                if (has_bias) {
+                    int b = in_val(mo.m_input[2]);
+                    need(mo, V(b).numel() == Ni, "invalid shape of bias.");
+                    be.check(be.api.osg_copy(be.ctx, (char*)V(bcat).dptr + (size_t)g.off[s2] * 2, P.ptr(b), (size_t)Ni * 2), "osg_copy");
+                }
+            }
+            be.check(be.api.osg_sync(be.ctx), "osg_sync");
+            Shape ys = as;
+            ys.back() = g.ntot;
+            g.y = P.new_val("", ys, OSG_F16, Lay::plain, V(a).batched);
+            const long M = prod(as) / K * B(a);
+            emit_gemm("Linear merged(" + std::to_string(g.members.size()) + ") " + op.m_name, a, wcat, bcat, -1, g.y, M, g.ntot, K, 1, 0, 0, 0, 1);
+        }
+        Shape os = V(g.y).shape;
+        os.back() = w0->shape[1];
+        check_out(op, os);
+        int v = P.alias(g.y, os, Lay::plain, op.m_output[0].m_name);
+        V(v).ld = g.ntot;
+        V(v).view_off = (size_t)g.off[slot] * 2;
+        V(v).is_const = false;
+        return v;
     }
 
     // MatMul with a static 2-D weight, optional fused bias / residual
@@ -1049,7 +1246,7 @@ struct Lowering {
     }
 
     void lower_attention(const Operation& op) {
-        int q = P.ensure_plain(in_val(op.m_input[0])), k = P.ensure_plain(in_val(op.m_input[1])), v = P.ensure_plain(in_val(op.m_input[2]));
+        int q = P.ensure_plain(in_val_raw(op.m_input[0])), k = P.ensure_plain(in_val_raw(op.m_input[1])), v = P.ensure_plain(in_val_raw(op.m_input[2]));
         const long h = std::stol(*attr(op, "heads"));
         const float scale = std::stof(*attr(op, "scale"));
         const Shape qs = V(q).shape;
@@ -1058,8 +1255,9 @@ struct Lowering {
         need(op, V(q).batched == V(k).batched && V(k).batched == V(v).batched, "q/k/v batching mismatch.");
         const long nb = B(q);
         P.add_step("Attention " + op.m_name, {q, k, v}, {y}, [=, this] {
-            be.check(be.api.osg_attention_strided(be.ctx, OSG_F16, P.ptr(q), C, d, Tq * C, P.ptr(k), C, d, Tk * C, P.ptr(v), C, d, Tk * C, P.ptr(y), C, d,
-                                                  Tq * C, (int)nb, (int)h, (int)Tq, (int)Tk, (int)d, scale),
+            const long lq = P.vals[q].ld ? P.vals[q].ld : C, lk = P.vals[k].ld ? P.vals[k].ld : C, lv = P.vals[v].ld ? P.vals[v].ld : C;
+            be.check(be.api.osg_attention_strided(be.ctx, OSG_F16, P.ptr(q), lq, d, Tq * lq, P.ptr(k), lk, d, Tk * lk, P.ptr(v), lv, d, Tk * lv,
+                                                  P.ptr(y), C, d, Tq * C, (int)nb, (int)h, (int)Tq, (int)Tk, (int)d, scale),
                      "Attention");
         });
         P.steps.back().flops = 4.0 * nb * h * Tq * Tk * d;

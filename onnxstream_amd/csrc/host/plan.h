@@ -37,7 +37,10 @@ struct Val {
     std::vector<float> host_f;    // small constants, available at plan time
     std::vector<int64_t> host_i;
     bool host_valid = false;
-    int as_plain = -1, as_nhwc = -1;
+    int as_plain = -1, as_nhwc = -1, as_dense = -1;
+    // column-slice view of a wider 2-D buffer (merged projections): rows are `ld` elements apart, starting `view_off` bytes into the root
+    long ld = 0;
+    size_t view_off = 0;
     long numel() const { long n = 1; for (auto d : shape) n *= d; return n; }
 };
 
@@ -99,6 +102,7 @@ struct Plan {
     void add_step(const std::string& what, std::vector<int> reads, std::vector<int> writes, std::function<void()> fn);
     int ensure_plain(int v);
     int ensure_nhwc(int v);
+    int ensure_dense(int v);   // materialise a strided column view as a dense tensor (for consumers that cannot take a leading dimension)
 };
 
 }  // namespace onnxstream

@@ -25,6 +25,9 @@ struct GemmParams {
     f16* C;
     const void* bias;
     const f16* residual;
+    const f16* rowbias;          // optional [M / rb_rows][rb_ld] per-image channel bias (the resnet time-embedding add)
+    int rb_rows;
+    long rb_ld;
     float* partial;
     int M, N, K;
     long lda;
@@ -72,6 +75,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                             for (int r = 0; r < 4; r++) v[r] += (float)bv[r];
                         }
                     }
+                    if (p.rowbias) {
+                        f16x4 rb = *reinterpret_cast<const f16x4*>(p.rowbias + (long)(m / p.rb_rows) * p.rb_ld + n);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) v[r] += (float)rb[r];
+                    }
                     if (R) {
                         f16x4 rv = *reinterpret_cast<const f16x4*>(R + (long)m * N + n);
 #pragma unroll
@@ -87,6 +95,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                         if (n + r >= N) break;
                         float x = v[r];
                         if (p.bias) x += p.bias_f32 ? ((const float*)p.bias)[n + r] : (float)((const f16*)p.bias)[n + r];
+                        if (p.rowbias) x += (float)p.rowbias[(long)(m / p.rb_rows) * p.rb_ld + n + r];
                         if (R) x += (float)R[(long)m * N + n + r];
                         C[(long)m * N + n + r] = (f16)osg_apply_act(x, p.act);
                     }
@@ -504,6 +513,11 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
                     for (int e = 0; e < 4; e++) sum[e] += (float)bv[e];
                 }
             }
+            if (p.rowbias) {
+                f16x4 rb = *reinterpret_cast<const f16x4*>(p.rowbias + (long)(m / p.rb_rows) * p.rb_ld + n);
+#pragma unroll
+                for (int e = 0; e < 4; e++) sum[e] += (float)rb[e];
+            }
             if (R) {
                 f16x4 rv = *reinterpret_cast<const f16x4*>(R + (long)m * p.N + n);
 #pragma unroll
@@ -539,10 +553,8 @@ int launch_v2(osg_ctx* ctx, GemmParams& p, int batch) {
 __global__ __launch_bounds__(256) void conv_small_cin_kernel(GemmParams p, int KH, int pix_per_block) {
     extern __shared__ __attribute__((aligned(16))) f16 wsm[];   // [K][N]
     const int K = p.K, N = p.N;
-    for (int i = threadIdx.x; i < K * N; i += 256) {
-        const int n = i / K, k = i - n * K;
-        wsm[k * N + n] = p.Bt[i];
-    }
+    for (int n = threadIdx.x; n < N; n += 256)
+        for (int k = 0; k < K; k++) wsm[k * N + n] = p.Bt[(long)n * K + k];
     __syncthreads();
     const int tc = N / 8;
     const int pl_ = threadIdx.x / tc, cc = threadIdx.x - pl_ * tc;
@@ -554,6 +566,25 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(GemmParams p, int K
     const int n_img = m / hw, r2 = m - n_img * hw, ho = r2 / p.Wo, wo = r2 - ho * p.Wo;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const f16* xin = p.A + (long)n_img * p.H * p.W * p.Cin;
+    if (KH == 3 && p.KW == 3 && p.Cin == 4) {
+        // the SD conv_in shape: fetch the 3x3x4 patch with nine independent 8-byte loads, then 36 x 8 FMAs
+        f16x4 patch[9];
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+            const int hi = ho * p.sh - p.pt + t / 3, wi = wo * p.sw - p.pl + t % 3;
+            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            patch[t] = ok ? *reinterpret_cast<const f16x4*>(xin + ((long)hi * p.W + wi) * 4) : f16x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float xv = (float)patch[t][c];
+                const f16x8 wv = *reinterpret_cast<const f16x8*>(wsm + (t * 4 + c) * N + cc * 8);
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[e] += xv * (float)wv[e];
+            }
+    } else {
     int k = 0;
     for (int kh = 0; kh < KH; kh++) {
         const int hi = ho * p.sh - p.pt + kh;
@@ -568,12 +599,14 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(GemmParams p, int K
             }
         }
     }
+    }
     f16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         float v = acc[e];
         const int n = cc * 8 + e;
         if (p.bias) v += p.bias_f32 ? ((const float*)p.bias)[n] : (float)((const f16*)p.bias)[n];
+        if (p.rowbias) v += (float)p.rowbias[(long)(m / p.rb_rows) * p.rb_ld + n];
         if (p.residual) v += (float)p.residual[(long)m * N + n];
         o[e] = (f16)osg_apply_act(v, p.act);
     }
@@ -585,7 +618,7 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(GemmParams p, int K
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, f16* __restrict__ C,
                                                             const void* __restrict__ bias, int bias_f32,
                                                             const f16* __restrict__ residual, long MN, int N, int splits, int batch,
-                                                            long strideC, int act) {
+                                                            long strideC, int act, const f16* __restrict__ rowbias, int rb_rows, long rb_ld) {
     long idx = (long)blockIdx.x * 256 + threadIdx.x;
     long total = MN * batch;
     if (idx >= total) return;
@@ -595,6 +628,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     for (int s = 0; s < splits; s++) v += partial[((long)(b * splits + s)) * MN + e];
     int n = (int)(e % N);
     if (bias) v += bias_f32 ? ((const float*)bias)[n] : (float)((const f16*)bias)[n];
+    if (rowbias) v += (float)rowbias[(e / N / rb_rows) * rb_ld + n];
     if (residual) v += (float)residual[b * strideC + e];
     C[b * strideC + e] = (f16)osg_apply_act(v, act);
 }
@@ -749,7 +783,7 @@ static int launch_splitk_reduce(osg_ctx* ctx, const GemmParams& p, int batch) {
     long MN = (long)p.M * p.N;
     long total = MN * batch;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->compute, p.partial, p.C,
-                       p.bias, p.bias_f32, p.residual, MN, p.N, p.splits, batch, p.strideC, p.act);
+                       p.bias, p.bias_f32, p.residual, MN, p.N, p.splits, batch, p.strideC, p.act, p.rowbias, p.rb_rows, p.rb_ld);
     OSG_LAUNCH_CHECK(ctx);
     return 0;
 }
@@ -816,6 +850,12 @@ int osg_gemm(osg_ctx* ctx, osg_dtype dtype, const void* A, const void* B, int b_
 int osg_conv2d_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* w, const void* bias, osg_dtype bias_dtype,
                     const void* residual, void* y, int N, int H, int W, int Cin, int Cout, int KH, int KW, int sh, int sw,
                     int pt, int pl, int pb, int pr, osg_act act) {
+    return osg_conv2d_nhwc_rb(ctx, dtype, x, w, bias, bias_dtype, nullptr, 0, residual, y, N, H, W, Cin, Cout, KH, KW, sh, sw, pt, pl, pb, pr, act);
+}
+
+int osg_conv2d_nhwc_rb(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* w, const void* bias, osg_dtype bias_dtype,
+                       const void* image_bias, long image_bias_ld, const void* residual, void* y, int N, int H, int W, int Cin, int Cout,
+                       int KH, int KW, int sh, int sw, int pt, int pl, int pb, int pr, osg_act act) {
     if (dtype != OSG_F16) OSG_FAIL(ctx, "osg_conv2d_nhwc: only f16 arithmetic is implemented on the device");
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || sh <= 0 || sw <= 0)
         OSG_FAIL(ctx, "osg_conv2d_nhwc: invalid argument");
@@ -827,6 +867,7 @@ int osg_conv2d_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* w,
     p.M = N * Ho * Wo; p.N = Cout; p.K = KH * KW * Cin; p.lda = 0;
     p.bias_f32 = bias_dtype == OSG_F32; p.act = act;
     p.a_bytes_l = (long)N * H * W * Cin * 2;
+    p.rowbias = (const f16*)image_bias; p.rb_rows = Ho * Wo; p.rb_ld = image_bias_ld;
     p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.KW = KW; p.sh = sh; p.sw = sw; p.pt = pt; p.pl = pl;
     if (Cin < 8 && Cout % 8 == 0 && Cout / 8 <= 256 && (size_t)p.K * Cout * 2 <= 64 * 1024) {
         const int ppb = 256 / (Cout / 8);

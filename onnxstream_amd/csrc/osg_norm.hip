@@ -74,7 +74,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
             float sm[V], sq[V];
 #pragma unroll
             for (int e = 0; e < V; e++) sm[e] = sq[e] = 0.f;
-            for (long p = p0 + tr; p < p1; p += R) {
+            long p = p0 + tr;
+            for (; p + 3L * R < p1; p += 4L * R) {   // 4 independent 16-byte loads in flight
+                T xv[4][V];
+#pragma unroll
+                for (int u = 0; u < 4; u++) *reinterpret_cast<uint4*>(xv[u]) = *reinterpret_cast<const uint4*>(base + (p + (long)u * R) * C + (long)c * V);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int e = 0; e < V; e++) {
+                        float v = to_f32<T>(xv[u][e]);
+                        sm[e] += v;
+                        sq[e] += v * v;
+                    }
+            }
+            for (; p < p1; p += R) {
                 T xv[V];
                 *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(base + p * C + (long)c * V);
 #pragma unroll
@@ -110,67 +124,87 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     }
 }
 
-// pass 2: normalise + affine (+SiLU); each block first folds the S partials of the G groups of its image into LDS
+// pass 2 (tiny): one block per image folds the S partials of every group in f64 (fixed order => deterministic) and writes the
+// per-channel affine table  y = x * ca[c] + cb[c]   (ca = rstd*gamma, cb = beta - mean*rstd*gamma)  to tab[n][2][C]
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ part, const T* __restrict__ gamma,
-                                                       const T* __restrict__ beta, T* __restrict__ y, long HW, int C, int G, int S,
-                                                       float eps, int act, int blocks_per_img) {
-    constexpr int V = 8 / (sizeof(T) / 2);  // f16: 8, f32: 4  (16-byte accesses)
-    extern __shared__ float stat[];         // [G][2] mean, rstd
-    const int n = blockIdx.x / blocks_per_img;
-    const int bi = blockIdx.x - n * blocks_per_img;
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                          float* __restrict__ tab, long HW, int C, int G, int S, float eps) {
+    extern __shared__ float stat[];  // [G][2] mean, rstd
+    const int n = blockIdx.x;
     const int cpg = C / G;
-    // fold the S partials of every group: `tpg` lanes per group load independent partials, shuffle-reduce in f64
-    {
-        int tpg = 1;
-        while (tpg * 2 * G <= 256 && tpg < 64) tpg *= 2;
-        const double cnt = (double)HW * cpg;
-        for (int g0 = 0; g0 < G; g0 += 256 / tpg) {
-            const int g = g0 + threadIdx.x / tpg, l = threadIdx.x % tpg;
-            double sm = 0, q = 0;
-            if (g < G)
-                for (int k = l; k < S; k += tpg) {
-                    sm += part[(((long)n * G + g) * S + k) * 2 + 0];
-                    q += part[(((long)n * G + g) * S + k) * 2 + 1];
-                }
-            for (int o = tpg >> 1; o > 0; o >>= 1) {
-                sm += __shfl_xor(sm, o, 64);
-                q += __shfl_xor(q, o, 64);
+    int tpg = 1;
+    while (tpg * 2 * G <= 256 && tpg < 64) tpg *= 2;
+    const double cnt = (double)HW * cpg;
+    for (int g0 = 0; g0 < G; g0 += 256 / tpg) {
+        const int g = g0 + threadIdx.x / tpg, l = threadIdx.x % tpg;
+        double sm = 0, q = 0;
+        if (g < G)
+            for (int k = l; k < S; k += tpg) {
+                sm += part[(((long)n * G + g) * S + k) * 2 + 0];
+                q += part[(((long)n * G + g) * S + k) * 2 + 1];
             }
-            if (g < G && l == 0) {
-                double mean = sm / cnt;
-                double var = q / cnt - mean * mean;
-                if (var < 0) var = 0;
-                stat[g * 2 + 0] = (float)mean;
-                stat[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-            }
+        for (int o = tpg >> 1; o > 0; o >>= 1) {
+            sm += __shfl_xor(sm, o, 64);
+            q += __shfl_xor(q, o, 64);
+        }
+        if (g < G && l == 0) {
+            double mean = sm / cnt;
+            double var = q / cnt - mean * mean;
+            if (var < 0) var = 0;
+            stat[g * 2 + 0] = (float)mean;
+            stat[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
         }
     }
     __syncthreads();
-    // per-channel affine table: y = x * ca[c] + cb[c]   (ca = rstd*gamma, cb = beta - mean*rstd*gamma)
-    float* ca = stat + 2 * G;
-    float* cb = ca + C;
     for (int c = threadIdx.x; c < C; c += 256) {
         const int g = c / cpg;
         const float a = stat[g * 2 + 1] * to_f32<T>(gamma[c]);
-        ca[c] = a;
-        cb[c] = to_f32<T>(beta[c]) - stat[g * 2] * a;
+        tab[((long)n * 2 + 0) * C + c] = a;
+        tab[((long)n * 2 + 1) * C + c] = to_f32<T>(beta[c]) - stat[g * 2] * a;
     }
-    __syncthreads();
+}
+
+// pass 3: pure streaming  y = act(x * ca[c] + cb[c]).  A thread keeps ONE vector column (its 2*V table entries live in
+// registers), sweeps pixel rows with 4 independent 16-byte loads in flight; grid (slabs, N).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ tab, T* __restrict__ y, long HW,
+                                                       int C, int act, int slabs) {
+    constexpr int V = 8 / (sizeof(T) / 2);  // f16: 8, f32: 4  (16-byte accesses)
+    const int n = blockIdx.y, sl = blockIdx.x;
     const int cv = C / V;
-    const long total = HW * cv;
+    const int cols = cv < 256 ? cv : 256, R = 256 / cols;
+    const int tr = threadIdx.x / cols, tc = threadIdx.x - tr * cols;
+    if (tr >= R) return;
+    const long p0 = HW * sl / slabs, p1 = HW * (sl + 1) / slabs;
     const T* xb = x + (long)n * HW * C;
     T* yb = y + (long)n * HW * C;
-    for (long i = (long)bi * 256 + threadIdx.x; i < total; i += (long)blocks_per_img * 256) {
-        const int c0 = (int)(i % cv) * V;
-        T xv[V], ov[V];
-        *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(xb + i * V);
+    const float* ta = tab + (long)n * 2 * C;
+    for (int c = tc; c < cv; c += cols) {
+        float ca[V], cb[V];
 #pragma unroll
         for (int e = 0; e < V; e++) {
-            float v = to_f32<T>(xv[e]) * ca[c0 + e] + cb[c0 + e];
-            ov[e] = from_f32<T>(osg_apply_act(v, act));
+            ca[e] = ta[c * V + e];
+            cb[e] = ta[C + c * V + e];
         }
-        *reinterpret_cast<uint4*>(yb + i * V) = *reinterpret_cast<uint4*>(ov);
+        long p = p0 + tr;
+        for (; p + 3L * R < p1; p += 4L * R) {
+            T xv[4][V], ov[V];
+#pragma unroll
+            for (int u = 0; u < 4; u++) *reinterpret_cast<uint4*>(xv[u]) = *reinterpret_cast<const uint4*>(xb + (p + (long)u * R) * C + (long)c * V);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+#pragma unroll
+                for (int e = 0; e < V; e++) ov[e] = from_f32<T>(osg_apply_act(to_f32<T>(xv[u][e]) * ca[e] + cb[e], act));
+                *reinterpret_cast<uint4*>(yb + (p + (long)u * R) * C + (long)c * V) = *reinterpret_cast<uint4*>(ov);
+            }
+        }
+        for (; p < p1; p += R) {
+            T xv[V], ov[V];
+            *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(xb + p * C + (long)c * V);
+#pragma unroll
+            for (int e = 0; e < V; e++) ov[e] = from_f32<T>(osg_apply_act(to_f32<T>(xv[e]) * ca[e] + cb[e], act));
+            *reinterpret_cast<uint4*>(yb + p * C + (long)c * V) = *reinterpret_cast<uint4*>(ov);
+        }
     }
 }
 
@@ -302,26 +336,34 @@ int osg_group_norm_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void
     // slabs of >= ~8 pixel rows per sweep-row, at most 64 per image (the apply pass folds S partials per group)
     const int cols = C / V < 256 ? C / V : 256;
     const int Rr = 256 / cols;
-    int S = (int)(HW / ((long)Rr * 4));
+    int S = (int)(HW / ((long)Rr * 8));
     if (S > 64) S = 64;
     if (S < 1) S = 1;
-    size_t need = (size_t)N * G * S * 2 * sizeof(float);
+    const size_t part_bytes = ((size_t)N * G * S * 2 * sizeof(float) + 255) & ~(size_t)255;
+    const size_t need = part_bytes + (size_t)N * 2 * C * sizeof(float);
     if (osg_ensure_workspace(ctx, need)) return 1;
     float* part = (float*)ctx->ws;
-    long total_v = HW * (C / V);
-    int bpi = (int)((total_v + 256 * 8 - 1) / (256 * 8));
-    if (bpi < 1) bpi = 1;
-    if (bpi > 1024) bpi = 1024;
+    float* tab = (float*)((char*)ctx->ws + part_bytes);
+    // apply: ~8 pixel rows per thread-row
+    long slabs_l = HW / ((long)Rr * 8);
+    if (slabs_l < 1) slabs_l = 1;
+    if (slabs_l > 4096) slabs_l = 4096;
+    const int slabs = (int)slabs_l;
     if (dtype == OSG_F16) {
         hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(S, N), dim3(256), G * 2 * sizeof(float), ctx->compute, (const f16*)x, part, HW, C, G, S);
         OSG_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(N * bpi), dim3(256), (G * 2 + 2 * C) * sizeof(float), ctx->compute, (const f16*)x, part,
-                           (const f16*)gamma, (const f16*)beta, (f16*)y, HW, C, G, S, eps, (int)act, bpi);
+        hipLaunchKernelGGL(gn_finalize_kernel<f16>, dim3(N), dim3(256), G * 2 * sizeof(float), ctx->compute, part, (const f16*)gamma,
+                           (const f16*)beta, tab, HW, C, G, S, eps);
+        OSG_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(slabs, N), dim3(256), 0, ctx->compute, (const f16*)x, tab, (f16*)y, HW, C, (int)act, slabs);
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(S, N), dim3(256), G * 2 * sizeof(float), ctx->compute, (const float*)x, part, HW, C, G, S);
         OSG_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(N * bpi), dim3(256), (G * 2 + 2 * C) * sizeof(float), ctx->compute, (const float*)x, part,
-                           (const float*)gamma, (const float*)beta, (float*)y, HW, C, G, S, eps, (int)act, bpi);
+        hipLaunchKernelGGL(gn_finalize_kernel<float>, dim3(N), dim3(256), G * 2 * sizeof(float), ctx->compute, part, (const float*)gamma,
+                           (const float*)beta, tab, HW, C, G, S, eps);
+        OSG_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(slabs, N), dim3(256), 0, ctx->compute, (const float*)x, tab, (float*)y, HW, C, (int)act,
+                           slabs);
     }
     OSG_LAUNCH_CHECK(ctx);
     return 0;
