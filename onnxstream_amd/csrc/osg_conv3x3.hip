@@ -1,0 +1,347 @@
+// libosgpu: halo-reuse 3x3 / stride 1 / pad 1 convolution (the resnet convolutions: 55 % of an SD UNet pass).
+//
+// Measured on MI355X the implicit-GEMM kernel of osg_gemm.hip is bound by the per-CU L2->LDS path (~23 B/clk/CU), not by
+// the MFMA pipe, and a 3x3 convolution run as a GEMM fetches every input pixel NINE times (once per filter tap).  Here a
+// workgroup owns 128 consecutive output pixels (TH full rows of the image) x BN output channels and walks K as
+// (64-channel slab) x (9 taps):
+//   * the input PATCH of the slab -- (TH+2) x (W+2) pixels x 64 channels, zero halo supplied by the buffer descriptor's
+//     bounds check -- is DMA'd into LDS ONCE and read by all 9 taps (A traffic / ~5);
+//   * per (slab, tap) only the [BN][64] weight tile streams in: 4-deep LDS ring, counted vmcnt, ONE barrier per tap;
+//   * the patch of the NEXT slab arrives piecewise during taps 0..4 of the current slab (double-buffered);
+//   * both images are lane-linear 128-byte rows with the 16-byte chunk index XOR-swizzled by (row & 7) on the SOURCE address,
+//     so every fragment read is a conflict-free ds_read_b128 (a fragment's 16 pixels are consecutive patch pixels);
+//   * BN in {80, 128, 160}: 320 / 640 / 1280 output channels tile without padding; wave layouts 4x1 / 2x2 / 2x2.
+// Arithmetic, accumulation order class and epilogue are those of the GEMM kernel (f16 operands, f32 accumulate on
+// v_mfma_f32_16x16x32_f16, one RNE rounding): XnnPack::convolution, reference src/onnxstream.cpp:1292-1534.
+#include "osg_gemm_common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+
+using namespace osg_mm;
+
+namespace {
+
+template <int I> using ic = std::integral_constant<int, I>;
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(ic<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ---- compile-time geometry of one instantiation ------------------------------------------------------------------------------
+template <int W_, int BN>
+struct Geo {
+    static constexpr int TI = W_ == 8 ? 2 : 1;              // images per tile
+    static constexpr int TH = 128 / (W_ * TI);              // output rows per image per tile
+    static constexpr int PW = W_ == 8 ? 16 : W_ + 2;        // patch row pitch in pixels (16 for W=8 keeps fragment reads conflict-free)
+    static constexpr int PH = TH + 2;
+    static constexpr int PPI = PH * PW;                     // patch pixels per image
+    static constexpr int PP = TI * PPI;
+    static constexpr int NPW = ((PP + 7) / 8 + 3) / 4;      // patch wave-loads per wave
+    static constexpr int PATCH_BYTES = NPW * 4096;
+    static constexpr int WLB = (BN / 8 + 3) / 4;            // weight wave-loads per wave per tap
+    static constexpr int BST_BYTES = WLB * 4096;            // one weight stage (padded to whole rounds of the 4 waves)
+    static constexpr int NSTW_ = (160 * 1024 - 2 * PATCH_BYTES) / BST_BYTES;
+    static constexpr int NSTW = NSTW_ > 8 ? 8 : NSTW_;      // weight stages: whatever the 160 KiB of LDS hold (the kernel is
+    static constexpr int D = NSTW - 1;                      // latency-bound: bytes in flight per CU are what buys throughput)
+    static constexpr int PT = 10 - D;                       // the next slab's patch is issued during taps 0..PT-1 ...
+    static constexpr int PPT = (NPW + PT - 1) / PT;         // ... PPT pieces per tap per wave
+    static constexpr size_t SMEM = 2 * (size_t)PATCH_BYTES + (size_t)NSTW * BST_BYTES;
+    static_assert(D >= 3 && PT >= 2, "pipeline depth out of range");
+    static constexpr int patch_loads(int t) {               // real patch pieces issued at tap t
+        if (t >= PT) return 0;
+        int n = NPW - t * PPT;
+        return n < 0 ? 0 : (n > PPT ? PPT : n);
+    }
+    static constexpr int allowed_outstanding(int t) {       // at the top of tap t: what the previous D-2 units issued
+        int n = 0;
+        for (int d = 1; d <= D - 2; d++) n += WLB + patch_loads((t - d + 18) % 9);
+        return n;
+    }
+};
+
+// W_: image width (= tile width); BN: output channels per tile; WGM x WGN: grid of the 4 MATH waves.
+// 512 threads = 4 math waves + 4 LOADER waves (one pair per SIMD).  Measured (tools/pmc_conv.sh): one `buffer_load ... lds`
+// costs its issuing wave ~100+ cycles, so with loads and MFMAs in the same instruction stream the matrix pipe idled 75 % of
+// the time whatever the ring depth; with the DMA issue moved to waves that do nothing else, the math waves' stream is
+// ds_read + MFMA only and the two streams overlap on the SIMD.
+// (the body is a __device__ function: hipcc emits no host stub for a __global__ template whose body holds a generic lambda)
+template <int W_, int BN, int WGM, int WGN, int MODE>
+__device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
+    using G = Geo<W_, BN>;
+    constexpr int TH = G::TH, PW = G::PW, PPI = G::PPI, PP = G::PP, NPW = G::NPW, PATCH_BYTES = G::PATCH_BYTES;
+    constexpr int WLB = G::WLB, BST_BYTES = G::BST_BYTES, NSTW = G::NSTW, D = G::D, PPT = G::PPT;
+    constexpr int WM = 128 / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
+    static_assert(WM % 16 == 0 && WN % 16 == 0 && WGM * WGN == 4, "bad wave layout");
+    constexpr unsigned OOB = 0x80000000u;
+
+    extern __shared__ __attribute__((aligned(16))) char smem3[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    char* const patch0 = smem3;                      // 2 patch buffers, then NSTW weight stages
+    char* const bst0 = smem3 + 2 * PATCH_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave8 >= 4;
+    const int wave = wave8 & 3;                      // index inside the role
+
+    // ---- XCD-aware bijective remap of the flat grid (see osg_gemm.hip) ------------------------------------------------
+    int L;
+    {
+        const int total = gridDim.x, bid = blockIdx.x, x = bid & 7, i = bid >> 3, q = total >> 3, r = total & 7;
+        L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    int m_tile, n_tile, zs;
+    if (p.n_major) {
+        n_tile = L / (p.splits * p.mt); L -= n_tile * p.splits * p.mt;
+        zs = L / p.mt; m_tile = L - zs * p.mt;
+    } else {
+        m_tile = L / (p.splits * p.nt); L -= m_tile * p.splits * p.nt;
+        zs = L / p.nt; n_tile = L - zs * p.nt;
+    }
+    const int m0 = m_tile * 128, n0 = n_tile * BN;
+    const int slab_b = zs * (p.k_per_split >> 6);
+    const int slab_e = min(p.Cin >> 6, slab_b + (p.k_per_split >> 6));
+
+    if (loader) {
+        // =========================================== LOADER waves ==============================================================
+        const int img0 = m0 / (p.H * W_);                       // first image of the tile
+        const int y0 = (m0 - img0 * p.H * W_) / W_;             // first output row (0 when the tile holds whole images)
+        __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bt, 0, p.b_bytes, 0x00020000);
+        const int rsub = lane >> 3;
+        const int gch = (lane & 7) ^ rsub;
+        // patch source offsets: this wave issues patch wave-loads g = piece * 4 + wave, piece = 0..NPW-1
+        unsigned pa_off[NPW];
+#pragma unroll
+        for (int pc = 0; pc < NPW; pc++) {
+            const int pp = (pc * 4 + wave) * 8 + rsub;          // patch pixel
+            const int ti = pp / PPI, rr = pp - ti * PPI;
+            const int py = rr / PW, px = rr - py * PW;
+            const int img = img0 + ti, y = y0 + py - 1, x = px - 1;
+            const bool ok = pp < PP && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)W_ && img * p.H * W_ < p.M;
+            pa_off[pc] = ok ? (unsigned)((((img * p.H + y) * W_ + x) * p.Cin + gch * 8) * 2) : OOB;
+        }
+        // weight source offsets: wave-load j covers rows (j*4 + wave)*8 .. +7 of the [BN][64] tile
+        unsigned b_off[WLB];
+#pragma unroll
+        for (int j = 0; j < WLB; j++) {
+            const int nl = (j * 4 + wave) * 8 + rsub;
+            const int n = n0 + nl;
+            b_off[j] = (nl < BN && n < p.N) ? (unsigned)(((long)n * p.K + gch * 8) * 2) : OOB;
+        }
+        auto issue_patch_piece = [&](int pc, int slab, char* buf) {     // slab may be past the end: dummy (zero-filling) load
+            const unsigned kill = (slab < slab_e && MODE != 2) ? 0u : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(buf + (pc * 4 + wave) * 1024), 16, pa_off[pc] | kill, slab * 128, 0, 0);
+        };
+        auto issue_weights = [&](int stage, int tap, int slab) {
+            const unsigned kill = (slab < slab_e && MODE != 2) ? 0u : OOB;
+            const int soff = (tap * p.Cin + slab * 64) * 2;
+            char* dst = bst0 + stage * BST_BYTES;
+#pragma unroll
+            for (int j = 0; j < WLB; j++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(dst + (j * 4 + wave) * 1024), 16, b_off[j] | kill, soff, 0, 0);
+        };
+        // prologue == units -D .. -1 of the steady state (D = NSTW - 1 units of weights in flight)
+        issue_weights(0, 0, slab_b);
+#pragma unroll
+        for (int pc = 0; pc < NPW; pc++) issue_patch_piece(pc, slab_b, patch0);
+#pragma unroll
+        for (int d = 1; d < D; d++) issue_weights(d, d % 9, slab_b + d / 9);
+        wait_vmcnt<(D - 1) * WLB>();                         // unit 0's weights + the first patch have landed
+        __builtin_amdgcn_s_barrier();
+        int ust = 0;                                         // weight stage of the current unit
+        for (int slab = slab_b; slab < slab_e; slab++) {
+            char* patch_next = patch0 + (((slab - slab_b) & 1) ^ 1) * PATCH_BYTES;
+            static_for<0, 9>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                // after this wait + barrier the tiles of unit u+1 are resident too: what the previous D-2 units issued may stay in flight
+                wait_vmcnt<G::allowed_outstanding(t)>();
+                __builtin_amdgcn_s_barrier();
+                constexpr int td = (t + D) % 9;
+                int std_ = ust + D;
+                std_ = std_ >= NSTW ? std_ - NSTW : std_;
+                issue_weights(std_, td, slab + (t + D) / 9);   // into the stage unit u-1 just released
+                static_for<0, G::patch_loads(t)>([&](auto pc) { issue_patch_piece(t * PPT + decltype(pc)::value, slab + 1, patch_next); });
+                ust = ust + 1 == NSTW ? 0 : ust + 1;
+            });
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the dummy tail loads before the LDS is released
+        return;
+    }
+
+    // ============================================== MATH waves ==================================================================
+    const int wm0 = (wave / WGN) * WM;
+    const int wn0 = (wave % WGN) * WN;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addressing
+    const int frow = lane & 15, fq = lane >> 4;
+    int pp0[TM];                                        // patch pixel of this lane's output pixel at tap (0,0)
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int ml = wm0 + i * 16 + frow;
+        const int ti = ml / (TH * W_), rr = ml - ti * (TH * W_);
+        const int ty = rr / W_, tx = rr - ty * W_;
+        pp0[i] = ti * PPI + ty * PW + tx;
+    }
+    const int b_rd = (wn0 + frow) * 128 + ((fq ^ (frow & 7)) << 4);
+
+    // fragment sets: set 0 holds (unit, k-half 0), set 1 (unit, k-half 1); each is fetched while the MFMAs of the other run, the
+    // first half of unit u+1 already during the second half of unit u (its tiles are guaranteed resident one barrier ahead).
+    f16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    auto read_frags = [&](f16x8 (&fa)[TM], f16x8 (&fb)[TN], const char* pbuf, const char* bbuf, int tap_off, int ks) {
+        if (MODE == 1) return;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int pp = pp0[i] + tap_off;
+            fa[i] = *reinterpret_cast<const f16x8*>(pbuf + ((pp * 128 + ((fq ^ (pp & 7)) << 4)) ^ (ks << 6)));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; j++) fb[j] = *reinterpret_cast<const f16x8*>(bbuf + ((b_rd + j * 16 * 128) ^ (ks << 6)));
+    };
+    auto mma = [&](f16x8 (&fa)[TM], f16x8 (&fb)[TN]) {
+        if (MODE == 1) return;   // experiment: loads + barriers only
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    };
+
+    __builtin_amdgcn_s_barrier();                       // unit 0's weights + the first patch have landed
+    read_frags(fa0, fb0, patch0, bst0, 0, 0);
+    int ust = 0;
+    for (int slab = slab_b; slab < slab_e; slab++) {
+        const char* patch = patch0 + ((slab - slab_b) & 1) * PATCH_BYTES;
+        const char* patch_next = patch0 + (((slab - slab_b) & 1) ^ 1) * PATCH_BYTES;
+        static_for<0, 9>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            __builtin_amdgcn_s_barrier();               // units <= u+1 resident; the loaders may now overwrite unit u-1's stage
+            constexpr int kh = t / 3, kw = t % 3;
+            const char* Bs = bst0 + ust * BST_BYTES;
+            // sched_barrier(0) pins the order "issue the NEXT half's ds_reads, then run THIS half's MFMAs": left alone, hipcc sinks
+            // the reads next to their uses and re-serialises LDS latency with the matrix pipe
+            read_frags(fa1, fb1, patch, Bs, kh * PW + kw, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            ust = ust + 1 == NSTW ? 0 : ust + 1;
+            constexpr int tn = (t + 1) % 9;
+            read_frags(fa0, fb0, t == 8 ? patch_next : patch, bst0 + ust * BST_BYTES, (tn / 3) * PW + tn % 3, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    gemm_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0, lane, 0, zs);
+}
+
+template <int W_, int BN, int WGM, int WGN, int MODE>
+__global__ __launch_bounds__(512) void conv3x3_kernel(GemmParams p) {
+    conv3x3_body<W_, BN, WGM, WGN, MODE>(p);
+}
+
+template <int W_, int BN, int WGM, int WGN, int MODE = 0>
+int launch3(osg_ctx* ctx, GemmParams& p) {
+    constexpr size_t smem = Geo<W_, BN>::SMEM;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    auto kern = conv3x3_kernel<W_, BN, WGM, WGN, MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    p.mt = (p.M + 127) / 128;
+    p.nt = (p.N + BN - 1) / BN;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.mt * p.nt * p.splits)), dim3(512), smem, ctx->compute, p);
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+template <int W_>
+int launch3_bn(osg_ctx* ctx, GemmParams& p, int bn) {
+    if (W_ == 64 && bn == 80) {   // experiments (tools/gemm_probe.py): 1 = loads + barriers only, 2 = no global loads (compute on stale LDS)
+        const char* e = getenv("OSG_CONV3X3_DBG");
+        const int dbg = e ? atoi(e) : 0;
+        if (dbg == 1) return launch3<64, 80, 4, 1, 1>(ctx, p);
+        if (dbg == 2) return launch3<64, 80, 4, 1, 2>(ctx, p);
+    }
+    if (bn == 80) return launch3<W_, 80, 4, 1>(ctx, p);
+    if (bn == 160) return launch3<W_, 160, 2, 2>(ctx, p);
+    return launch3<W_, 128, 2, 2>(ctx, p);
+}
+
+}  // namespace
+
+// Shape gate + tile/split choice.  Model (cycles, calibrated like choose_v2 in osg_gemm.hip): a (slab, tap) unit costs
+// max(MFMA, bytes / 23 B/clk) with bytes = the weight tile + 1/9 of the patch; whole rounds of tiles over the CUs.
+int osg_conv3x3_run(osg_ctx* ctx, GemmParams& p) {
+    static const bool off = getenv("OSG_CONV3X3_OFF") != nullptr;
+    if (off) return -1;
+    const int W = p.W, H = p.H;
+    if (!(W == 64 || W == 32 || W == 16 || W == 8)) return -1;
+    if (p.Wo != W || p.Ho != H || p.sh != 1 || p.sw != 1 || p.pt != 1 || p.pl != 1 || p.KW != 3 || p.K != 9 * p.Cin) return -1;
+    if (p.Cin % 64 || p.N % 4) return -1;
+    const int TI = W == 8 ? 2 : 1, TH = 128 / (W * TI);
+    if (H % TH) return -1;
+    if (W == 8 && H != 8) return -1;
+    if (p.a_bytes_l >= 2147483648L || (double)p.N * p.K * 2.0 >= 2147483648.0) return -1;
+    if ((((uintptr_t)p.A | (uintptr_t)p.Bt) & 15) != 0) return -1;
+    p.a_bytes = (unsigned)p.a_bytes_l;
+    p.b_bytes = (unsigned)((long)p.N * p.K * 2);
+
+    const double cus = ctx->num_cu;
+    const int slabs = p.Cin / 64;
+    const int mt = (p.M + 127) / 128;
+    const int pp = TI * (TH + 2) * (W == 8 ? 16 : W + 2);
+    int best_bn = 128, best_s = 1;
+    double best = 1e300;
+    static const int bns[3] = {80, 128, 160};
+    for (int bn : bns) {
+        if (bn != 128 && p.N % bn) continue;
+        const double tiles = (double)mt * ((p.N + bn - 1) / bn);
+        const double mfma = 128.0 * bn * 128.0 / 4069.0;
+        const double tload = (bn * 128.0 + pp * 128.0 / 9.0) / 23.0;
+        for (int s = 1; s <= 8; s++) {
+            if (s > 1 && slabs / s < 2) break;
+            const int sl = (slabs + s - 1) / s;
+            if (s > 1 && sl * (s - 1) >= slabs) continue;
+            const double blocks = tiles * s;
+            const double rounds = std::ceil(blocks / cus);
+            double cost = rounds * (sl * 9.0 * (std::max(mfma, tload) + 250.0) + 6000.0);
+            if (s > 1) cost += 9000.0 + (double)p.M * p.N * s * 4.0 / 2000.0;
+            if (cost < best) { best = cost; best_bn = bn; best_s = s; }
+        }
+    }
+    if (const char* e = getenv("OSG_CONV3X3_BN")) best_bn = atoi(e);
+    if (const char* e = getenv("OSG_CONV3X3_SPLITS")) best_s = atoi(e);
+    const int sl = (slabs + best_s - 1) / best_s;
+    p.splits = (slabs + sl - 1) / sl;
+    p.k_per_split = sl * 64;
+    p.tickets = nullptr;
+    if (p.splits > 1) {
+        size_t need = (size_t)p.splits * p.M * p.N * sizeof(float);
+        if (osg_ensure_workspace(ctx, need)) return 1;
+        p.partial = (float*)ctx->ws;
+    }
+    p.n_major = (double)p.N * p.K * 2.0 > (double)p.a_bytes_l;
+    int rc;
+    if (W == 64) rc = launch3_bn<64>(ctx, p, best_bn);
+    else if (W == 32) rc = launch3_bn<32>(ctx, p, best_bn);
+    else if (W == 16) rc = launch3_bn<16>(ctx, p, best_bn);
+    else rc = launch3_bn<8>(ctx, p, best_bn);
+    if (rc) return rc;
+    if (p.splits > 1) return launch_splitk_reduce(ctx, p, 1);
+    return 0;
+}

@@ -12,117 +12,14 @@
 //   * operands are swapped (weights as MFMA "A") so each lane owns 4 consecutive output channels of one pixel:
 //     8-byte epilogue stores, bias/residual fused in f32 before the single rounding.
 //   * split-K (grid.z) with f32 partial slabs + a fused reduce epilogue for the small-M (8x8, 16x16 latent) layers.
-#include "osg_common.h"
+#include "osg_gemm_common.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
+using namespace osg_mm;
+
 namespace {
-
-struct GemmParams {
-    const f16* A;
-    const f16* Bt;
-    f16* C;
-    const void* bias;
-    const f16* residual;
-    const f16* rowbias;          // optional [M / rb_rows][rb_ld] per-image channel bias (the resnet time-embedding add)
-    int rb_rows;
-    long rb_ld;
-    float* partial;
-    int M, N, K;
-    long lda;
-    long strideA, strideB, strideC;
-    int bias_f32, act;
-    int splits, k_per_split;
-    // conv geometry (CONV only)
-    int H, W, Cin, Ho, Wo, KW, sh, sw, pt, pl;
-    // v2 (direct-to-LDS) kernel only
-    unsigned a_bytes, b_bytes;   // buffer-descriptor extents of one batch item of A / Bt
-    long a_bytes_l;              // conv: byte size of the whole NHWC input (host side, before the 2 GiB check)
-    int mt, nt, n_major;         // tile grid and the order tiles are walked inside an XCD's contiguous chunk
-    int* tickets;                // split-K arrival counters (one per output tile), zero between launches
-};
-
-// ---- epilogue shared by both kernels: lane owns C[m][n..n+3], m = tile_m + (lane&15), n = tile_n + (lane>>4)*4 --------
-// (operands are swapped -- weights feed the MFMA "A" port -- so the 4 accumulator registers of a lane are 4 consecutive
-// output channels of one pixel); bias/residual/activation fused in f32 before the single RNE rounding to f16.
-template <int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane,
-                                              int zb, int zslab) {
-    const int N = p.N;
-    if (p.splits == 1) {
-        f16* __restrict__ C = p.C + zb * p.strideC;
-        const f16* __restrict__ R = p.residual ? p.residual + zb * p.strideC : nullptr;
-        const bool vec_ok = (N & 3) == 0;
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-            const int m = m0 + wm0 + i * 16 + (lane & 15);
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < TN; j++) {
-                const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
-                if (n >= N) continue;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (vec_ok) {
-                    if (p.bias) {
-                        if (p.bias_f32) {
-                            f32x4 bv = *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
-#pragma unroll
-                            for (int r = 0; r < 4; r++) v[r] += bv[r];
-                        } else {
-                            f16x4 bv = *reinterpret_cast<const f16x4*>((const f16*)p.bias + n);
-#pragma unroll
-                            for (int r = 0; r < 4; r++) v[r] += (float)bv[r];
-                        }
-                    }
-                    if (p.rowbias) {
-                        f16x4 rb = *reinterpret_cast<const f16x4*>(p.rowbias + (long)(m / p.rb_rows) * p.rb_ld + n);
-#pragma unroll
-                        for (int r = 0; r < 4; r++) v[r] += (float)rb[r];
-                    }
-                    if (R) {
-                        f16x4 rv = *reinterpret_cast<const f16x4*>(R + (long)m * N + n);
-#pragma unroll
-                        for (int r = 0; r < 4; r++) v[r] += (float)rv[r];
-                    }
-                    f16x4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) o[r] = (f16)osg_apply_act(v[r], p.act);
-                    *reinterpret_cast<f16x4*>(C + (long)m * N + n) = o;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        if (n + r >= N) break;
-                        float x = v[r];
-                        if (p.bias) x += p.bias_f32 ? ((const float*)p.bias)[n + r] : (float)((const f16*)p.bias)[n + r];
-                        if (p.rowbias) x += (float)p.rowbias[(long)(m / p.rb_rows) * p.rb_ld + n + r];
-                        if (R) x += (float)R[(long)m * N + n + r];
-                        C[(long)m * N + n + r] = (f16)osg_apply_act(x, p.act);
-                    }
-                }
-            }
-        }
-    } else {
-        float* __restrict__ P = p.partial + ((long)zslab) * p.M * N;
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-            const int m = m0 + wm0 + i * 16 + (lane & 15);
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < TN; j++) {
-                const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
-                if (n >= N) continue;
-                if ((N & 3) == 0) {
-                    *reinterpret_cast<f32x4*>(P + (long)m * N + n) = acc[i][j];
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        if (n + r < N) P[(long)m * N + n + r] = acc[i][j][r];
-                }
-            }
-        }
-    }
-}
 
 template <int BM, int BN, int BK, bool CONV, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
@@ -649,7 +546,6 @@ int launch_cfg(osg_ctx* ctx, const GemmParams& p, int batch) {
     return 0;
 }
 
-static int launch_splitk_reduce(osg_ctx* ctx, const GemmParams& p, int batch);
 
 // v2 tile / ring / split-K choice.  Measured on MI355X (tools/gemm_probe.py): the L2->LDS DMA path sustains ~23 B/clk per CU
 // and bounds every configuration (a 128x128x64 k-tile moves 32 KiB for 515 MFMA cycles), so the model is: k-tile time =
@@ -779,14 +675,6 @@ int run_gemm(osg_ctx* ctx, GemmParams p, int batch) {
     return 0;
 }
 
-static int launch_splitk_reduce(osg_ctx* ctx, const GemmParams& p, int batch) {
-    long MN = (long)p.M * p.N;
-    long total = MN * batch;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->compute, p.partial, p.C,
-                       p.bias, p.bias_f32, p.residual, MN, p.N, p.splits, batch, p.strideC, p.act, p.rowbias, p.rb_rows, p.rb_ld);
-    OSG_LAUNCH_CHECK(ctx);
-    return 0;
-}
 
 // [K,N] -> [N,K] tiled transpose through LDS
 __global__ __launch_bounds__(256) void transpose_kn_nk_kernel(const f16* __restrict__ src, f16* __restrict__ dst, int K, int N) {
@@ -805,6 +693,16 @@ __global__ __launch_bounds__(256) void transpose_kn_nk_kernel(const f16* __restr
 }
 
 }  // namespace
+
+int osg_mm::launch_splitk_reduce(osg_ctx* ctx, const GemmParams& p, int batch) {
+    long MN = (long)p.M * p.N;
+    long total = MN * batch;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->compute, p.partial, p.C,
+                       p.bias, p.bias_f32, p.residual, MN, p.N, p.splits, batch, p.strideC, p.act, p.rowbias, p.rb_rows, p.rb_ld);
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
 
 extern "C" {
 
@@ -879,6 +777,10 @@ int osg_conv2d_nhwc_rb(osg_ctx* ctx, osg_dtype dtype, const void* x, const void*
     if (KH == 1 && KW == 1 && sh == 1 && sw == 1 && pt == 0 && pl == 0 && pb == 0 && pr == 0) {
         p.lda = Cin;
         return run_gemm<false>(ctx, p, 1);
+    }
+    if (KH == 3) {
+        int rc3 = osg_conv3x3_run(ctx, p);
+        if (rc3 >= 0) return rc3;
     }
     return run_gemm<true>(ctx, p, 1);
 }

@@ -1,0 +1,118 @@
+// Shared by the contraction kernels of libosgpu (osg_gemm.hip, osg_conv3x3.hip): launch parameters and the fused epilogue.
+#pragma once
+#include "osg_common.h"
+
+namespace osg_mm {
+
+struct GemmParams {
+    const f16* A;
+    const f16* Bt;
+    f16* C;
+    const void* bias;
+    const f16* residual;
+    const f16* rowbias;          // optional [M / rb_rows][rb_ld] per-image channel bias (the resnet time-embedding add)
+    int rb_rows;
+    long rb_ld;
+    float* partial;
+    int M, N, K;
+    long lda;
+    long strideA, strideB, strideC;
+    int bias_f32, act;
+    int splits, k_per_split;
+    // conv geometry (CONV only)
+    int H, W, Cin, Ho, Wo, KW, sh, sw, pt, pl;
+    // v2 (direct-to-LDS) kernel only
+    unsigned a_bytes, b_bytes;   // buffer-descriptor extents of one batch item of A / Bt
+    long a_bytes_l;              // conv: byte size of the whole NHWC input (host side, before the 2 GiB check)
+    int mt, nt, n_major;         // tile grid and the order tiles are walked inside an XCD's contiguous chunk
+    int* tickets;                // split-K arrival counters (one per output tile), zero between launches
+};
+
+// ---- epilogue shared by both kernels: lane owns C[m][n..n+3], m = tile_m + (lane&15), n = tile_n + (lane>>4)*4 --------
+// (operands are swapped -- weights feed the MFMA "A" port -- so the 4 accumulator registers of a lane are 4 consecutive
+// output channels of one pixel); bias/residual/activation fused in f32 before the single RNE rounding to f16.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane,
+                                              int zb, int zslab) {
+    const int N = p.N;
+    if (p.splits == 1) {
+        f16* __restrict__ C = p.C + zb * p.strideC;
+        const f16* __restrict__ R = p.residual ? p.residual + zb * p.strideC : nullptr;
+        const bool vec_ok = (N & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int m = m0 + wm0 + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
+                if (n >= N) continue;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (vec_ok) {
+                    if (p.bias) {
+                        if (p.bias_f32) {
+                            f32x4 bv = *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
+#pragma unroll
+                            for (int r = 0; r < 4; r++) v[r] += bv[r];
+                        } else {
+                            f16x4 bv = *reinterpret_cast<const f16x4*>((const f16*)p.bias + n);
+#pragma unroll
+                            for (int r = 0; r < 4; r++) v[r] += (float)bv[r];
+                        }
+                    }
+                    if (p.rowbias) {
+                        f16x4 rb = *reinterpret_cast<const f16x4*>(p.rowbias + (long)(m / p.rb_rows) * p.rb_ld + n);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) v[r] += (float)rb[r];
+                    }
+                    if (R) {
+                        f16x4 rv = *reinterpret_cast<const f16x4*>(R + (long)m * N + n);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) v[r] += (float)rv[r];
+                    }
+                    f16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (f16)osg_apply_act(v[r], p.act);
+                    *reinterpret_cast<f16x4*>(C + (long)m * N + n) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        if (n + r >= N) break;
+                        float x = v[r];
+                        if (p.bias) x += p.bias_f32 ? ((const float*)p.bias)[n + r] : (float)((const f16*)p.bias)[n + r];
+                        if (p.rowbias) x += (float)p.rowbias[(long)(m / p.rb_rows) * p.rb_ld + n + r];
+                        if (R) x += (float)R[(long)m * N + n + r];
+                        C[(long)m * N + n + r] = (f16)osg_apply_act(x, p.act);
+                    }
+                }
+            }
+        }
+    } else {
+        float* __restrict__ P = p.partial + ((long)zslab) * p.M * N;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int m = m0 + wm0 + i * 16 + (lane & 15);
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
+                if (n >= N) continue;
+                if ((N & 3) == 0) {
+                    *reinterpret_cast<f32x4*>(P + (long)m * N + n) = acc[i][j];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (n + r < N) P[(long)m * N + n + r] = acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+
+int launch_splitk_reduce(osg_ctx* ctx, const GemmParams& p, int batch);   // osg_gemm.hip
+
+}  // namespace osg_mm
+
+// osg_conv3x3.hip: halo-reuse 3x3 / stride 1 / pad 1 convolution.  Returns -1 when the shape is not one it takes.
+int osg_conv3x3_run(osg_ctx* ctx, osg_mm::GemmParams& p);

@@ -172,7 +172,8 @@ class Gpu:
     def _p(b: Optional[DevBuf]):
         return b.ptr if b is not None else None
 
-    def conv2d_nhwc(self, x: DevBuf, w: DevBuf, bias: Optional[DevBuf], stride=1, pads=(1, 1, 1, 1), residual=None, act=ACT_NONE):
+    def conv2d_nhwc(self, x: DevBuf, w: DevBuf, bias: Optional[DevBuf], stride=1, pads=(1, 1, 1, 1), residual=None, act=ACT_NONE,
+                    image_bias: Optional[DevBuf] = None):
         n, h, wd, cin = x.shape
         cout, kh, kw, cin2 = w.shape
         assert cin == cin2
@@ -181,6 +182,10 @@ class Gpu:
         ho, wo = (h + pt + pb - kh) // sh + 1, (wd + pl + pr - kw) // sw + 1
         y = self.empty((n, ho, wo, cout), x.dtype)
         bdt = _NP2DT[bias.dtype] if bias is not None else F16
+        if image_bias is not None:   # [n, cout] f16, added per image (fused resnet time-embedding add)
+            self._ck(self.lib.osg_conv2d_nhwc_rb(self.ctx, _NP2DT[x.dtype], x.ptr, w.ptr, self._p(bias), bdt, image_bias.ptr, cout,
+                                                 self._p(residual), y.ptr, n, h, wd, cin, cout, kh, kw, sh, sw, pt, pl, pb, pr, act))
+            return y
         self._ck(self.lib.osg_conv2d_nhwc(self.ctx, _NP2DT[x.dtype], x.ptr, w.ptr, self._p(bias), bdt, self._p(residual), y.ptr, n, h,
                                           wd, cin, cout, kh, kw, sh, sw, pt, pl, pb, pr, act))
         return y

@@ -75,6 +75,26 @@ def test_conv2d(gpu, N, H, W, Cin, Cout, k, stride, pad):
     assert rel_max(got2, want2) <= 1e-3
 
 
+@pytest.mark.parametrize("N,H,Cin,Cout,bn,splits", [
+    (2, 64, 64, 320, 80, 1), (1, 64, 128, 160, 160, 2), (2, 32, 192, 128, 128, 3), (1, 32, 64, 640, 160, 1), (2, 16, 128, 320, 80, 2),
+    (1, 16, 64, 96, 128, 1), (2, 8, 128, 160, 80, 1), (1, 8, 64, 160, 160, 1), (3, 8, 192, 128, 128, 3), (2, 64, 64, 320, 0, 0)])
+def test_conv3x3_halo_kernel(gpu, N, H, Cin, Cout, bn, splits, monkeypatch):
+    """The halo-reuse 3x3 kernel (osg_conv3x3.hip) at every tile geometry (W = 64/32/16/8), channel tile and split-K setting,
+    incl. partial tiles (1 image of 8x8 = 64 pixels; 3 images of 8x8), bias + per-image bias + residual epilogue."""
+    if bn:
+        monkeypatch.setenv("OSG_CONV3X3_BN", str(bn))
+        monkeypatch.setenv("OSG_CONV3X3_SPLITS", str(splits))
+    rng = np.random.default_rng(N * 131 + H * 7 + Cin + Cout)
+    x = rnd(rng, (N, H, H, Cin))
+    w = rnd(rng, (Cout, 3, 3, Cin), (9 * Cin) ** -0.5)
+    bias = rnd(rng, (Cout,), 0.1)
+    res = rnd(rng, (N, H, H, Cout))
+    ib = rnd(rng, (N, Cout), 0.5)
+    want = ref.conv2d_nhwc(x, w, bias, (1, 1), (1, 1, 1, 1), res.astype(f32) + ib.astype(f32)[:, None, None, :])
+    got = gpu.conv2d_nhwc(gpu.to_dev(x), gpu.to_dev(w), gpu.to_dev(bias), 1, (1, 1, 1, 1), gpu.to_dev(res), image_bias=gpu.to_dev(ib)).numpy()
+    assert rel_max(got, want) <= 1e-3
+
+
 def test_conv_linearity_full_size(gpu):
     """Size-independent property at SD1.5 full size: conv(a*x) + conv(b*y) == conv(a*x + b*y) up to f16 rounding."""
     rng = np.random.default_rng(11)
