@@ -198,7 +198,7 @@ def main():
         rows = m.hip_profile(args.profile_reps)
         by_kind = {}
         for ms, fl, by, what in rows:
-            k = what.split(" ", 1)[0]
+            k = what.split(" ", 1)[0].split("+", 1)[0]
             e = by_kind.setdefault(k, [0.0, 0.0, 0.0, 0])
             e[0] += ms; e[1] += fl; e[2] += by; e[3] += 1
         g_ms = sum(by_kind[k][0] for k in GEMM_KINDS if k in by_kind)

@@ -34,7 +34,15 @@ typedef struct osg_graph osg_graph;
 
 typedef enum { OSG_U8 = 1, OSG_F16 = 2, OSG_F32 = 3, OSG_I64 = 4 } osg_dtype; /* == onnxstream::TensorDataType */
 
-typedef enum { OSG_ACT_NONE = 0, OSG_ACT_SILU = 1, OSG_ACT_SIGMOID = 2 } osg_act;
+typedef enum {
+  OSG_ACT_NONE = 0,
+  OSG_ACT_SILU = 1,
+  OSG_ACT_SIGMOID = 2,
+  /* osg_gemm only: C[M,N/2] = v * gelu_erf(g) with v/g the "value"/"gate" halves of the projection (+bias); the [N,K] weight and
+   * the bias must be pair-interleaved in blocks of 16 rows: rows 32k..32k+15 = value columns 16k.., rows 32k+16..32k+31 = the
+   * matching gate columns (the host Model builds this layout once when the weight becomes resident). */
+  OSG_ACT_GEGLU = 3
+} osg_act;
 
 typedef enum {
   OSG_UN_SIGMOID = 0, /* XnnPack::sigmoid            onnxstream.cpp:1217 */

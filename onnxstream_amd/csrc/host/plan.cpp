@@ -356,6 +356,7 @@ struct Lowering {
             index_graph(); fuse_attention(true);
             index_graph(); fuse_linear();
             index_graph(); fuse_residual();
+            index_graph(); fuse_linear_geglu();
             index_graph(); cse_silu();
             index_graph(); fuse_image_bias();
         } else if (m.m_fuse_ops_in_attention) {
@@ -666,6 +667,28 @@ struct Lowering {
                 for (int k : chain) dead[k] = 1;
                 ops()[mm1] = std::move(f);
             }
+        }
+    }
+
+    // osg.Linear(x, W[K,2C], b) -> osg.GEGLU  ==> the GEGLU rides in the GEMM epilogue (value/gate columns pair-interleaved at plan time)
+    void fuse_linear_geglu() {
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (!is((int)i, "osg.Linear")) continue;
+            Operation& op = ops()[i];
+            if (attr(op, "osg_residual") || op.m_output.size() != 1) continue;
+            const Val* w = cval(op.m_input[1]);
+            if (!w || w->shape.size() != 2 || w->dtype != OSG_F16 || w->shape[1] % 32 || w->shape[0] % 64) continue;
+            if (op.m_input.size() > 2 && !op.m_input[2].m_name.empty()) {
+                const Val* b = cval(op.m_input[2]);
+                if (!b || b->dtype != OSG_F16) continue;
+            }
+            int ge = sole_consumer(op.m_output[0]);
+            if (!is(ge, "osg.GEGLU")) continue;
+            Operation f = op;
+            f.m_attributes.emplace_back("osg_geglu", "1");
+            f.m_output = {ops()[ge].m_output[0]};
+            dead[i] = 1;
+            ops()[ge] = std::move(f);
         }
     }
 
@@ -1042,7 +1065,54 @@ struct Lowering {
     }
 
     // MatMul with a static 2-D weight, optional fused bias / residual
+    // [N,K] weight (and bias) re-ordered so that rows 32k..32k+15 are value columns 16k.. and rows 32k+16..32k+31 the matching gate
+    // columns (N = 2C): what the GEGLU GEMM epilogue expects
+    std::pair<int, int> geglu_interleave(int wnk, int bias) {
+        const long Nn = V(wnk).shape[0], K = V(wnk).shape[1], C = Nn / 2;
+        int wi = P.new_val("", {Nn, K}, OSG_F16, Lay::plain, false);
+        V(wi).is_const = true;
+        V(wi).name = V(wnk).name + "|geglu";
+        V(wi).dptr = be.malloc((size_t)Nn * K * 2);
+        P.owned.push_back(V(wi).dptr);
+        be.check(be.api.osg_copy_2d(be.ctx, 2, P.ptr(wnk), 16 * K, 0, V(wi).dptr, 32 * K, 0, C / 16, 16 * K), "osg_copy_2d");
+        be.check(be.api.osg_copy_2d(be.ctx, 2, P.ptr(wnk), 16 * K, C * K, V(wi).dptr, 32 * K, 16 * K, C / 16, 16 * K), "osg_copy_2d");
+        int bi = -1;
+        if (bias >= 0) {
+            bi = P.new_val("", {Nn}, OSG_F16, Lay::plain, false);
+            V(bi).is_const = true;
+            V(bi).dptr = be.malloc((size_t)Nn * 2);
+            P.owned.push_back(V(bi).dptr);
+            be.check(be.api.osg_copy_2d(be.ctx, 2, P.ptr(bias), 16, 0, V(bi).dptr, 32, 0, C / 16, 16), "osg_copy_2d");
+            be.check(be.api.osg_copy_2d(be.ctx, 2, P.ptr(bias), 16, C, V(bi).dptr, 32, 16, C / 16, 16), "osg_copy_2d");
+        }
+        be.check(be.api.osg_sync(be.ctx), "osg_sync");
+        return {wi, bi};
+    }
+
     void lower_linear(const Operation& op) {
+        if (attr(op, "osg_geglu")) {
+            int a = P.ensure_plain(in_val(op.m_input[0]));
+            int w = in_val(op.m_input[1]);
+            const Shape as = V(a).shape;
+            const long K = V(w).shape[0], Nn = V(w).shape[1];
+            need(op, !as.empty() && as.back() == K, "invalid shape of inputs.");
+            int bias = op.m_input.size() > 2 && !op.m_input[2].m_name.empty() ? in_val(op.m_input[2]) : -1;
+            auto [wi, bi] = geglu_interleave(weight_nk(w), bias);
+            Shape os = as;
+            os.back() = Nn / 2;
+            int y = out_val(op, os, Lay::plain, V(a).batched);
+            const long M = prod(as) / K * B(a);
+            std::vector<int> reads = {a, wi};
+            if (bi >= 0) reads.push_back(bi);
+            const std::string what = "Linear+GEGLU " + op.m_name;
+            P.add_step(what, reads, {y}, [=, this] {
+                be.check(be.api.osg_gemm(be.ctx, OSG_F16, P.ptr(a), P.ptr(wi), 1, bi >= 0 ? P.ptr(bi) : nullptr, OSG_F16, nullptr, P.ptr(y), (int)M,
+                                         (int)Nn, (int)K, 1, 0, 0, 0, OSG_ACT_GEGLU),
+                         what.c_str());
+            });
+            P.steps.back().flops = 2.0 * M * Nn * K;
+            return;
+        }
         const bool has_res = attr(op, "osg_residual") != nullptr;
         int a = P.ensure_plain(in_val(op.m_input[0]));
         int w = in_val(op.m_input[1]);

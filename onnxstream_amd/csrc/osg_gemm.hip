@@ -369,6 +369,10 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
         nxt = nxt + 1 == NST ? 0 : nxt + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the dummy tail loads before the LDS is released
+    if (p.act == OSG_ACT_GEGLU) {
+        if constexpr (TN % 2 == 0) gemm_epilogue_geglu<TM, TN>(p, acc, m0, n0, wm0, wn0, lane, zb);
+        return;
+    }
     gemm_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0, lane, zb, zb * p.splits + zs);
 
     // ---- split-K: the LAST k-slice block to arrive at this tile folds the f32 slabs (fixed order => deterministic) and writes
@@ -584,6 +588,7 @@ static V2Choice choose_v2(const osg_ctx* ctx, int M, int N, int K, int batch) {
 template <bool CONV>
 int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch) {
     V2Choice ch = choose_v2(ctx, p.M, p.N, p.K, batch);
+    if (p.act == OSG_ACT_GEGLU) ch.splits = 1;   // the pairing lives in the tile epilogue
     if (const char* e = getenv("OSG_GEMM_CFG")) ch.cfg = atoi(e);
     if (const char* e = getenv("OSG_GEMM_SPLITS")) ch.splits = atoi(e);
     if (const char* e = getenv("OSG_GEMM_NST")) ch.nst = atoi(e);
@@ -633,6 +638,7 @@ int run_gemm(osg_ctx* ctx, GemmParams p, int batch) {
             p.b_bytes = (unsigned)b_ext;
             return run_gemm_v2<CONV>(ctx, p, batch);
         }
+        if (p.act == OSG_ACT_GEGLU) OSG_FAIL(ctx, "osg_gemm: GEGLU epilogue needs 16-byte aligned operands (direct-to-LDS kernel only)");
     }
     const bool vec = CONV ? (p.Cin % 8 == 0) : (p.K % 8 == 0 && p.lda % 8 == 0);
     // ---- tile / split-K selection -------------------------------------------------------------------------
@@ -720,6 +726,8 @@ int osg_gemm(osg_ctx* ctx, osg_dtype dtype, const void* A, const void* B, int b_
     if (dtype != OSG_F16) OSG_FAIL(ctx, "osg_gemm: only f16 arithmetic is implemented on the device");
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) OSG_FAIL(ctx, "osg_gemm: invalid shape of inputs");
     if (bias && bias_dtype != OSG_F16 && bias_dtype != OSG_F32) OSG_FAIL(ctx, "osg_gemm: invalid bias dtype");
+    if (act == OSG_ACT_GEGLU && (!b_is_nk || residual || N % 32 || K % 64 || batch != 1))
+        OSG_FAIL(ctx, "osg_gemm: the GEGLU epilogue needs a pair-interleaved [N,K] weight, N % 32 == 0, K % 64 == 0, no residual");
     const f16* Bt = (const f16*)B;
     long sb = stride_b;
     if (!b_is_nk) {

@@ -110,6 +110,39 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 }
 
 
+// ---- fused GEGLU epilogue (act == OSG_ACT_GEGLU): the weight rows were pair-interleaved in blocks of 16 at plan time, so MFMA
+// tile 2j holds 16 "value" columns and tile 2j+1 the matching 16 "gate" columns; out[m][c] = (v + bv) * gelu_erf(g + bg), written
+// to a [M, N/2] matrix.  Replaces Add(bias) + Slice,Slice,Div,Erf,Add,Mul,Mul,Mul (reference src/onnxstream.cpp:6499,4001,...).
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_geglu(const GemmParams& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane,
+                                                    int zb) {
+    static_assert(TN % 2 == 0, "GEGLU epilogue needs value/gate tile pairs");
+    const int No = p.N >> 1;
+    f16* __restrict__ C = p.C + zb * p.strideC;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        const int m = m0 + wm0 + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; j += 2) {
+            const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;      // column of the value tile in the interleaved space
+            if (n >= p.N) continue;
+            const int c = ((n0 + wn0 + j * 16) >> 1) + (lane >> 4) * 4;   // output column
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = acc[i][j][r], g = acc[i][j + 1][r];
+                if (p.bias) {
+                    v += p.bias_f32 ? ((const float*)p.bias)[n + r] : (float)((const f16*)p.bias)[n + r];
+                    g += p.bias_f32 ? ((const float*)p.bias)[n + 16 + r] : (float)((const f16*)p.bias)[n + 16 + r];
+                }
+                o[r] = (f16)(v * (0.5f * g * (1.0f + erff(g * 0.70710678118654752440f))));
+            }
+            *reinterpret_cast<f16x4*>(C + (long)m * No + c) = o;
+        }
+    }
+}
+
 int launch_splitk_reduce(osg_ctx* ctx, const GemmParams& p, int batch);   // osg_gemm.hip
 
 }  // namespace osg_mm

@@ -44,6 +44,30 @@ def test_gemm(gpu, M, N, K):
         assert np.array_equal(gpu.gemm(gpu.to_dev(eye), db).numpy(), b)
 
 
+@pytest.mark.parametrize("M,K,C", [(300, 128, 128), (8192, 320, 1280), (64, 1280, 5120)])
+def test_gemm_geglu_epilogue(gpu, M, K, C):
+    """Linear + GEGLU fused in the GEMM epilogue (pair-interleaved [N,K] weight) vs x[:, :C] * gelu_erf(x[:, C:])."""
+    from scipy.special import erf
+    rng = np.random.default_rng(M + K + C)
+    a, w = rnd(rng, (M, K)), rnd(rng, (K, 2 * C), K ** -0.5)
+    b = rnd(rng, (2 * C,), 0.1)
+    x = a.astype(np.float64) @ w.astype(np.float64) + b.astype(np.float64)
+    v, g = x[:, :C], x[:, C:]
+    want = v * 0.5 * g * (1.0 + erf(g / np.sqrt(2.0)))
+    wt = w.T.copy()                                   # [N, K]
+    wi = np.empty_like(wt)
+    bi = np.empty_like(b)
+    for k in range(C // 16):
+        wi[32 * k:32 * k + 16] = wt[16 * k:16 * k + 16]
+        wi[32 * k + 16:32 * k + 32] = wt[C + 16 * k:C + 16 * k + 16]
+        bi[32 * k:32 * k + 16] = b[16 * k:16 * k + 16]
+        bi[32 * k + 16:32 * k + 32] = b[C + 16 * k:C + 16 * k + 16]
+    y = gpu.empty((M, C), f16)
+    da, dw, db = gpu.to_dev(a), gpu.to_dev(wi), gpu.to_dev(bi)
+    gpu._ck(gpu.lib.osg_gemm(gpu.ctx, 2, da.ptr, dw.ptr, 1, db.ptr, 2, None, y.ptr, M, 2 * C, K, 1, 0, 0, 0, 3))
+    assert rel_max(y.numpy(), want) <= 1e-3
+
+
 def test_gemm_batched(gpu):
     rng = np.random.default_rng(5)
     a, b = rnd(rng, (8, 256, 160)), rnd(rng, (8, 160, 77), 0.1)
