@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="SD15", help="SD15 (headline) | SDXL | TINY | TINY_XL")
     ap.add_argument("--fusion", type=int, default=2)
+    ap.add_argument("--mode", default="pipeline", choices=["pipeline", "replay"],
+                    help="pipeline: full txt2img loop (host CFG + Euler-A, VAE decode every 20 steps); replay: UNet graph replays only")
     ap.add_argument("--cpu-passes", type=int, default=4, help="reference CPU passes in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--profile-reps", type=int, default=3)
     ap.add_argument("--breakdown", default="", help="write the per-step HIP-event profile to this file")
@@ -149,45 +151,95 @@ def main():
     cond = {k: v[0] for k, v in pack.items()}
     uncond = {k: v[1] for k, v in pack.items()}
 
-    # ---- the product path: model_* C API -> host planner -> libosgpu HIP kernels -------------------------------------------
-    m = Model(b.LIB_HOST, 0, "ram+nocache")
-    m._set_option("hip_device", local_rank)
-    m.read_file(model_dir + "model.txt")
+    # ---- the product path: model_* C API -> host planner -> libosgpu HIP kernels, driven by the txt2img harness ---------------
+    from onnxstream_amd.pipeline import Txt2Img, sigma_schedule
+    from onnxstream_amd.synth import sd_vae
+    vcfg = sd_vae.SD_VAE if cfg.latent >= 64 else sd_vae.TINY_VAE
+    vae_dir = None
+    if args.mode == "pipeline" and not cfg.sdxl_add_embed:
+        from onnxstream_amd.synth.graph import DirSink
+        vae_dir = os.path.join(os.environ.get("OSA_SYNTH_DIR", "/tmp/onnxstream_amd_synth"), vcfg.name) + "/"
+        if local_rank == 0 and not os.path.exists(vae_dir + ".complete"):
+            sd_vae.build_vae_decoder(DirSink(vae_dir), vcfg)
+            open(vae_dir + ".complete", "w").write("ok")
+        barrier()
     t_build = time.time()
-    for r in range(2):                       # run 1: plan + eager pass (weights become resident); run 2: hipGraph capture
-        for ins in (cond, uncond):
-            for k, v in ins.items():
-                m.add_tensor(k, v)
-        if r == 0:
+    pipe = Txt2Img(b.LIB_HOST, model_dir, vae_dir, batched=True, device=local_rank, fusion=args.fusion)
+    m = pipe.unet
+    L = cfg.latent
+    lat_shape = (1, cfg.in_ch, L, L)
+    ctx_c, ctx_u = cond["encoder_hidden_states"], uncond["encoder_hidden_states"]
+    sig = sigma_schedule(STEPS_PER_IMAGE, pipe.log_sigmas)
+    rng = np.random.default_rng(1234 + rank)
+    state = {"x": rng.standard_normal(lat_shape, dtype=np.float32) * sig[0], "i": 0, "images": 0, "last": None}
+
+    def one_step():
+        """One denoising step of the 20-step loop (UNet over cond+uncond as one batch-2 pass, CFG combine, Euler-Ancestral update on
+        the host exactly as the reference app does); after the 20th step of an image: VAE decode, then a fresh latent."""
+        i = state["i"]
+        x = state["x"]
+        if args.mode == "replay":
+            m.hip_replay(1)
+            state["i"] = (i + 1) % STEPS_PER_IMAGE
+            return
+        den = pipe.denoise(x, float(sig[i]), ctx_c, ctx_u)
+        s_i, s_n = np.float64(sig[i]), np.float64(sig[i + 1])
+        s_up = min(s_n, abs(s_n * np.sqrt(s_i * s_i - s_n * s_n) / s_i))
+        s_down = np.float32(np.sqrt(s_n * s_n - s_up * s_up))
+        x = ((x - den) * np.float32(s_down / np.float32(s_i)) + den + rng.standard_normal(lat_shape, dtype=np.float32) * np.float32(s_up)).astype(np.float32)
+        # random-weight UNets do not denoise (|x| would grow without bound over 20 CFG-7 steps): clamp to the scale a real trajectory has
+        x = np.clip(x, -4.0 * max(float(s_n), 1.0), 4.0 * max(float(s_n), 1.0))
+        if i + 1 == STEPS_PER_IMAGE:
+            if pipe.vae is not None:
+                state["last"] = pipe.decode(x)
+            state["images"] += 1
+            x = rng.standard_normal(lat_shape, dtype=np.float32) * sig[0]
+        state["x"], state["i"] = x, (i + 1) % STEPS_PER_IMAGE
+
+    # plan + eager pass (weights become resident), hipGraph capture, and the VAE's plan/capture: all before the timed region
+    if args.mode == "replay":
+        for r in range(2):
+            for ins in (cond, uncond):
+                for k, v in ins.items():
+                    m.add_tensor(k, v)
             m.set_use_fp16_arithmetic(True)
             m.set_fuse_ops_in_attention(True)
-            m._set_option("hip_fusion_level", args.fusion)
-        m.run()
-        if r == 0:
-            m.clear_tensors()
-    all_names = m.get_all_tensor_names()
-    out_name = "out_sample" if "out_sample" in all_names else all_names[0]
-    out, out_shape = m.get_tensor(out_name)
-    assert np.isfinite(out).all()
+            m.run()
+            if r == 0:
+                m.clear_tensors()
+    else:
+        for _ in range(3):
+            pipe.denoise(state["x"], float(sig[0]), ctx_c, ctx_u)
+        if pipe.vae is not None:
+            for _ in range(3):
+                pipe.decode(state["x"] / sig[0])
     kernels = m.hip_last_kernel_count()
-    log(f"[bench r{rank}] plan+capture {time.time()-t_build:.1f} s, {kernels} launches/pass, eager pass {m.hip_last_pass_ms():.3f} ms")
+    vae_kernels = pipe.vae.hip_last_kernel_count() if pipe.vae is not None else 0
+    log(f"[bench r{rank}] plan+capture {time.time()-t_build:.1f} s, UNet {kernels} launches/pass ({m.hip_last_pass_ms():.3f} ms device)"
+        + (f", VAE {vae_kernels} launches ({pipe.vae.hip_last_pass_ms():.3f} ms device)" if pipe.vae is not None else ""))
 
     # ---- warmup, then EXACTLY K timed steps ---------------------------------------------------------------------------
-    if args.warmup > 0:
-        m.hip_replay(args.warmup)
+    for _ in range(args.warmup):
+        one_step()
+    state["i"], state["images"] = 0, 0           # the timed region starts at the first step of an image
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    dev_ms = m.hip_replay(args.steps)        # K back-to-back launches; returns after the stop event (device idle)
+    dev_acc = 0.0
+    for _ in range(args.steps):
+        one_step()
+        dev_acc += m.hip_last_pass_ms()
     torch.cuda.synchronize()
     barrier()
     wall = time.perf_counter() - t0
+    dev_ms = dev_acc / max(args.steps, 1)
+    out = state["last"] if state["last"] is not None else state["x"]
     if dist is not None:
         tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
-        # gather every prompt's predicted noise on rank 0 (what the samplers on rank 0 would consume)
-        allr = shard.gather_results(dist, rank, world, world, {my_prompt: out}, device="cuda")
+        # gather every prompt's result (image, or latents when no image completed) on rank 0
+        allr = shard.gather_results(dist, rank, world, world, {my_prompt: np.asarray(out, np.float32)}, device="cuda")
         assert rank != 0 or (allr.shape[0] == world and np.isfinite(allr).all())
     ms_per_step = wall * 1e3 / args.steps
     images_per_s = world / (STEPS_PER_IMAGE * ms_per_step * 1e-3)
@@ -222,8 +274,8 @@ def main():
                     f.write(f"{ms:.5f}\t{fl:.0f}\t{by:.0f}\t{what}\n")
         cpu = None
         if world == 1 and args.cpu_passes > 0:
-            m.close()
-            m = None
+            pipe.close()
+            pipe = None
             try:
                 cpu = cpu_baseline(model_dir, cond, uncond, args.cpu_passes)
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
@@ -232,14 +284,19 @@ def main():
             "metric": "sd15_unet_step_latency_ms+images_per_sec_512x512_20step", "value": round(images_per_s, 4), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{cfg.name} UNet denoising step: cond+uncond 2x4x{cfg.latent}x{cfg.latent} latents, ctx 77x{cfg.ctx_dim}, "
-                                   f"W16A16, weights resident, images/s = gpus/(20 x step); VAE decode not included",
+            "config": {"workload": (f"{cfg.name} 512x512 20-step txt2img: per step the UNet over cond+uncond (2x4x{cfg.latent}x{cfg.latent} latents, ctx 77x{cfg.ctx_dim}) "
+                                    f"as one batch-2 pass + CFG 7 + Euler-Ancestral update, VAE decode after every 20th step (inside the timed region), "
+                                    f"W16A16, weights resident; ms_per_step = wall / K with the decode amortised; images/s = gpus / (20 x ms_per_step)")
+                                   if vae_dir else (f"{cfg.name} UNet denoising step: cond+uncond 2x4x{cfg.latent}x{cfg.latent} latents, W16A16, "
+                                                    f"weights resident, mode={args.mode}; NO VAE decode"),
+                       "mode": args.mode, "vae_decode_in_timed_region": bool(vae_dir), "images_completed": state["images"],
                        "prompts_per_gpu": 1, "unet_passes_per_step": 2, "steps_per_image": STEPS_PER_IMAGE, "launches_per_step": kernels,
-                       "fusion_level": args.fusion, "device_ms_per_step": round(dev_ms, 4), "parallelism": f"replica x{world}"},
+                       "vae_launches": vae_kernels, "fusion_level": args.fusion, "unet_device_ms_per_step": round(dev_ms, 4),
+                       "parallelism": f"replica x{world}"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
-    if m is not None:
-        m.close()
+    if pipe is not None:
+        pipe.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

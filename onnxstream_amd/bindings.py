@@ -106,8 +106,14 @@ class Model:
         p = self._lib.model_add_tensor(self._h, ty, self._name(name), data.ndim, dims)
         ctypes.memmove(p, data.ctypes.data, data.nbytes)
 
-    def get_tensor(self, name: str):
-        p = self._lib.model_get_tensor(self._h, self._name(name))
+    def get_tensor(self, name: str, index: int = 0):
+        """index > 0: the result for the index-th extra sample pushed under the same input names (backend addition)."""
+        if index:
+            f = self._lib.model_hip_get_tensor_batch
+            f.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint]; f.restype = ctypes.c_void_p
+            p = f(self._h, self._name(name), index)
+        else:
+            p = self._lib.model_get_tensor(self._h, self._name(name))
         if not p:
             return None
         r = ctypes.cast(p, ctypes.POINTER(_GetTensorReturnLayout)).contents

@@ -157,6 +157,33 @@ void* model_get_tensor(Handle* h, char* name) {
     return nullptr;
 }
 
+// sample `index` of a tensor that was produced for several pushed samples (index 0 == model_get_tensor); the reference app reaches
+// the same data through Tensor::m_batch (src/sd.cpp:1098-1161 SDCoroState::get_result)
+void* model_hip_get_tensor_batch(Handle* h, char* name, unsigned int index) {
+    struct Ret {
+        size_t dims_num;
+        size_t* dims;
+        size_t data_num;
+        float* data;
+    };
+    for (auto& t : h->model.m_data)
+        if (t.m_name == name) {
+            Tensor* src = &t;
+            if (index > 0) {
+                if (!t.m_batch || index - 1 >= t.m_batch->size()) return nullptr;
+                src = &(*t.m_batch)[index - 1];
+            }
+            if (src->m_type != TensorDataType::float32) return nullptr;
+            Ret* r = (Ret*)std::malloc(sizeof(Ret));
+            r->dims_num = src->m_shape.size();
+            r->dims = src->m_shape.data();
+            r->data_num = src->get_vector<float>().size();
+            r->data = src->get_vector<float>().data();
+            return r;
+        }
+    return nullptr;
+}
+
 char* model_get_all_tensor_names(Handle* h) {
     std::string out;
     for (auto& t : h->model.m_data) out += (out.empty() ? "" : "|") + t.m_name;

@@ -57,6 +57,29 @@ float half_to_float(uint16_t h) {
     return sign ? -v : v;
 }
 
+uint16_t float_to_half(float f) {   // round-to-nearest-even, like the reference's fp32 -> fp16 convert
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    int32_t e = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+    uint32_t m = x & 0x7fffffu;
+    if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (m ? 0x200u : 0));
+    if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        m |= 0x800000u;
+        const int shift = 14 - e;
+        uint32_t hm = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (hm & 1))) hm++;
+        return (uint16_t)(sign | hm);
+    }
+    uint32_t h = ((uint32_t)e << 10) | (m >> 13);
+    const uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) h++;
+    return (uint16_t)(sign | h);
+}
+
 bool is_const_tensor(const Tensor& t) { return !t.m_name.empty() && t.m_type != TensorDataType::none; }
 
 }  // namespace
@@ -1355,6 +1378,32 @@ struct Lowering {
         int y = out_val(op, os, Lay::plain, V(q).batched);
         need(op, V(q).batched == V(k).batched && V(k).batched == V(v).batched, "q/k/v batching mismatch.");
         const long heads = qs[0] * B(q), Tq = qs[1], d = qs[2], Tk = ks[2];
+        if (d > 160 || d % 8) {
+            // head dims the flash kernel does not take (the VAE's single 512-wide head): the reference's own sequence, unsliced --
+            // S = f16(Q K^T); S = f16(S * s); P = softmax_rows(S); O = f16(P V)  (reference :6796-6929)
+            int sv = P.new_val("", {qs[0], Tq, Tk}, OSG_F16, Lay::plain, V(q).batched);
+            int pv = P.new_val("", {qs[0], Tq, Tk}, OSG_F16, Lay::plain, V(q).batched);
+            emit_gemm("MatMul " + op.m_name + "/QK", q, k, -1, -1, sv, Tq, Tk, d, heads, Tq * d, d * Tk, Tq * Tk, 0);
+            int cur = sv;
+            if (scale != 1.0f) {
+                int sc = P.new_val("", {1}, OSG_F16, Lay::plain, false);
+                V(sc).is_const = true;
+                V(sc).dptr = be.malloc(256);
+                P.owned.push_back(V(sc).dptr);
+                const uint16_t hbits = float_to_half(scale);
+                be.check(be.api.osg_upload_sync(be.ctx, V(sc).dptr, &hbits, 2), "osg_upload_sync");
+                const long tot = heads * Tq * Tk;
+                P.add_step("Mul " + op.m_name + "/scale", {sv, sc}, {sv}, [=, this] {
+                    long as[1] = {tot}, bs[1] = {1};
+                    be.check(be.api.osg_binary(be.ctx, OSG_F16, OSG_BIN_MUL, P.ptr(sv), as, P.ptr(sc), bs, P.ptr(sv), 1), "osg_binary");
+                });
+            }
+            P.add_step("Softmax " + op.m_name, {cur}, {pv}, [=, this] {
+                be.check(be.api.osg_softmax_last(be.ctx, OSG_F16, P.ptr(cur), P.ptr(pv), heads * Tq, Tk), "osg_softmax_last");
+            });
+            emit_gemm("MatMul " + op.m_name + "/PV", pv, v, -1, -1, y, Tq, d, Tk, heads, Tq * Tk, Tk * d, Tq * d, 0);
+            return;
+        }
         P.add_step("AttentionFusedOps " + op.m_name, {q, k, v}, {y}, [=, this] {
             be.check(be.api.osg_attention(be.ctx, OSG_F16, P.ptr(q), P.ptr(k), P.ptr(v), P.ptr(y), (int)heads, (int)Tq, (int)Tk, (int)d, scale, 1),
                      "AttentionFusedOps");

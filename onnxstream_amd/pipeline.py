@@ -1,0 +1,141 @@
+"""txt2img harness: the denoising loop + VAE decode of the reference app, host side (reference src/sd.cpp ``diffusion_solver``
+:1574-1780, ``CFGDenoiser_CompVisDenoiser`` :1397-1559, Euler-Ancestral ``src/samplers.h`` :1430-1472, ``decoder_solver`` :1174-1256).
+
+It drives ANY library that exports the reference's model_* C API through ``bindings.Model`` -- the HIP backend
+(``libonnxstream_amd.so``) or the reference oracle -- which is what makes it a parity harness: same schedule, same CFG
+combine (scale 7, hard-coded in the reference), same sampler arithmetic, only the UNet/VAE executor differs.
+With the HIP backend the cond and uncond samples are pushed under the same names and run as ONE batch-2 pass
+(the reference's ``m_batch``); with the reference library they run back to back, as ``sd.cpp`` does without ``--num``.
+
+Out of scope (host glue of the app): tokenizer, text encoder, PNG writer.  The text context is an input.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+
+from .bindings import Model
+
+f32 = np.float32
+
+
+def log_sigmas_table() -> np.ndarray:
+    """The 1000-entry table hard-coded at src/sd.cpp:1591: log(sqrt((1-acp)/acp)) of SD's scaled-linear beta schedule
+    (beta 0.00085 -> 0.012 over 1000 steps), here recomputed in float64 (agrees with the table to ~1e-6)."""
+    betas = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=np.float64) ** 2
+    acp = np.cumprod(1.0 - betas)
+    return (0.5 * np.log((1.0 - acp) / acp)).astype(f32)
+
+
+def sigma_schedule(steps: int, log_sigmas: np.ndarray) -> np.ndarray:
+    """t_to_sigma over linspace(999, 0, steps) + a trailing 0 (src/sd.cpp:1597-1612)."""
+    sig = np.empty(steps + 1, f32)
+    delta = -999.0 / (steps - 1) if steps > 1 else 0.0
+    for i in range(steps):
+        t = f32(999.0 + i * delta)
+        lo, hi = int(np.floor(t)), int(np.ceil(t))
+        w = f32(t - lo)
+        sig[i] = np.exp((1 - w) * log_sigmas[lo] + w * log_sigmas[hi])
+    sig[steps] = 0.0
+    return sig
+
+
+def sigma_to_t(sigma: float, log_sigmas: np.ndarray) -> float:
+    """src/sd.cpp:1403-1425."""
+    ls = np.log(f32(sigma))
+    dists = np.cumsum((ls - log_sigmas >= 0).astype(np.int64))
+    low = min(int(np.argmax(dists)), 1000 - 2)
+    high = low + 1
+    lo, hi = log_sigmas[low], log_sigmas[high]
+    w = float(np.clip((lo - ls) / (lo - hi), 0.0, 1.0))
+    return (1 - w) * low + w * high
+
+
+class Txt2Img:
+    def __init__(self, library: str, unet_dir: str, vae_dir: Optional[str], batched: bool = True, device: int = 0,
+                 names: Dict[str, str] = None, fusion: Optional[int] = None, threads: int = 0):
+        self.batched = batched
+        self.names = dict(timestep="timestep", sample="sample", ctx="encoder_hidden_states", out="out_sample", vae_in="input.1",
+                          vae_out="out_image")
+        if names:
+            self.names.update(names)
+        self.log_sigmas = log_sigmas_table()
+        self.unet = Model(library, threads, "ram+nocache")
+        self.vae = Model(library, threads, "ram+nocache") if vae_dir else None
+        for m, d in ((self.unet, unet_dir), (self.vae, vae_dir)):
+            if m is None:
+                continue
+            if batched:
+                m._set_option("hip_device", device)
+                if fusion is not None:
+                    m._set_option("hip_fusion_level", fusion)
+            m.read_file(d + "model.txt")
+        self._configured = False
+
+    def close(self):
+        self.unet.close()
+        if self.vae:
+            self.vae.close()
+
+    def _run(self, m: Model, pushes: List[Dict[str, np.ndarray]], out: str) -> List[np.ndarray]:
+        if self.batched:
+            for ins in pushes:
+                for k, v in ins.items():
+                    m.add_tensor(k, np.ascontiguousarray(v, f32))
+            m.set_use_fp16_arithmetic(True)
+            m.set_fuse_ops_in_attention(True)
+            m.run()
+            res = [m.get_tensor(out, i)[0] for i in range(len(pushes))]
+            m.clear_tensors()
+            return res
+        res = []
+        for ins in pushes:            # the reference C API takes fp32 inputs only while fp16 arithmetic is off (see oracle/ref.py)
+            m.set_use_fp16_arithmetic(False)
+            for k, v in ins.items():
+                m.add_tensor(k, np.ascontiguousarray(v, f32))
+            m.set_use_fp16_arithmetic(True)
+            m.set_fuse_ops_in_attention(True)
+            m.run()
+            res.append(m.get_tensor(out)[0])
+            m.clear_tensors()
+        return res
+
+    def denoise(self, x: np.ndarray, sigma: float, cond: np.ndarray, uncond: np.ndarray, guidance: float = 7.0) -> np.ndarray:
+        """CFGDenoiser_CompVisDenoiser: eps-prediction wrapped as a denoiser, then the CFG combine (src/sd.cpp:1397-1559)."""
+        n = self.names
+        c_out = f32(-1.0 * sigma)
+        c_in = f32(1.0 / np.sqrt(f32(sigma) * f32(sigma) + 1))
+        t = f32(sigma_to_t(sigma, self.log_sigmas))
+        xin = (x * c_in).astype(f32)
+        pushes = [{n["timestep"]: np.asarray([t], f32), n["sample"]: xin, n["ctx"]: c} for c in (cond, uncond)]
+        eps_c, eps_u = self._run(self.unet, pushes, n["out"])
+        den_c = eps_c * c_out + x
+        den_u = eps_u * c_out + x
+        return (den_u + f32(guidance) * (den_c - den_u)).astype(f32)
+
+    def sample(self, cond: np.ndarray, uncond: np.ndarray, steps: int = 20, seed: int = 42, latent_shape=(1, 4, 64, 64),
+               on_step: Optional[Callable[[int, np.ndarray], None]] = None) -> np.ndarray:
+        """diffusion_solver with the default sampler (Euler Ancestral, src/samplers.h:1430-1472; non-original arithmetic branch)."""
+        sig = sigma_schedule(steps, self.log_sigmas)
+        rng = np.random.default_rng(seed)     # the reference draws mt19937 normals; any N(0,1) stream is equivalent for the harness
+        x = rng.standard_normal(latent_shape, dtype=f32) * sig[0]
+        for i in range(steps):
+            den = self.denoise(x, float(sig[i]), cond, uncond)
+            s_i, s_n = np.float64(sig[i]), np.float64(sig[i + 1])
+            sigma_up = min(s_n, abs(s_n * np.sqrt(s_i * s_i - s_n * s_n) / s_i))
+            sigma_down = f32(np.sqrt(s_n * s_n - sigma_up * sigma_up))
+            noise = rng.standard_normal(latent_shape, dtype=f32)
+            x = ((x - den) * f32(sigma_down / f32(s_i)) + den + noise * f32(sigma_up)).astype(f32)
+            if on_step:
+                on_step(i, x)
+        return x
+
+    def decode(self, latents: np.ndarray) -> np.ndarray:
+        """decoder_solver: latents * 5.48998 -> VAE decoder -> (y + 1) * 127.5 (src/sd.cpp:1174-1256)."""
+        z = (latents * f32(5.48998)).astype(f32)
+        (y,) = self._run(self.vae, [{self.names["vae_in"]: z}], self.names["vae_out"])
+        return ((y + f32(1.0)) * f32(127.5)).astype(f32)
+
+    def txt2img(self, cond: np.ndarray, uncond: np.ndarray, steps: int = 20, seed: int = 42, latent_shape=(1, 4, 64, 64)) -> np.ndarray:
+        return self.decode(self.sample(cond, uncond, steps, seed, latent_shape))

@@ -33,3 +33,20 @@ for name in gc.all_case_names():
         print(f"{name:20s} out={oname} shape={v16.shape} max|ref32|={mx:.3f} |ref16-ref32|/max={np.abs(v16 - v32).max() / mx:.2e}")
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), out_name=np.asarray(oname), ref16=v16, ref32=v32,
                             **{"in_" + k: v for k, v in ins.items()})
+
+# ---- end-to-end: 3 Euler-A steps with CFG + VAE decode, driven through the reference library by the same harness the product uses
+from onnxstream_amd.pipeline import Txt2Img  # noqa: E402
+from onnxstream_amd.synth import sd_unet, sd_vae  # noqa: E402
+with tempfile.TemporaryDirectory() as d:
+    du, dv = d + "/unet/", d + "/vae/"
+    sd_unet.build_unet(DirSink(du), sd_unet.TINY)
+    sd_vae.build_vae_decoder(DirSink(dv), sd_vae.TINY_VAE)
+    rng = np.random.default_rng(5)
+    cond = rng.standard_normal((1, 11, 48), dtype=np.float32)
+    uncond = rng.standard_normal((1, 11, 48), dtype=np.float32)
+    p = Txt2Img(oref.REF_LIB, du, dv, batched=False, threads=1)
+    lat = p.sample(cond, uncond, steps=3, seed=9, latent_shape=(1, 4, 16, 16))
+    img = p.decode(lat)
+    p.close()
+    print(f"pipeline_tiny latents max {np.abs(lat).max():.3f} image range [{img.min():.1f}, {img.max():.1f}]")
+    np.savez_compressed(os.path.join(out_dir, "pipeline_tiny.npz"), cond=cond, uncond=uncond, latents=lat, image=img)
