@@ -133,13 +133,20 @@ def time_embedding(g):
 CASES = [conv3x3, conv3x3_stride2, conv1x1_nobias, conv_in_4ch, conv_ragged, linear_bias, gemm_temb, group_norm_silu, layer_norm,
          self_attention, cross_attention, geglu_ff, resnet_block, transformer_block, upsample_concat, time_embedding]
 # whole (miniature) networks: SD1.5-shaped and SDXL-shaped UNets, the VAE decoder (single 32-wide attention head + 3 resolutions)
-UNETS = {"unet_tiny": sd_unet.TINY, "unet_tinyxl": sd_unet.TINY_XL, "vae_tiny": sd_vae.TINY_VAE}
+UNETS = {"unet_tiny": sd_unet.TINY, "unet_tinyxl": sd_unet.TINY_XL, "vae_tiny": sd_vae.TINY_VAE,
+         # W8A16 (BASELINE config 3, UNet half): uint8 weights + per-tensor scale/zero-point in model.txt, dequantised at load
+         # (reference get_tensor_data :2887-2891 -> Model::dequantize :3353)
+         "unet_tiny_w8": (sd_unet.TINY, True)}
 
 
 def emit(case, sink, seed=1234):
     """Emit a case's graph + weights into `sink`; returns the fp32 input dict."""
     if isinstance(case, str):
         cfg = UNETS[case]
+        if isinstance(cfg, tuple):
+            cfg, quant = cfg
+            sd_unet.build_unet(sink, cfg, seed=seed, quant_weights=quant)
+            return sd_unet.unet_inputs(cfg, 42)
         if isinstance(cfg, sd_vae.VAEConfig):
             sd_vae.build_vae_decoder(sink, cfg)
             return sd_vae.vae_inputs(cfg)
