@@ -76,6 +76,11 @@ int osg_malloc(osg_ctx* ctx, size_t bytes, void** dptr);
 int osg_free(osg_ctx* ctx, void* dptr);
 int osg_upload(osg_ctx* ctx, void* dst, const void* host_src, size_t bytes);         /* pinned staging + async H2D on the COPY stream; compute stream waits on it */
 int osg_upload_sync(osg_ctx* ctx, void* dst, const void* host_src, size_t bytes);    /* plain blocking H2D */
+/* streamed-weights mode: page-lock a weights provider's own host buffer once, then DMA from it with no staging copy
+ * (async on the COPY stream; the compute stream waits on the copy's event).  The caller keeps the memory alive and registered. */
+int osg_host_register(osg_ctx* ctx, void* host_ptr, size_t bytes);
+int osg_host_unregister(osg_ctx* ctx, void* host_ptr);
+int osg_upload_pinned(osg_ctx* ctx, void* dst, const void* pinned_host_src, size_t bytes);
 int osg_download(osg_ctx* ctx, void* host_dst, const void* src, size_t bytes);       /* D2H + wait == ensure_is_ready */
 int osg_copy(osg_ctx* ctx, void* dst, const void* src, size_t bytes);                /* async D2D on compute stream */
 int osg_memset(osg_ctx* ctx, void* dst, int value, size_t bytes);

@@ -188,6 +188,11 @@ class Model:
         f.argtypes = [ctypes.c_void_p]; f.restype = ctypes.c_double
         return f(self._h)
 
+    def hip_streamed_bytes(self) -> int:
+        f = self._lib.model_hip_streamed_bytes
+        f.argtypes = [ctypes.c_void_p]; f.restype = ctypes.c_ulonglong
+        return int(f(self._h))
+
     def hip_last_kernel_count(self) -> int:
         f = self._lib.model_hip_last_kernel_count
         f.argtypes = [ctypes.c_void_p]; f.restype = ctypes.c_ulonglong

@@ -247,6 +247,8 @@ void model_free_buffer(void* ptr) { std::free(ptr); }
 double model_hip_last_pass_ms(Handle* h) { return h->model.hip_last_pass_ms(); }
 unsigned long long model_hip_last_kernel_count(Handle* h) { return h->model.hip_last_kernel_count(); }
 void model_hip_invalidate_plan(Handle* h) { h->model.hip_invalidate_plan(); }
+// bytes the last pass pulled through the WeightsProvider and streamed host->device (0 in resident mode)
+unsigned long long model_hip_streamed_bytes(Handle* h) { return h->model.hip_streamed_bytes(); }
 // relaunch the captured pass n times on the resident inputs; ms_each (may be NULL) receives per-launch device times
 char* model_hip_replay(Handle* h, int n, float* ms_each) {
     try {

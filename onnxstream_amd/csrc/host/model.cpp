@@ -223,6 +223,8 @@ std::string Model::hip_profile(int reps) {
     return m_plan->profile(reps);
 }
 
+size_t Model::hip_streamed_bytes() const { return m_plan ? m_plan->streamed_bytes : 0; }
+
 size_t Model::hip_last_kernel_count() const { return m_last_kernels; }
 double Model::hip_last_pass_ms() const { return m_last_ms; }
 

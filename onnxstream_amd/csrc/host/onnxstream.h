@@ -552,6 +552,7 @@ public:
     size_t hip_last_kernel_count() const;
     double hip_last_pass_ms() const;   // device time of the last pass (HIP events on the compute stream)
     void hip_invalidate_plan();
+    size_t hip_streamed_bytes() const;
     void hip_replay(int n, float* ms_each);   // relaunch the captured pass on resident inputs (per-launch device ms)
     std::string hip_profile(int reps);         // per-step HIP-event timing report of an eager pass
 

@@ -88,11 +88,13 @@ bool is_const_tensor(const Tensor& t) { return !t.m_name.empty() && t.m_type != 
 Plan::Plan(Model& model, HipBackend& backend, size_t batch) : m(model), be(backend), N((long)batch) {
     fp16 = m.m_use_fp16_arithmetic;
     fusion = m.m_hip_fusion_level;
+    stream_weights = m.m_hip_stream_weights;
     extra_outputs = m.m_extra_outputs;
 }
 
 bool Plan::compatible(Model& mm, size_t batch) const {
-    return (long)batch == N && mm.m_use_fp16_arithmetic == fp16 && mm.m_hip_fusion_level == fusion && mm.m_extra_outputs == extra_outputs;
+    return (long)batch == N && mm.m_use_fp16_arithmetic == fp16 && mm.m_hip_fusion_level == fusion && mm.m_hip_stream_weights == stream_weights &&
+           mm.m_extra_outputs == extra_outputs;
 }
 
 int Plan::new_val(const std::string& name, const Shape& shape, osg_dtype dt, Lay lay, bool batched) {
@@ -279,6 +281,11 @@ struct Lowering {
                     if ((long)data.size() != count) throw std::invalid_argument("Model::get_tensor_data: mismatch between tensor shape and data size.");
                     if (it != const_cache.end()) {
                         v = it->second;
+                        if (P.stream_weights) {
+                            Plan::WRecipe r;
+                            r.fn = fn; r.ty = ty;
+                            P.recipes.push_back(r);
+                        }
                         return;
                     }
                     v = P.new_val("", shape, want, lay, false);
@@ -291,6 +298,9 @@ struct Lowering {
                     P.weight_bytes += bytes;
                     constexpr osg_dtype have = std::is_same_v<T, uint8_t> ? OSG_U8 : std::is_same_v<T, uint16_t> ? OSG_F16
                                                : std::is_same_v<T, float> ? OSG_F32 : OSG_I64;
+                    Plan::WRecipe rec;
+                    rec.val = v; rec.fn = fn; rec.ty = ty; rec.have = have; rec.want = want; rec.count = count;
+                    rec.scale = t.m_scale; rec.zp = (int)t.m_zero_point;
                     if (have == want) {
                         be.check(be.api.osg_upload(be.ctx, val.dptr, data.data(), bytes), "osg_upload");
                     } else {
@@ -299,8 +309,10 @@ struct Lowering {
                         be.check(be.api.osg_upload(be.ctx, tmp, data.data(), (size_t)count * sizeof(T)), "osg_upload");
                         be.check(be.api.osg_convert(be.ctx, have, want, tmp, val.dptr, count, t.m_scale, (int)t.m_zero_point), "osg_convert");
                         be.check(be.api.osg_sync(be.ctx), "osg_sync");
-                        be.free(tmp);
+                        if (P.stream_weights) { rec.raw = tmp; P.owned.push_back(tmp); }
+                        else be.free(tmp);
                     }
+                    if (P.stream_weights) P.recipes.push_back(rec);
                     // small constants stay readable on the host for the planner (shapes, axes, eps, scales ...)
                     if (have == OSG_I64) {
                         val.host_i.assign((const int64_t*)data.data(), (const int64_t*)data.data() + count);
@@ -316,7 +328,7 @@ struct Lowering {
                     }
                     const_cache[key] = v;
                 });
-                if (m.m_use_ops_cache && !m.m_weights_exclusion_set.count(fn)) {
+                if (m.m_use_ops_cache && !P.stream_weights && !m.m_weights_exclusion_set.count(fn)) {
                     // resident from now on: drop the provider's host copy, like the reference's ops cache does (:4556-4569)
                     try { wp->remove(fn); } catch (const std::exception&) {}
                     m.m_weights_exclusion_set.insert(fn);
@@ -695,6 +707,7 @@ struct Lowering {
 
     // osg.Linear(x, W[K,2C], b) -> osg.GEGLU  ==> the GEGLU rides in the GEMM epilogue (value/gate columns pair-interleaved at plan time)
     void fuse_linear_geglu() {
+        if (P.stream_weights) return;   // needs a re-ordered resident copy of the weight
         for (size_t i = 0; i < ops().size(); i++) {
             if (!is((int)i, "osg.Linear")) continue;
             Operation& op = ops()[i];
@@ -994,7 +1007,7 @@ struct Lowering {
     std::map<int, std::pair<int, int>> group_of;   // op index -> (group, slot)
 
     void plan_linear_groups() {
-        if (P.fusion < 2) return;
+        if (P.fusion < 2 || P.stream_weights) return;   // streamed weights are consumed as the provider hands them over: no merged copies
         dead.assign(ops().size(), 0);
         index_graph();
         std::map<std::string, std::vector<int>> by_key;
@@ -1148,7 +1161,8 @@ struct Lowering {
         os.back() = Nn;
         int y = out_val(op, os, Lay::plain, V(a).batched);
         const long M = prod(as) / K * B(a);
-        emit_gemm("Linear " + op.m_name, a, weight_nk(w), bias, res, y, M, Nn, K, 1, 0, 0, 0, 1);
+        if (P.stream_weights) emit_gemm("Linear " + op.m_name, a, w, bias, res, y, M, Nn, K, 1, 0, 0, 0, 0);   // [K,N] as streamed; the kernel re-lays it out
+        else emit_gemm("Linear " + op.m_name, a, weight_nk(w), bias, res, y, M, Nn, K, 1, 0, 0, 0, 1);
     }
 
     // MatMul (reference :5669-5861): [.., M,K] x [K,N] (static weight, broadcast) or batched [n,M,K] x [n,K,N]
@@ -1193,7 +1207,8 @@ struct Lowering {
         need(op, V(w).shape[0] == K, "invalid shape of inputs.");
         need(op, M == 1 && V(bias).numel() == Nn, "invalid shape of bias.");
         int y = out_val(op, {M, Nn}, Lay::plain, V(a).batched);
-        emit_gemm("Gemm " + op.m_name, a, weight_nk(w), bias, -1, y, M * B(a), Nn, K, 1, 0, 0, 0, 1);
+        if (P.stream_weights) emit_gemm("Gemm " + op.m_name, a, w, bias, -1, y, M * B(a), Nn, K, 1, 0, 0, 0, 0);
+        else emit_gemm("Gemm " + op.m_name, a, weight_nk(w), bias, -1, y, M * B(a), Nn, K, 1, 0, 0, 0, 1);
     }
 
     // Add/Sub/Mul/Div with NumPy broadcasting (reference :3906-4000, :5056-5175, :5394-5477, :5605-5668)
@@ -1727,6 +1742,7 @@ struct Lowering {
 // ======================================================================================================================
 Plan::~Plan() {
     be.api.osg_sync(be.ctx);
+    for (auto& kv : registered) be.api.osg_host_unregister(be.ctx, (void*)kv.first);
     if (graph) be.api.osg_graph_destroy(graph);
     delete lowering;
     for (void* p : owned) be.free(p);
@@ -1893,6 +1909,24 @@ void Plan::execute() {
     // ---- run the pass -------------------------------------------------------------------------------------------------
     be.check(be.api.osg_timer_start(be.ctx), "osg_timer_start");
     const bool print = m.m_ops_printf;
+    if (stream_weights && runs >= 1) {
+        // ---- streamed-weights pass: every weight is pulled from the provider again, in model order, and sent H2D on the COPY stream
+        // (pinned double-buffered staging, or straight out of a RAM provider's page-locked buffer) while the compute stream works on
+        // the previous steps; a step is launched right after the uploads of ITS weights were enqueued (the compute stream waits on
+        // their events), so upload(i+1) overlaps compute(i).  No hipGraph: host-side copies interleave with the launches.
+        streamed_bytes = 0;
+        size_t ri = 0;
+        for (size_t si = 0; si < steps.size(); si++) {
+            while (ri < recipes.size()) {
+                const WRecipe& r = recipes[ri];
+                if (r.val >= 0 && vals[r.val].first > (int)si && vals[r.val].last >= 0) break;
+                restream(r);
+                ri++;
+            }
+            steps[si].run();
+        }
+        while (ri < recipes.size()) restream(recipes[ri++]);   // keep the provider's sequence complete
+    } else
     if (graph && !print) {
         be.check(be.api.osg_graph_launch(be.ctx, graph), "osg_graph_launch");
     } else if (runs >= 1 && m.m_hip_use_graph && !print && !graph) {
@@ -1943,6 +1977,47 @@ void Plan::execute() {
             if (m.m_data[i].m_name == o.name) { m.m_data.erase(m.m_data.begin() + i); break; }
         m.m_data.push_back(std::move(first));
     }
+}
+
+void Plan::restream(const WRecipe& r) {
+    WeightsProvider* wp = m.get_wp();
+    detail::dispatch_dtype(r.ty, [&](auto tag) {
+        using T = typename decltype(tag)::type;
+        const size_t bytes = (size_t)r.count * sizeof(T);
+        auto send = [&](const T* host, bool stable) {
+            if (r.val < 0) return;
+            void* dst = r.raw ? r.raw : vals[r.val].dptr;
+            if (stable) {   // provider-owned memory that outlives the pass: page-lock once, DMA without a staging copy
+                auto it = registered.find(host);
+                if (it == registered.end()) {
+                    be.check(be.api.osg_host_register(be.ctx, (void*)host, bytes), "osg_host_register");
+                    registered[host] = bytes;
+                }
+                be.check(be.api.osg_upload_pinned(be.ctx, dst, host, bytes), "osg_upload_pinned");
+            } else {
+                be.check(be.api.osg_upload(be.ctx, dst, host, bytes), "osg_upload");
+            }
+            if (r.raw) be.check(be.api.osg_convert(be.ctx, r.have, r.want, r.raw, vals[r.val].dptr, r.count, r.scale, r.zp), "osg_convert");
+            streamed_bytes += bytes;
+        };
+        if (wp->supports_getptr()) {
+            std::shared_ptr<tensor_vector<T>> sp;
+            if constexpr (std::is_same_v<T, uint8_t>) sp = wp->getptr_uint8(r.fn);
+            else if constexpr (std::is_same_v<T, uint16_t>) sp = wp->getptr_float16(r.fn);
+            else if constexpr (std::is_same_v<T, float>) sp = wp->getptr_float32(r.fn);
+            else sp = wp->getptr_int64(r.fn);
+            if (r.val >= 0 && (long)sp->size() != r.count) throw std::invalid_argument("Model::get_tensor_data: mismatch between tensor shape and data size.");
+            send(sp->data(), true);
+        } else {
+            tensor_vector<T> data;
+            if constexpr (std::is_same_v<T, uint8_t>) data = wp->get_uint8(r.fn);
+            else if constexpr (std::is_same_v<T, uint16_t>) data = wp->get_float16(r.fn);
+            else if constexpr (std::is_same_v<T, float>) data = wp->get_float32(r.fn);
+            else data = wp->get_int64(r.fn);
+            if (r.val >= 0 && (long)data.size() != r.count) throw std::invalid_argument("Model::get_tensor_data: mismatch between tensor shape and data size.");
+            send(data.data(), false);   // osg_upload copies into pinned staging before returning: `data` may die here
+        }
+    });
 }
 
 void Plan::replay(int n, float* ms_each) {

@@ -78,6 +78,22 @@ struct Plan {
     void* arena = nullptr;
     size_t arena_bytes = 0, weight_bytes = 0;
 
+    // streamed-weights mode: how each resident constant is (re)filled from the provider, in the provider's (model) order
+    struct WRecipe {
+        int val = -1;                 // -1: a repeated occurrence -- fetched (providers serve strictly in order) but not uploaded
+        std::string fn;
+        TensorDataType ty = TensorDataType::none;
+        osg_dtype have = OSG_F16, want = OSG_F16;
+        long count = 0;
+        float scale = 1.f;
+        int zp = 0;
+        void* raw = nullptr;          // device staging for weights that need a dtype conversion after the copy
+    };
+    std::vector<WRecipe> recipes;
+    std::map<const void*, size_t> registered;   // provider host buffers page-locked for zero-copy DMA
+    size_t streamed_bytes = 0;
+    void restream(const WRecipe& r);
+
     struct In { std::string name; int val; int staging; TensorDataType host_type; std::vector<size_t> shape; };
     struct Out { std::string name; int val; int f32val; std::vector<size_t> shape; };
     std::vector<In> inputs;
@@ -89,6 +105,7 @@ struct Plan {
     double m_last_ms = 0;
     // options the plan was built with
     bool fp16 = true;
+    bool stream_weights = false;   // m_hip_stream_weights: weights are re-pulled from the WeightsProvider and re-streamed H2D every pass
     int fusion = 2;
     std::vector<std::string> extra_outputs;
 

@@ -101,6 +101,26 @@ int osg_upload(osg_ctx* c, void* dst, const void* src, size_t bytes) {
     return 0;
 }
 
+// Zero-copy variant for host memory the caller keeps alive and has page-locked with osg_host_register (a RAM weights provider's
+// buffers): one hipMemcpyAsync on the COPY stream straight out of the caller's memory, the compute stream waits on its event.
+int osg_upload_pinned(osg_ctx* c, void* dst, const void* pinned_src, size_t bytes) {
+    if (c->capturing) OSG_FAIL(c, "osg_upload_pinned inside graph capture");
+    OSG_HIP(c, hipMemcpyAsync(dst, pinned_src, bytes, hipMemcpyHostToDevice, c->copy));
+    OSG_HIP(c, hipEventRecord(c->ev_copy, c->copy));
+    OSG_HIP(c, hipStreamWaitEvent(c->compute, c->ev_copy, 0));
+    return 0;
+}
+
+int osg_host_register(osg_ctx* c, void* ptr, size_t bytes) {
+    OSG_HIP(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return 0;
+}
+
+int osg_host_unregister(osg_ctx* c, void* ptr) {
+    OSG_HIP(c, hipHostUnregister(ptr));
+    return 0;
+}
+
 int osg_upload_sync(osg_ctx* c, void* dst, const void* src, size_t bytes) {
     if (c->capturing) OSG_FAIL(c, "osg_upload_sync inside graph capture");
     OSG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->compute));

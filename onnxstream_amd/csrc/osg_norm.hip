@@ -59,21 +59,23 @@ __global__ __launch_bounds__(1024) void instance_norm_kernel(const T* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ part, long HW, int C, int G, int S) {
     constexpr int V = 8 / (sizeof(T) / 2);
-    extern __shared__ float gsum[];  // [G][2]
+    extern __shared__ float gsum[];  // [G][2] running group sums, then [R][cols*V][2] per-thread element sums of one column sweep
     const int s = blockIdx.x, n = blockIdx.y;
     const int cpg = C / G, cv = C / V;
     for (int i = threadIdx.x; i < G * 2; i += 256) gsum[i] = 0.f;
-    __syncthreads();
     const long p0 = HW * s / S, p1 = HW * (s + 1) / S;
     const T* base = x + (long)n * HW * C;
     const int cols = cv < 256 ? cv : 256;          // vector columns covered per sweep
     const int R = 256 / cols;                      // pixel rows covered per sweep
     const int tr = threadIdx.x / cols, tc = threadIdx.x - tr * cols;
-    if (tr < R) {
-        for (int c = tc; c < cv; c += cols) {
-            float sm[V], sq[V];
+    float* esum = gsum + 2 * G;                    // [R][cols*V][2]
+    const int ew = cols * V;                       // channels covered per sweep
+    for (int c0 = 0; c0 < cv; c0 += cols) {        // (one sweep unless C > 2048)
+        const int c = c0 + tc;
+        float sm[V], sq[V];
 #pragma unroll
-            for (int e = 0; e < V; e++) sm[e] = sq[e] = 0.f;
+        for (int e = 0; e < V; e++) sm[e] = sq[e] = 0.f;
+        if (tr < R && c < cv) {
             long p = p0 + tr;
             for (; p + 3L * R < p1; p += 4L * R) {   // 4 independent 16-byte loads in flight
                 T xv[4][V];
@@ -98,24 +100,32 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
                     sq[e] += v * v;
                 }
             }
-            // elements of one vector span at most 2 groups when cpg >= V/2 ... fold runs of equal group first
-            int g_prev = (c * V) / cpg;
-            float as = 0.f, aq = 0.f;
+        }
+        // deterministic fold (no atomics: a float atomicAdd's order -- hence its rounding -- varies from launch to launch):
+        // per-thread element sums -> LDS, then ONE thread per group adds its channels over the R rows in a fixed order
+        if (tr < R) {
 #pragma unroll
             for (int e = 0; e < V; e++) {
-                int g = (c * V + e) / cpg;
-                if (g != g_prev) {
-                    atomicAdd(&gsum[g_prev * 2], as);
-                    atomicAdd(&gsum[g_prev * 2 + 1], aq);
-                    as = aq = 0.f;
-                    g_prev = g;
-                }
-                as += sm[e];
-                aq += sq[e];
+                esum[((tr * ew) + tc * V + e) * 2 + 0] = sm[e];
+                esum[((tr * ew) + tc * V + e) * 2 + 1] = sq[e];
             }
-            atomicAdd(&gsum[g_prev * 2], as);
-            atomicAdd(&gsum[g_prev * 2 + 1], aq);
         }
+        __syncthreads();
+        const int ch_lo = c0 * V, ch_hi = min(C, ch_lo + ew);
+        for (int g = threadIdx.x; g < G; g += 256) {
+            const int lo = max(g * cpg, ch_lo), hi = min((g + 1) * cpg, ch_hi);
+            float as = 0.f, aq = 0.f;
+            for (int ch = lo; ch < hi; ch++)
+                for (int r = 0; r < R; r++) {
+                    as += esum[((r * ew) + (ch - ch_lo)) * 2 + 0];
+                    aq += esum[((r * ew) + (ch - ch_lo)) * 2 + 1];
+                }
+            if (lo < hi) {
+                gsum[g * 2] += as;
+                gsum[g * 2 + 1] += aq;
+            }
+        }
+        __syncthreads();
     }
     __syncthreads();
     for (int g = threadIdx.x; g < G; g += 256) {
@@ -350,14 +360,14 @@ int osg_group_norm_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void
     if (slabs_l > 4096) slabs_l = 4096;
     const int slabs = (int)slabs_l;
     if (dtype == OSG_F16) {
-        hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(S, N), dim3(256), G * 2 * sizeof(float), ctx->compute, (const f16*)x, part, HW, C, G, S);
+        hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(S, N), dim3(256), (G * 2 + 2 * 256 * 8) * sizeof(float), ctx->compute, (const f16*)x, part, HW, C, G, S);
         OSG_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(gn_finalize_kernel<f16>, dim3(N), dim3(256), G * 2 * sizeof(float), ctx->compute, part, (const f16*)gamma,
                            (const f16*)beta, tab, HW, C, G, S, eps);
         OSG_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(slabs, N), dim3(256), 0, ctx->compute, (const f16*)x, tab, (f16*)y, HW, C, (int)act, slabs);
     } else {
-        hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(S, N), dim3(256), G * 2 * sizeof(float), ctx->compute, (const float*)x, part, HW, C, G, S);
+        hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(S, N), dim3(256), (G * 2 + 2 * 256 * 4) * sizeof(float), ctx->compute, (const float*)x, part, HW, C, G, S);
         OSG_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(gn_finalize_kernel<float>, dim3(N), dim3(256), G * 2 * sizeof(float), ctx->compute, part, (const float*)gamma,
                            (const float*)beta, tab, HW, C, G, S, eps);

@@ -22,7 +22,7 @@ BIN = dict(add=0, sub=1, mul=2, div=3)
 
 EXPORTS = [
     "osg_device_count", "osg_init", "osg_destroy", "osg_last_error", "osg_device_name", "osg_stream",
-    "osg_malloc", "osg_free", "osg_upload", "osg_upload_sync", "osg_download", "osg_copy", "osg_memset", "osg_sync",
+    "osg_malloc", "osg_free", "osg_upload", "osg_upload_sync", "osg_host_register", "osg_host_unregister", "osg_upload_pinned", "osg_download", "osg_copy", "osg_memset", "osg_sync",
     "osg_graph_begin", "osg_graph_end", "osg_graph_launch", "osg_graph_destroy", "osg_timer_start", "osg_timer_stop",
     "osg_conv2d_nhwc", "osg_conv2d_nhwc_rb", "osg_gemm", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided",
     "osg_instance_norm", "osg_group_norm_nhwc", "osg_layer_norm", "osg_reduce_mean_last", "osg_softmax_last",
@@ -51,7 +51,9 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_stream.restype = vp
     lib.osg_malloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
     lib.osg_free.argtypes = [vp, vp]
-    for f in ("osg_upload", "osg_upload_sync", "osg_download", "osg_copy"):
+    lib.osg_host_register.argtypes = [vp, vp, ctypes.c_size_t]
+    lib.osg_host_unregister.argtypes = [vp, vp]
+    for f in ("osg_upload", "osg_upload_sync", "osg_upload_pinned", "osg_download", "osg_copy"):
         getattr(lib, f).argtypes = [vp, vp, vp, ctypes.c_size_t]
     lib.osg_memset.argtypes = [vp, vp, ci, ctypes.c_size_t]
     lib.osg_sync.argtypes = [vp]
