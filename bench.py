@@ -46,14 +46,14 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def ensure_model_dir(cfg, local_rank, barrier):
+def ensure_model_dir(cfg, local_rank, barrier, quant=False):
     from onnxstream_amd.synth import sd_unet
     from onnxstream_amd.synth.graph import DirSink
-    d = os.path.join(os.environ.get("OSA_SYNTH_DIR", "/tmp/onnxstream_amd_synth"), cfg.name) + "/"
+    d = os.path.join(os.environ.get("OSA_SYNTH_DIR", "/tmp/onnxstream_amd_synth"), cfg.name + ("_w8" if quant else "")) + "/"
     if local_rank == 0 and not os.path.exists(d + ".complete"):
         t0 = time.time()
         os.makedirs(d, exist_ok=True)
-        g, _ = sd_unet.build_unet(DirSink(d), cfg)
+        g, _ = sd_unet.build_unet(DirSink(d), cfg, quant_weights=quant)
         open(d + ".complete", "w").write("ok")
         log(f"[bench] emitted synthetic {cfg.name} UNet: {len(g.lines)} ops, {g.n_params/1e6:.1f} M params in {time.time()-t0:.1f} s")
     barrier()
@@ -105,6 +105,8 @@ def main():
                     help="pipeline: full txt2img loop (host CFG + Euler-A, VAE decode every 20 steps); replay: UNet graph replays only")
     ap.add_argument("--cpu-passes", type=int, default=4, help="reference CPU passes in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--profile-reps", type=int, default=3)
+    ap.add_argument("--steps-per-image", type=int, default=0, help="denoising steps per image (default 20; BASELINE config 4 = SDXL uses 10)")
+    ap.add_argument("--quant-weights", action="store_true", help="W8A16: uint8 weights + scale/zero-point in model.txt, dequantised at load")
     ap.add_argument("--breakdown", default="", help="write the per-step HIP-event profile to this file")
     args = ap.parse_args()
 
@@ -137,7 +139,10 @@ def main():
         raise SystemExit("native libraries missing: run `python __graft_entry__.py` (build()) first")
 
     cfg = getattr(sd_unet, args.config)
-    model_dir = ensure_model_dir(cfg, local_rank, barrier)
+    model_dir = ensure_model_dir(cfg, local_rank, barrier, args.quant_weights)
+    global STEPS_PER_IMAGE
+    if args.steps_per_image > 0:
+        STEPS_PER_IMAGE = args.steps_per_image
 
     # ---- inputs: rank 0 draws every prompt's latents/contexts, RCCL-broadcasts them over xGMI, each rank keeps its own ------
     # (one prompt per rank; a prompt = its cond and its uncond sample, stacked on a leading axis of 2)
@@ -154,9 +159,11 @@ def main():
     # ---- the product path: model_* C API -> host planner -> libosgpu HIP kernels, driven by the txt2img harness ---------------
     from onnxstream_amd.pipeline import Txt2Img, sigma_schedule
     from onnxstream_amd.synth import sd_vae
-    vcfg = sd_vae.SD_VAE if cfg.latent >= 64 else sd_vae.TINY_VAE
+    import dataclasses
+    vcfg = dataclasses.replace(sd_vae.SD_VAE, latent=cfg.latent, name=f"sd_vae{cfg.latent}") if cfg.latent >= 64 else \
+        dataclasses.replace(sd_vae.TINY_VAE, latent=cfg.latent, name=f"tiny_vae{cfg.latent}")
     vae_dir = None
-    if args.mode == "pipeline" and not cfg.sdxl_add_embed:
+    if args.mode == "pipeline":
         from onnxstream_amd.synth.graph import DirSink
         vae_dir = os.path.join(os.environ.get("OSA_SYNTH_DIR", "/tmp/onnxstream_amd_synth"), vcfg.name) + "/"
         if local_rank == 0 and not os.path.exists(vae_dir + ".complete"):
@@ -169,6 +176,8 @@ def main():
     L = cfg.latent
     lat_shape = (1, cfg.in_ch, L, L)
     ctx_c, ctx_u = cond["encoder_hidden_states"], uncond["encoder_hidden_states"]
+    ex_c = {k: cond[k] for k in ("text_embeds", "time_ids") if k in cond} or None
+    ex_u = {k: uncond[k] for k in ("text_embeds", "time_ids") if k in uncond} or None
     sig = sigma_schedule(STEPS_PER_IMAGE, pipe.log_sigmas)
     rng = np.random.default_rng(1234 + rank)
     state = {"x": rng.standard_normal(lat_shape, dtype=np.float32) * sig[0], "i": 0, "images": 0, "last": None}
@@ -182,7 +191,7 @@ def main():
             m.hip_replay(1)
             state["i"] = (i + 1) % STEPS_PER_IMAGE
             return
-        den = pipe.denoise(x, float(sig[i]), ctx_c, ctx_u)
+        den = pipe.denoise(x, float(sig[i]), ctx_c, ctx_u, extra_cond=ex_c, extra_uncond=ex_u)
         s_i, s_n = np.float64(sig[i]), np.float64(sig[i + 1])
         s_up = min(s_n, abs(s_n * np.sqrt(s_i * s_i - s_n * s_n) / s_i))
         s_down = np.float32(np.sqrt(s_n * s_n - s_up * s_up))
@@ -209,7 +218,7 @@ def main():
                 m.clear_tensors()
     else:
         for _ in range(3):
-            pipe.denoise(state["x"], float(sig[0]), ctx_c, ctx_u)
+            pipe.denoise(state["x"], float(sig[0]), ctx_c, ctx_u, extra_cond=ex_c, extra_uncond=ex_u)
         if pipe.vae is not None:
             for _ in range(3):
                 pipe.decode(state["x"] / sig[0])
@@ -291,12 +300,12 @@ def main():
             except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
                 log(f"[bench] cpu_baseline failed: {e!r}")
         line = {
-            "metric": "sd15_unet_step_latency_ms+images_per_sec_512x512_20step", "value": round(images_per_s, 4), "unit": "images/s",
+            "metric": "sd15_unet_step_latency_ms+images_per_sec_512x512_20step" if cfg.name == "sd15" else f"{cfg.name}_unet_step_latency_ms+images_per_sec_{STEPS_PER_IMAGE}step", "value": round(images_per_s, 4), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": (f"{cfg.name} 512x512 20-step txt2img: per step the UNet over cond+uncond (2x4x{cfg.latent}x{cfg.latent} latents, ctx 77x{cfg.ctx_dim}) "
-                                    f"as one batch-2 pass + CFG 7 + Euler-Ancestral update, VAE decode after every 20th step (inside the timed region), "
-                                    f"W16A16, weights resident; ms_per_step = wall / K with the decode amortised; images/s = gpus / (20 x ms_per_step)")
+            "config": {"workload": (f"{cfg.name} {8 * cfg.latent}x{8 * cfg.latent} {STEPS_PER_IMAGE}-step txt2img ({'W8A16' if args.quant_weights else 'W16A16'}): per step the UNet over cond+uncond (2x4x{cfg.latent}x{cfg.latent} latents, ctx 77x{cfg.ctx_dim}) "
+                                    f"as one batch-2 pass + CFG 7 + Euler-Ancestral update, VAE decode after the last step of every image (inside the timed region), "
+                                    f"weights resident; ms_per_step = wall / K with the decode amortised; images/s = gpus / (steps_per_image x ms_per_step)")
                                    if vae_dir else (f"{cfg.name} UNet denoising step: cond+uncond 2x4x{cfg.latent}x{cfg.latent} latents, W16A16, "
                                                     f"weights resident, mode={args.mode}; NO VAE decode"),
                        "mode": args.mode, "vae_decode_in_timed_region": bool(vae_dir), "images_completed": state["images"],

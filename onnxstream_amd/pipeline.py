@@ -101,7 +101,8 @@ class Txt2Img:
             m.clear_tensors()
         return res
 
-    def denoise(self, x: np.ndarray, sigma: float, cond: np.ndarray, uncond: np.ndarray, guidance: float = 7.0) -> np.ndarray:
+    def denoise(self, x: np.ndarray, sigma: float, cond: np.ndarray, uncond: np.ndarray, guidance: float = 7.0,
+                extra_cond: Optional[Dict[str, np.ndarray]] = None, extra_uncond: Optional[Dict[str, np.ndarray]] = None) -> np.ndarray:
         """CFGDenoiser_CompVisDenoiser: eps-prediction wrapped as a denoiser, then the CFG combine (src/sd.cpp:1397-1559)."""
         n = self.names
         c_out = f32(-1.0 * sigma)
@@ -109,6 +110,10 @@ class Txt2Img:
         t = f32(sigma_to_t(sigma, self.log_sigmas))
         xin = (x * c_in).astype(f32)
         pushes = [{n["timestep"]: np.asarray([t], f32), n["sample"]: xin, n["ctx"]: c} for c in (cond, uncond)]
+        # SDXL micro-conditioning (text_embeds [1,1280], time_ids [1,6]; reference src/sd.cpp:1488-1516) rides along per branch
+        for push, extra in zip(pushes, (extra_cond, extra_uncond)):
+            if extra:
+                push.update(extra)
         eps_c, eps_u = self._run(self.unet, pushes, n["out"])
         den_c = eps_c * c_out + x
         den_u = eps_u * c_out + x
