@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--cpu-passes", type=int, default=4, help="reference CPU passes in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--profile-reps", type=int, default=3)
     ap.add_argument("--steps-per-image", type=int, default=0, help="denoising steps per image (default 20; BASELINE config 4 = SDXL uses 10)")
+    ap.add_argument("--prompts-per-gpu", type=int, default=1, help="prompts denoised together on each GPU (2P samples per UNet pass: the reference's --num batching)")
     ap.add_argument("--quant-weights", action="store_true", help="W8A16: uint8 weights + scale/zero-point in model.txt, dequantised at load")
     ap.add_argument("--breakdown", default="", help="write the per-step HIP-event profile to this file")
     args = ap.parse_args()
@@ -174,8 +175,12 @@ def main():
     pipe = Txt2Img(b.LIB_HOST, model_dir, vae_dir, batched=True, device=local_rank, fusion=args.fusion)
     m = pipe.unet
     L = cfg.latent
-    lat_shape = (1, cfg.in_ch, L, L)
+    P = max(1, args.prompts_per_gpu if args.mode == "pipeline" and not cfg.sdxl_add_embed else 1)
+    lat_shape = (P, cfg.in_ch, L, L)
     ctx_c, ctx_u = cond["encoder_hidden_states"], uncond["encoder_hidden_states"]
+    # P prompts per GPU share the schedule; prompt p's contexts are a fixed perturbation of this rank's (synthetic data)
+    ctx_cs = ctx_c if P == 1 else [np.roll(ctx_c, p_i, axis=1) for p_i in range(P)]
+    ctx_us = ctx_u if P == 1 else [np.roll(ctx_u, p_i, axis=1) for p_i in range(P)]
     ex_c = {k: cond[k] for k in ("text_embeds", "time_ids") if k in cond} or None
     ex_u = {k: uncond[k] for k in ("text_embeds", "time_ids") if k in uncond} or None
     sig = sigma_schedule(STEPS_PER_IMAGE, pipe.log_sigmas)
@@ -191,7 +196,7 @@ def main():
             m.hip_replay(1)
             state["i"] = (i + 1) % STEPS_PER_IMAGE
             return
-        den = pipe.denoise(x, float(sig[i]), ctx_c, ctx_u, extra_cond=ex_c, extra_uncond=ex_u)
+        den = pipe.denoise(x, float(sig[i]), ctx_cs, ctx_us, extra_cond=ex_c, extra_uncond=ex_u)
         s_i, s_n = np.float64(sig[i]), np.float64(sig[i + 1])
         s_up = min(s_n, abs(s_n * np.sqrt(s_i * s_i - s_n * s_n) / s_i))
         s_down = np.float32(np.sqrt(s_n * s_n - s_up * s_up))
@@ -201,7 +206,7 @@ def main():
         if i + 1 == STEPS_PER_IMAGE:
             if pipe.vae is not None:
                 state["last"] = pipe.decode(x)
-            state["images"] += 1
+            state["images"] += P
             x = rng.standard_normal(lat_shape, dtype=np.float32) * sig[0]
         state["x"], state["i"] = x, (i + 1) % STEPS_PER_IMAGE
 
@@ -218,7 +223,7 @@ def main():
                 m.clear_tensors()
     else:
         for _ in range(3):
-            pipe.denoise(state["x"], float(sig[0]), ctx_c, ctx_u, extra_cond=ex_c, extra_uncond=ex_u)
+            pipe.denoise(state["x"], float(sig[0]), ctx_cs, ctx_us, extra_cond=ex_c, extra_uncond=ex_u)
         if pipe.vae is not None:
             for _ in range(3):
                 pipe.decode(state["x"] / sig[0])
@@ -251,7 +256,7 @@ def main():
         allr = shard.gather_results(dist, rank, world, world, {my_prompt: np.asarray(out, np.float32)}, device="cuda")
         assert rank != 0 or (allr.shape[0] == world and np.isfinite(allr).all())
     ms_per_step = wall * 1e3 / args.steps
-    images_per_s = world / (STEPS_PER_IMAGE * ms_per_step * 1e-3)
+    images_per_s = world * P / (STEPS_PER_IMAGE * ms_per_step * 1e-3)
 
     line = None
     if rank == 0:
@@ -305,11 +310,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": (f"{cfg.name} {8 * cfg.latent}x{8 * cfg.latent} {STEPS_PER_IMAGE}-step txt2img ({'W8A16' if args.quant_weights else 'W16A16'}): per step the UNet over cond+uncond (2x4x{cfg.latent}x{cfg.latent} latents, ctx 77x{cfg.ctx_dim}) "
                                     f"as one batch-2 pass + CFG 7 + Euler-Ancestral update, VAE decode after the last step of every image (inside the timed region), "
-                                    f"weights resident; ms_per_step = wall / K with the decode amortised; images/s = gpus / (steps_per_image x ms_per_step)")
+                                    f"weights resident; ms_per_step = wall / K with the decode amortised; images/s = gpus x prompts_per_gpu / (steps_per_image x ms_per_step)")
                                    if vae_dir else (f"{cfg.name} UNet denoising step: cond+uncond 2x4x{cfg.latent}x{cfg.latent} latents, W16A16, "
                                                     f"weights resident, mode={args.mode}; NO VAE decode"),
                        "mode": args.mode, "vae_decode_in_timed_region": bool(vae_dir), "images_completed": state["images"],
-                       "prompts_per_gpu": 1, "unet_passes_per_step": 2, "steps_per_image": STEPS_PER_IMAGE, "launches_per_step": kernels,
+                       "prompts_per_gpu": P, "unet_passes_per_step": 2 * P, "steps_per_image": STEPS_PER_IMAGE, "launches_per_step": kernels,
                        "vae_launches": vae_kernels, "fusion_level": args.fusion, "unet_device_ms_per_step": round(dev_ms, 4),
                        "parallelism": f"replica x{world}"},
             "roofline": roofline, "cpu_baseline": cpu,

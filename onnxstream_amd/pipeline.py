@@ -61,6 +61,7 @@ class Txt2Img:
         if names:
             self.names.update(names)
         self.log_sigmas = log_sigmas_table()
+        self._t_cache: Dict[float, float] = {}
         self.unet = Model(library, threads, "ram+nocache")
         self.vae = Model(library, threads, "ram+nocache") if vae_dir else None
         for m, d in ((self.unet, unet_dir), (self.vae, vae_dir)):
@@ -71,7 +72,7 @@ class Txt2Img:
                 if fusion is not None:
                     m._set_option("hip_fusion_level", fusion)
             m.read_file(d + "model.txt")
-        self._configured = False
+        self._configured: Dict[int, bool] = {}
 
     def close(self):
         self.unet.close()
@@ -82,9 +83,11 @@ class Txt2Img:
         if self.batched:
             for ins in pushes:
                 for k, v in ins.items():
-                    m.add_tensor(k, np.ascontiguousarray(v, f32))
-            m.set_use_fp16_arithmetic(True)
-            m.set_fuse_ops_in_attention(True)
+                    m.add_tensor(k, v if (v.dtype == f32 and v.flags.c_contiguous) else np.ascontiguousarray(v, f32))
+            if not self._configured.get(id(m)):
+                m.set_use_fp16_arithmetic(True)
+                m.set_fuse_ops_in_attention(True)
+                self._configured[id(m)] = True
             m.run()
             res = [m.get_tensor(out, i)[0] for i in range(len(pushes))]
             m.clear_tensors()
@@ -107,8 +110,21 @@ class Txt2Img:
         n = self.names
         c_out = f32(-1.0 * sigma)
         c_in = f32(1.0 / np.sqrt(f32(sigma) * f32(sigma) + 1))
-        t = f32(sigma_to_t(sigma, self.log_sigmas))
+        if sigma not in self._t_cache:            # the schedule revisits the same 20 sigmas for every image
+            self._t_cache[sigma] = sigma_to_t(sigma, self.log_sigmas)
+        t = f32(self._t_cache[sigma])
         xin = (x * c_in).astype(f32)
+        if xin.shape[0] > 1 and isinstance(cond, (list, tuple)):
+            # several prompts at the same step of the schedule (the reference's `--num N` batching, src/sd.cpp:1098-1161): 2N samples
+            # pushed under the same names -> ONE batched pass; prompt p = pushes 2p (cond) and 2p+1 (uncond)
+            pushes = []
+            for p_i in range(xin.shape[0]):
+                for c in (cond[p_i], uncond[p_i]):
+                    pushes.append({n["timestep"]: np.asarray([t], f32), n["sample"]: xin[p_i:p_i + 1], n["ctx"]: c})
+            eps = self._run(self.unet, pushes, n["out"])
+            den_c = np.concatenate(eps[0::2]) * c_out + x
+            den_u = np.concatenate(eps[1::2]) * c_out + x
+            return (den_u + f32(guidance) * (den_c - den_u)).astype(f32)
         pushes = [{n["timestep"]: np.asarray([t], f32), n["sample"]: xin, n["ctx"]: c} for c in (cond, uncond)]
         # SDXL micro-conditioning (text_embeds [1,1280], time_ids [1,6]; reference src/sd.cpp:1488-1516) rides along per branch
         for push, extra in zip(pushes, (extra_cond, extra_uncond)):
@@ -139,8 +155,8 @@ class Txt2Img:
     def decode(self, latents: np.ndarray) -> np.ndarray:
         """decoder_solver: latents * 5.48998 -> VAE decoder -> (y + 1) * 127.5 (src/sd.cpp:1174-1256)."""
         z = (latents * f32(5.48998)).astype(f32)
-        (y,) = self._run(self.vae, [{self.names["vae_in"]: z}], self.names["vae_out"])
-        return ((y + f32(1.0)) * f32(127.5)).astype(f32)
+        ys = self._run(self.vae, [{self.names["vae_in"]: z[i:i + 1]} for i in range(z.shape[0])], self.names["vae_out"])
+        return ((np.concatenate(ys) + f32(1.0)) * f32(127.5)).astype(f32)
 
     def txt2img(self, cond: np.ndarray, uncond: np.ndarray, steps: int = 20, seed: int = 42, latent_shape=(1, 4, 64, 64)) -> np.ndarray:
         return self.decode(self.sample(cond, uncond, steps, seed, latent_shape))
