@@ -158,5 +158,44 @@ class Txt2Img:
         ys = self._run(self.vae, [{self.names["vae_in"]: z[i:i + 1]} for i in range(z.shape[0])], self.names["vae_out"])
         return ((np.concatenate(ys) + f32(1.0)) * f32(127.5)).astype(f32)
 
+    def decode_tiled(self, latents: np.ndarray, tile: int = 32, names=("latent_sample", "out_image")) -> np.ndarray:
+        """sd_tiled_decoder (src/sd.cpp:1258-1346): a VAE graph built for `tile` x `tile` latents is run over overlapping tiles
+        (origins 0, 0.75*tile, ... and a last one flush with the border: 0/24/32 for 64-wide latents) and the 8x upscaled tiles are
+        blended with linear ramps over the first tile/2 * 8... = 64 output pixels of every non-border edge.  self.vae must be the
+        tile-sized decoder.  With the HIP backend all tiles run as ONE batched pass."""
+        z = (latents * f32(5.48998)).astype(f32)
+        _, _, H, W = z.shape
+        step, ramp = (tile * 3) // 4, tile * 2           # 24 latent pixels, 64 output pixels for tile = 32
+
+        def origins(n):
+            o, v = [], 0
+            while True:
+                v = min(v, n - tile)
+                o.append(v)
+                if v == n - tile:
+                    return o
+                v += step
+        oy, ox = origins(H), origins(W)
+        pushes = [{names[0]: np.ascontiguousarray(z[:, :, y:y + tile, x:x + tile])} for y in oy for x in ox]
+        outs = self._run(self.vae, pushes, names[1])
+        up = outs[0].shape[-1] // tile                   # 8 for the SD decoders
+        ramp = ramp * up // 8
+        res = np.zeros((1, outs[0].shape[1], H * up, W * up), f32)
+        T8 = tile * up
+        yy = np.arange(T8, dtype=f32)[:, None]
+        xx = np.arange(T8, dtype=f32)[None, :]
+        k = 0
+        for y in oy:
+            for x in ox:
+                f = np.ones((T8, T8), f32)
+                if y:
+                    f = f * np.where(yy < ramp, yy / f32(ramp), f32(1.0))
+                if x:
+                    f = f * np.where(xx < ramp, xx / f32(ramp), f32(1.0))
+                d = res[:, :, y * up:y * up + T8, x * up:x * up + T8]
+                res[:, :, y * up:y * up + T8, x * up:x * up + T8] = outs[k] * f + d * (f32(1.0) - f)
+                k += 1
+        return ((res + f32(1.0)) * f32(127.5)).astype(f32)
+
     def txt2img(self, cond: np.ndarray, uncond: np.ndarray, steps: int = 20, seed: int = 42, latent_shape=(1, 4, 64, 64)) -> np.ndarray:
         return self.decode(self.sample(cond, uncond, steps, seed, latent_shape))

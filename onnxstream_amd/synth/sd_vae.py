@@ -26,6 +26,7 @@ class VAEConfig:
     out_ch: int = 3
     latent: int = 64
     groups: int = 32
+    in_name: str = "input.1"          # the tiled / SDXL decoders are fed as "latent_sample" (src/sd.cpp:1290)
     name: str = "sd_vae"
 
 
@@ -84,7 +85,7 @@ class _Decoder:
     def build(self):
         g, cfg = self.g, self.cfg
         L = cfg.latent
-        z = g.input("input.1", (1, cfg.latent_ch, L, L))
+        z = g.input(cfg.in_name, (1, cfg.latent_ch, L, L))
         x = g.conv("/post_quant_conv", z, cfg.latent_ch, 1)
         cm = cfg.block_out[-1]
         x = g.conv("/decoder/conv_in", x, cm, 3)
@@ -116,4 +117,4 @@ def build_vae_decoder(sink, cfg: VAEConfig = SD_VAE, wdtype: str = "float16", se
 
 def vae_inputs(cfg: VAEConfig, seed: int = 7):
     rng = np.random.default_rng(seed)
-    return {"input.1": rng.standard_normal((1, cfg.latent_ch, cfg.latent, cfg.latent), dtype=np.float32)}
+    return {cfg.in_name: rng.standard_normal((1, cfg.latent_ch, cfg.latent, cfg.latent), dtype=np.float32)}

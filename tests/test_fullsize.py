@@ -1,0 +1,68 @@
+"""-m gpu, BASELINE.json's full size: the complete SD 1.5 UNet (2 127 graph ops, 859.5 M parameters, 2x4x64x64 latents).
+
+* against the reference itself (oracle/_ref travels to the GPU box; one fp16 and one fp32 CPU pass, a few seconds each):
+  the triangulated bound of tests/test_golden.py at full size;
+* size-independent properties: bitwise reproducibility over eager / captured / replayed passes, and batch invariance --
+  a sample's result does not depend on what else shares the batched pass (cond alone == cond next to uncond)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from onnxstream_amd.synth import sd_unet
+from onnxstream_amd.synth.graph import DirSink
+from oracle import ref as oref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sd15_dir():
+    d = os.path.join(os.environ.get("OSA_SYNTH_DIR", "/tmp/onnxstream_amd_synth"), "sd15") + "/"
+    if not os.path.exists(d + ".complete"):
+        os.makedirs(d, exist_ok=True)
+        sd_unet.build_unet(DirSink(d), sd_unet.SD15)
+        open(d + ".complete", "w").write("ok")
+    return d
+
+
+def _run(lib, d, pushes, runs=1):
+    from onnxstream_amd.bindings import Model
+    m = Model(lib, 0, "ram+nocache")
+    m.read_file(d + "model.txt")
+    outs = []
+    for r in range(runs):
+        for ins in pushes:
+            for k, v in ins.items():
+                m.add_tensor(k, v)
+        m.set_use_fp16_arithmetic(True)
+        m.set_fuse_ops_in_attention(True)
+        m.run()
+        outs.append([m.get_tensor("out_sample", i)[0] for i in range(len(pushes))])
+        m.clear_tensors()
+    m.close()
+    return outs
+
+
+def test_sd15_unet_properties_and_reference_parity(sd15_dir):
+    from onnxstream_amd import build as b
+    a, c = sd_unet.unet_inputs(sd_unet.SD15, 42), sd_unet.unet_inputs(sd_unet.SD15, 43)
+    both = _run(b.LIB_HOST, sd15_dir, [a, c], runs=3)
+    for o in both[1:]:
+        assert np.array_equal(both[0][0], o[0]) and np.array_equal(both[0][1], o[1])      # eager == captured == replayed, bit for bit
+    alone = _run(b.LIB_HOST, sd15_dir, [a])[0][0]
+    mx = float(np.abs(alone).max())
+    # batch invariance: tile shapes / split-K choices may differ between M = 4096 and M = 8192 launches, roundings may not by more than f16 noise
+    assert float(np.abs(alone - both[0][0]).max()) / mx <= 5e-3
+    assert np.isfinite(both[0][0]).all() and np.isfinite(both[0][1]).all()
+    if not oref.available():
+        pytest.skip("oracle/_ref not present: properties checked, reference parity skipped")
+    r16 = oref.run_model(sd15_dir, a, fp16=True)["out_sample"]
+    r32 = oref.run_model(sd15_dir, a, fp16=False)["out_sample"]
+    mx = float(np.abs(r32).max())
+    err16 = float(np.abs(both[0][0] - r16).max()) / mx
+    err32 = float(np.abs(both[0][0] - r32).max()) / mx
+    noise = float(np.abs(r16 - r32).max()) / mx
+    print(f"SD1.5 UNet full size: |gpu-ref16|/max={err16:.2e} |gpu-ref32|/max={err32:.2e} reference fp16 drift={noise:.2e}")
+    assert err16 <= 1e-3 or err32 <= 1.5 * noise + 1e-3

@@ -37,6 +37,13 @@ def _emit(d):
     return du, dv
 
 
+def _emit_tiled(d):
+    import dataclasses
+    dt = d + "/vae_t/"
+    sd_vae.build_vae_decoder(DirSink(dt), dataclasses.replace(sd_vae.TINY_VAE, latent=8, in_name="latent_sample"))
+    return dt
+
+
 @pytest.mark.skipif(not oref.available(), reason="oracle/_ref not built (needs /root/reference)")
 def test_reference_reproduces_pipeline_golden():
     z = np.load(GOLD)
@@ -46,7 +53,10 @@ def test_reference_reproduces_pipeline_golden():
         lat = p.sample(z["cond"], z["uncond"], steps=3, seed=9, latent_shape=(1, 4, 16, 16))
         img = p.decode(lat)
         p.close()
-    assert np.array_equal(lat, z["latents"]) and np.array_equal(img, z["image"])
+        pt = Txt2Img(oref.REF_LIB, du, _emit_tiled(d), batched=False, threads=1)
+        img_t = pt.decode_tiled(lat, tile=8)
+        pt.close()
+    assert np.array_equal(lat, z["latents"]) and np.array_equal(img, z["image"]) and np.array_equal(img_t, z["image_tiled"])
 
 
 @pytest.mark.gpu
@@ -61,6 +71,11 @@ def test_hip_pipeline_vs_reference_golden():
         # the VAE on the REFERENCE's latents isolates the decoder from the (chaotic) accumulated sampler drift
         img_ref_lat = p.decode(z["latents"])
         p.close()
+        pt = Txt2Img(b.LIB_HOST, du, _emit_tiled(d), batched=True)       # 9 overlapping tiles as ONE batch-9 pass
+        img_t = pt.decode_tiled(z["latents"], tile=8)
+        pt.close()
+    e_tiled = float(np.abs(img_t - z["image_tiled"]).max() / np.abs(z["image_tiled"]).max())
+    assert e_tiled <= 5e-3, e_tiled
     e_lat = float(np.abs(lat - z["latents"]).max() / np.abs(z["latents"]).max())
     e_img = float(np.abs(img_ref_lat - z["image"]).max() / np.abs(z["image"]).max())
     e_e2e = float(np.abs(img - z["image"]).max() / np.abs(z["image"]).max())

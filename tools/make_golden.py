@@ -49,4 +49,11 @@ with tempfile.TemporaryDirectory() as d:
     img = p.decode(lat)
     p.close()
     print(f"pipeline_tiny latents max {np.abs(lat).max():.3f} image range [{img.min():.1f}, {img.max():.1f}]")
-    np.savez_compressed(os.path.join(out_dir, "pipeline_tiny.npz"), cond=cond, uncond=uncond, latents=lat, image=img)
+    # tiled decode (sd_tiled_decoder): an 8x8-latent decoder over the 16x16 latents, 3x3 overlapping tiles, blended
+    import dataclasses
+    dt = d + "/vae_t/"
+    sd_vae.build_vae_decoder(DirSink(dt), dataclasses.replace(sd_vae.TINY_VAE, latent=8, in_name="latent_sample"))
+    pt = Txt2Img(oref.REF_LIB, du, dt, batched=False, threads=1)
+    img_t = pt.decode_tiled(lat, tile=8)
+    pt.close()
+    np.savez_compressed(os.path.join(out_dir, "pipeline_tiny.npz"), cond=cond, uncond=uncond, latents=lat, image=img, image_tiled=img_t)
