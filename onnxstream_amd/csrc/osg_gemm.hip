@@ -223,8 +223,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 //     depth of the ring, not from co-resident blocks.
 //   * XCD-aware tile walk: the 1-D grid is remapped so each of the 8 XCDs (private L2) gets a CONTIGUOUS run of tiles,
 //     ordered so that the operand with more unique bytes is split across XCDs and read from HBM once.
-template <int BM, int BN, int NST, bool CONV, int MODE = 0>
-__global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
+// SPEC = 1: 512 threads -- waves 4..7 only issue the DMA loads, waves 0..3 only do ds_read + MFMA + epilogue (see osg_conv3x3.hip)
+template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0>
+__global__ __launch_bounds__(SPEC ? 512 : 256) void gemm2_kernel(GemmParams p) {
     constexpr int ROWB = 128;                       // bytes per tile row (BK = 64 halves)
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     constexpr int A_LD = BM / 32, B_LD = BN / 32;   // 1-KiB wave-loads per wave per k-tile
@@ -238,7 +239,10 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = SPEC && wave8 >= 4, math = !SPEC || wave8 < 4;
+    const bool loads = !SPEC || loader;
+    const int wave = wave8 & 3;
     const int wm0 = (wave >> 1) * WM;
     const int wn0 = (wave & 1) * WN;
 
@@ -344,15 +348,18 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
     const int a_rd = (wm0 + frow) * ROWB + fsw;
     const int b_rd = A_BYTES + (wn0 + frow) * ROWB + fsw;
 
+    if (loads) {
 #pragma unroll
-    for (int s2 = 0; s2 < NST - 1; s2++) issue_tile(s2);
+        for (int s2 = 0; s2 < NST - 1; s2++) issue_tile(s2);
+    }
 
     int cur = 0, nxt = NST - 1;
     for (int kt = 0; kt < nkt; kt++) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");   // my share of tile kt has landed
+        if (loads) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");   // my share of tile kt has landed
         __builtin_amdgcn_s_barrier();                                      // everyone's has; tile kt-1's buffer is free
-        issue_tile(nxt);
+        if (loads) issue_tile(nxt);
         const char* St = smem2 + cur * STAGE;
+        if (math)
 #pragma unroll
         for (int ks = 0; ks < (MODE == 1 ? 0 : 2); ks++) {
             f16x8 a[TM], b[TN];
@@ -369,6 +376,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
         nxt = nxt + 1 == NST ? 0 : nxt + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the dummy tail loads before the LDS is released
+    if (loader) return;
     if (p.act == OSG_ACT_GEGLU) {
         if constexpr (TN % 2 == 0) gemm_epilogue_geglu<TM, TN>(p, acc, m0, n0, wm0, wn0, lane, zb);
         return;
@@ -432,10 +440,10 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
     }
 }
 
-template <int BM, int BN, int NST, bool CONV, int MODE = 0>
+template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0>
 int launch_v2(osg_ctx* ctx, GemmParams& p, int batch) {
     constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
-    auto kern = gemm2_kernel<BM, BN, NST, CONV, MODE>;
+    auto kern = gemm2_kernel<BM, BN, NST, CONV, MODE, SPEC>;
     static bool attr_set = false;
     if (!attr_set) {
         OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -444,7 +452,7 @@ int launch_v2(osg_ctx* ctx, GemmParams& p, int batch) {
     p.mt = (p.M + BM - 1) / BM;
     p.nt = (p.N + BN - 1) / BN;
     dim3 grid((unsigned)(p.mt * p.nt * p.splits * batch));
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, ctx->compute, p);
+    hipLaunchKernelGGL(kern, grid, dim3(SPEC ? 512 : 256), smem, ctx->compute, p);
     OSG_LAUNCH_CHECK(ctx);
     return 0;
 }
@@ -742,6 +750,7 @@ int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch) {
     p.n_major = (double)p.N * p.K * 2.0 > a_unique;
     int rc;
     static const int dbg = getenv("OSG_GEMM_DBG") ? atoi(getenv("OSG_GEMM_DBG")) : 0;   // experiments (tools/gemm_probe.py)
+    if (dbg == 7) return launch_v2<128, 128, 4, CONV, 0, 1>(ctx, p, batch) || (p.splits > 1 ? launch_splitk_reduce(ctx, p, batch) : 0);   // specialized waves
     if (dbg == 6 && !CONV && batch == 1) return launch_v3(ctx, p);          // register-staged specialized loaders (experiment)
     if (dbg == 1) rc = launch_v2<128, 128, 4, CONV, 1>(ctx, p, batch);        // loads only
     else if (dbg == 2) rc = launch_v2<128, 128, 3, CONV>(ctx, p, batch);
