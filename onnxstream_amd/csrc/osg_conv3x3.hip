@@ -138,10 +138,12 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
             b_off[j] = (nl < BN && n < p.N) ? (unsigned)(((long)n * p.K + gch * 8) * 2) : OOB;
         }
         auto issue_patch_piece = [&](int pc, int slab, char* buf) {     // slab may be past the end: dummy (zero-filling) load
+            if (MODE >= 3) return;
             const unsigned kill = (slab < slab_e && MODE != 2) ? 0u : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(buf + (pc * 4 + wave) * 1024), 16, pa_off[pc] | kill, slab * 128, 0, 0);
         };
         auto issue_weights = [&](int stage, int tap, int slab) {
+            if (MODE >= 3) return;
             const unsigned kill = (slab < slab_e && MODE != 2) ? 0u : OOB;
             const int soff = (tap * p.Cin + slab * 64) * 2;
             char* dst = bst0 + stage * BST_BYTES;
@@ -164,7 +166,7 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
                 constexpr int t = decltype(tc)::value;
                 // after this wait + barrier the tiles of unit u+1 are resident too: what the previous D-2 units issued may stay in flight
                 wait_vmcnt<G::allowed_outstanding(t)>();
-                __builtin_amdgcn_s_barrier();
+                if (MODE != 5) __builtin_amdgcn_s_barrier();
                 constexpr int td = (t + D) % 9;
                 int std_ = ust + D;
                 std_ = std_ >= NSTW ? std_ - NSTW : std_;
@@ -202,7 +204,7 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
     // first half of unit u+1 already during the second half of unit u (its tiles are guaranteed resident one barrier ahead).
     f16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
     auto read_frags = [&](f16x8 (&fa)[TM], f16x8 (&fb)[TN], const char* pbuf, const char* bbuf, int tap_off, int ks) {
-        if (MODE == 1) return;
+        if (MODE == 1 || (MODE == 4 && ks == 1)) return;
 #pragma unroll
         for (int i = 0; i < TM; i++) {
             const int pp = pp0[i] + tap_off;
@@ -221,13 +223,19 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
 
     __builtin_amdgcn_s_barrier();                       // unit 0's weights + the first patch have landed
     read_frags(fa0, fb0, patch0, bst0, 0, 0);
+    if (MODE == 4) {
+#pragma unroll
+        for (int i = 0; i < TM; i++) fa1[i] = fa0[i];
+#pragma unroll
+        for (int j = 0; j < TN; j++) fb1[j] = fb0[j];
+    }
     int ust = 0;
     for (int slab = slab_b; slab < slab_e; slab++) {
         const char* patch = patch0 + ((slab - slab_b) & 1) * PATCH_BYTES;
         const char* patch_next = patch0 + (((slab - slab_b) & 1) ^ 1) * PATCH_BYTES;
         static_for<0, 9>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            __builtin_amdgcn_s_barrier();               // units <= u+1 resident; the loaders may now overwrite unit u-1's stage
+            if (MODE != 5) __builtin_amdgcn_s_barrier();               // units <= u+1 resident; the loaders may now overwrite unit u-1's stage
             constexpr int kh = t / 3, kw = t % 3;
             const char* Bs = bst0 + ust * BST_BYTES;
             // sched_barrier(0) pins the order "issue the NEXT half's ds_reads, then run THIS half's MFMAs": left alone, hipcc sinks
@@ -238,7 +246,7 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
             __builtin_amdgcn_sched_barrier(0);
             ust = ust + 1 == NSTW ? 0 : ust + 1;
             constexpr int tn = (t + 1) % 9;
-            read_frags(fa0, fb0, t == 8 ? patch_next : patch, bst0 + ust * BST_BYTES, (tn / 3) * PW + tn % 3, 0);
+            if (MODE != 4) read_frags(fa0, fb0, t == 8 ? patch_next : patch, bst0 + ust * BST_BYTES, (tn / 3) * PW + tn % 3, 0);
             __builtin_amdgcn_sched_barrier(0);
             mma(fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
@@ -276,6 +284,9 @@ int launch3_bn(osg_ctx* ctx, GemmParams& p, int bn) {
         const int dbg = e ? atoi(e) : 0;
         if (dbg == 1) return launch3<64, 80, 4, 1, 1>(ctx, p);
         if (dbg == 2) return launch3<64, 80, 4, 1, 2>(ctx, p);
+        if (dbg == 3) return launch3<64, 80, 4, 1, 3>(ctx, p);
+        if (dbg == 4) return launch3<64, 80, 4, 1, 4>(ctx, p);
+        if (dbg == 5) return launch3<64, 80, 4, 1, 5>(ctx, p);
     }
     if (bn == 80) return launch3<W_, 80, 4, 1>(ctx, p);
     if (bn == 160) return launch3<W_, 160, 2, 2>(ctx, p);
