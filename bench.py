@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--profile-reps", type=int, default=3)
     ap.add_argument("--steps-per-image", type=int, default=0, help="denoising steps per image (default 20; BASELINE config 4 = SDXL uses 10)")
     ap.add_argument("--prompts-per-gpu", type=int, default=1, help="prompts denoised together on each GPU (2P samples per UNet pass: the reference's --num batching)")
+    ap.add_argument("--w8-resident", action="store_true", help="with --quant-weights: keep the codes resident and dequantise on chip (osg_*_w8 kernels)")
     ap.add_argument("--quant-weights", action="store_true", help="W8A16: uint8 weights + scale/zero-point in model.txt, dequantised at load")
     ap.add_argument("--breakdown", default="", help="write the per-step HIP-event profile to this file")
     args = ap.parse_args()
@@ -174,6 +175,8 @@ def main():
     t_build = time.time()
     pipe = Txt2Img(b.LIB_HOST, model_dir, vae_dir, batched=True, device=local_rank, fusion=args.fusion)
     m = pipe.unet
+    if args.w8_resident:
+        m._set_option("hip_w8_resident", 1)
     L = cfg.latent
     P = max(1, args.prompts_per_gpu if args.mode == "pipeline" and not cfg.sdxl_add_embed else 1)
     lat_shape = (P, cfg.in_ch, L, L)

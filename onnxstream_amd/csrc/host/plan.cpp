@@ -89,11 +89,13 @@ Plan::Plan(Model& model, HipBackend& backend, size_t batch) : m(model), be(backe
     fp16 = m.m_use_fp16_arithmetic;
     fusion = m.m_hip_fusion_level;
     stream_weights = m.m_hip_stream_weights;
+    w8_resident = m.m_hip_w8_resident && !m.m_hip_stream_weights;
     extra_outputs = m.m_extra_outputs;
 }
 
 bool Plan::compatible(Model& mm, size_t batch) const {
     return (long)batch == N && mm.m_use_fp16_arithmetic == fp16 && mm.m_hip_fusion_level == fusion && mm.m_hip_stream_weights == stream_weights &&
+           (mm.m_hip_w8_resident && !mm.m_hip_stream_weights) == w8_resident &&
            mm.m_extra_outputs == extra_outputs;
 }
 
@@ -270,8 +272,14 @@ struct Lowering {
                 TensorDataType nt = wp->get_type_of_next();
                 if (nt != TensorDataType::none) ty = nt;
                 const bool f32 = wants_f32(op, i) || !P.fp16;
-                const osg_dtype want = ty == TensorDataType::int64 ? OSG_I64 : (f32 ? OSG_F32 : OSG_F16);
-                const std::string key = fn + (want == OSG_F32 ? "|f32" : want == OSG_F16 ? "|f16" : "|i64");
+                // W8A16: the weight operand of a contraction stays uint8 when the on-chip dequantising kernels take its shape
+                bool keep_u8 = false;
+                if (P.w8_resident && ty == TensorDataType::uint8 && !f32 && i == 1) {
+                    if (op.m_type == "Conv") keep_u8 = shape.size() == 4 && shape[1] % 64 == 0;                      // [O,I,kh,kw]: Cin % 64
+                    else if (op.m_type == "MatMul" || op.m_type == "Gemm") keep_u8 = shape.size() == 2 && shape[0] % 64 == 0;   // [K,N]
+                }
+                const osg_dtype want = keep_u8 ? OSG_U8 : ty == TensorDataType::int64 ? OSG_I64 : (f32 ? OSG_F32 : OSG_F16);
+                const std::string key = fn + (want == OSG_F32 ? "|f32" : want == OSG_F16 ? "|f16" : want == OSG_U8 ? "|u8" : "|i64");
                 const long count = prod(shape);
                 int v = -1;
                 auto it = const_cache.find(key);
@@ -292,6 +300,8 @@ struct Lowering {
                     Val& val = V(v);
                     val.is_const = true;
                     val.name = fn;
+                    val.qscale = t.m_scale;
+                    val.qzp = (int)t.m_zero_point;
                     size_t bytes = (size_t)count * esize(want);
                     val.dptr = be.malloc(bytes);
                     P.owned.push_back(val.dptr);
@@ -317,7 +327,7 @@ struct Lowering {
                     if (have == OSG_I64) {
                         val.host_i.assign((const int64_t*)data.data(), (const int64_t*)data.data() + count);
                         val.host_valid = true;
-                    } else if (count <= 4096) {
+                    } else if (count <= 4096 && want != OSG_U8) {
                         val.host_f.resize(count);
                         for (long k = 0; k < count; k++) {
                             if constexpr (std::is_same_v<T, uint8_t>) val.host_f[k] = (float)((int)data[k] - (int)t.m_zero_point) * t.m_scale;
@@ -952,6 +962,19 @@ struct Lowering {
         if (bias >= 0) reads.push_back(bias);
         if (res >= 0) reads.push_back(res);
         if (ib >= 0) reads.push_back(ib);
+        if (V(w).dtype == OSG_U8) {
+            const float qs = V(w).qscale;
+            const int qz = V(w).qzp;
+            P.add_step("Conv w8 " + op.m_name, reads, {y}, [=, this] {
+                be.check(be.api.osg_conv2d_nhwc_w8(be.ctx, P.ptr(x), P.ptr(w), qs, qz, bias >= 0 ? P.ptr(bias) : nullptr,
+                                                   bias >= 0 ? P.vals[bias].dtype : OSG_F16, ib >= 0 ? P.ptr(ib) : nullptr, ib_ld,
+                                                   res >= 0 ? P.ptr(res) : nullptr, P.ptr(y), (int)nb, (int)H, (int)W, (int)Cin, (int)Cout,
+                                                   (int)KH, (int)KW, sh, sw, pt, pl, pb, pr, OSG_ACT_NONE),
+                         "Conv");
+            });
+            P.steps.back().flops = 2.0 * nb * Ho * Wo * Cout * KH * KW * Cin;
+            return;
+        }
         P.add_step("Conv " + op.m_name, reads, {y}, [=, this] {
             be.check(be.api.osg_conv2d_nhwc_rb(be.ctx, OSG_F16, P.ptr(x), P.ptr(w), bias >= 0 ? P.ptr(bias) : nullptr,
                                                bias >= 0 ? P.vals[bias].dtype : OSG_F16, ib >= 0 ? P.ptr(ib) : nullptr, ib_ld,
@@ -977,6 +1000,41 @@ struct Lowering {
         be.check(be.api.osg_transpose_kn_to_nk(be.ctx, OSG_F16, P.ptr(w), tv.dptr, (int)K, (int)Nn), "osg_transpose_kn_to_nk");
         V(w).as_nhwc = t;
         return t;
+    }
+
+    // [K,N] uint8 codes -> [N,K] (done once, at plan time)
+    int weight_nk_u8(int w) {
+        if (V(w).as_nk_u8 >= 0) return V(w).as_nk_u8;
+        const long K = V(w).shape[0], Nn = V(w).shape[1];
+        int t = P.new_val("", {Nn, K}, OSG_U8, Lay::plain, false);
+        V(t).is_const = true;
+        V(t).name = V(w).name + "|nk";
+        V(t).qscale = V(w).qscale;
+        V(t).qzp = V(w).qzp;
+        V(t).dptr = be.malloc((size_t)K * Nn);
+        P.owned.push_back(V(t).dptr);
+        long shape[2] = {K, Nn};
+        int perm[2] = {1, 0};
+        be.check(be.api.osg_transpose(be.ctx, 1, P.ptr(w), V(t).dptr, 2, shape, perm), "osg_transpose");
+        be.check(be.api.osg_sync(be.ctx), "osg_sync");
+        V(w).as_nk_u8 = t;
+        return t;
+    }
+
+    void emit_gemm_w8(const std::string& what, int a, int w, int bias, int res, int y, long M, long Nn, long K) {
+        const int wq = weight_nk_u8(w);
+        const float qs = V(wq).qscale;
+        const int qz = V(wq).qzp;
+        std::vector<int> reads = {a, wq};
+        if (bias >= 0) reads.push_back(bias);
+        if (res >= 0) reads.push_back(res);
+        P.add_step(what, reads, {y}, [=, this] {
+            be.check(be.api.osg_gemm_w8(be.ctx, P.ptr(a), P.ptr(wq), qs, qz, bias >= 0 ? P.ptr(bias) : nullptr,
+                                        bias >= 0 ? P.vals[bias].dtype : OSG_F16, res >= 0 ? P.ptr(res) : nullptr, P.ptr(y), (int)M, (int)Nn, (int)K,
+                                        OSG_ACT_NONE),
+                     what.c_str());
+        });
+        P.steps.back().flops = 2.0 * M * Nn * K;
     }
 
     void emit_gemm(const std::string& what, int a, int wnk, int bias, int res, int y, long M, long Nn, long K, long batch, long sa, long sb,
@@ -1161,7 +1219,8 @@ struct Lowering {
         os.back() = Nn;
         int y = out_val(op, os, Lay::plain, V(a).batched);
         const long M = prod(as) / K * B(a);
-        if (P.stream_weights) emit_gemm("Linear " + op.m_name, a, w, bias, res, y, M, Nn, K, 1, 0, 0, 0, 0);   // [K,N] as streamed; the kernel re-lays it out
+        if (V(w).dtype == OSG_U8) emit_gemm_w8("Linear w8 " + op.m_name, a, w, bias, res, y, M, Nn, K);
+        else if (P.stream_weights) emit_gemm("Linear " + op.m_name, a, w, bias, res, y, M, Nn, K, 1, 0, 0, 0, 0);   // [K,N] as streamed; the kernel re-lays it out
         else emit_gemm("Linear " + op.m_name, a, weight_nk(w), bias, res, y, M, Nn, K, 1, 0, 0, 0, 1);
     }
 
@@ -1207,7 +1266,8 @@ struct Lowering {
         need(op, V(w).shape[0] == K, "invalid shape of inputs.");
         need(op, M == 1 && V(bias).numel() == Nn, "invalid shape of bias.");
         int y = out_val(op, {M, Nn}, Lay::plain, V(a).batched);
-        if (P.stream_weights) emit_gemm("Gemm " + op.m_name, a, w, bias, -1, y, M * B(a), Nn, K, 1, 0, 0, 0, 0);
+        if (V(w).dtype == OSG_U8) emit_gemm_w8("Gemm w8 " + op.m_name, a, w, bias, -1, y, M * B(a), Nn, K);
+        else if (P.stream_weights) emit_gemm("Gemm " + op.m_name, a, w, bias, -1, y, M * B(a), Nn, K, 1, 0, 0, 0, 0);
         else emit_gemm("Gemm " + op.m_name, a, weight_nk(w), bias, -1, y, M * B(a), Nn, K, 1, 0, 0, 0, 1);
     }
 

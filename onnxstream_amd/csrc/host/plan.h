@@ -41,6 +41,9 @@ struct Val {
     // column-slice view of a wider 2-D buffer (merged projections): rows are `ld` elements apart, starting `view_off` bytes into the root
     long ld = 0;
     size_t view_off = 0;
+    float qscale = 1.f;           // dtype == OSG_U8 weights: w = (q - qzp) * qscale
+    int qzp = 0;
+    int as_nk_u8 = -1;            // [N,K] twin of a [K,N] uint8 matrix
     long numel() const { long n = 1; for (auto d : shape) n *= d; return n; }
 };
 
@@ -105,7 +108,8 @@ struct Plan {
     double m_last_ms = 0;
     // options the plan was built with
     bool fp16 = true;
-    bool stream_weights = false;   // m_hip_stream_weights: weights are re-pulled from the WeightsProvider and re-streamed H2D every pass
+    bool stream_weights = false;
+    bool w8_resident = false;      // uint8 Conv/MatMul/Gemm weights kept as codes, dequantised inside the kernels (osg_*_w8)   // m_hip_stream_weights: weights are re-pulled from the WeightsProvider and re-streamed H2D every pass
     int fusion = 2;
     std::vector<std::string> extra_outputs;
 

@@ -26,6 +26,8 @@ struct GemmParams {
     long a_bytes_l;              // conv: byte size of the whole NHWC input (host side, before the 2 GiB check)
     int mt, nt, n_major;         // tile grid and the order tiles are walked inside an XCD's contiguous chunk
     int* tickets;                // split-K arrival counters (one per output tile), zero between launches
+    float w_scale;               // W8 kernels (osg_gemm_w8.hip): Bt holds uint8 codes, w = (q - w_zp) * w_scale
+    int w_zp;
 };
 
 // ---- epilogue shared by both kernels: lane owns C[m][n..n+3], m = tile_m + (lane&15), n = tile_n + (lane>>4)*4 --------

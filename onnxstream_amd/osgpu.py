@@ -24,7 +24,7 @@ EXPORTS = [
     "osg_device_count", "osg_init", "osg_destroy", "osg_last_error", "osg_device_name", "osg_stream",
     "osg_malloc", "osg_free", "osg_upload", "osg_upload_sync", "osg_host_register", "osg_host_unregister", "osg_upload_pinned", "osg_download", "osg_copy", "osg_memset", "osg_sync",
     "osg_graph_begin", "osg_graph_end", "osg_graph_launch", "osg_graph_destroy", "osg_timer_start", "osg_timer_stop",
-    "osg_conv2d_nhwc", "osg_conv2d_nhwc_rb", "osg_gemm", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided",
+    "osg_conv2d_nhwc", "osg_conv2d_nhwc_rb", "osg_gemm", "osg_gemm_w8", "osg_conv2d_nhwc_w8", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided",
     "osg_instance_norm", "osg_group_norm_nhwc", "osg_layer_norm", "osg_reduce_mean_last", "osg_softmax_last",
     "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_resize_nearest", "osg_gather_rows",
     "osg_maxpool_nhwc", "osg_convert",
@@ -66,6 +66,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_timer_stop.argtypes = [vp, ctypes.POINTER(cf)]
     lib.osg_conv2d_nhwc.argtypes = [vp, ci, vp, vp, vp, ci, vp, vp] + [ci] * 14
     lib.osg_conv2d_nhwc_rb.argtypes = [vp, ci, vp, vp, vp, ci, vp, cl, vp, vp] + [ci] * 14
+    lib.osg_gemm_w8.argtypes = [vp, vp, vp, cf, ci, vp, ci, vp, vp, ci, ci, ci, ci]
+    lib.osg_conv2d_nhwc_w8.argtypes = [vp, vp, vp, cf, ci, vp, ci, vp, cl, vp, vp] + [ci] * 14
     lib.osg_gemm.argtypes = [vp, ci, vp, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, cl, cl, cl, ci]
     lib.osg_transpose_kn_to_nk.argtypes = [vp, ci, vp, vp, ci, ci]
     lib.osg_attention.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, cf, ci]

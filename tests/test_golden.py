@@ -189,3 +189,35 @@ def test_passes_are_bitwise_reproducible():
             m.close()
         for o in outs[1:]:
             assert np.array_equal(outs[0], o), name
+
+
+@pytest.mark.gpu
+def test_w8_resident_equals_load_time_dequant():
+    """hip_w8_resident (uint8 codes resident, dequantised inside the kernels) vs dequantise-at-load (the reference's order of
+    operations): the dequantised weight VALUES are identical by construction, so the two runs may differ only through tile / split-K
+    choices -- f16 rounding noise -- and both must meet the golden bound."""
+    from onnxstream_amd import build as b
+    from onnxstream_amd.bindings import Model
+    ins, oname, r16, r32 = load("unet_tiny_w8")
+    outs = {}
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        gc.emit("unet_tiny_w8", DirSink(d))
+        for mode in (1, 0):
+            m = Model(b.LIB_HOST, 0, "ram+nocache")
+            m.read_file(d + "model.txt")
+            m._set_option("hip_w8_resident", mode)
+            for k, v in ins.items():
+                m.add_tensor(k, v)
+            m.set_use_fp16_arithmetic(True)
+            m.set_fuse_ops_in_attention(True)
+            m.run()
+            outs[mode] = m.get_tensor(oname)[0]
+            n_w8 = sum(1 for r in m.hip_profile(1) if " w8 " in r[3])
+            assert (n_w8 > 0) == (mode == 1)
+            m.close()
+    mx = float(np.abs(r32).max())
+    noise = float(np.abs(r16 - r32).max()) / mx
+    for mode in (1, 0):
+        assert float(np.abs(outs[mode] - r32).max()) / mx <= 1.5 * noise + 1e-3
+    assert float(np.abs(outs[1] - outs[0]).max()) / mx <= 5e-3
