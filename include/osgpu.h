@@ -154,6 +154,13 @@ int osg_instance_norm(osg_ctx* ctx, osg_dtype dtype, const void* x, const float*
 /* Fused GroupNorm on NHWC [N,HW,C] = Reshape->InstanceNorm->Reshape->Mul(gamma[C])->Add(beta[C]) (+SiLU). */
 int osg_group_norm_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* gamma, const void* beta, void* y, int N, long HW,
                         int C, int groups, float eps, osg_act act);
+/* Fused  GroupNorm(+SiLU) -> Conv3x3 / stride 1 / pad 1  (the resnet block's norm -> nonlinearity -> conv, reference ops
+ * Reshape, InstanceNormalization :4788, Reshape, Mul, Add, Sigmoid :4376, Mul, Conv :4494): the normalised activation is produced
+ * on chip inside the convolution's tile loaders and never stored.  Shapes: see osg_group_norm_conv3x3_supported (1 = taken). */
+int osg_group_norm_conv3x3_supported(int N, int H, int W, int Cin, int Cout);
+int osg_group_norm_conv3x3(osg_ctx* ctx, const void* x, const void* gamma, const void* beta, int groups, float eps, osg_act act_pre,
+                           const void* w_ohwi, const void* bias, osg_dtype bias_dtype, const void* image_bias, long image_bias_ld,
+                           const void* residual, void* y, int N, int H, int W, int Cin, int Cout);
 /* Fused LayerNorm over the last axis == ReduceMean,Sub,Pow,ReduceMean,Add,Sqrt,Div,Mul,Add (onnxstream.cpp:5237-5604). */
 int osg_layer_norm(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* gamma, const void* beta, void* y, long rows, int C,
                    float eps);

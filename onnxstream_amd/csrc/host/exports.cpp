@@ -233,6 +233,7 @@ void model_set_option(Handle* h, char* name, unsigned int value) {
     else if (n == "hip_use_graph") m.m_hip_use_graph = b;
     else if (n == "hip_stream_weights") m.m_hip_stream_weights = b;
     else if (n == "hip_w8_resident") m.m_hip_w8_resident = b;
+    else if (n == "hip_fuse_gn_conv") m.m_hip_fuse_gn_conv = b;
     else {
         const char* err = "model_set_option: 'name' not found.";
         printf("=== ERROR === %s\n", err);

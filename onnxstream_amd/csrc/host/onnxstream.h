@@ -551,6 +551,8 @@ public:
     bool m_hip_w8_resident = false;     // true: uint8 weights of Conv/MatMul/Gemm stay uint8 in HBM (half the footprint and weight traffic) and are
                                         // dequantised on chip by the osg_*_w8 kernels -- same VALUES as the reference's load-time dequantisation
                                         // (:2887-2891); false (default, currently the faster path: halo conv + merged projections): dequantise once at load
+    bool m_hip_fuse_gn_conv = false;    // GroupNorm(+SiLU) applied inside the 3x3 convolution's tile loaders (osg_group_norm_conv3x3): bit-identical,
+                                        // removes a pass over the tensor, but measured slower than the separate launches -> opt-in
     bool m_hip_stream_weights = false;  // true: weights are re-streamed through pinned buffers every pass (WeightsProvider mode)
     size_t hip_last_kernel_count() const;
     double hip_last_pass_ms() const;   // device time of the last pass (HIP events on the compute stream)

@@ -90,11 +90,12 @@ Plan::Plan(Model& model, HipBackend& backend, size_t batch) : m(model), be(backe
     fusion = m.m_hip_fusion_level;
     stream_weights = m.m_hip_stream_weights;
     w8_resident = m.m_hip_w8_resident && !m.m_hip_stream_weights;
+    fuse_gn_conv = m.m_hip_fuse_gn_conv;
     extra_outputs = m.m_extra_outputs;
 }
 
 bool Plan::compatible(Model& mm, size_t batch) const {
-    return (long)batch == N && mm.m_use_fp16_arithmetic == fp16 && mm.m_hip_fusion_level == fusion && mm.m_hip_stream_weights == stream_weights &&
+    return (long)batch == N && mm.m_use_fp16_arithmetic == fp16 && mm.m_hip_fusion_level == fusion && mm.m_hip_stream_weights == stream_weights && mm.m_hip_fuse_gn_conv == fuse_gn_conv &&
            (mm.m_hip_w8_resident && !mm.m_hip_stream_weights) == w8_resident &&
            mm.m_extra_outputs == extra_outputs;
 }
@@ -404,6 +405,7 @@ struct Lowering {
             index_graph(); fuse_linear_geglu();
             index_graph(); cse_silu();
             index_graph(); fuse_image_bias();
+            index_graph(); fuse_group_norm_conv();   // last: the conv's epilogue inputs (residual, image bias) are final by now
         } else if (m.m_fuse_ops_in_attention) {
             index_graph(); fuse_attention(false);
         }
@@ -715,6 +717,47 @@ struct Lowering {
         }
     }
 
+    // osg.GroupNorm(+SiLU) -> Conv 3x3/s1/p1  ==> the normalisation rides in the convolution's tile loaders (osg_group_norm_conv3x3):
+    // the normalised activation is never written.  Runs after the residual / image-bias fusions so the conv's epilogue inputs are final.
+    void fuse_group_norm_conv() {
+        // measured SLOWER than GroupNorm + conv as separate launches (tools/gnconv_probe.py: 51 vs 42 us at 64x64x320): the loader waves
+        // spend ~100 VALU instructions per 1-KiB patch piece on the affine + SiLU and become the critical path.  Opt-in only.
+        if (P.stream_weights || !m.m_hip_fuse_gn_conv) return;
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (!is((int)i, "osg.GroupNorm")) continue;
+            Operation& gn = ops()[i];
+            int ci = sole_consumer(gn.m_output[0]);
+            if (!is(ci, "Conv")) continue;
+            Operation& cv = ops()[ci];
+            if (cv.m_input.empty() || cv.m_input[0].m_name != gn.m_output[0].m_name) continue;
+            bool other_use = false;   // the normalised tensor must not also be the residual / image bias of the same conv
+            for (size_t k = 1; k < cv.m_input.size(); k++) other_use |= cv.m_input[k].m_name == gn.m_output[0].m_name;
+            if (other_use) continue;
+            const Val* w = cval(cv.m_input[1]);
+            const auto& xs = gn.m_input[0].m_shape;
+            if (!w || w->dtype != OSG_F16 || w->shape.size() != 4 || xs.size() != 4 || xs[0] != 1) continue;
+            if (w->shape[2] != 3 || w->shape[3] != 3) continue;
+            auto* st = attr(cv, "strides");
+            auto* pd = attr(cv, "pads");
+            if (st && int_list(*st) != std::vector<int>{1, 1}) continue;
+            if (!pd || int_list(*pd) != std::vector<int>{1, 1, 1, 1}) continue;
+            const Val* gam = cval(gn.m_input[1]);
+            const Val* bet = cval(gn.m_input[2]);
+            if (!gam || !bet || gam->dtype != OSG_F16 || bet->dtype != OSG_F16) continue;
+            if (!be.api.osg_group_norm_conv3x3_supported((int)N, (int)xs[2], (int)xs[3], (int)xs[1], (int)w->shape[0])) continue;
+            Operation f = cv;
+            f.m_input[0] = gn.m_input[0];
+            while (f.m_input.size() < 5) f.m_input.push_back(Tensor());
+            f.m_input.push_back(gn.m_input[1]);
+            f.m_input.push_back(gn.m_input[2]);
+            f.m_attributes.emplace_back("osg_prenorm", *attr(gn, "silu"));
+            f.m_attributes.emplace_back("osg_pre_groups", *attr(gn, "groups"));
+            f.m_attributes.emplace_back("osg_pre_eps", *attr(gn, "epsilon"));
+            dead[i] = 1;
+            ops()[ci] = std::move(f);
+        }
+    }
+
     // osg.Linear(x, W[K,2C], b) -> osg.GEGLU  ==> the GEGLU rides in the GEMM epilogue (value/gate columns pair-interleaved at plan time)
     void fuse_linear_geglu() {
         if (P.stream_weights) return;   // needs a re-ordered resident copy of the weight
@@ -910,7 +953,8 @@ struct Lowering {
     void lower_conv(const Operation& op) {
         const bool has_res = attr(op, "osg_residual") != nullptr;
         const bool has_ib = attr(op, "osg_image_bias") != nullptr;
-        const size_t nin = op.m_input.size();
+        const bool has_pre = attr(op, "osg_prenorm") != nullptr;
+        const size_t nin = has_pre ? (op.m_input.size() == 7 ? (has_ib ? 5 : has_res ? 4 : !op.m_input[2].m_name.empty() ? 3 : 2) : 0) : op.m_input.size();
         need(op, nin == 2 || nin == 3 || (has_res && nin == 4) || (has_ib && nin == 5), "wrong number of inputs.");
         need(op, op.m_output.size() == 1, "wrong number of outputs.");
         std::vector<int> dil = {1, 1}, ks, pads = {0, 0, 0, 0}, strides = {1, 1};
@@ -921,7 +965,8 @@ struct Lowering {
             else if (a.first == "kernel_shape") ks = int_list(a.second);
             else if (a.first == "pads") pads = int_list(a.second);
             else if (a.first == "strides") strides = int_list(a.second);
-            else if (a.first == "osg_residual" || a.first == "osg_image_bias") {}
+            else if (a.first == "osg_residual" || a.first == "osg_image_bias" || a.first == "osg_prenorm" || a.first == "osg_pre_groups" ||
+                     a.first == "osg_pre_eps") {}
             else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
         }
         int x = in_val(op.m_input[0]);
@@ -962,6 +1007,24 @@ struct Lowering {
         if (bias >= 0) reads.push_back(bias);
         if (res >= 0) reads.push_back(res);
         if (ib >= 0) reads.push_back(ib);
+        if (has_pre) {
+            const int gam = in_val(op.m_input[5]), bet = in_val(op.m_input[6]);
+            const int G = std::stoi(*attr(op, "osg_pre_groups"));
+            const float eps = std::stof(*attr(op, "osg_pre_eps"));
+            const int pact = *attr(op, "osg_prenorm") == "1" ? OSG_ACT_SILU : OSG_ACT_NONE;
+            need(op, V(gam).numel() == Cin && V(bet).numel() == Cin && V(w).dtype == OSG_F16, "invalid fused GroupNorm operands.");
+            reads.push_back(gam);
+            reads.push_back(bet);
+            P.add_step("Conv gn+ " + op.m_name, reads, {y}, [=, this] {
+                be.check(be.api.osg_group_norm_conv3x3(be.ctx, P.ptr(x), P.ptr(gam), P.ptr(bet), G, eps, (osg_act)pact, P.ptr(w),
+                                                       bias >= 0 ? P.ptr(bias) : nullptr, bias >= 0 ? P.vals[bias].dtype : OSG_F16,
+                                                       ib >= 0 ? P.ptr(ib) : nullptr, ib_ld, res >= 0 ? P.ptr(res) : nullptr, P.ptr(y), (int)nb,
+                                                       (int)H, (int)W, (int)Cin, (int)Cout),
+                         "Conv");
+            });
+            P.steps.back().flops = 2.0 * nb * Ho * Wo * Cout * KH * KW * Cin;
+            return;
+        }
         if (V(w).dtype == OSG_U8) {
             const float qs = V(w).qscale;
             const int qz = V(w).qzp;
@@ -1087,7 +1150,7 @@ struct Lowering {
                 for (int c : cit->second) {
                     const Operation& co = ops()[c];
                     if (co.m_type == "osg.Attention") continue;
-                    if (co.m_type == "Conv" && attr(co, "osg_image_bias") && co.m_input.size() == 5 && co.m_input[4].m_name == op.m_output[0].m_name) continue;
+                    if (co.m_type == "Conv" && attr(co, "osg_image_bias") && co.m_input.size() >= 5 && co.m_input[4].m_name == op.m_output[0].m_name) continue;
                     ok = false;
                 }
             if (!ok) continue;

@@ -72,7 +72,12 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float osg_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// 1 / (1 + e^-x) on the hardware transcendentals (v_exp_f32 + v_rcp_f32, ~1 ulp each): the reference's XNNPACK f16 sigmoid is itself an
+// approximation; saturates correctly (exp2 -> inf -> rcp -> 0).  One definition for every kernel, so fused and unfused
+// paths produce the same bits.
+__device__ __forceinline__ float osg_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+}
 __device__ __forceinline__ float osg_apply_act(float v, int act) {
     if (act == OSG_ACT_SILU) return v * osg_sigmoid(v);
     if (act == OSG_ACT_SIGMOID) return osg_sigmoid(v);

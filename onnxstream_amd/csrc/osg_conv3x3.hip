@@ -64,6 +64,15 @@ struct Geo {
         for (int d = 1; d <= D - 2; d++) n += WLB + patch_loads((t - d + 18) % 9);
         return n;
     }
+    // PRE (fused GroupNorm + SiLU on the input): the next slab's patch comes through REGISTERS -- all NPW pieces plus the slab's
+    // affine-table rows are issued at tap 0, transformed and written to LDS two pieces per tap from tap 2 on
+    static constexpr int NTAB = 4 * TI;                     // 16-byte table loads per lane per slab (ca, cb: 8 floats each, per image)
+    static constexpr int pre_loads(int t) { return t == 0 ? NPW + NTAB : 0; }
+    static constexpr int allowed_outstanding_pre(int t) {
+        int n = 0;
+        for (int d = 1; d <= D - 2; d++) n += WLB + pre_loads((t - d + 18) % 9);
+        return n;
+    }
 };
 
 // W_: image width (= tile width); BN: output channels per tile; WGM x WGN: grid of the 4 MATH waves.
@@ -72,10 +81,10 @@ struct Geo {
 // the time whatever the ring depth; with the DMA issue moved to waves that do nothing else, the math waves' stream is
 // ds_read + MFMA only and the two streams overlap on the SIMD.
 // (the body is a __device__ function: hipcc emits no host stub for a __global__ template whose body holds a generic lambda)
-template <int W_, int BN, int WGM, int WGN, int MODE>
+template <int W_, int BN, int WGM, int WGN, int MODE, bool PRE>
 __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
     using G = Geo<W_, BN>;
-    constexpr int TH = G::TH, PW = G::PW, PPI = G::PPI, PP = G::PP, NPW = G::NPW, PATCH_BYTES = G::PATCH_BYTES;
+    constexpr int TI = G::TI, TH = G::TH, PW = G::PW, PPI = G::PPI, PP = G::PP, NPW = G::NPW, PATCH_BYTES = G::PATCH_BYTES;
     constexpr int WLB = G::WLB, BST_BYTES = G::BST_BYTES, NSTW = G::NSTW, D = G::D, PPT = G::PPT;
     constexpr int WM = 128 / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
     static_assert(WM % 16 == 0 && WN % 16 == 0 && WGM * WGN == 4, "bad wave layout");
@@ -151,12 +160,56 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
             for (int j = 0; j < WLB; j++)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(dst + (j * 4 + wave) * 1024), 16, b_off[j] | kill, soff, 0, 0);
         };
+        // ---- PRE: register-staged patch with the GroupNorm affine + SiLU applied on the way into LDS -----------------------------
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        v4i preg[PRE ? NPW : 1];
+        f32x4 tca[PRE ? 2 * TI : 1], tcb[PRE ? 2 * TI : 1];      // ca / cb of this lane's 8 channels, per image of the tile
+        auto pre_issue = [&](int slab) {                         // all pieces of `slab` + its table rows -> registers
+            const unsigned kill = slab < slab_e ? 0u : OOB;
+#pragma unroll
+            for (int pc = 0; pc < NPW; pc++) preg[pc] = __builtin_amdgcn_raw_buffer_load_b128(rsA, pa_off[pc] | kill, slab * 128, 0);
+            const int sl = slab < slab_e ? slab : slab_b;        // (past the end: any valid row, the values are not used)
+#pragma unroll
+            for (int ti = 0; ti < TI; ti++) {
+                const int img = min(img0 + ti, p.pre_imgs - 1);
+                const float* row = p.pre_tab + ((long)img * 2) * p.Cin + sl * 64 + gch * 8;
+                tca[2 * ti] = *reinterpret_cast<const f32x4*>(row);
+                tca[2 * ti + 1] = *reinterpret_cast<const f32x4*>(row + 4);
+                tcb[2 * ti] = *reinterpret_cast<const f32x4*>(row + p.Cin);
+                tcb[2 * ti + 1] = *reinterpret_cast<const f32x4*>(row + p.Cin + 4);
+            }
+        };
+        auto pre_commit = [&](int pc, int slab, char* buf) {     // y = act(x * ca + cb) for image pixels, 0 for the halo; one ds_write_b128
+            const bool valid = pa_off[pc] != OOB && slab < slab_e;
+            const int ti = TI == 1 ? 0 : ((pc * 4 + wave) * 8 + rsub) / PPI;
+            f16x8 xv;
+            __builtin_memcpy(&xv, &preg[pc], 16);
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float ca = TI == 1 ? tca[e >> 2][e & 3] : (ti ? tca[2 + (e >> 2)][e & 3] : tca[e >> 2][e & 3]);
+                const float cb = TI == 1 ? tcb[e >> 2][e & 3] : (ti ? tcb[2 + (e >> 2)][e & 3] : tcb[e >> 2][e & 3]);
+                const float v = osg_apply_act((float)xv[e] * ca + cb, p.pre_act);
+                o[e] = valid ? (f16)v : (f16)0;
+            }
+            *reinterpret_cast<f16x8*>(buf + (pc * 4 + wave) * 1024 + lane * 16) = o;
+        };
+
         // prologue == units -D .. -1 of the steady state (D = NSTW - 1 units of weights in flight)
         issue_weights(0, 0, slab_b);
+        if constexpr (PRE) {
+            pre_issue(slab_b);
+        } else {
 #pragma unroll
-        for (int pc = 0; pc < NPW; pc++) issue_patch_piece(pc, slab_b, patch0);
+            for (int pc = 0; pc < NPW; pc++) issue_patch_piece(pc, slab_b, patch0);
+        }
 #pragma unroll
         for (int d = 1; d < D; d++) issue_weights(d, d % 9, slab_b + d / 9);
+        if constexpr (PRE) {
+#pragma unroll
+            for (int pc = 0; pc < NPW; pc++) pre_commit(pc, slab_b, patch0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         wait_vmcnt<(D - 1) * WLB>();                         // unit 0's weights + the first patch have landed
         __builtin_amdgcn_s_barrier();
         int ust = 0;                                         // weight stage of the current unit
@@ -165,13 +218,26 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
             static_for<0, 9>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 // after this wait + barrier the tiles of unit u+1 are resident too: what the previous D-2 units issued may stay in flight
-                wait_vmcnt<G::allowed_outstanding(t)>();
+                if constexpr (PRE) {
+                    if constexpr (t == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // next slab's patch fully written
+                    wait_vmcnt<G::allowed_outstanding_pre(t)>();
+                } else {
+                    wait_vmcnt<G::allowed_outstanding(t)>();
+                }
                 if (MODE != 5) __builtin_amdgcn_s_barrier();
                 constexpr int td = (t + D) % 9;
                 int std_ = ust + D;
                 std_ = std_ >= NSTW ? std_ - NSTW : std_;
                 issue_weights(std_, td, slab + (t + D) / 9);   // into the stage unit u-1 just released
-                static_for<0, G::patch_loads(t)>([&](auto pc) { issue_patch_piece(t * PPT + decltype(pc)::value, slab + 1, patch_next); });
+                if constexpr (PRE) {
+                    if constexpr (t == 0) pre_issue(slab + 1);
+                    if constexpr (t >= 2) {
+                        if constexpr (2 * (t - 2) < NPW) pre_commit(2 * (t - 2), slab + 1, patch_next);
+                        if constexpr (2 * (t - 2) + 1 < NPW) pre_commit(2 * (t - 2) + 1, slab + 1, patch_next);
+                    }
+                } else {
+                    static_for<0, G::patch_loads(t)>([&](auto pc) { issue_patch_piece(t * PPT + decltype(pc)::value, slab + 1, patch_next); });
+                }
                 ust = ust + 1 == NSTW ? 0 : ust + 1;
             });
         }
@@ -255,16 +321,16 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
     gemm_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0, lane, 0, zs);
 }
 
-template <int W_, int BN, int WGM, int WGN, int MODE>
+template <int W_, int BN, int WGM, int WGN, int MODE, bool PRE>
 __global__ __launch_bounds__(512) void conv3x3_kernel(GemmParams p) {
-    conv3x3_body<W_, BN, WGM, WGN, MODE>(p);
+    conv3x3_body<W_, BN, WGM, WGN, MODE, PRE>(p);
 }
 
-template <int W_, int BN, int WGM, int WGN, int MODE = 0>
+template <int W_, int BN, int WGM, int WGN, int MODE = 0, bool PRE = false>
 int launch3(osg_ctx* ctx, GemmParams& p) {
     constexpr size_t smem = Geo<W_, BN>::SMEM;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = conv3x3_kernel<W_, BN, WGM, WGN, MODE>;
+    auto kern = conv3x3_kernel<W_, BN, WGM, WGN, MODE, PRE>;
     static bool attr_set = false;
     if (!attr_set) {
         OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -279,7 +345,7 @@ int launch3(osg_ctx* ctx, GemmParams& p) {
 
 template <int W_>
 int launch3_bn(osg_ctx* ctx, GemmParams& p, int bn) {
-    if (W_ == 64 && bn == 80) {   // experiments (tools/gemm_probe.py): 1 = loads + barriers only, 2 = no global loads (compute on stale LDS)
+    if (W_ == 64 && bn == 80 && !p.pre_tab) {   // experiments (tools/gemm_probe.py): 1 = loads + barriers only, 2 = no global loads (compute on stale LDS)
         const char* e = getenv("OSG_CONV3X3_DBG");
         const int dbg = e ? atoi(e) : 0;
         if (dbg == 1) return launch3<64, 80, 4, 1, 1>(ctx, p);
@@ -288,12 +354,59 @@ int launch3_bn(osg_ctx* ctx, GemmParams& p, int bn) {
         if (dbg == 4) return launch3<64, 80, 4, 1, 4>(ctx, p);
         if (dbg == 5) return launch3<64, 80, 4, 1, 5>(ctx, p);
     }
+    if (p.pre_tab) {
+        if (bn == 80) return launch3<W_, 80, 4, 1, 0, true>(ctx, p);
+        if (bn == 160) return launch3<W_, 160, 2, 2, 0, true>(ctx, p);
+        return launch3<W_, 128, 2, 2, 0, true>(ctx, p);
+    }
     if (bn == 80) return launch3<W_, 80, 4, 1>(ctx, p);
     if (bn == 160) return launch3<W_, 160, 2, 2>(ctx, p);
     return launch3<W_, 128, 2, 2>(ctx, p);
 }
 
 }  // namespace
+
+int osg_gn_table(osg_ctx* ctx, const void* x, const void* gamma, const void* beta, int N, long HW, int C, int G, float eps, float** tab_out);
+
+int osg_conv3x3_supported(int N, int H, int W, int Cin, int Cout) {
+    if (!(W == 64 || W == 32 || W == 16 || W == 8)) return 0;
+    const int TI = W == 8 ? 2 : 1, TH = 128 / (W * TI);
+    if (H % TH || (W == 8 && H != 8)) return 0;
+    if (Cin % 64 || Cout % 4) return 0;
+    if ((double)N * H * W * Cin * 2.0 >= 2147483648.0 || (double)Cout * 9.0 * Cin * 2.0 >= 2147483648.0) return 0;
+    return 1;
+}
+
+extern "C" {
+
+int osg_group_norm_conv3x3_supported(int N, int H, int W, int Cin, int Cout) { return osg_conv3x3_supported(N, H, W, Cin, Cout); }
+
+// y = Conv3x3/s1/p1( act_pre( GroupNorm(x) ) ) (+bias, per-image bias, residual): the resnet block's  GroupNorm -> SiLU -> Conv
+// with the normalised activation never written to memory -- statistics + affine table (2 small launches), then the halo-reuse
+// convolution whose loader waves apply  act(x*ca[c] + cb[c])  to each input-patch pixel on its way into LDS (zero halo AFTER
+// the activation, as the reference pads the normalised tensor).  The f16 values the MFMAs read are exactly those the separate
+// osg_group_norm_nhwc would have stored.
+int osg_group_norm_conv3x3(osg_ctx* ctx, const void* x, const void* gamma, const void* beta, int groups, float eps, osg_act act_pre,
+                           const void* w_ohwi, const void* bias, osg_dtype bias_dtype, const void* image_bias, long image_bias_ld,
+                           const void* residual, void* y, int N, int H, int W, int Cin, int Cout) {
+    if (!osg_conv3x3_supported(N, H, W, Cin, Cout)) OSG_FAIL(ctx, "osg_group_norm_conv3x3: shape not supported (see osg_group_norm_conv3x3_supported)");
+    if (bias && bias_dtype != OSG_F16 && bias_dtype != OSG_F32) OSG_FAIL(ctx, "osg_group_norm_conv3x3: invalid bias dtype");
+    float* tab = nullptr;
+    if (osg_gn_table(ctx, x, gamma, beta, N, (long)H * W, Cin, groups, eps, &tab)) return 1;
+    GemmParams p{};
+    p.A = (const f16*)x; p.Bt = (const f16*)w_ohwi; p.C = (f16*)y; p.bias = bias; p.residual = (const f16*)residual;
+    p.M = N * H * W; p.N = Cout; p.K = 9 * Cin; p.lda = 0;
+    p.bias_f32 = bias_dtype == OSG_F32; p.act = OSG_ACT_NONE;
+    p.a_bytes_l = (long)N * H * W * Cin * 2;
+    p.rowbias = (const f16*)image_bias; p.rb_rows = H * W; p.rb_ld = image_bias_ld;
+    p.H = H; p.W = W; p.Cin = Cin; p.Ho = H; p.Wo = W; p.KW = 3; p.sh = 1; p.sw = 1; p.pt = 1; p.pl = 1;
+    p.pre_tab = tab; p.pre_act = (int)act_pre; p.pre_imgs = N;
+    const int rc = osg_conv3x3_run(ctx, p);
+    if (rc < 0) OSG_FAIL(ctx, "osg_group_norm_conv3x3: convolution shape rejected");
+    return rc;
+}
+
+}  // extern "C"
 
 // Shape gate + tile/split choice.  Model (cycles, calibrated like choose_v2 in osg_gemm.hip): a (slab, tap) unit costs
 // max(MFMA, bytes / 23 B/clk) with bytes = the weight tile + 1/9 of the patch; whole rounds of tiles over the CUs.

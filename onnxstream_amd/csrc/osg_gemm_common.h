@@ -26,6 +26,8 @@ struct GemmParams {
     long a_bytes_l;              // conv: byte size of the whole NHWC input (host side, before the 2 GiB check)
     int mt, nt, n_major;         // tile grid and the order tiles are walked inside an XCD's contiguous chunk
     int* tickets;                // split-K arrival counters (one per output tile), zero between launches
+    const float* pre_tab;        // osg_conv3x3.hip PRE variant: per-image affine table [n][2][Cin] (ca, cb) of a fused GroupNorm on the INPUT
+    int pre_act, pre_imgs;       //   activation applied after the affine (OSG_ACT_SILU), number of images
     float w_scale;               // W8 kernels (osg_gemm_w8.hip): Bt holds uint8 codes, w = (q - w_zp) * w_scale
     int w_zp;
 };
@@ -151,3 +153,4 @@ int launch_splitk_reduce(osg_ctx* ctx, const GemmParams& p, int batch);   // osg
 
 // osg_conv3x3.hip: halo-reuse 3x3 / stride 1 / pad 1 convolution.  Returns -1 when the shape is not one it takes.
 int osg_conv3x3_run(osg_ctx* ctx, osg_mm::GemmParams& p);
+int osg_conv3x3_supported(int N, int H, int W, int Cin, int Cout);

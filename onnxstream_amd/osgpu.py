@@ -25,7 +25,7 @@ EXPORTS = [
     "osg_malloc", "osg_free", "osg_upload", "osg_upload_sync", "osg_host_register", "osg_host_unregister", "osg_upload_pinned", "osg_download", "osg_copy", "osg_memset", "osg_sync",
     "osg_graph_begin", "osg_graph_end", "osg_graph_launch", "osg_graph_destroy", "osg_timer_start", "osg_timer_stop",
     "osg_conv2d_nhwc", "osg_conv2d_nhwc_rb", "osg_gemm", "osg_gemm_w8", "osg_conv2d_nhwc_w8", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided",
-    "osg_instance_norm", "osg_group_norm_nhwc", "osg_layer_norm", "osg_reduce_mean_last", "osg_softmax_last",
+    "osg_instance_norm", "osg_group_norm_nhwc", "osg_group_norm_conv3x3_supported", "osg_group_norm_conv3x3", "osg_layer_norm", "osg_reduce_mean_last", "osg_softmax_last",
     "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_resize_nearest", "osg_gather_rows",
     "osg_maxpool_nhwc", "osg_convert",
 ]
@@ -75,6 +75,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
                                           ci, cf]
     lib.osg_instance_norm.argtypes = [vp, ci, vp, vp, vp, vp, ci, cl, ci, cf]
     lib.osg_group_norm_nhwc.argtypes = [vp, ci, vp, vp, vp, vp, ci, cl, ci, ci, cf, ci]
+    lib.osg_group_norm_conv3x3_supported.argtypes = [ci] * 5
+    lib.osg_group_norm_conv3x3.argtypes = [vp, vp, vp, vp, ci, cf, ci, vp, vp, ci, vp, cl, vp, vp, ci, ci, ci, ci, ci]
     lib.osg_layer_norm.argtypes = [vp, ci, vp, vp, vp, vp, cl, ci, cf]
     lib.osg_reduce_mean_last.argtypes = [vp, ci, vp, vp, cl, cl]
     lib.osg_softmax_last.argtypes = [vp, ci, vp, vp, cl, cl]

@@ -163,6 +163,35 @@ def test_conv3x3_halo_kernel(gpu, N, H, Cin, Cout, bn, splits, monkeypatch):
     assert rel_max(got, want) <= 1e-3
 
 
+@pytest.mark.parametrize("N,H,Cin,Cout,bn,splits", [(2, 64, 64, 320, 80, 1), (1, 32, 128, 160, 160, 2), (2, 16, 192, 128, 128, 3),
+                                                    (2, 8, 128, 80, 80, 1), (3, 8, 64, 160, 160, 1), (2, 64, 320, 320, 0, 0)])
+def test_group_norm_conv3x3_fused(gpu, N, H, Cin, Cout, bn, splits, monkeypatch):
+    """GroupNorm(+SiLU) applied inside the convolution's tile loaders == osg_group_norm_nhwc followed by the convolution, BIT FOR BIT
+    (the loaders produce the very f16 values the separate kernel would have stored; zero halo after the activation)."""
+    if bn:
+        monkeypatch.setenv("OSG_CONV3X3_BN", str(bn))
+        monkeypatch.setenv("OSG_CONV3X3_SPLITS", str(splits))
+    rng = np.random.default_rng(N * 17 + H + Cin + Cout)
+    x = (rnd(rng, (N, H, H, Cin), 2.0).astype(f32) + 0.7).astype(f16)
+    gamma, beta = (1 + rnd(rng, (Cin,), 0.1).astype(f32)).astype(f16), rnd(rng, (Cin,), 0.1)
+    w = rnd(rng, (Cout, 3, 3, Cin), (9 * Cin) ** -0.5)
+    bias = rnd(rng, (Cout,), 0.1)
+    res = rnd(rng, (N, H, H, Cout))
+    G = 32
+    assert gpu.lib.osg_group_norm_conv3x3_supported(N, H, H, Cin, Cout) == 1
+    dx, dg, db, dw, dbias, dres = (gpu.to_dev(t) for t in (x, gamma, beta, w, bias, res))
+    yn = gpu.empty((N, H, H, Cin), f16)
+    gpu._ck(gpu.lib.osg_group_norm_nhwc(gpu.ctx, 2, dx.ptr, dg.ptr, db.ptr, yn.ptr, N, H * H, Cin, G, 1e-5, 1))
+    want = gpu.conv2d_nhwc(yn, dw, dbias, 1, (1, 1, 1, 1), dres).numpy()
+    y = gpu.empty((N, H, H, Cout), f16)
+    gpu._ck(gpu.lib.osg_group_norm_conv3x3(gpu.ctx, dx.ptr, dg.ptr, db.ptr, G, 1e-5, 1, dw.ptr, dbias.ptr, 2, None, 0, dres.ptr, y.ptr, N, H, H,
+                                           Cin, Cout))
+    assert np.array_equal(y.numpy(), want)
+    # and against the numpy restatement of the reference ops
+    ref_y = ref.conv2d_nhwc(ref.group_norm_nhwc_exact(x, gamma, beta, G, 1e-5, silu_act=True), w, bias, (1, 1), (1, 1, 1, 1), res)
+    assert rel_max(y.numpy(), ref_y) <= 2e-3
+
+
 def test_conv_linearity_full_size(gpu):
     """Size-independent property at SD1.5 full size: conv(a*x) + conv(b*y) == conv(a*x + b*y) up to f16 rounding."""
     rng = np.random.default_rng(11)
