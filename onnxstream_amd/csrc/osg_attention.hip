@@ -15,6 +15,7 @@
 //   between lanes.  The O^T layout gives each lane 4 consecutive d of one query row: 8-byte stores.
 // Head dims are zero-padded in LDS/registers to a multiple of 32 (QK^T) / 16 (PV): 40->64/48, 80->96/80, 160->160.
 #include "osg_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -81,24 +82,46 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     }
 
     const int dchunks = D / 8;
-    for (int kv0 = 0; kv0 < p.Tkv; kv0 += BKV) {
-        __syncthreads();  // previous tile fully consumed (also orders the initial zero fill)
-        // ---- stage K (natural [kv][d]) and V (transposed [d][kv]); lane = kv row, waves stride over d-chunks ----
-        {
-            const int kv = kv0 + lane;
-            const bool ok = kv < p.Tkv;
-            for (int dc = wave; dc < dchunks; dc += 4) {
-                f16x8 kvv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (ok) {
-                    kvv = *reinterpret_cast<const f16x8*>(K + (long)kv * p.k_tok + dc * 8);
-                    vv = *reinterpret_cast<const f16x8*>(V + (long)kv * p.v_tok + dc * 8);
-                }
-                *reinterpret_cast<f16x8*>(&Ks[lane * KLD + dc * 8]) = kvv;
+    // K/V staging: lane = kv row of the tile, the 4 waves stride over the 16-byte d-chunks.  The NEXT tile's global loads are issued
+    // into registers BEFORE this tile's MFMAs and written to LDS after them, so their latency hides behind the math.
+    constexpr int NCH = (DP / 8 + 3) / 4;            // d-chunks per wave (upper bound)
+    f16x8 kreg[NCH], vreg[NCH];
+    // loads are UNCONDITIONAL (row / chunk clamped into range) and the out-of-range zeroing happens at store time: a predicated load
+    // makes hipcc wait for it right after the issue (it needs the value for the select), which serialises the prefetch
+    bool tile_ok = false;
+    auto load_tile = [&](int kv0) {
+        const int kv = kv0 + lane;
+        tile_ok = kv < p.Tkv;
+        const long krow = (long)(tile_ok ? kv : p.Tkv - 1) * p.k_tok, vrow = (long)(tile_ok ? kv : p.Tkv - 1) * p.v_tok;
 #pragma unroll
-                for (int e = 0; e < 8; e++) Vt[(dc * 8 + e) * VLD + lane] = vv[e];
+        for (int c = 0; c < NCH; c++) {
+            const int dc = min(wave + c * 4, dchunks - 1);
+            kreg[c] = *reinterpret_cast<const f16x8*>(K + krow + dc * 8);
+            vreg[c] = *reinterpret_cast<const f16x8*>(V + vrow + dc * 8);
+        }
+    };
+    // V^T columns are stored PERMUTED inside each 32-wide block -- kv = t*16 + g*4 + r  ->  st*32 + g*8 + (t&1)*4 + r -- which is the
+    // order a lane's 8 probabilities come out of the S^T tiles, so the PV operand is ONE ds_read_b128 (no register shuffling)
+    const int vcol = ((lane >> 5) << 5) + (((lane >> 2) & 3) << 3) + (((lane >> 4) & 1) << 2) + (lane & 3);
+    auto store_tile = [&]() {
+        const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int dc = wave + c * 4;
+            if (dc < dchunks) {
+                const f16x8 kv8 = tile_ok ? kreg[c] : zero, vv8 = tile_ok ? vreg[c] : zero;
+                *reinterpret_cast<f16x8*>(&Ks[lane * KLD + dc * 8]) = kv8;
+#pragma unroll
+                for (int e = 0; e < 8; e++) Vt[(dc * 8 + e) * VLD + vcol] = vv8[e];
             }
         }
+    };
+    load_tile(0);
+    for (int kv0 = 0; kv0 < p.Tkv; kv0 += BKV) {
+        __syncthreads();  // previous tile fully consumed (also orders the initial zero fill)
+        store_tile();
         __syncthreads();
+        if (kv0 + BKV < p.Tkv) load_tile(kv0 + BKV);   // in flight during the MFMAs / softmax below
 
         // ---- S^T = K Q^T -------------------------------------------------------------------------------
         f32x4 s[QT][4];
@@ -116,30 +139,42 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
             }
         }
 
-        // ---- online softmax (log2 domain) ----------------------------------------------------------------
+        // ---- online softmax (log2 domain).  The kernel is VALU-bound here (28 MFMAs vs ~300 vector ops per tile and wave), so the
+        // per-score work is kept to max / fma / v_exp_f32 / add: the scale rides in the fma (scores stay raw, max is tracked raw),
+        // the kv-bound mask only exists on the last, partial tile, and exp2 is the bare hardware op (arguments are <= 0).
+        const bool full = kv0 + BKV <= p.Tkv;
+        const float c = p.scale_log2e;
         f16x8 pf[QT][2];
 #pragma unroll
         for (int qt = 0; qt < QT; qt++) {
             float mx = -INFINITY;
+            if (full) {
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+                for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int kv = kv0 + t * 16 + g * 4 + r;
-                    float x = kv < p.Tkv ? s[qt][t][r] * p.scale_log2e : -INFINITY;
-                    s[qt][t][r] = x;
-                    mx = fmaxf(mx, x);
-                }
+                    for (int r = 0; r < 4; r++) mx = fmaxf(mx, s[qt][t][r]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int kv = kv0 + t * 16 + g * 4 + r;
+                        const float x = kv < p.Tkv ? s[qt][t][r] : -INFINITY;
+                        s[qt][t][r] = x;
+                        mx = fmaxf(mx, x);
+                    }
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run[qt], mx);
-            const float alpha = exp2f(m_run[qt] - m_new);
+            const float m_new = fmaxf(m_run[qt], mx);             // raw (unscaled) running max; scale > 0
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * c);
+            const float mc = -m_new * c;
             float sum = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; t++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    float e = exp2f(s[qt][t][r] - m_new);
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[qt][t][r], c, mc));
                     s[qt][t][r] = e;
                     sum += e;
                 }
@@ -168,10 +203,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         for (int dt = 0; dt < DT; dt++) {
 #pragma unroll
             for (int st = 0; st < 2; st++) {
-                const f16* vrow = &Vt[(dt * 16 + lq) * VLD + st * 32 + g * 4];
-                f16x4 lo = *reinterpret_cast<const f16x4*>(vrow);
-                f16x4 hi = *reinterpret_cast<const f16x4*>(vrow + 16);
-                f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const f16x8 vf = *reinterpret_cast<const f16x8*>(&Vt[(dt * 16 + lq) * VLD + st * 32 + g * 8]);
 #pragma unroll
                 for (int qt = 0; qt < QT; qt++)
                     oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][st], oacc[qt][dt], 0, 0, 0);
@@ -199,7 +231,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 
 template <int DP, int DT>
 int launch_attn(osg_ctx* ctx, const AttnParams& p, int batch) {
-    if (p.Tq >= 1024) {
+    static const int force_qt = getenv("OSG_ATTN_QT") ? atoi(getenv("OSG_ATTN_QT")) : 0;
+    // 128 query rows per workgroup halve the K/V staging per row, but only pay when the grid still has >= 2 workgroups per CU
+    const long blocks128 = (long)((p.Tq + 127) / 128) * batch * p.heads;
+    if (p.Tq >= 1024 && force_qt != 1 && (blocks128 >= 2L * ctx->num_cu || force_qt == 2)) {
         dim3 grid((p.Tq + 127) / 128, batch * p.heads);
         hipLaunchKernelGGL((attn_kernel<DP, DT, 2>), grid, dim3(256), 0, ctx->compute, p);
     } else {
@@ -219,6 +254,7 @@ int osg_attention_strided(osg_ctx* ctx, osg_dtype dtype, const void* q, long q_t
                           long o_head, long o_batch, int batch, int heads, int Tq, int Tkv, int D, float scale) {
     if (dtype != OSG_F16) OSG_FAIL(ctx, "osg_attention: only f16 arithmetic is implemented on the device");
     if (batch <= 0 || heads <= 0 || Tq <= 0 || Tkv <= 0 || D <= 0) OSG_FAIL(ctx, "osg_attention: invalid shape(s) of q, k and/or v");
+    if (!(scale > 0.f)) OSG_FAIL(ctx, "osg_attention: the fused kernel tracks the row maximum of the raw scores and needs scale > 0");
     if (D % 8) OSG_FAIL(ctx, "osg_attention: head dim must be a multiple of 8");
     if ((q_tok | q_head | q_batch | k_tok | k_head | k_batch | v_tok | v_head | v_batch) % 8 || (o_tok | o_head | o_batch) % 4)
         OSG_FAIL(ctx, "osg_attention: strides must keep 16-byte (q,k,v) / 8-byte (o) alignment");
