@@ -218,6 +218,129 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+// ---- GroupNorm, one launch: block (gblk, n) owns `gb` whole groups (= CW contiguous channels, CW % 8 == 0) of one image and keeps its
+// [HW x CW] slab in registers between the statistics and the apply: x is read once, y written once, no workspace, no second launch.
+// The UNet's 8x8 / 16x16 / 32x32 levels (45 of SD1.5's 61 GroupNorms) are launch-latency bound, not bandwidth bound, and run this way;
+// larger slabs use the three-pass path below.  Thread t keeps ONE vector column (8 channels => at most two groups when cpg >= 8).
+template <int NV>
+__global__ __launch_bounds__(1024) void gn_slab_kernel(const f16* __restrict__ x, const f16* __restrict__ gamma, const f16* __restrict__ beta,
+                                                       f16* __restrict__ y, int HW, int C, int cpg, int gb, float eps, int act) {
+    __shared__ float red[8][16][2];   // [local group][wave][sum, sumsq]
+    __shared__ float stat[8][2];      // [local group][mean, rstd]
+    const int NT = blockDim.x, nw = NT >> 6;
+    const int CW = gb * cpg, VR = CW >> 3, RT = NT / VR;
+    const int t = threadIdx.x, tr = t / VR, tc = t - tr * VR;
+    const bool active = tr < RT;
+    const int ch = blockIdx.x * CW + tc * 8;                 // first of this thread's 8 channels
+    const long img = (long)blockIdx.y * HW * C + blockIdx.x * CW;   // uniform base; per-thread offsets stay 32-bit (scalar base + voffset loads)
+    const f16* xb = x + img;
+    f16* yb = y + img;
+    const unsigned off0 = (unsigned)tr * C + tc * 8, step = (unsigned)RT * C;
+    f16x8 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int row = tr + j * RT;
+        if (active && row < HW) v[j] = *reinterpret_cast<const f16x8*>(xb + (off0 + j * step));
+        else v[j] = (f16x8)(f16)0;
+    }
+    float sm[8], sq[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) sm[e] = sq[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; j++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float f = (float)v[j][e];
+            sm[e] += f;
+            sq[e] = fmaf(f, f, sq[e]);
+        }
+    // keep the slab PACKED (f16) across the reduction: without this the compiler holds the converted f32 copies live (2x the registers)
+#pragma unroll
+    for (int j = 0; j < NV; j++) asm volatile("" : "+v"(v[j]));
+    // elements [0, esplit) belong to local group g0, the rest to g0 + 1
+    const int g0 = (tc * 8) / cpg;
+    const int esplit = (g0 + 1) * cpg - tc * 8;
+    float as = 0.f, aq = 0.f, bs = 0.f, bq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        if (e < esplit) { as += sm[e]; aq += sq[e]; }
+        else            { bs += sm[e]; bq += sq[e]; }
+    }
+    // deterministic block reduction per local group: xor-shuffle tree inside a wave, then a fixed-order sum over the waves
+    const int lane = t & 63, wave = t >> 6;
+    for (int gl = 0; gl < gb; gl++) {
+        float s = active ? (g0 == gl ? as : (g0 + 1 == gl ? bs : 0.f)) : 0.f;
+        float q = active ? (g0 == gl ? aq : (g0 + 1 == gl ? bq : 0.f)) : 0.f;
+        s = wave_sum(s);
+        q = wave_sum(q);
+        if (lane == 0) { red[gl][wave][0] = s; red[gl][wave][1] = q; }
+    }
+    __syncthreads();
+    if (t < gb) {
+        double s = 0, q = 0;
+        for (int w = 0; w < nw; w++) { s += red[t][w][0]; q += red[t][w][1]; }
+        const double cnt = (double)HW * cpg;
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0) var = 0;
+        stat[t][0] = (float)mean;
+        stat[t][1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    if (!active) return;
+    float ca[8], cb[8];
+    {
+        const f16x8 ga = *reinterpret_cast<const f16x8*>(gamma + ch);
+        const f16x8 be = *reinterpret_cast<const f16x8*>(beta + ch);
+        const float m0 = stat[g0][0], r0 = stat[g0][1];
+        const int g1 = g0 + 1 < gb ? g0 + 1 : g0;
+        const float m1 = stat[g1][0], r1 = stat[g1][1];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float a = (e < esplit ? r0 : r1) * (float)ga[e];
+            ca[e] = a;
+            cb[e] = (float)be[e] - (e < esplit ? m0 : m1) * a;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+        const int row = tr + j * RT;
+        if (row < HW) {
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = (f16)osg_apply_act(fmaf((float)v[j][e], ca[e], cb[e]), act);
+            *reinterpret_cast<f16x8*>(yb + (off0 + j * step)) = o;
+        }
+    }
+}
+
+// launch plan of the slab kernel: groups per block (smallest gb with gb*cpg % 8 == 0), threads, vectors per thread; false => three-pass path
+struct GnSlabPlan { int gb, nt, nv; };
+bool gn_slab_plan(long HW, int C, int G, GnSlabPlan* pl) {
+    const bool off = getenv("OSG_GN_SLAB_OFF") != nullptr;  // (tests: pin the three-pass statistics)
+    if (off || G <= 0 || C % G || C % 8) return false;
+    const int cpg = C / G;
+    if (cpg < 8) return false;
+    int gb = 1;
+    while (gb <= 8 && ((gb * cpg) % 8 || G % gb)) gb++;
+    if (gb > 8) return false;
+    const int VR = gb * cpg / 8;
+    if (VR > 128 || HW > (1 << 20)) return false;
+    for (int nt = 256; nt <= 1024; nt *= 2) {
+        const int RT = nt / VR;
+        if (RT < 1) continue;
+        const long need = (HW + RT - 1) / RT;
+        const long cap = nt < 1024 ? 4 : 8;   // (16 vectors per thread spills and is no faster than the three-pass path)
+        if (need <= cap) {
+            int nv = 1;
+            while (nv < need) nv *= 2;
+            *pl = {gb, nt, nv};
+            return true;
+        }
+    }
+    return false;
+}
+
 // ---- LayerNorm over the last axis: one wave per row, row cached in registers (C <= 64*8*MAXV) --------------------
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void layer_norm_kernel(const T* __restrict__ x, const T* __restrict__ gamma, const T* __restrict__ beta,
@@ -369,6 +492,22 @@ int osg_group_norm_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void
     const int V = dtype == OSG_F16 ? 8 : 4;
     if (dtype != OSG_F16 && dtype != OSG_F32) OSG_FAIL(ctx, "osg_group_norm_nhwc: unsupported dtype");
     if (C % V) OSG_FAIL(ctx, "osg_group_norm_nhwc: C must be a multiple of the 16-byte vector width");
+    GnSlabPlan sp;
+    if (dtype == OSG_F16 && gn_slab_plan(HW, C, G, &sp)) {
+        const dim3 grid(G / sp.gb, N), block(sp.nt);
+#define OSG_GN_SLAB(NV_)                                                                                                             \
+    hipLaunchKernelGGL(gn_slab_kernel<NV_>, grid, block, 0, ctx->compute, (const f16*)x, (const f16*)gamma, (const f16*)beta, (f16*)y, \
+                       (int)HW, C, C / G, sp.gb, eps, (int)act)
+        switch (sp.nv) {
+            case 1: OSG_GN_SLAB(1); break;
+            case 2: OSG_GN_SLAB(2); break;
+            case 4: OSG_GN_SLAB(4); break;
+            default: OSG_GN_SLAB(8); break;
+        }
+#undef OSG_GN_SLAB
+        OSG_LAUNCH_CHECK(ctx);
+        return 0;
+    }
     // slabs of >= ~8 pixel rows per sweep-row, at most 64 per image (the apply pass folds S partials per group)
     const int cols = C / V < 256 ? C / V : 256;
     const int Rr = 256 / cols;

@@ -149,6 +149,7 @@ def test_conv2d(gpu, N, H, W, Cin, Cout, k, stride, pad):
 def test_conv3x3_halo_kernel(gpu, N, H, Cin, Cout, bn, splits, monkeypatch):
     """The halo-reuse 3x3 kernel (osg_conv3x3.hip) at every tile geometry (W = 64/32/16/8), channel tile and split-K setting,
     incl. partial tiles (1 image of 8x8 = 64 pixels; 3 images of 8x8), bias + per-image bias + residual epilogue."""
+    monkeypatch.setenv("OSG_GN_SLAB_OFF", "1")   # the fused path takes its statistics from the three-pass kernels: compare like with like
     if bn:
         monkeypatch.setenv("OSG_CONV3X3_BN", str(bn))
         monkeypatch.setenv("OSG_CONV3X3_SPLITS", str(splits))
@@ -257,7 +258,10 @@ def test_instance_norm(gpu, rows, L):
     assert rel_max(got, want) <= 1e-3
 
 
-@pytest.mark.parametrize("N,H,W,C,act", [(2, 64, 64, 320, 1), (1, 8, 8, 2560, 0), (2, 16, 16, 1280, 1), (1, 5, 3, 64, 0)])
+@pytest.mark.parametrize("N,H,W,C,act", [(2, 64, 64, 320, 1), (1, 8, 8, 2560, 0), (2, 16, 16, 1280, 1), (1, 5, 3, 64, 0),
+                                         # single-launch slab kernel: every vectors-per-thread instantiation, ragged HW, groups straddling a vector
+                                         (2, 32, 32, 640, 1), (2, 32, 32, 1920, 1), (1, 32, 32, 960, 0), (2, 16, 16, 2560, 1), (2, 8, 8, 1280, 1),
+                                         (1, 7, 9, 320, 1), (1, 3, 3, 256, 0), (1, 16, 16, 1920, 0), (3, 1, 1, 384, 1)])
 def test_group_norm_nhwc(gpu, N, H, W, C, act):
     rng = np.random.default_rng(C + H)
     x = rnd(rng, (N, H, W, C), 1.5) + f16(0.3)
