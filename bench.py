@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--cpu-passes", type=int, default=4, help="reference CPU passes in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--profile-reps", type=int, default=3)
     ap.add_argument("--steps-per-image", type=int, default=0, help="denoising steps per image (default 20; BASELINE config 4 = SDXL uses 10)")
+    ap.add_argument("--host-loop", action="store_true", help="pipeline mode: CFG + Euler-A on the host with one round trip per step (the reference app's shape) instead of the device loop")
     ap.add_argument("--prompts-per-gpu", type=int, default=1, help="prompts denoised together on each GPU (2P samples per UNet pass: the reference's --num batching)")
     ap.add_argument("--w8-resident", action="store_true", help="with --quant-weights: keep the codes resident and dequantise on chip (osg_*_w8 kernels)")
     ap.add_argument("--quant-weights", action="store_true", help="W8A16: uint8 weights + scale/zero-point in model.txt, dequantised at load")
@@ -190,28 +191,50 @@ def main():
     rng = np.random.default_rng(1234 + rank)
     state = {"x": rng.standard_normal(lat_shape, dtype=np.float32) * sig[0], "i": 0, "images": 0, "last": None}
 
-    def one_step():
-        """One denoising step of the 20-step loop (UNet over cond+uncond as one batch-2 pass, CFG combine, Euler-Ancestral update on
-        the host exactly as the reference app does); after the 20th step of an image: VAE decode, then a fresh latent."""
-        i = state["i"]
-        x = state["x"]
-        if args.mode == "replay":
-            m.hip_replay(1)
-            state["i"] = (i + 1) % STEPS_PER_IMAGE
-            return
-        den = pipe.denoise(x, float(sig[i]), ctx_cs, ctx_us, extra_cond=ex_c, extra_uncond=ex_u)
-        s_i, s_n = np.float64(sig[i]), np.float64(sig[i + 1])
-        s_up = min(s_n, abs(s_n * np.sqrt(s_i * s_i - s_n * s_n) / s_i))
-        s_down = np.float32(np.sqrt(s_n * s_n - s_up * s_up))
-        x = ((x - den) * np.float32(s_down / np.float32(s_i)) + den + rng.standard_normal(lat_shape, dtype=np.float32) * np.float32(s_up)).astype(np.float32)
-        # random-weight UNets do not denoise (|x| would grow without bound over 20 CFG-7 steps): clamp to the scale a real trajectory has
-        x = np.clip(x, -4.0 * max(float(s_n), 1.0), 4.0 * max(float(s_n), 1.0))
-        if i + 1 == STEPS_PER_IMAGE:
-            if pipe.vae is not None:
-                state["last"] = pipe.decode(x)
-            state["images"] += P
-            x = rng.standard_normal(lat_shape, dtype=np.float32) * sig[0]
-        state["x"], state["i"] = x, (i + 1) % STEPS_PER_IMAGE
+    host_loop = args.host_loop
+    scal = pipe.loop_scalars(sig)
+    # random-weight UNets do not denoise (|x| would grow without bound over 20 CFG-7 steps): clamp to the scale a real trajectory has
+    clip = np.asarray([4.0 * max(float(sig[i + 1]), 1.0) for i in range(STEPS_PER_IMAGE)], np.float32)
+    n_names = pipe.names
+
+    def end_of_image(x):
+        if pipe.vae is not None:
+            state["last"] = pipe.decode(x)
+        state["images"] += P
+        return rng.standard_normal(lat_shape, dtype=np.float32) * sig[0]
+
+    def run_steps(k):
+        """k denoising steps of the 20-step loop: per step the UNet over cond+uncond as one batch-2P pass, the CFG combine and the
+        Euler-Ancestral update; after the 20th step of an image the VAE decode, then a fresh latent.  Default: the loop runs on the
+        device (Model.hip_sampler_loop: scaling kernel -> captured pass -> CFG/Euler-A kernel per step, one host sync per image);
+        --host-loop: sampler arithmetic on the host exactly as the reference app does (one upload/sync/download per step).
+        Returns the device ms spent in the steps."""
+        dev = 0.0
+        while k > 0:
+            i = state["i"]
+            if args.mode == "replay":
+                m.hip_replay(1)
+                dev += m.hip_last_pass_ms()
+                state["i"] = (i + 1) % STEPS_PER_IMAGE
+                k -= 1
+                continue
+            if host_loop:
+                x = state["x"]
+                den = pipe.denoise(x, float(sig[i]), ctx_cs, ctx_us, extra_cond=ex_c, extra_uncond=ex_u)
+                dev += m.hip_last_pass_ms()
+                x = ((x - den) * scal[3][i] + den + rng.standard_normal(lat_shape, dtype=np.float32) * scal[4][i]).astype(np.float32)
+                x = np.clip(x, -clip[i], clip[i])
+                n = 1
+            else:
+                n = min(k, STEPS_PER_IMAGE - i)
+                x = np.ascontiguousarray(state["x"], np.float32)
+                noise = rng.standard_normal((n,) + lat_shape, dtype=np.float32)
+                dev += m.hip_sampler_loop(n_names["sample"], n_names["timestep"], n_names["out"], x, noise, *[a[i:i + n] for a in scal], 7.0, clip[i:i + n])
+            if i + n == STEPS_PER_IMAGE:
+                x = end_of_image(x)
+            state["x"], state["i"] = x, (i + n) % STEPS_PER_IMAGE
+            k -= n
+        return dev
 
     # plan + eager pass (weights become resident), hipGraph capture, and the VAE's plan/capture: all before the timed region
     if args.mode == "replay":
@@ -236,16 +259,12 @@ def main():
         + (f", VAE {vae_kernels} launches ({pipe.vae.hip_last_pass_ms():.3f} ms device)" if pipe.vae is not None else ""))
 
     # ---- warmup, then EXACTLY K timed steps ---------------------------------------------------------------------------
-    for _ in range(args.warmup):
-        one_step()
+    run_steps(args.warmup)
     state["i"], state["images"] = 0, 0           # the timed region starts at the first step of an image
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    dev_acc = 0.0
-    for _ in range(args.steps):
-        one_step()
-        dev_acc += m.hip_last_pass_ms()
+    dev_acc = run_steps(args.steps)
     torch.cuda.synchronize()
     barrier()
     wall = time.perf_counter() - t0
@@ -312,11 +331,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": (f"{cfg.name} {8 * cfg.latent}x{8 * cfg.latent} {STEPS_PER_IMAGE}-step txt2img ({'W8A16' if args.quant_weights else 'W16A16'}): per step the UNet over cond+uncond (2x4x{cfg.latent}x{cfg.latent} latents, ctx 77x{cfg.ctx_dim}) "
-                                    f"as one batch-2 pass + CFG 7 + Euler-Ancestral update, VAE decode after the last step of every image (inside the timed region), "
+                                    f"as one batch-2 pass + CFG 7 + Euler-Ancestral update ({'on the host, one round trip per step' if args.host_loop else 'on the device, one host sync per image'}), VAE decode after the last step of every image (inside the timed region), "
                                     f"weights resident; ms_per_step = wall / K with the decode amortised; images/s = gpus x prompts_per_gpu / (steps_per_image x ms_per_step)")
                                    if vae_dir else (f"{cfg.name} UNet denoising step: cond+uncond 2x4x{cfg.latent}x{cfg.latent} latents, W16A16, "
                                                     f"weights resident, mode={args.mode}; NO VAE decode"),
-                       "mode": args.mode, "vae_decode_in_timed_region": bool(vae_dir), "images_completed": state["images"],
+                       "mode": args.mode, "sampler": "host" if args.host_loop else "device", "vae_decode_in_timed_region": bool(vae_dir), "images_completed": state["images"],
                        "prompts_per_gpu": P, "unet_passes_per_step": 2 * P, "steps_per_image": STEPS_PER_IMAGE, "launches_per_step": kernels,
                        "vae_launches": vae_kernels, "fusion_level": args.fusion, "unet_device_ms_per_step": round(dev_ms, 4),
                        "parallelism": f"replica x{world}"},

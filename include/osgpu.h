@@ -177,6 +177,19 @@ int osg_binary(osg_ctx* ctx, osg_dtype dtype, osg_binary_kind kind, const void* 
 /* GEGLU: x:[rows,2C] -> y:[rows,C] = x[:, :C] * gelu_erf(x[:, C:]) (Slice,Slice,Div,Erf,Add,Mul,Mul,Mul). */
 int osg_geglu(osg_ctx* ctx, osg_dtype dtype, const void* x, void* y, long rows, long C);
 
+/* ---- denoising-loop glue on the device -------------------------------------------------------- */
+/* CFGDenoiser input side (src/sd.cpp:1427-1470): sample[2p] = sample[2p+1] = x[p] * c_in for p < prompts (L floats each, fp32);
+ * timestep[0 .. 2*prompts*t_per_sample) = t.  x, sample, timestep are DEVICE fp32 buffers (the plan's input staging). */
+int osg_sampler_prepare(osg_ctx* ctx, const float* x, float* sample, float* timestep, int prompts, long L, float c_in, float t,
+                        long t_per_sample);
+/* One Euler-Ancestral step with the CFG combine (src/sd.cpp:1545-1556, src/samplers.h:1430-1472), in place on x:[prompts,L]:
+ *   den_c = eps[2p]*c_out + x;  den_u = eps[2p+1]*c_out + x;  den = den_u + guidance*(den_c - den_u);
+ *   x = (x - den)*k_down + den + noise*k_up        (k_down = sigma_down/sigma_i, k_up = sigma_up; noise may be NULL: term skipped)
+ * every product and sum rounded separately to fp32, i.e. bit-identical to the host loop.  clip > 0 additionally clamps the new x to
+ * [-clip, clip] (not in the reference; used with random-weight synthetic UNets, which do not denoise, to keep the trajectory finite). */
+int osg_sampler_cfg_euler_a(osg_ctx* ctx, float* x, const float* eps, const float* noise, int prompts, long L, float c_out,
+                            float guidance, float k_down, float k_up, float clip);
+
 /* ---- data movement ------------------------------------------------------------------------------------------ */
 /* N-d transpose (XnnPack::transpose, onnxstream.cpp:1748): out.shape[i] = shape[perm[i]]. elem_size in {1,2,4,8}. */
 int osg_transpose(osg_ctx* ctx, int elem_size, const void* x, void* y, int rank, const long* shape, const int* perm);

@@ -168,6 +168,40 @@ class Model:
         self._err(f(self._h, n, None))
         return self.hip_last_pass_ms()
 
+    def hip_set_input(self, name: str, index: int, data):
+        """Overwrite pushed sample `index` of a graph input that is resident from an earlier run() (no pass is executed)."""
+        import numpy as np
+        f = self._lib.model_hip_set_input
+        f.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_float), ctypes.c_ulonglong]
+        f.restype = ctypes.c_void_p
+        a = np.ascontiguousarray(data, np.float32)
+        self._err(f(self._h, self._name(name), index, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), a.size))
+
+    def hip_sampler_loop(self, sample: str, timestep: str, out: str, x, noise, c_in, c_out, t, k_down, k_up, guidance: float = 7.0, clip=None) -> float:
+        """The denoising loop (CFG combine + Euler-Ancestral update) enqueued on the device, one host sync at the end.
+        x: float32 [prompts, ...] (updated IN PLACE); noise: float32 [steps, prompts, ...] or None; the per-step scalar arrays have
+        `steps` float32 entries.  The plan must have been built by a run() with 2*prompts pushes.  Returns the loop's device ms."""
+        import numpy as np
+        f = self._lib.model_hip_sampler_loop
+        fp = ctypes.POINTER(ctypes.c_float)
+        f.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp, fp, fp,
+                      ctypes.c_float, fp, ctypes.POINTER(ctypes.c_double)]
+        f.restype = ctypes.c_void_p
+        assert x.dtype == np.float32 and x.flags.c_contiguous
+        arrs = [np.ascontiguousarray(a, np.float32) for a in (c_in, c_out, t, k_down, k_up)]
+        steps = len(arrs[0])
+        if noise is not None:
+            noise = np.ascontiguousarray(noise, np.float32)
+            assert noise.size == steps * x.size
+        if clip is not None:
+            clip = np.ascontiguousarray(clip, np.float32)
+            assert clip.size == steps
+        ms = ctypes.c_double(0)
+        self._err(f(self._h, self._name(sample), self._name(timestep), self._name(out), steps, x.shape[0], x.ctypes.data_as(fp),
+                    noise.ctypes.data_as(fp) if noise is not None else None, *[a.ctypes.data_as(fp) for a in arrs], guidance,
+                    clip.ctypes.data_as(fp) if clip is not None else None, ctypes.byref(ms)))
+        return ms.value
+
     def hip_profile(self, reps: int = 1):
         """Eager pass with HIP events around every step -> list of (ms, flops, bytes, what)."""
         f = self._lib.model_hip_profile

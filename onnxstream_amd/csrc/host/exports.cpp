@@ -260,6 +260,29 @@ char* model_hip_replay(Handle* h, int n, float* ms_each) {
         return dup_cstr(e.what());
     }
 }
+// refresh sample `index` of a resident graph input (fp32, `count` elements) without running a pass
+char* model_hip_set_input(Handle* h, char* name, long long index, const float* data, unsigned long long count) {
+    try {
+        h->model.hip_set_input(name, (long)index, data, (size_t)count);
+        return nullptr;
+    } catch (const std::exception& e) {
+        return dup_cstr(e.what());
+    }
+}
+// the reference app's denoising loop (CFG combine + Euler-Ancestral, src/sd.cpp:1397-1559, src/samplers.h:1430-1472) enqueued on the device
+// without per-step host round trips.  x:[prompts,L] fp32 is updated in place; noise:[steps,prompts,L]; the five per-step scalar arrays
+// have `steps` entries; clip (may be NULL) is a sixth: per-step clamp of the new latents, 0 = none.  *ms (may be NULL) receives the device time of the loop.
+char* model_hip_sampler_loop(Handle* h, char* sample_name, char* timestep_name, char* out_name, int steps, int prompts, float* x, const float* noise,
+                             const float* c_in, const float* c_out, const float* t, const float* k_down, const float* k_up, float guidance, const float* clip,
+                             double* ms) {
+    try {
+        const double v = h->model.hip_sampler_loop(sample_name, timestep_name, out_name, steps, prompts, x, noise, c_in, c_out, t, k_down, k_up, guidance, clip);
+        if (ms) *ms = v;
+        return nullptr;
+    } catch (const std::exception& e) {
+        return dup_cstr(e.what());
+    }
+}
 // per-step timing report (malloc'ed text, free with model_free_buffer); on error the text starts with "ERROR: "
 char* model_hip_profile(Handle* h, int reps) {
     try {

@@ -1867,6 +1867,8 @@ Plan::~Plan() {
     be.api.osg_sync(be.ctx);
     for (auto& kv : registered) be.api.osg_host_unregister(be.ctx, (void*)kv.first);
     if (graph) be.api.osg_graph_destroy(graph);
+    if (samp_x) be.api.osg_free(be.ctx, samp_x);
+    if (samp_noise) be.api.osg_free(be.ctx, samp_noise);
     delete lowering;
     for (void* p : owned) be.free(p);
     if (arena) be.free(arena);
@@ -2161,6 +2163,69 @@ void Plan::replay(int n, float* ms_each) {
         ms_each[i] = ms;
         m_last_ms = ms;
     }
+}
+
+void Plan::set_input(const std::string& name, long index, const float* data, size_t count) {
+    for (auto& in : inputs)
+        if (in.name == name) {
+            const size_t per = (size_t)vals[in.staging].numel();
+            if (count != per) throw std::invalid_argument("Model::get_tensor_data: mismatch between tensor shape and data size.");
+            if (index < 0 || index >= N) throw std::invalid_argument("Model::hip_set_input: sample index out of range.");
+            be.check(be.api.osg_upload(be.ctx, (char*)ptr(in.staging) + index * per * sizeof(float), data, per * sizeof(float)), "osg_upload");
+            return;
+        }
+    throw std::invalid_argument("Model::get_tensor_data: input tensor not found: " + name);
+}
+
+double Plan::sampler_loop(const std::string& sample_name, const std::string& timestep_name, const std::string& out_name, int n_steps, int prompts,
+                          float* x, const float* noise, const float* c_in, const float* c_out, const float* t, const float* k_down,
+                          const float* k_up, float guidance, const float* clip) {
+    if (runs < 1) throw std::runtime_error("Model::hip_sampler_loop: run() once first (the context inputs must be resident).");
+    if (stream_weights) throw std::runtime_error("Model::hip_sampler_loop: not available in streamed-weights mode.");
+    if (prompts <= 0 || 2L * prompts != N) throw std::invalid_argument("Model::hip_sampler_loop: the plan's batch must be 2 * prompts (cond, uncond per prompt).");
+    const In *in_s = nullptr, *in_t = nullptr;
+    for (auto& in : inputs) {
+        if (in.name == sample_name) in_s = &in;
+        if (in.name == timestep_name) in_t = &in;
+    }
+    const Out* out = nullptr;
+    for (auto& o : outputs)
+        if (o.name == out_name) out = &o;
+    if (!in_s || !in_t || !out) throw std::invalid_argument("Model::hip_sampler_loop: input/output tensor not found.");
+    const long L = vals[in_s->staging].numel(), TL = vals[in_t->staging].numel();
+    if (vals[out->f32val].numel() != L || !vals[out->f32val].batched)
+        throw std::invalid_argument("Model::hip_sampler_loop: the output must have the shape of the sample input.");
+    const size_t xb = (size_t)prompts * L * sizeof(float), nb = (size_t)n_steps * xb;
+    auto grow = [&](void*& p, size_t& have, size_t need) {
+        if (have >= need) return;
+        if (p) be.check(be.api.osg_free(be.ctx, p), "osg_free");
+        p = nullptr;
+        have = 0;
+        be.check(be.api.osg_malloc(be.ctx, need, &p), "osg_malloc");
+        have = need;
+    };
+    grow(samp_x, samp_x_bytes, xb);
+    if (noise) grow(samp_noise, samp_noise_bytes, nb);
+    be.check(be.api.osg_upload(be.ctx, samp_x, x, xb), "osg_upload");
+    if (noise) be.check(be.api.osg_upload(be.ctx, samp_noise, noise, nb), "osg_upload");
+    be.check(be.api.osg_timer_start(be.ctx), "osg_timer_start");
+    for (int i = 0; i < n_steps; i++) {
+        be.check(be.api.osg_sampler_prepare(be.ctx, (const float*)samp_x, (float*)ptr(in_s->staging), (float*)ptr(in_t->staging), prompts, L, c_in[i], t[i], TL),
+                 "osg_sampler_prepare");
+        if (graph) be.check(be.api.osg_graph_launch(be.ctx, graph), "osg_graph_launch");
+        else for (auto& s : steps) s.run();
+        const bool with_noise = noise != nullptr;
+        be.check(be.api.osg_sampler_cfg_euler_a(be.ctx, (float*)samp_x, (const float*)ptr(out->f32val),
+                                               with_noise ? (const float*)samp_noise + (size_t)i * prompts * L : nullptr, prompts, L, c_out[i], guidance,
+                                               k_down[i], k_up[i], clip ? clip[i] : 0.f),
+                 "osg_sampler_cfg_euler_a");
+    }
+    float ms = 0;
+    be.check(be.api.osg_timer_stop(be.ctx, &ms), "osg_timer_stop");
+    be.check(be.api.osg_download(be.ctx, x, samp_x, xb), "osg_download");
+    runs += n_steps;
+    m_last_ms = n_steps > 0 ? ms / n_steps : 0;
+    return ms;
 }
 
 std::string Plan::profile(int reps) {

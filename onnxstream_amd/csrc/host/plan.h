@@ -63,6 +63,16 @@ struct Plan {
     void execute();
     // relaunch the captured pass `n` times on the inputs already resident in HBM; per-launch device ms (HIP events)
     void replay(int n, float* ms_each);
+    // the reference app's denoising loop with the CFG combine and the Euler-Ancestral update on the device: `steps`
+    // passes enqueued back to back, one host sync at the end.  The plan's batch must be 2*prompts (push 2p = cond, 2p+1 = uncond of
+    // prompt p) and every other input (context, ...) must already be resident from an earlier run().  Per-step scalars come from the
+    // caller (who owns the schedule): c_in, c_out, t, k_down = sigma_down/sigma, k_up = sigma_up, clip (NULL or per-step clamp of the new latents, 0 = none).  x: [prompts, L] fp32 host, updated
+    // in place; noise: [steps, prompts, L] fp32 host.  Returns the device time of the whole loop in ms.
+    // overwrite sample `index` of a graph input in its device staging (what run() does for every pushed tensor) without running a pass
+    void set_input(const std::string& name, long index, const float* data, size_t count);
+    double sampler_loop(const std::string& sample_name, const std::string& timestep_name, const std::string& out_name, int n_steps, int prompts,
+                        float* x, const float* noise, const float* c_in, const float* c_out, const float* t, const float* k_down,
+                        const float* k_up, float guidance, const float* clip);
     // eager pass with HIP events around every step, `reps` times; "ms<TAB>flops<TAB>bytes<TAB>what" per line (ms = mean)
     std::string profile(int reps);
     bool compatible(Model& m, size_t batch) const;
@@ -101,6 +111,10 @@ struct Plan {
     struct Out { std::string name; int val; int f32val; std::vector<size_t> shape; };
     std::vector<In> inputs;
     std::vector<Out> outputs;
+
+    void* samp_x = nullptr;       // sampler_loop state: latents [prompts, L] and the pre-drawn noise [steps, prompts, L], device fp32
+    void* samp_noise = nullptr;
+    size_t samp_x_bytes = 0, samp_noise_bytes = 0;
 
     osg_graph* graph = nullptr;
     Lowering* lowering = nullptr;  // kept alive: the launch closures capture it

@@ -27,7 +27,7 @@ EXPORTS = [
     "osg_conv2d_nhwc", "osg_conv2d_nhwc_rb", "osg_gemm", "osg_gemm_w8", "osg_conv2d_nhwc_w8", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided",
     "osg_instance_norm", "osg_group_norm_nhwc", "osg_group_norm_conv3x3_supported", "osg_group_norm_conv3x3", "osg_layer_norm", "osg_reduce_mean_last", "osg_softmax_last",
     "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_resize_nearest", "osg_gather_rows",
-    "osg_maxpool_nhwc", "osg_convert",
+    "osg_maxpool_nhwc", "osg_convert", "osg_sampler_prepare", "osg_sampler_cfg_euler_a",
 ]
 
 
@@ -89,6 +89,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_gather_rows.argtypes = [vp, ci, vp, vp, vp, cl, cl, cl]
     lib.osg_maxpool_nhwc.argtypes = [vp, ci, vp, vp] + [ci] * 12
     lib.osg_convert.argtypes = [vp, ci, ci, vp, vp, cl, cf, ci]
+    lib.osg_sampler_prepare.argtypes = [vp, vp, vp, vp, ci, cl, cf, cf, cl]
+    lib.osg_sampler_cfg_euler_a.argtypes = [vp, vp, vp, vp, ci, cl, cf, cf, cf, cf, cf]
     return lib
 
 

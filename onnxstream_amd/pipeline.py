@@ -73,6 +73,8 @@ class Txt2Img:
                     m._set_option("hip_fusion_level", fusion)
             m.read_file(d + "model.txt")
         self._configured: Dict[int, bool] = {}
+        self._dev_ready: Dict[tuple, bool] = {}
+        self.last_loop_ms = 0.0
 
     def close(self):
         self.unet.close()
@@ -150,6 +152,57 @@ class Txt2Img:
             x = ((x - den) * f32(sigma_down / f32(s_i)) + den + noise * f32(sigma_up)).astype(f32)
             if on_step:
                 on_step(i, x)
+        return x
+
+    def loop_scalars(self, sig: np.ndarray):
+        """Per-step fp32 scalars of the loop, computed exactly as denoise()/sample() do: c_in, c_out, t (sigma_to_t), k_down = sigma_down /
+        sigma_i and k_up = sigma_up of the Euler-Ancestral update."""
+        steps = len(sig) - 1
+        c_in, c_out, ts, k_down, k_up = (np.empty(steps, f32) for _ in range(5))
+        for i in range(steps):
+            sigma = float(sig[i])
+            c_out[i] = f32(-1.0 * sigma)
+            c_in[i] = f32(1.0 / np.sqrt(f32(sigma) * f32(sigma) + 1))
+            if sigma not in self._t_cache:
+                self._t_cache[sigma] = sigma_to_t(sigma, self.log_sigmas)
+            ts[i] = f32(self._t_cache[sigma])
+            s_i, s_n = np.float64(sig[i]), np.float64(sig[i + 1])
+            sigma_up = min(s_n, abs(s_n * np.sqrt(s_i * s_i - s_n * s_n) / s_i))
+            sigma_down = f32(np.sqrt(s_n * s_n - sigma_up * sigma_up))
+            k_down[i] = f32(sigma_down / f32(s_i))
+            k_up[i] = f32(sigma_up)
+        return c_in, c_out, ts, k_down, k_up
+
+    def sample_device(self, cond, uncond, steps: int = 20, seed: int = 42, latent_shape=(1, 4, 64, 64), guidance: float = 7.0) -> np.ndarray:
+        """sample() with the whole loop enqueued on the GPU (HIP backend only): per step a scaling kernel fills the UNet's input staging,
+        the captured pass is launched, and one kernel does eps -> denoised, the CFG combine and the Euler-Ancestral update -- no host
+        round trip until the last step.  Same schedule, same random stream, same fp32 operation order as sample(): the two agree bit
+        for bit.  cond / uncond: one context each, or lists with one entry per prompt (latent_shape[0] prompts)."""
+        if not self.batched:
+            raise RuntimeError("sample_device needs the HIP backend (batched=True)")
+        n, P = self.names, latent_shape[0]
+        conds = list(cond) if isinstance(cond, (list, tuple)) else [cond] * P
+        unconds = list(uncond) if isinstance(uncond, (list, tuple)) else [uncond] * P
+        sig = sigma_schedule(steps, self.log_sigmas)
+        rng = np.random.default_rng(seed)
+        x = np.ascontiguousarray(rng.standard_normal(latent_shape, dtype=f32) * sig[0], f32)
+        noise = np.empty((steps,) + tuple(latent_shape), f32)
+        c_in, c_out, ts, k_down, k_up = self.loop_scalars(sig)
+        for i in range(steps):
+            noise[i] = rng.standard_normal(latent_shape, dtype=f32)
+        key = (id(self.unet), P)
+        if self._dev_ready.get(key):
+            for p in range(P):      # plan + captured pass exist: only the contexts change between images
+                self.unet.hip_set_input(n["ctx"], 2 * p, conds[p])
+                self.unet.hip_set_input(n["ctx"], 2 * p + 1, unconds[p])
+        else:
+            for _ in range(2):      # run() #1 plans and runs eagerly, #2 captures the pass; both leave the contexts resident
+                if P > 1:
+                    self.denoise(x, float(sig[0]), conds, unconds, guidance)
+                else:
+                    self.denoise(x, float(sig[0]), conds[0], unconds[0], guidance)
+            self._dev_ready[key] = True
+        self.last_loop_ms = self.unet.hip_sampler_loop(n["sample"], n["timestep"], n["out"], x, noise, c_in, c_out, ts, k_down, k_up, guidance)
         return x
 
     def decode(self, latents: np.ndarray) -> np.ndarray:

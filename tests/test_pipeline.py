@@ -82,3 +82,34 @@ def test_hip_pipeline_vs_reference_golden():
     print(f"pipeline: latents {e_lat:.2e}  decode(ref latents) {e_img:.2e}  end-to-end image {e_e2e:.2e}")
     # three CFG-7 steps through a random-weight UNet amplify rounding differences; the per-pass bound is in test_golden.py
     assert e_lat <= 2e-2 and e_img <= 5e-3 and e_e2e <= 5e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prompts", [1, 3])
+def test_device_sampler_loop_matches_host_loop_bitwise(prompts):
+    """The loop with CFG + Euler-Ancestral on the device (osg_sampler_prepare / osg_sampler_cfg_euler_a around the captured pass, no host
+    round trips) against the host loop driving the same backend: same schedule, same random stream, same fp32 operation order => the
+    latents are identical bit for bit, for one prompt and for several prompts batched into one pass; a second image on new contexts
+    (resident plan, only model_hip_set_input) stays identical too."""
+    from onnxstream_amd import build as b
+    z = np.load(GOLD)
+    rng = np.random.default_rng(5)
+    shape = (prompts, 4, 16, 16)
+    with tempfile.TemporaryDirectory() as d:
+        du, _ = _emit(d)
+        for round_ in range(2):
+            conds = [z["cond"] + np.float32(0.01 * (k + 3 * round_)) * rng.standard_normal(z["cond"].shape, dtype=np.float32) for k in range(prompts)]
+            unconds = [z["uncond"]] * prompts
+            if round_ == 0:
+                ph = Txt2Img(b.LIB_HOST, du, None, batched=True)
+                pd = Txt2Img(b.LIB_HOST, du, None, batched=True)
+            if prompts == 1:
+                want = ph.sample(conds[0], unconds[0], steps=4, seed=21 + round_, latent_shape=shape)
+                got = pd.sample_device(conds[0], unconds[0], steps=4, seed=21 + round_, latent_shape=shape)
+            else:
+                want = ph.sample(conds, unconds, steps=4, seed=21 + round_, latent_shape=shape)
+                got = pd.sample_device(conds, unconds, steps=4, seed=21 + round_, latent_shape=shape)
+            assert np.isfinite(want).all() and np.abs(want).max() > 0
+            assert np.array_equal(got, want), float(np.abs(got - want).max())
+        ph.close()
+        pd.close()
