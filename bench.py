@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--cpu-passes", type=int, default=4, help="reference CPU passes in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--profile-reps", type=int, default=3)
     ap.add_argument("--steps-per-image", type=int, default=0, help="denoising steps per image (default 20; BASELINE config 4 = SDXL uses 10)")
+    ap.add_argument("--no-autotune", action="store_true", help="tile / split-K configurations from the cost model only (no measured choice in the first pass)")
     ap.add_argument("--host-loop", action="store_true", help="pipeline mode: CFG + Euler-A on the host with one round trip per step (the reference app's shape) instead of the device loop")
     ap.add_argument("--prompts-per-gpu", type=int, default=1, help="prompts denoised together on each GPU (2P samples per UNet pass: the reference's --num batching)")
     ap.add_argument("--w8-resident", action="store_true", help="with --quant-weights: keep the codes resident and dequantise on chip (osg_*_w8 kernels)")
@@ -174,7 +175,7 @@ def main():
             open(vae_dir + ".complete", "w").write("ok")
         barrier()
     t_build = time.time()
-    pipe = Txt2Img(b.LIB_HOST, model_dir, vae_dir, batched=True, device=local_rank, fusion=args.fusion)
+    pipe = Txt2Img(b.LIB_HOST, model_dir, vae_dir, batched=True, device=local_rank, fusion=args.fusion, autotune=not args.no_autotune)
     m = pipe.unet
     if args.w8_resident:
         m._set_option("hip_w8_resident", 1)
@@ -335,7 +336,7 @@ def main():
                                     f"weights resident; ms_per_step = wall / K with the decode amortised; images/s = gpus x prompts_per_gpu / (steps_per_image x ms_per_step)")
                                    if vae_dir else (f"{cfg.name} UNet denoising step: cond+uncond 2x4x{cfg.latent}x{cfg.latent} latents, W16A16, "
                                                     f"weights resident, mode={args.mode}; NO VAE decode"),
-                       "mode": args.mode, "sampler": "host" if args.host_loop else "device", "vae_decode_in_timed_region": bool(vae_dir), "images_completed": state["images"],
+                       "mode": args.mode, "sampler": "host" if args.host_loop else "device", "autotune": not args.no_autotune, "vae_decode_in_timed_region": bool(vae_dir), "images_completed": state["images"],
                        "prompts_per_gpu": P, "unet_passes_per_step": 2 * P, "steps_per_image": STEPS_PER_IMAGE, "launches_per_step": kernels,
                        "vae_launches": vae_kernels, "fusion_level": args.fusion, "unet_device_ms_per_step": round(dev_ms, 4),
                        "parallelism": f"replica x{world}"},

@@ -70,6 +70,10 @@ void osg_destroy(osg_ctx* ctx);           /* replaces XnnPack::~XnnPack         
 const char* osg_last_error(const osg_ctx* ctx);
 const char* osg_device_name(const osg_ctx* ctx);
 void* osg_stream(const osg_ctx* ctx);     /* the compute hipStream_t (for callers that record their own events) */
+/* on != 0: the first eager launch of each GEMM / convolution shape TIMES the legal tile / split-K configurations on the caller's operands
+ * and later launches (graph captures included) reuse the fastest; the choice is shared by every context of the process on that device.
+ * Takes the seat of XNNPACK's per-operator microkernel selection at xnn_create_* time (onnxstream.cpp:1104-1182).  Default off. */
+int osg_set_autotune(osg_ctx* ctx, int on);
 
 /* ---- memory / transfers (CublasOps buffer pool + cudaMemcpyAsync precedent, onnxstream.cpp:141-230,325,347) --- */
 int osg_malloc(osg_ctx* ctx, size_t bytes, void** dptr);

@@ -16,7 +16,7 @@ namespace onnxstream {
 
 struct OsgApi {
 #define OSG_FN(name) decltype(&::name) name = nullptr;
-    OSG_FN(osg_device_count) OSG_FN(osg_init) OSG_FN(osg_destroy) OSG_FN(osg_last_error) OSG_FN(osg_device_name) OSG_FN(osg_stream)
+    OSG_FN(osg_device_count) OSG_FN(osg_init) OSG_FN(osg_destroy) OSG_FN(osg_last_error) OSG_FN(osg_device_name) OSG_FN(osg_stream) OSG_FN(osg_set_autotune)
     OSG_FN(osg_malloc) OSG_FN(osg_free) OSG_FN(osg_upload) OSG_FN(osg_upload_sync) OSG_FN(osg_host_register) OSG_FN(osg_host_unregister) OSG_FN(osg_upload_pinned) OSG_FN(osg_download) OSG_FN(osg_copy)
     OSG_FN(osg_memset) OSG_FN(osg_sync) OSG_FN(osg_graph_begin) OSG_FN(osg_graph_end) OSG_FN(osg_graph_launch)
     OSG_FN(osg_graph_destroy) OSG_FN(osg_timer_start) OSG_FN(osg_timer_stop) OSG_FN(osg_conv2d_nhwc) OSG_FN(osg_conv2d_nhwc_rb) OSG_FN(osg_gemm) OSG_FN(osg_gemm_w8) OSG_FN(osg_conv2d_nhwc_w8)
@@ -50,7 +50,7 @@ public:
 #define OSG_FN(name)                                                                                   \
     api.name = reinterpret_cast<decltype(api.name)>(dlsym(m_handle, #name));                           \
     if (!api.name) throw std::runtime_error(std::string("HipBackend: symbol missing in libosgpu.so: ") + #name);
-        OSG_FN(osg_device_count) OSG_FN(osg_init) OSG_FN(osg_destroy) OSG_FN(osg_last_error) OSG_FN(osg_device_name) OSG_FN(osg_stream)
+        OSG_FN(osg_device_count) OSG_FN(osg_init) OSG_FN(osg_destroy) OSG_FN(osg_last_error) OSG_FN(osg_device_name) OSG_FN(osg_stream) OSG_FN(osg_set_autotune)
         OSG_FN(osg_malloc) OSG_FN(osg_free) OSG_FN(osg_upload) OSG_FN(osg_upload_sync) OSG_FN(osg_host_register) OSG_FN(osg_host_unregister) OSG_FN(osg_upload_pinned) OSG_FN(osg_download) OSG_FN(osg_copy)
         OSG_FN(osg_memset) OSG_FN(osg_sync) OSG_FN(osg_graph_begin) OSG_FN(osg_graph_end) OSG_FN(osg_graph_launch)
         OSG_FN(osg_graph_destroy) OSG_FN(osg_timer_start) OSG_FN(osg_timer_stop) OSG_FN(osg_conv2d_nhwc) OSG_FN(osg_conv2d_nhwc_rb) OSG_FN(osg_gemm) OSG_FN(osg_gemm_w8) OSG_FN(osg_conv2d_nhwc_w8)

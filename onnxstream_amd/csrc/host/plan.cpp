@@ -1880,6 +1880,7 @@ void Plan::build() {
                                  "(the configuration the reference uses for the SD UNet, src/sd.cpp:1633).");
     if (m.m_use_uint8_arithmetic || m.m_use_uint8_qdq)
         throw std::runtime_error("Model::run: uint8 activations (m_use_uint8_arithmetic / m_use_uint8_qdq) are not implemented on the HIP backend yet.");
+    be.check(be.api.osg_set_autotune(be.ctx, m.m_hip_autotune ? 1 : 0), "osg_set_autotune");
     ops = m.m_ops;
     vals.reserve(ops.size() * 12 + 1024);  // belt and braces: lowering code copies shapes, never holds Val& across new_val
     lowering = new Lowering(*this);

@@ -28,6 +28,8 @@ struct osg_ctx {
     static constexpr long kTickets = 1 << 16;
     int* tickets = nullptr;             // split-K arrival counters (zeroed once; the last arriver of a tile resets its counter)
     bool capturing = false;
+    bool autotune = false;              // osg_set_autotune: contraction launches pick tile/split configurations by measurement (osg_tune.h)
+    hipEvent_t ev_a0 = nullptr, ev_a1 = nullptr;
     std::string err;
     std::string name;
     int num_cu = 256;

@@ -410,7 +410,8 @@ int osg_group_norm_conv3x3(osg_ctx* ctx, const void* x, const void* gamma, const
 
 // Shape gate + tile/split choice.  Model (cycles, calibrated like choose_v2 in osg_gemm.hip): a (slab, tap) unit costs
 // max(MFMA, bytes / 23 B/clk) with bytes = the weight tile + 1/9 of the patch; whole rounds of tiles over the CUs.
-int osg_conv3x3_run(osg_ctx* ctx, GemmParams& p) {
+// shape gate: -1 when the halo-reuse kernel does not take the shape; fills the buffer extents otherwise
+int osg_conv3x3_prepare(osg_ctx* ctx, GemmParams& p) {
     static const bool off = getenv("OSG_CONV3X3_OFF") != nullptr;
     if (off) return -1;
     const int W = p.W, H = p.H;
@@ -424,13 +425,18 @@ int osg_conv3x3_run(osg_ctx* ctx, GemmParams& p) {
     if ((((uintptr_t)p.A | (uintptr_t)p.Bt) & 15) != 0) return -1;
     p.a_bytes = (unsigned)p.a_bytes_l;
     p.b_bytes = (unsigned)((long)p.N * p.K * 2);
+    return 0;
+}
 
+// every legal (BN, splits) with its modelled cost in cycles, cheapest first
+std::vector<std::pair<double, std::pair<int, int>>> osg_conv3x3_rank(const osg_ctx* ctx, const GemmParams& p) {
+    const int W = p.W;
+    const int TI = W == 8 ? 2 : 1, TH = 128 / (W * TI);
     const double cus = ctx->num_cu;
     const int slabs = p.Cin / 64;
     const int mt = (p.M + 127) / 128;
     const int pp = TI * (TH + 2) * (W == 8 ? 16 : W + 2);
-    int best_bn = 128, best_s = 1;
-    double best = 1e300;
+    std::vector<std::pair<double, std::pair<int, int>>> out;
     static const int bns[3] = {80, 128, 160};
     for (int bn : bns) {
         if (bn != 128 && p.N % bn) continue;
@@ -445,12 +451,18 @@ int osg_conv3x3_run(osg_ctx* ctx, GemmParams& p) {
             const double rounds = std::ceil(blocks / cus);
             double cost = rounds * (sl * 9.0 * (std::max(mfma, tload) + 250.0) + 6000.0);
             if (s > 1) cost += 9000.0 + (double)p.M * p.N * s * 4.0 / 2000.0;
-            if (cost < best) { best = cost; best_bn = bn; best_s = s; }
+            out.push_back({cost, {bn, s}});
         }
     }
-    if (const char* e = getenv("OSG_CONV3X3_BN")) best_bn = atoi(e);
-    if (const char* e = getenv("OSG_CONV3X3_SPLITS")) best_s = atoi(e);
-    const int sl = (slabs + best_s - 1) / best_s;
+    std::stable_sort(out.begin(), out.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    return out;
+}
+
+// launch one configuration (reduce kernel included); p must have passed osg_conv3x3_prepare
+int osg_conv3x3_launch(osg_ctx* ctx, GemmParams p, int bn, int s) {
+    const int slabs = p.Cin / 64;
+    if (s < 1) s = 1;
+    const int sl = (slabs + s - 1) / s;
     p.splits = (slabs + sl - 1) / sl;
     p.k_per_split = sl * 64;
     p.tickets = nullptr;
@@ -461,11 +473,21 @@ int osg_conv3x3_run(osg_ctx* ctx, GemmParams& p) {
     }
     p.n_major = (double)p.N * p.K * 2.0 > (double)p.a_bytes_l;
     int rc;
-    if (W == 64) rc = launch3_bn<64>(ctx, p, best_bn);
-    else if (W == 32) rc = launch3_bn<32>(ctx, p, best_bn);
-    else if (W == 16) rc = launch3_bn<16>(ctx, p, best_bn);
-    else rc = launch3_bn<8>(ctx, p, best_bn);
+    if (p.W == 64) rc = launch3_bn<64>(ctx, p, bn);
+    else if (p.W == 32) rc = launch3_bn<32>(ctx, p, bn);
+    else if (p.W == 16) rc = launch3_bn<16>(ctx, p, bn);
+    else rc = launch3_bn<8>(ctx, p, bn);
     if (rc) return rc;
     if (p.splits > 1) return launch_splitk_reduce(ctx, p, 1);
     return 0;
+}
+
+int osg_conv3x3_run(osg_ctx* ctx, GemmParams& p) {
+    if (osg_conv3x3_prepare(ctx, p)) return -1;
+    auto ranked = osg_conv3x3_rank(ctx, p);
+    int best_bn = 128, best_s = 1;
+    if (!ranked.empty()) { best_bn = ranked[0].second.first; best_s = ranked[0].second.second; }
+    if (const char* e = getenv("OSG_CONV3X3_BN")) best_bn = atoi(e);
+    if (const char* e = getenv("OSG_CONV3X3_SPLITS")) best_s = atoi(e);
+    return osg_conv3x3_launch(ctx, p, best_bn, best_s);
 }

@@ -1,6 +1,25 @@
 // libosgpu: context, memory, transfers, graph capture, timing.  (C ABI: include/osgpu.h)
 #include "osg_common.h"
+#include "osg_tune.h"
 #include <cstring>
+#include <map>
+#include <mutex>
+
+namespace osg_tune {
+static std::mutex g_mu;
+static std::map<Key, Choice> g_table;
+bool lookup(const Key& k, Choice* out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_table.find(k);
+    if (it == g_table.end()) return false;
+    *out = it->second;
+    return true;
+}
+void store(const Key& k, const Choice& c) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_table[k] = c;
+}
+}  // namespace osg_tune
 
 extern "C" {
 
@@ -27,7 +46,8 @@ int osg_init(int device, osg_ctx** out) {
     bool ok = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreate(&c->ev_t0) == hipSuccess && hipEventCreate(&c->ev_t1) == hipSuccess;
+              hipEventCreate(&c->ev_t0) == hipSuccess && hipEventCreate(&c->ev_t1) == hipSuccess &&
+              hipEventCreate(&c->ev_a0) == hipSuccess && hipEventCreate(&c->ev_a1) == hipSuccess;
     c->stage_bytes = 64u << 20;
     for (int i = 0; ok && i < osg_ctx::kStages; i++) {
         ok = hipHostMalloc(&c->stage[i], c->stage_bytes, hipHostMallocDefault) == hipSuccess &&
@@ -57,9 +77,17 @@ void osg_destroy(osg_ctx* c) {
     if (c->ev_copy) hipEventDestroy(c->ev_copy);
     if (c->ev_t0) hipEventDestroy(c->ev_t0);
     if (c->ev_t1) hipEventDestroy(c->ev_t1);
+    if (c->ev_a0) hipEventDestroy(c->ev_a0);
+    if (c->ev_a1) hipEventDestroy(c->ev_a1);
     if (c->compute) hipStreamDestroy(c->compute);
     if (c->copy) hipStreamDestroy(c->copy);
     delete c;
+}
+
+int osg_set_autotune(osg_ctx* c, int on) {
+    if (!c) return 1;
+    c->autotune = on != 0;
+    return 0;
 }
 
 const char* osg_last_error(const osg_ctx* c) { return c ? c->err.c_str() : "null context"; }

@@ -13,6 +13,7 @@
 //     8-byte epilogue stores, bias/residual fused in f32 before the single rounding.
 //   * split-K (grid.z) with f32 partial slabs + a fused reduce epilogue for the small-M (8x8, 16x16 latent) layers.
 #include "osg_gemm_common.h"
+#include "osg_tune.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -695,11 +696,11 @@ int launch_cfg(osg_ctx* ctx, const GemmParams& p, int batch) {
 // a fixed fill + epilogue per round, and the extra pass of a split-K reduce.
 struct V2Choice { int cfg, nst, splits; };
 static const int kV2BM[3] = {128, 128, 64}, kV2BN[3] = {128, 64, 64};
-static V2Choice choose_v2(const osg_ctx* ctx, int M, int N, int K, int batch) {
+// every legal (tile, stages, splits) with its modelled cost in cycles, cheapest first
+static std::vector<std::pair<double, V2Choice>> rank_v2(const osg_ctx* ctx, int M, int N, int K, int batch, bool allow_split) {
     const double cus = ctx->num_cu;
     const int kt = K / 64;
-    V2Choice best{0, 4, 1};
-    double best_cost = 1e300;
+    std::vector<std::pair<double, V2Choice>> out;
     for (int c = 0; c < 3; c++)
         for (int nst = 4; nst >= 2; nst -= 2) {
             const double tiles = (double)((M + kV2BM[c] - 1) / kV2BM[c]) * ((N + kV2BN[c] - 1) / kV2BN[c]) * batch;
@@ -707,7 +708,7 @@ static V2Choice choose_v2(const osg_ctx* ctx, int M, int N, int K, int batch) {
             const double tload = (kV2BM[c] + kV2BN[c]) * 128.0 / 23.0;
             const int smem = nst * (kV2BM[c] + kV2BN[c]) * 128;
             const int bpc = std::min(4, 163840 / smem);
-            for (int s = 1; s <= 16; s++) {
+            for (int s = 1; s <= (allow_split ? 16 : 1); s++) {
                 if (s > 1 && (kt / s < 8)) break;
                 const int kts = (kt + s - 1) / s;
                 if (s > 1 && (kts * (s - 1) >= kt)) continue;   // an empty split
@@ -717,19 +718,31 @@ static V2Choice choose_v2(const osg_ctx* ctx, int M, int N, int K, int batch) {
                 const double tk = conc <= 1.0 ? std::max(mfma, tload) + 450.0 : conc * std::max(mfma, tload);
                 double cost = rounds * (kts * tk + 3500.0);
                 if (s > 1) cost += 9000.0 + (double)M * N * batch * s * 4.0 / 2000.0;   // reduce launch (measured ~4-7 us) + slab traffic
-                if (cost < best_cost) { best_cost = cost; best = {c, nst, s}; }
+                out.push_back({cost, V2Choice{c, nst, s}});
             }
         }
-    return best;
+    std::stable_sort(out.begin(), out.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    return out;
+}
+static V2Choice choose_v2(const osg_ctx* ctx, int M, int N, int K, int batch) {
+    auto r = rank_v2(ctx, M, N, K, batch, true);
+    return r.empty() ? V2Choice{0, 4, 1} : r[0].second;
 }
 
+static osg_tune::Key tune_key(const osg_ctx* ctx, int kind, const GemmParams& p, int batch) {
+    osg_tune::Key k{};
+    k.kind = kind; k.device = ctx->device; k.M = p.M; k.N = p.N; k.K = p.K; k.batch = batch;
+    if (kind != 0) { k.H = p.H; k.W = p.W; k.Cin = p.Cin; k.KW = p.KW; k.sh = p.sh; k.sw = p.sw; }
+    else k.H = p.lda;
+    k.flags = (int)p.act | (p.residual ? 16 : 0) | (p.rowbias ? 32 : 0) | (p.bias_f32 ? 64 : 0);
+    return k;
+}
+// a launch may be repeated for timing only when it does not consume its own output
+static bool tune_safe(const GemmParams& p) { return (const void*)p.C != (const void*)p.A && (const void*)p.C != (const void*)p.residual; }
+
+// launch one configuration (reduce kernel included)
 template <bool CONV>
-int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch) {
-    V2Choice ch = choose_v2(ctx, p.M, p.N, p.K, batch);
-    if (p.act == OSG_ACT_GEGLU) ch.splits = 1;   // the pairing lives in the tile epilogue
-    if (const char* e = getenv("OSG_GEMM_CFG")) ch.cfg = atoi(e);
-    if (const char* e = getenv("OSG_GEMM_SPLITS")) ch.splits = atoi(e);
-    if (const char* e = getenv("OSG_GEMM_NST")) ch.nst = atoi(e);
+int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
     const int ktiles = p.K / 64;
     int kt_per = (ktiles + ch.splits - 1) / ch.splits;
     p.splits = (ktiles + kt_per - 1) / kt_per;
@@ -766,7 +779,42 @@ int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch) {
 }
 
 template <bool CONV>
-int run_gemm(osg_ctx* ctx, GemmParams p, int batch) {
+int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced) {
+    const bool allow_split = p.act != OSG_ACT_GEGLU;   // the GEGLU pairing lives in the tile epilogue
+    V2Choice ch;
+    const bool env_forced = getenv("OSG_GEMM_CFG") || getenv("OSG_GEMM_SPLITS") || getenv("OSG_GEMM_NST") || getenv("OSG_GEMM_DBG");
+    if (forced) {
+        ch = *forced;
+    } else if (ctx->autotune && !env_forced) {
+        const osg_tune::Key key = tune_key(ctx, CONV ? 2 : 0, p, batch);
+        osg_tune::Choice tc;
+        if (osg_tune::lookup(key, &tc)) {
+            ch = {tc.cfg, tc.nst, tc.splits};
+        } else {
+            auto ranked = rank_v2(ctx, p.M, p.N, p.K, batch, allow_split);
+            ch = ranked.empty() ? V2Choice{0, 4, 1} : ranked[0].second;
+            if (!ctx->capturing && tune_safe(p) && !ranked.empty()) {
+                float best = -1.f;
+                for (auto& cand : ranked) {
+                    const float us = osg_tune::time_us(ctx, [&] { return launch_v2_choice<CONV>(ctx, p, batch, cand.second); });
+                    if (us >= 0.f && (best < 0.f || us < best)) { best = us; ch = cand.second; }
+                }
+                if (best < 0.f) OSG_FAIL(ctx, "osg_gemm: autotune could not time any configuration");
+                osg_tune::store(key, osg_tune::Choice{0, ch.cfg, ch.nst, ch.splits, 0, best});
+            }
+        }
+    } else {
+        ch = choose_v2(ctx, p.M, p.N, p.K, batch);
+        if (!allow_split) ch.splits = 1;
+        if (const char* e = getenv("OSG_GEMM_CFG")) ch.cfg = atoi(e);
+        if (const char* e = getenv("OSG_GEMM_SPLITS")) ch.splits = atoi(e);
+        if (const char* e = getenv("OSG_GEMM_NST")) ch.nst = atoi(e);
+    }
+    return launch_v2_choice<CONV>(ctx, p, batch, ch);
+}
+
+template <bool CONV>
+int run_gemm(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced = nullptr) {
     {
         static const bool force_v1 = getenv("OSG_GEMM_V1") != nullptr;
         const bool shape_ok = p.K % 64 == 0 && (CONV ? p.Cin % 64 == 0 : p.lda % 8 == 0);
@@ -776,7 +824,7 @@ int run_gemm(osg_ctx* ctx, GemmParams p, int batch) {
         if (!force_v1 && shape_ok && align_ok && a_ext < 2147483648.0 && b_ext < 2147483648.0) {
             p.a_bytes = (unsigned)a_ext;
             p.b_bytes = (unsigned)b_ext;
-            return run_gemm_v2<CONV>(ctx, p, batch);
+            return run_gemm_v2<CONV>(ctx, p, batch, forced);
         }
         if (p.act == OSG_ACT_GEGLU) OSG_FAIL(ctx, "osg_gemm: GEGLU epilogue needs 16-byte aligned operands (direct-to-LDS kernel only)");
     }
@@ -927,8 +975,39 @@ int osg_conv2d_nhwc_rb(osg_ctx* ctx, osg_dtype dtype, const void* x, const void*
         return run_gemm<false>(ctx, p, 1);
     }
     if (KH == 3) {
-        int rc3 = osg_conv3x3_run(ctx, p);
-        if (rc3 >= 0) return rc3;
+        const bool env_forced = getenv("OSG_CONV3X3_BN") || getenv("OSG_CONV3X3_SPLITS") || getenv("OSG_CONV3X3_DBG") || getenv("OSG_GEMM_CFG") ||
+                                getenv("OSG_GEMM_SPLITS") || getenv("OSG_GEMM_NST") || getenv("OSG_GEMM_DBG");
+        if (!ctx->autotune || env_forced) {
+            int rc3 = osg_conv3x3_run(ctx, p);
+            if (rc3 >= 0) return rc3;
+        } else if (osg_conv3x3_prepare(ctx, p) == 0) {
+            // measured choice between the halo-reuse kernel's (BN, splits) and the implicit-GEMM kernel's (tile, stages, splits)
+            const osg_tune::Key key = tune_key(ctx, 1, p, 1);
+            osg_tune::Choice tc;
+            if (!osg_tune::lookup(key, &tc)) {
+                auto r3 = osg_conv3x3_rank(ctx, p);
+                tc = osg_tune::Choice{1, 0, 0, r3.empty() ? 1 : r3[0].second.second, r3.empty() ? 128 : r3[0].second.first, -1.f};
+                if (!ctx->capturing && tune_safe(p)) {
+                    float best = -1.f;
+                    for (auto& c : r3) {
+                        const float us = osg_tune::time_us(ctx, [&] { return osg_conv3x3_launch(ctx, p, c.second.first, c.second.second); });
+                        if (us >= 0.f && (best < 0.f || us < best)) { best = us; tc = osg_tune::Choice{1, 0, 0, c.second.second, c.second.first, us}; }
+                    }
+                    auto r2 = rank_v2(ctx, p.M, p.N, p.K, 1, true);
+                    if (r2.size() > 6) r2.resize(6);
+                    for (auto& c : r2) {
+                        const V2Choice ch = c.second;
+                        const float us = osg_tune::time_us(ctx, [&] { return run_gemm<true>(ctx, p, 1, &ch); });
+                        if (us >= 0.f && (best < 0.f || us < best)) { best = us; tc = osg_tune::Choice{0, ch.cfg, ch.nst, ch.splits, 0, us}; }
+                    }
+                    if (best < 0.f) OSG_FAIL(ctx, "osg_conv2d_nhwc: autotune could not time any configuration");
+                    osg_tune::store(key, tc);
+                }
+            }
+            if (tc.family == 1) return osg_conv3x3_launch(ctx, p, tc.bn, tc.splits);
+            const V2Choice ch{tc.cfg, tc.nst, tc.splits};
+            return run_gemm<true>(ctx, p, 1, &ch);
+        }
     }
     return run_gemm<true>(ctx, p, 1);
 }

@@ -1,5 +1,7 @@
 // Shared by the contraction kernels of libosgpu (osg_gemm.hip, osg_conv3x3.hip): launch parameters and the fused epilogue.
 #pragma once
+#include <utility>
+#include <vector>
 #include "osg_common.h"
 
 namespace osg_mm {
@@ -153,4 +155,8 @@ int launch_splitk_reduce(osg_ctx* ctx, const GemmParams& p, int batch);   // osg
 
 // osg_conv3x3.hip: halo-reuse 3x3 / stride 1 / pad 1 convolution.  Returns -1 when the shape is not one it takes.
 int osg_conv3x3_run(osg_ctx* ctx, osg_mm::GemmParams& p);
+// the same in pieces, for the measured configuration choice (osg_tune.h): shape gate, ranked (BN, splits) candidates, one launch
+int osg_conv3x3_prepare(osg_ctx* ctx, osg_mm::GemmParams& p);
+std::vector<std::pair<double, std::pair<int, int>>> osg_conv3x3_rank(const osg_ctx* ctx, const osg_mm::GemmParams& p);
+int osg_conv3x3_launch(osg_ctx* ctx, osg_mm::GemmParams p, int bn, int splits);
 int osg_conv3x3_supported(int N, int H, int W, int Cin, int Cout);

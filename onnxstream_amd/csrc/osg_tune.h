@@ -1,0 +1,49 @@
+// Measured configuration choice for the contraction launches (osg_gemm.hip, osg_conv3x3.hip).
+//
+// The tile / pipeline-depth / split-K choice of a GEMM or convolution is made by a small cost model (choose_v2, osg_conv3x3_run).  With
+// osg_set_autotune(ctx, 1) the first EAGER launch of a shape instead times every configuration the model considers legal on the caller's
+// own operands (HIP events on the compute stream, 1 warm + 2 timed launches each) and remembers the fastest; later launches -- including
+// the ones captured into a hipGraph -- reuse it.  The table is process-wide and keyed by the device, so every context (every Model) of a
+// process makes the same choice for the same shape: results stay bit-reproducible inside a process.  Contexts without autotune never
+// consult the table.  Nothing is tuned during graph capture (no synchronisation is allowed there): the model's choice is used.
+#pragma once
+#include <tuple>
+#include "osg_common.h"
+
+namespace osg_tune {
+
+struct Key {
+    int kind;       // 0: GEMM, 1: 3x3/s1/p1 convolution (halo-reuse kernel and implicit GEMM compete), 2: other implicit-GEMM convolution
+    int device;
+    int M, N, K, batch;
+    int H, W, Cin, KW, sh, sw;
+    int flags;      // epilogue shape: act | residual << 4 | rowbias << 5 | bias_f32 << 6
+    bool operator<(const Key& o) const {
+        return std::tie(kind, device, M, N, K, batch, H, W, Cin, KW, sh, sw, flags) <
+               std::tie(o.kind, o.device, o.M, o.N, o.K, o.batch, o.H, o.W, o.Cin, o.KW, o.sh, o.sw, o.flags);
+    }
+};
+
+struct Choice {
+    int family;     // 0: gemm2 (cfg, nst, splits); 1: conv3x3 (bn, splits)
+    int cfg, nst, splits, bn;
+    float us;       // measured time of the winner
+};
+
+bool lookup(const Key& k, Choice* out);
+void store(const Key& k, const Choice& c);
+
+// microseconds per launch of f() (which enqueues the whole operation, reduce kernel included, and returns 0 on success); < 0 on failure
+template <class F>
+float time_us(osg_ctx* ctx, F&& f) {
+    if (f()) return -1.f;
+    if (hipEventRecord(ctx->ev_a0, ctx->compute) != hipSuccess) return -1.f;
+    if (f() || f()) return -1.f;
+    if (hipEventRecord(ctx->ev_a1, ctx->compute) != hipSuccess) return -1.f;
+    if (hipEventSynchronize(ctx->ev_a1) != hipSuccess) return -1.f;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev_a0, ctx->ev_a1) != hipSuccess) return -1.f;
+    return ms * 500.f;
+}
+
+}  // namespace osg_tune

@@ -21,7 +21,7 @@ UN = dict(sigmoid=0, erf=1, sqrt=2, sin=3, cos=4, neg=5, pow=6, silu=7, gelu_erf
 BIN = dict(add=0, sub=1, mul=2, div=3)
 
 EXPORTS = [
-    "osg_device_count", "osg_init", "osg_destroy", "osg_last_error", "osg_device_name", "osg_stream",
+    "osg_device_count", "osg_init", "osg_destroy", "osg_last_error", "osg_device_name", "osg_stream", "osg_set_autotune",
     "osg_malloc", "osg_free", "osg_upload", "osg_upload_sync", "osg_host_register", "osg_host_unregister", "osg_upload_pinned", "osg_download", "osg_copy", "osg_memset", "osg_sync",
     "osg_graph_begin", "osg_graph_end", "osg_graph_launch", "osg_graph_destroy", "osg_timer_start", "osg_timer_stop",
     "osg_conv2d_nhwc", "osg_conv2d_nhwc_rb", "osg_gemm", "osg_gemm_w8", "osg_conv2d_nhwc_w8", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided",

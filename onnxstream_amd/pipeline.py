@@ -54,7 +54,7 @@ def sigma_to_t(sigma: float, log_sigmas: np.ndarray) -> float:
 
 class Txt2Img:
     def __init__(self, library: str, unet_dir: str, vae_dir: Optional[str], batched: bool = True, device: int = 0,
-                 names: Dict[str, str] = None, fusion: Optional[int] = None, threads: int = 0):
+                 names: Dict[str, str] = None, fusion: Optional[int] = None, threads: int = 0, autotune: Optional[bool] = None):
         self.batched = batched
         self.names = dict(timestep="timestep", sample="sample", ctx="encoder_hidden_states", out="out_sample", vae_in="input.1",
                           vae_out="out_image")
@@ -71,6 +71,8 @@ class Txt2Img:
                 m._set_option("hip_device", device)
                 if fusion is not None:
                     m._set_option("hip_fusion_level", fusion)
+                if autotune is not None:
+                    m._set_option("hip_autotune", int(bool(autotune)))
             m.read_file(d + "model.txt")
         self._configured: Dict[int, bool] = {}
         self._dev_ready: Dict[tuple, bool] = {}
