@@ -193,6 +193,8 @@ def main():
     state = {"x": rng.standard_normal(lat_shape, dtype=np.float32) * sig[0], "i": 0, "images": 0, "last": None}
 
     host_loop = args.host_loop
+    from concurrent.futures import ThreadPoolExecutor
+    noise_pool, noise_rng = ThreadPoolExecutor(1), np.random.default_rng(99 + rank)
     scal = pipe.loop_scalars(sig)
     # random-weight UNets do not denoise (|x| would grow without bound over 20 CFG-7 steps): clamp to the scale a real trajectory has
     clip = np.asarray([4.0 * max(float(sig[i + 1]), 1.0) for i in range(STEPS_PER_IMAGE)], np.float32)
@@ -229,7 +231,13 @@ def main():
             else:
                 n = min(k, STEPS_PER_IMAGE - i)
                 x = np.ascontiguousarray(state["x"], np.float32)
-                noise = rng.standard_normal((n,) + lat_shape, dtype=np.float32)
+                # the ancestral noise of this chunk was drawn on a worker thread while the previous chunk ran on the GPU
+                fut = state.pop("noise", None)
+                noise = fut.result() if fut is not None and fut.n == n else noise_rng.standard_normal((n,) + lat_shape, dtype=np.float32)
+                rem_img = STEPS_PER_IMAGE - (i + n) % STEPS_PER_IMAGE
+                nxt = min(k - n, rem_img) if k > n else rem_img
+                state["noise"] = noise_pool.submit(noise_rng.standard_normal, (nxt,) + lat_shape, np.float32)
+                state["noise"].n = nxt
                 dev += m.hip_sampler_loop(n_names["sample"], n_names["timestep"], n_names["out"], x, noise, *[a[i:i + n] for a in scal], 7.0, clip[i:i + n])
             if i + n == STEPS_PER_IMAGE:
                 x = end_of_image(x)

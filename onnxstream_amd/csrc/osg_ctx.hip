@@ -8,8 +8,27 @@
 namespace osg_tune {
 static std::mutex g_mu;
 static std::map<Key, Choice> g_table;
+static bool g_loaded = false;
+// OSG_TUNE_CACHE=<file>: measured choices persist across processes (text, one "key... choice..." line per shape, appended as they are
+// made) -- a second process starts tuned, makes the same choices (bit-identical results run to run) and issues no timing launches.
+static const char* cache_path() { return getenv("OSG_TUNE_CACHE"); }
+static void load_locked() {
+    if (g_loaded) return;
+    g_loaded = true;
+    const char* path = cache_path();
+    if (!path) return;
+    FILE* f = fopen(path, "r");
+    if (!f) return;
+    Key k{};
+    Choice c{};
+    while (fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %f", &k.kind, &k.device, &k.M, &k.N, &k.K, &k.batch, &k.H, &k.W, &k.Cin, &k.KW,
+                  &k.sh, &k.sw, &k.flags, &c.family, &c.cfg, &c.nst, &c.splits, &c.bn, &c.us) == 19)
+        g_table[k] = c;
+    fclose(f);
+}
 bool lookup(const Key& k, Choice* out) {
     std::lock_guard<std::mutex> lk(g_mu);
+    load_locked();
     auto it = g_table.find(k);
     if (it == g_table.end()) return false;
     *out = it->second;
@@ -17,7 +36,15 @@ bool lookup(const Key& k, Choice* out) {
 }
 void store(const Key& k, const Choice& c) {
     std::lock_guard<std::mutex> lk(g_mu);
+    load_locked();
     g_table[k] = c;
+    if (const char* path = cache_path()) {
+        if (FILE* f = fopen(path, "a")) {
+            fprintf(f, "%d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %.3f\n", k.kind, k.device, k.M, k.N, k.K, k.batch, k.H, k.W, k.Cin, k.KW, k.sh,
+                    k.sw, k.flags, c.family, c.cfg, c.nst, c.splits, c.bn, c.us);
+            fclose(f);
+        }
+    }
 }
 }  // namespace osg_tune
 

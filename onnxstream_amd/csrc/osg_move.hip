@@ -237,7 +237,13 @@ int osg_resize_nearest(osg_ctx* ctx, int elem_size, const void* x, void* y, int 
     long n = (long)N * C * Ho * Wo;
     float shi = (float)H / (float)Ho, swi = (float)W / (float)Wo;
     unsigned g = grid_for(n);
-    if (elem_size == 2)
+    if (nhwc && ((long)C * elem_size) % 16 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+        // channels-last: a pixel's channel run moves as 16-byte words (the UNet's 2x upsamples: 3 launches per pass)
+        const int C16 = (int)((long)C * elem_size / 16);
+        g = grid_for((long)N * C16 * Ho * Wo);
+        hipLaunchKernelGGL(resize_nearest_kernel<uint4>, dim3(g), dim3(256), 0, ctx->compute, (const uint4*)x, (uint4*)y, N, C16, H, W, Ho, Wo, 1, shi,
+                           swi);
+    } else if (elem_size == 2)
         hipLaunchKernelGGL(resize_nearest_kernel<uint16_t>, dim3(g), dim3(256), 0, ctx->compute, (const uint16_t*)x, (uint16_t*)y, N, C, H,
                            W, Ho, Wo, nhwc, shi, swi);
     else if (elem_size == 4)

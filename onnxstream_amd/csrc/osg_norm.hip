@@ -134,14 +134,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     }
 }
 
-// pass 2 (tiny): one block per image folds the S partials of every group in f64 (fixed order => deterministic) and writes the
+// pass 2 (tiny): one block per image folds the partials and writes the
 // per-channel affine table  y = x * ca[c] + cb[c]   (ca = rstd*gamma, cb = beta - mean*rstd*gamma)  to tab[n][2][C]
-template <typename T>
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const T* __restrict__ gamma, const T* __restrict__ beta,
-                                                          float* __restrict__ tab, long HW, int C, int G, int S, float eps) {
-    extern __shared__ float stat[];  // [G][2] mean, rstd
-    const int n = blockIdx.x;
-    const int cpg = C / G;
+// fold of the S partials of every group of image n in f64 (fixed order => deterministic) -> stat[g] = (mean, rstd) in LDS
+__device__ __forceinline__ void gn_fold_stats(const float* __restrict__ part, float* stat, int n, long HW, int cpg, int G, int S, float eps) {
     int tpg = 1;
     while (tpg * 2 * G <= 256 && tpg < 64) tpg *= 2;
     const double cnt = (double)HW * cpg;
@@ -166,6 +162,15 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
         }
     }
     __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                          float* __restrict__ tab, long HW, int C, int G, int S, float eps) {
+    extern __shared__ float stat[];  // [G][2] mean, rstd
+    const int n = blockIdx.x;
+    const int cpg = C / G;
+    gn_fold_stats(part, stat, n, HW, cpg, G, S, eps);
     for (int c = threadIdx.x; c < C; c += 256) {
         const int g = c / cpg;
         const float a = stat[g * 2 + 1] * to_f32<T>(gamma[c]);
@@ -176,11 +181,15 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 
 // pass 3: pure streaming  y = act(x * ca[c] + cb[c]).  A thread keeps ONE vector column (its 2*V table entries live in
 // registers), sweeps pixel rows with 4 independent 16-byte loads in flight; grid (slabs, N).
-template <typename T>
+template <typename T, bool FOLD>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ tab, T* __restrict__ y, long HW,
-                                                       int C, int act, int slabs) {
+                                                       int C, int act, int slabs, const float* __restrict__ part, const T* __restrict__ gamma,
+                                                       const T* __restrict__ beta, int G, int S, float eps) {
     constexpr int V = 8 / (sizeof(T) / 2);  // f16: 8, f32: 4  (16-byte accesses)
+    extern __shared__ float stat[];         // FOLD: [G][2] mean, rstd -- pass 2 folded into every block's prologue (one launch fewer)
     const int n = blockIdx.y, sl = blockIdx.x;
+    const int cpg = FOLD ? C / G : 1;
+    if (FOLD) gn_fold_stats(part, stat, n, HW, cpg, G, S, eps);
     const int cv = C / V;
     const int cols = cv < 256 ? cv : 256, R = 256 / cols;
     const int tr = threadIdx.x / cols, tc = threadIdx.x - tr * cols;
@@ -193,8 +202,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
         float ca[V], cb[V];
 #pragma unroll
         for (int e = 0; e < V; e++) {
-            ca[e] = ta[c * V + e];
-            cb[e] = ta[C + c * V + e];
+            if (FOLD) {     // the very expressions of gn_finalize_kernel: identical bits
+                const int ch = c * V + e, g = ch / cpg;
+                const float a = stat[g * 2 + 1] * to_f32<T>(gamma[ch]);
+                ca[e] = a;
+                cb[e] = to_f32<T>(beta[ch]) - stat[g * 2] * a;
+            } else {
+                ca[e] = ta[c * V + e];
+                cb[e] = ta[C + c * V + e];
+            }
         }
         long p = p0 + tr;
         for (; p + 3L * R < p1; p += 4L * R) {
@@ -527,18 +543,25 @@ int osg_group_norm_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void
     if (dtype == OSG_F16) {
         hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(S, N), dim3(256), (G * 2 + 2 * 256 * 8) * sizeof(float), ctx->compute, (const f16*)x, part, HW, C, G, S);
         OSG_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(gn_finalize_kernel<f16>, dim3(N), dim3(256), G * 2 * sizeof(float), ctx->compute, part, (const f16*)gamma,
-                           (const f16*)beta, tab, HW, C, G, S, eps);
-        OSG_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(slabs, N), dim3(256), 0, ctx->compute, (const f16*)x, tab, (f16*)y, HW, C, (int)act, slabs);
+        if ((long)slabs * N <= 1024) {
+            // few apply blocks (the UNet's 64x64 level): each folds the partials itself -- 16 KB of L2 reads buy one launch less
+            hipLaunchKernelGGL((gn_apply_kernel<f16, true>), dim3(slabs, N), dim3(256), G * 2 * sizeof(float), ctx->compute, (const f16*)x, tab, (f16*)y,
+                               HW, C, (int)act, slabs, part, (const f16*)gamma, (const f16*)beta, G, S, eps);
+        } else {
+            hipLaunchKernelGGL(gn_finalize_kernel<f16>, dim3(N), dim3(256), G * 2 * sizeof(float), ctx->compute, part, (const f16*)gamma,
+                               (const f16*)beta, tab, HW, C, G, S, eps);
+            OSG_LAUNCH_CHECK(ctx);
+            hipLaunchKernelGGL((gn_apply_kernel<f16, false>), dim3(slabs, N), dim3(256), 0, ctx->compute, (const f16*)x, tab, (f16*)y, HW, C, (int)act,
+                               slabs, nullptr, nullptr, nullptr, G, S, eps);
+        }
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(S, N), dim3(256), (G * 2 + 2 * 256 * 4) * sizeof(float), ctx->compute, (const float*)x, part, HW, C, G, S);
         OSG_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(gn_finalize_kernel<float>, dim3(N), dim3(256), G * 2 * sizeof(float), ctx->compute, part, (const float*)gamma,
                            (const float*)beta, tab, HW, C, G, S, eps);
         OSG_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(slabs, N), dim3(256), 0, ctx->compute, (const float*)x, tab, (float*)y, HW, C, (int)act,
-                           slabs);
+        hipLaunchKernelGGL((gn_apply_kernel<float, false>), dim3(slabs, N), dim3(256), 0, ctx->compute, (const float*)x, tab, (float*)y, HW, C, (int)act,
+                           slabs, nullptr, nullptr, nullptr, G, S, eps);
     }
     OSG_LAUNCH_CHECK(ctx);
     return 0;

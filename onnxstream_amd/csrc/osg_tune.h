@@ -5,7 +5,7 @@
 // own operands (HIP events on the compute stream, 1 warm + 2 timed launches each) and remembers the fastest; later launches -- including
 // the ones captured into a hipGraph -- reuse it.  The table is process-wide and keyed by the device, so every context (every Model) of a
 // process makes the same choice for the same shape: results stay bit-reproducible inside a process.  Contexts without autotune never
-// consult the table.  Nothing is tuned during graph capture (no synchronisation is allowed there): the model's choice is used.
+// consult the table.  OSG_TUNE_CACHE=<file> persists the table across processes.  Nothing is tuned during graph capture (no synchronisation is allowed there): the model's choice is used.
 #pragma once
 #include <tuple>
 #include "osg_common.h"

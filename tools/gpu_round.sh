@@ -3,6 +3,7 @@
 set -x
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+export OSG_TUNE_CACHE=/tmp/osg_tune_cache.txt   # the bench run tunes; the rocprofv3 run after it reuses the choices (no timing launches in the profile)
 TAG=${1:-r1}
 timeout 600 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_$TAG.log 2>&1; tail -3 gpurun_out/pytest_gpu_$TAG.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1; tail -2 gpurun_out/smoke_$TAG.log
