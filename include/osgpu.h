@@ -136,6 +136,15 @@ int osg_conv2d_nhwc_w8(osg_ctx* ctx, const void* x, const void* wq_ohwi, float w
 
 /* Re-layout a [K,N] row-major matrix into [N,K] (done once per resident weight). */
 int osg_transpose_kn_to_nk(osg_ctx* ctx, osg_dtype dtype, const void* src_kn, void* dst_nk, int K, int N);
+/* LayerNorm folded into the GEMM that consumes it (the decomposed LayerNorm chain, onnxstream.cpp:5237-5604, followed by MatMul :5669):
+ *   y[m][n] = act( rstd_m * ( sum_k x[m][k] * W'[n][k]  -  mean_m * c1[n] )  +  c2[n]  (+ residual[m][n]) )
+ * with mean_m / rstd_m = LayerNorm statistics of row m of x over K (eps inside the sqrt), W'[n][k] = f16(gamma[k] * W[n][k]) prepared by
+ * the caller, c1[n] = sum_k W'[n][k], c2[n] = sum_k beta[k] * W[n][k] + bias[n] (fp32 device vectors).  Algebraically
+ * LayerNorm(x) . W^T + bias without materialising (or f16-rounding) the normalised activation; the row sums and sums of squares are
+ * accumulated in fp32 beside the MFMAs from the very A fragments they consume (no second pass over x), the variance is formed in f64.
+ * K % 64 == 0, N % 4 == 0; act may be OSG_ACT_GEGLU (pair-interleaved W', c1, c2). */
+int osg_gemm_ln(osg_ctx* ctx, const void* x, const void* w_nk_folded, const float* c1, const float* c2, float eps, const void* residual,
+                void* y, int M, int N, int K, osg_act act);
 
 /* Fused attention == the reference's AttentionFusedOps pseudo-op (onnxstream.cpp:6696-6929):
  * for each of `heads` items: O = softmax(scale * Q K^T) V, with Q:[heads,Tq,D], K given TRANSPOSED as the reference

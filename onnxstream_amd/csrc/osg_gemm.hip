@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 //   * XCD-aware tile walk: the 1-D grid is remapped so each of the 8 XCDs (private L2) gets a CONTIGUOUS run of tiles,
 //     ordered so that the operand with more unique bytes is split across XCDs and read from HBM once.
 // SPEC = 1: 512 threads -- waves 4..7 only issue the DMA loads, waves 0..3 only do ds_read + MFMA + epilogue (see osg_conv3x3.hip)
-template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0>
+template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0, bool LN = false>
 __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm2_kernel(GemmParams p) {
     constexpr int ROWB = 128;                       // bytes per tile row (BK = 64 halves)
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
@@ -354,6 +354,10 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm2_kernel(GemmParams p) {
         for (int s2 = 0; s2 < NST - 1; s2++) issue_tile(s2);
     }
 
+    float ls[TM], lq[TM];          // LN: running row sums / sums of squares of this lane's rows (see ln_accumulate)
+#pragma unroll
+    for (int i = 0; i < TM; i++) ls[i] = lq[i] = 0.f;
+
     int cur = 0, nxt = NST - 1;
     for (int kt = 0; kt < nkt; kt++) {
         if (loads) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");   // my share of tile kt has landed
@@ -372,12 +376,14 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm2_kernel(GemmParams p) {
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
+            if constexpr (LN) ln_accumulate<TM>(a, ls, lq);
         }
         cur = cur + 1 == NST ? 0 : cur + 1;
         nxt = nxt + 1 == NST ? 0 : nxt + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the dummy tail loads before the LDS is released
     if (loader) return;
+    if constexpr (LN) ln_apply<TM, TN>(p, acc, ls, lq, n0, wn0, lane);
     if (p.act == OSG_ACT_GEGLU) {
         if constexpr (TN % 2 == 0) gemm_epilogue_geglu<TM, TN>(p, acc, m0, n0, wm0, wn0, lane, zb);
         return;
@@ -441,10 +447,10 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm2_kernel(GemmParams p) {
     }
 }
 
-template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0>
+template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0, bool LN = false>
 int launch_v2(osg_ctx* ctx, GemmParams& p, int batch) {
     constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
-    auto kern = gemm2_kernel<BM, BN, NST, CONV, MODE, SPEC>;
+    auto kern = gemm2_kernel<BM, BN, NST, CONV, MODE, SPEC, LN>;
     static bool attr_set = false;
     if (!attr_set) {
         OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -734,7 +740,7 @@ static osg_tune::Key tune_key(const osg_ctx* ctx, int kind, const GemmParams& p,
     k.kind = kind; k.device = ctx->device; k.M = p.M; k.N = p.N; k.K = p.K; k.batch = batch;
     if (kind != 0) { k.H = p.H; k.W = p.W; k.Cin = p.Cin; k.KW = p.KW; k.sh = p.sh; k.sw = p.sw; }
     else k.H = p.lda;
-    k.flags = (int)p.act | (p.residual ? 16 : 0) | (p.rowbias ? 32 : 0) | (p.bias_f32 ? 64 : 0);
+    k.flags = (int)p.act | (p.residual ? 16 : 0) | (p.rowbias ? 32 : 0) | (p.bias_f32 ? 64 : 0) | (p.ln_c1 ? 128 : 0);
     return k;
 }
 // a launch may be repeated for timing only when it does not consume its own output
@@ -762,13 +768,19 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
     const double a_unique = CONV ? (double)p.a_bytes : (double)p.M * p.K * 2.0;
     p.n_major = (double)p.N * p.K * 2.0 > a_unique;
     int rc;
+    if constexpr (!CONV) {
+        if (p.ln_c1) {   // LayerNorm folded into the GEMM: the variants that accumulate row statistics beside the MFMAs
+            if (ch.cfg == 0) rc = ch.nst == 4 ? launch_v2<128, 128, 4, false, 0, 0, true>(ctx, p, batch) : launch_v2<128, 128, 2, false, 0, 0, true>(ctx, p, batch);
+            else if (ch.cfg == 1) rc = ch.nst == 4 ? launch_v2<128, 64, 4, false, 0, 0, true>(ctx, p, batch) : launch_v2<128, 64, 2, false, 0, 0, true>(ctx, p, batch);
+            else rc = ch.nst == 4 ? launch_v2<64, 64, 4, false, 0, 0, true>(ctx, p, batch) : launch_v2<64, 64, 2, false, 0, 0, true>(ctx, p, batch);
+            return rc;
+        }
+    }
     static const int dbg = getenv("OSG_GEMM_DBG") ? atoi(getenv("OSG_GEMM_DBG")) : 0;   // experiments (tools/gemm_probe.py)
     if (dbg == 7) return launch_v2<128, 128, 4, CONV, 0, 1>(ctx, p, batch) || (p.splits > 1 ? launch_splitk_reduce(ctx, p, batch) : 0);   // specialized waves
     if (dbg == 6 && !CONV && batch == 1) return launch_v3(ctx, p);          // register-staged specialized loaders (experiment)
     if (dbg == 1) rc = launch_v2<128, 128, 4, CONV, 1>(ctx, p, batch);        // loads only
     else if (dbg == 2) rc = launch_v2<128, 128, 3, CONV>(ctx, p, batch);
-    else if (dbg == 3) rc = launch_v2<128, 128, 5, CONV>(ctx, p, batch);
-    else if (dbg == 4) rc = launch_v2<128, 128, 5, CONV, 1>(ctx, p, batch);
     else if (dbg == 5) rc = launch_v2<128, 128, 2, CONV>(ctx, p, batch);
     else if (ch.cfg == 0) rc = ch.nst == 4 ? launch_v2<128, 128, 4, CONV>(ctx, p, batch) : launch_v2<128, 128, 2, CONV>(ctx, p, batch);
     else if (ch.cfg == 1) rc = ch.nst == 4 ? launch_v2<128, 64, 4, CONV>(ctx, p, batch) : launch_v2<128, 64, 2, CONV>(ctx, p, batch);
@@ -780,7 +792,7 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
 
 template <bool CONV>
 int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced) {
-    const bool allow_split = p.act != OSG_ACT_GEGLU;   // the GEGLU pairing lives in the tile epilogue
+    const bool allow_split = p.act != OSG_ACT_GEGLU && !p.ln_c1;   // the GEGLU pairing / the folded LayerNorm live in the tile epilogue
     V2Choice ch;
     const bool env_forced = getenv("OSG_GEMM_CFG") || getenv("OSG_GEMM_SPLITS") || getenv("OSG_GEMM_NST") || getenv("OSG_GEMM_DBG");
     if (forced) {
@@ -805,9 +817,9 @@ int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced) {
         }
     } else {
         ch = choose_v2(ctx, p.M, p.N, p.K, batch);
-        if (!allow_split) ch.splits = 1;
         if (const char* e = getenv("OSG_GEMM_CFG")) ch.cfg = atoi(e);
         if (const char* e = getenv("OSG_GEMM_SPLITS")) ch.splits = atoi(e);
+        if (!allow_split) ch.splits = 1;
         if (const char* e = getenv("OSG_GEMM_NST")) ch.nst = atoi(e);
     }
     return launch_v2_choice<CONV>(ctx, p, batch, ch);
@@ -827,6 +839,7 @@ int run_gemm(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced = nul
             return run_gemm_v2<CONV>(ctx, p, batch, forced);
         }
         if (p.act == OSG_ACT_GEGLU) OSG_FAIL(ctx, "osg_gemm: GEGLU epilogue needs 16-byte aligned operands (direct-to-LDS kernel only)");
+        if (p.ln_c1) OSG_FAIL(ctx, "osg_gemm_ln: needs K % 64 == 0 and 16-byte aligned operands (direct-to-LDS kernel only)");
     }
     const bool vec = CONV ? (p.Cin % 8 == 0) : (p.K % 8 == 0 && p.lda % 8 == 0);
     // ---- tile / split-K selection -------------------------------------------------------------------------
@@ -939,6 +952,20 @@ int osg_gemm(osg_ctx* ctx, osg_dtype dtype, const void* A, const void* B, int b_
     p.strideA = stride_a; p.strideB = sb; p.strideC = stride_c;
     p.bias_f32 = bias_dtype == OSG_F32; p.act = act;
     return run_gemm<false>(ctx, p, batch);
+}
+
+int osg_gemm_ln(osg_ctx* ctx, const void* x, const void* w_nk_folded, const float* c1, const float* c2, float eps, const void* residual, void* y,
+                int M, int N, int K, osg_act act) {
+    if (M <= 0 || N <= 0 || K <= 0) OSG_FAIL(ctx, "osg_gemm_ln: invalid shape of inputs");
+    if (!c1 || !c2) OSG_FAIL(ctx, "osg_gemm_ln: c1 and c2 are required");
+    if (K % 64 || N % 4) OSG_FAIL(ctx, "osg_gemm_ln: needs K % 64 == 0, N % 4 == 0");
+    if (act == OSG_ACT_GEGLU && (residual || N % 32)) OSG_FAIL(ctx, "osg_gemm_ln: the GEGLU epilogue needs N % 32 == 0 and no residual");
+    GemmParams p{};
+    p.A = (const f16*)x; p.Bt = (const f16*)w_nk_folded; p.C = (f16*)y; p.bias = c2; p.residual = (const f16*)residual;
+    p.M = M; p.N = N; p.K = K; p.lda = K;
+    p.bias_f32 = 1; p.act = act;
+    p.ln_c1 = c1; p.ln_eps = eps;
+    return run_gemm<false>(ctx, p, 1);
 }
 
 int osg_conv2d_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* w, const void* bias, osg_dtype bias_dtype,

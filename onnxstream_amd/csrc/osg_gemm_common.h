@@ -32,7 +32,51 @@ struct GemmParams {
     int pre_act, pre_imgs;       //   activation applied after the affine (OSG_ACT_SILU), number of images
     float w_scale;               // W8 kernels (osg_gemm_w8.hip): Bt holds uint8 codes, w = (q - w_zp) * w_scale
     int w_zp;
+    const float* ln_c1;          // osg_gemm_ln: LayerNorm over K folded into this GEMM -- c1[n] = sum_k W'[n][k]; bias holds c2 (f32)
+    float ln_eps;
 };
+
+// ---- LayerNorm folded into the consuming GEMM (osg_gemm_ln) ----------------------------------------------------------------
+// The math waves already read every A fragment of their rows out of LDS for the MFMAs: two v_dot2c_f32_f16 per f16 pair accumulate
+// the row's sum and sum of squares on the side (fp32, in the shadow of the MFMA pipe).  A lane holds row (lane & 15) + 16 i and the
+// k-chunk (lane >> 4) of every 32-deep half, so the row totals are a 2-step butterfly over the four 16-lane groups -- and they are
+// the rows of this lane's own accumulators: no LDS, no extra pass over A.
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+template <int TM>
+__device__ __forceinline__ void ln_accumulate(const f16x8 (&a)[TM], float (&ls)[TM], float (&lq)[TM]) {
+    const f16x2v ones = {(f16)1.0f, (f16)1.0f};
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const f16x2v pr = {a[i][2 * e], a[i][2 * e + 1]};
+            ls[i] = __builtin_amdgcn_fdot2(pr, ones, ls[i], false);
+            lq[i] = __builtin_amdgcn_fdot2(pr, pr, lq[i], false);
+        }
+}
+// acc <- rstd_m * (acc - mean_m * c1[n]): what the GEMM of the NORMALISED rows with the gamma-folded weight would have accumulated
+template <int TM, int TN>
+__device__ __forceinline__ void ln_apply(const GemmParams& p, f32x4 (&acc)[TM][TN], float (&ls)[TM], float (&lq)[TM], int n0, int wn0, int lane) {
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        float s = ls[i], q = lq[i];
+        s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+        s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+        const double mean_d = (double)s / (double)p.K;
+        double var = (double)q / (double)p.K - mean_d * mean_d;
+        if (var < 0) var = 0;
+        const float mean = (float)mean_d;
+        const float rstd = (float)(1.0 / sqrt(var + (double)p.ln_eps));
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            if (n < p.N) c = *reinterpret_cast<const f32x4*>(p.ln_c1 + n);
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[i][j][r] = rstd * (acc[i][j][r] - mean * c[r]);
+        }
+    }
+}
 
 // ---- epilogue shared by both kernels: lane owns C[m][n..n+3], m = tile_m + (lane&15), n = tile_n + (lane>>4)*4 --------
 // (operands are swapped -- weights feed the MFMA "A" port -- so the 4 accumulator registers of a lane are 4 consecutive

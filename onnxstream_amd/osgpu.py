@@ -24,7 +24,7 @@ EXPORTS = [
     "osg_device_count", "osg_init", "osg_destroy", "osg_last_error", "osg_device_name", "osg_stream", "osg_set_autotune",
     "osg_malloc", "osg_free", "osg_upload", "osg_upload_sync", "osg_host_register", "osg_host_unregister", "osg_upload_pinned", "osg_download", "osg_copy", "osg_memset", "osg_sync",
     "osg_graph_begin", "osg_graph_end", "osg_graph_launch", "osg_graph_destroy", "osg_timer_start", "osg_timer_stop",
-    "osg_conv2d_nhwc", "osg_conv2d_nhwc_rb", "osg_gemm", "osg_gemm_w8", "osg_conv2d_nhwc_w8", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided",
+    "osg_conv2d_nhwc", "osg_conv2d_nhwc_rb", "osg_gemm", "osg_gemm_ln", "osg_gemm_w8", "osg_conv2d_nhwc_w8", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided",
     "osg_instance_norm", "osg_group_norm_nhwc", "osg_group_norm_conv3x3_supported", "osg_group_norm_conv3x3", "osg_layer_norm", "osg_reduce_mean_last", "osg_softmax_last",
     "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_resize_nearest", "osg_gather_rows",
     "osg_maxpool_nhwc", "osg_convert", "osg_sampler_prepare", "osg_sampler_cfg_euler_a",
@@ -89,6 +89,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_gather_rows.argtypes = [vp, ci, vp, vp, vp, cl, cl, cl]
     lib.osg_maxpool_nhwc.argtypes = [vp, ci, vp, vp] + [ci] * 12
     lib.osg_convert.argtypes = [vp, ci, ci, vp, vp, cl, cf, ci]
+    lib.osg_gemm_ln.argtypes = [vp, vp, vp, vp, vp, cf, vp, vp, ci, ci, ci, ci]
     lib.osg_sampler_prepare.argtypes = [vp, vp, vp, vp, ci, cl, cf, cf, cl]
     lib.osg_sampler_cfg_euler_a.argtypes = [vp, vp, vp, vp, ci, cl, cf, cf, cf, cf, cf]
     return lib
@@ -209,6 +210,19 @@ class Gpu:
         self._ck(self.lib.osg_gemm(self.ctx, _NP2DT[a.dtype], a.ptr, b.ptr, int(b_is_nk), self._p(bias), bdt, self._p(residual), c.ptr, m,
                                    n, k, batch, m * k if batch > 1 else 0, sb, m * n if batch > 1 else 0, act))
         return c
+
+    def gemm_ln(self, x: DevBuf, w_nk: np.ndarray, gamma: np.ndarray, beta: np.ndarray, bias=None, eps: float = 1e-5, residual=None, act=ACT_NONE):
+        """LayerNorm(x; gamma, beta, eps) . w_nk^T + bias through osg_gemm_ln: folds gamma into the [N,K] weight and builds c1 / c2 on the
+        host exactly as the planner does (plan.cpp ln_fold_weight).  x:[M,K] device f16; w_nk, gamma, beta, bias: host f16 arrays."""
+        m, k = x.shape
+        n = w_nk.shape[0]
+        wf = (gamma.astype(np.float32)[None, :] * w_nk.astype(np.float32)).astype(np.float16)
+        c1 = wf.astype(np.float64).sum(axis=1).astype(np.float32)
+        c2 = (w_nk.astype(np.float64) @ beta.astype(np.float64) + (bias.astype(np.float64) if bias is not None else 0.0)).astype(np.float32)
+        dw, d1, d2 = self.to_dev(wf), self.to_dev(c1), self.to_dev(c2)
+        y = self.empty((m, n // 2 if act == 3 else n), x.dtype)
+        self._ck(self.lib.osg_gemm_ln(self.ctx, x.ptr, dw.ptr, d1.ptr, d2.ptr, eps, self._p(residual), y.ptr, m, n, k, act))
+        return y
 
     def transpose_kn_to_nk(self, w: DevBuf):
         k, n = w.shape

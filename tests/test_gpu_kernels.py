@@ -68,6 +68,41 @@ def test_gemm_geglu_epilogue(gpu, M, K, C):
     assert rel_max(y.numpy(), want) <= 1e-3
 
 
+@pytest.mark.parametrize("M,K,N,geglu", [(300, 320, 320, False), (8192, 320, 960, False), (2048, 640, 640, False), (512, 1280, 1280, False),
+                                          (130, 64, 36, False), (1024, 640, 5120, True), (128, 1280, 10240, True), (77, 1536, 64, True)])
+def test_gemm_ln_folded_layer_norm(gpu, M, K, N, geglu):
+    """LayerNorm folded into its consuming GEMM (osg_gemm_ln: gamma in the weight, row sums / sums of squares accumulated beside the MFMAs,
+    beta and the mean correction in two fp32 epilogue vectors) vs LayerNorm -> Linear (+GEGLU) in float64.  Rows with a large common
+    offset exercise the mean-correction and the single-pass variance cancellation."""
+    from scipy.special import erf
+    rng = np.random.default_rng(M + K + N)
+    x = (rnd(rng, (M, K), 1.5).astype(f32) + rng.standard_normal((M, 1), dtype=f32) * 3.0).astype(f16)
+    gamma, beta = (1 + rnd(rng, (K,), 0.2).astype(f32)).astype(f16), rnd(rng, (K,), 0.2)
+    w = rnd(rng, (N, K), K ** -0.5)
+    bias = rnd(rng, (N,), 0.1)
+    x64 = x.astype(np.float64)
+    ln = (x64 - x64.mean(-1, keepdims=True)) / np.sqrt(x64.var(-1, keepdims=True) + 1e-5) * gamma.astype(np.float64) + beta.astype(np.float64)
+    want = ln @ w.astype(np.float64).T + bias.astype(np.float64)
+    wk, bk = w, bias
+    if geglu:
+        C = N // 2
+        v, g = want[:, :C], want[:, C:]
+        want = v * 0.5 * g * (1.0 + erf(g / np.sqrt(2.0)))
+        wk, bk = np.empty_like(w), np.empty_like(bias)
+        for k in range(C // 16):
+            wk[32 * k:32 * k + 16] = w[16 * k:16 * k + 16]
+            wk[32 * k + 16:32 * k + 32] = w[C + 16 * k:C + 16 * k + 16]
+            bk[32 * k:32 * k + 16] = bias[16 * k:16 * k + 16]
+            bk[32 * k + 16:32 * k + 32] = bias[C + 16 * k:C + 16 * k + 16]
+    got = gpu.gemm_ln(gpu.to_dev(x), wk, gamma, beta, bk, 1e-5, act=3 if geglu else 0).numpy()
+    assert rel_max(got, want) <= 1e-3
+    # against the unfused device sequence (LayerNorm rounds to f16 first): within the two paths' roundings
+    if not geglu:
+        lnd = gpu.layer_norm(gpu.to_dev(x), gpu.to_dev(gamma), gpu.to_dev(beta), 1e-5)
+        two = gpu.gemm(lnd, gpu.to_dev(w), gpu.to_dev(bias), b_is_nk=True).numpy()
+        assert rel_max(got, two.astype(np.float64)) <= 2e-3
+
+
 def _quant(rng, shape, std):
     w = (rng.standard_normal(shape, dtype=f32) * std).astype(f32)
     lo, hi = min(float(w.min()), 0.0), max(float(w.max()), 0.0)
