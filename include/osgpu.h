@@ -142,9 +142,15 @@ int osg_transpose_kn_to_nk(osg_ctx* ctx, osg_dtype dtype, const void* src_kn, vo
  * the caller, c1[n] = sum_k W'[n][k], c2[n] = sum_k beta[k] * W[n][k] + bias[n] (fp32 device vectors).  Algebraically
  * LayerNorm(x) . W^T + bias without materialising (or f16-rounding) the normalised activation; the row sums and sums of squares are
  * accumulated in fp32 beside the MFMAs from the very A fragments they consume (no second pass over x), the variance is formed in f64.
- * K % 64 == 0, N % 4 == 0; act may be OSG_ACT_GEGLU (pair-interleaved W', c1, c2). */
-int osg_gemm_ln(osg_ctx* ctx, const void* x, const void* w_nk_folded, const float* c1, const float* c2, float eps, const void* residual,
-                void* y, int M, int N, int K, osg_act act);
+ * K % 64 == 0, N % 4 == 0; act may be OSG_ACT_GEGLU (pair-interleaved W', c1, c2).
+ * rowstats (may be NULL): partial row statistics of x emitted by the GEMM that produced it (osg_gemm_rowstats) -- [M][K/32][2] floats,
+ * (sum, sum of squares) of each 32-column slot; with them this GEMM does no statistics work of its own (K <= 1280). */
+int osg_gemm_ln(osg_ctx* ctx, const void* x, const void* w_nk_folded, const float* c1, const float* c2, float eps, const float* rowstats,
+                const void* residual, void* y, int M, int N, int K, osg_act act);
+/* osg_gemm ([N,K] weight, batch 1) whose epilogue also emits rowstats[M][N/32][2] = (sum, sum of squares) of the f16-ROUNDED outputs over
+ * every 32-column slot of every row: the hand-over to an osg_gemm_ln that normalises this output.  N % 32 == 0, K % 64 == 0. */
+int osg_gemm_rowstats(osg_ctx* ctx, const void* A, const void* B_nk, const void* bias, osg_dtype bias_dtype, const void* residual, void* C,
+                      int M, int N, int K, osg_act act, float* rowstats);
 
 /* Fused attention == the reference's AttentionFusedOps pseudo-op (onnxstream.cpp:6696-6929):
  * for each of `heads` items: O = softmax(scale * Q K^T) V, with Q:[heads,Tq,D], K given TRANSPOSED as the reference

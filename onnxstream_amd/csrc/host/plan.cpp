@@ -951,6 +951,37 @@ struct Lowering {
     }
 
     // Conv (reference :4494-4707 -> XnnPack::convolution :1292): group 1, dilation 1, pads re-centred (:1315-1329)
+    // GEMM-shaped steps ([M,K] x [N,K]^T, plain epilogue) that can ALSO emit the partial row statistics of their output when a folded
+    // LayerNorm turns out to consume it (osg_gemm_rowstats): keyed by the root val they write
+    struct RsProducer { size_t step; int a, w, bias, res, y; long M, N, K; };
+    std::map<int, RsProducer> rs_producers;
+    void note_rs_producer(int a, int w, int bias, int res, int y, long M, long Nn, long K) {
+        if (P.fusion < 2 || !P.fuse_ln_gemm || Nn % 32 || K % 64 || Nn > 1280) return;
+        rs_producers[P.root_of(y)] = RsProducer{P.steps.size() - 1, a, w, bias, res, y, M, Nn, K};
+    }
+    // switch the producer of x to the row-statistics variant; returns the [M, N/32, 2] fp32 val or -1
+    int upgrade_rs_producer(int x, long rows, long C) {
+        auto it = rs_producers.find(P.root_of(x));
+        if (it == rs_producers.end()) return -1;
+        const RsProducer r = it->second;
+        if (r.M != rows || r.N != C || V(x).view_off != 0 || r.step >= P.steps.size()) return -1;
+        if (V(r.y).batched != V(x).batched) return -1;
+        int rs = P.new_val("", {r.M / (V(x).batched ? N : 1), C / 32, 2}, OSG_F32, Lay::plain, V(x).batched);
+        Step& st = P.steps[r.step];
+        st.writes.push_back(rs);
+        st.what += " +rowstats";
+        const int a = r.a, w = r.w, bias = r.bias, res = r.res, y = r.y;
+        const long M = r.M, Nn = r.N, K = r.K;
+        const std::string what = st.what;
+        st.run = [=, this] {
+            be.check(be.api.osg_gemm_rowstats(be.ctx, P.ptr(a), P.ptr(w), bias >= 0 ? P.ptr(bias) : nullptr, bias >= 0 ? P.vals[bias].dtype : OSG_F16,
+                                              res >= 0 ? P.ptr(res) : nullptr, P.ptr(y), (int)M, (int)Nn, (int)K, OSG_ACT_NONE, (float*)P.ptr(rs)),
+                     what.c_str());
+        };
+        rs_producers.erase(it);
+        return rs;
+    }
+
     void lower_conv(const Operation& op) {
         const bool has_res = attr(op, "osg_residual") != nullptr;
         const bool has_ib = attr(op, "osg_image_bias") != nullptr;
@@ -1047,6 +1078,8 @@ struct Lowering {
                      "Conv");
         });
         P.steps.back().flops = 2.0 * nb * Ho * Wo * Cout * KH * KW * Cin;
+        if (KH == 1 && KW == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && ib < 0)   // a 1x1 convolution IS a GEMM over the pixels (OHWI == [N,K])
+            note_rs_producer(x, w, bias, res, y, nb * Ho * Wo, Cout, Cin);
     }
 
     // resident [K,N] weight -> [N,K] (done once, at plan time)
@@ -1113,6 +1146,7 @@ struct Lowering {
                      what.c_str());
         });
         P.steps.back().flops = 2.0 * M * Nn * K * batch;
+        if (b_is_nk && batch == 1 && V(y).ld == 0) note_rs_producer(a, wnk, bias, res, y, M, Nn, K);
     }
 
     // ---- merged projections: osg.Linear / Gemm ops that read the SAME activation and whose results are only consumed through
@@ -1480,7 +1514,7 @@ struct Lowering {
     // up in ONE GEMM launch (a single Linear / Linear+GEGLU, or the members of one merged group: self-attention Q|K|V), the LayerNorm is
     // not launched at all -- gamma moves into the weight, beta and the mean correction into two fp32 epilogue vectors, the row
     // statistics are accumulated by the GEMM's math waves beside the MFMAs, from the A fragments they read anyway.  48 launches less in the SD 1.5 UNet.
-    struct LnFold { int x, g, b; float eps; long C; };
+    struct LnFold { int x, g, b; float eps; long C; int rs; };   // rs: partial row statistics handed over by the producer of x (-1: none)
     std::map<std::string, LnFold> ln_deferred;   // LayerNorm output name -> what its consumers fold
 
     bool ln_can_fold(const Operation& op, int x, int g, int b, long C) {
@@ -1562,13 +1596,14 @@ struct Lowering {
     }
 
     void emit_gemm_ln(const std::string& what, const LnFold& f, int wfold, int c1, int c2, int res, int y, long M, long Nn, long K, osg_act act_) {
-        const int x = f.x;
+        const int x = f.x, rs = f.rs;
         const float eps = f.eps;
         std::vector<int> reads = {x, wfold, c1, c2};
         if (res >= 0) reads.push_back(res);
+        if (rs >= 0) reads.push_back(rs);
         P.add_step(what, reads, {y}, [=, this] {
-            be.check(be.api.osg_gemm_ln(be.ctx, P.ptr(x), P.ptr(wfold), (const float*)P.ptr(c1), (const float*)P.ptr(c2), eps, res >= 0 ? P.ptr(res) : nullptr,
-                                        P.ptr(y), (int)M, (int)Nn, (int)K, act_),
+            be.check(be.api.osg_gemm_ln(be.ctx, P.ptr(x), P.ptr(wfold), (const float*)P.ptr(c1), (const float*)P.ptr(c2), eps,
+                                        rs >= 0 ? (const float*)P.ptr(rs) : nullptr, res >= 0 ? P.ptr(res) : nullptr, P.ptr(y), (int)M, (int)Nn, (int)K, act_),
                      what.c_str());
         });
         P.steps.back().flops = 2.0 * M * Nn * K;
@@ -1581,7 +1616,8 @@ struct Lowering {
         const float eps = std::stof(*attr(op, "epsilon"));
         if (ln_can_fold(op, x, g, b, s.back())) {
             check_out(op, s);
-            ln_deferred[op.m_output[0].m_name] = LnFold{x, g, b, eps, s.back()};
+            const int rs = upgrade_rs_producer(x, P.total_elems(x) / s.back(), s.back());
+            ln_deferred[op.m_output[0].m_name] = LnFold{x, g, b, eps, s.back(), rs};
             return;
         }
         int y = out_val(op, s, Lay::plain, V(x).batched);

@@ -124,7 +124,7 @@ struct Plan {
     bool fp16 = true;
     bool stream_weights = false;
     bool fuse_gn_conv = false;
-    bool fuse_ln_gemm = true;
+    bool fuse_ln_gemm = false;
     bool w8_resident = false;      // uint8 Conv/MatMul/Gemm weights kept as codes, dequantised inside the kernels (osg_*_w8)   // m_hip_stream_weights: weights are re-pulled from the WeightsProvider and re-streamed H2D every pass
     int fusion = 2;
     std::vector<std::string> extra_outputs;

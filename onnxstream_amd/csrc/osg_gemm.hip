@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 //   * XCD-aware tile walk: the 1-D grid is remapped so each of the 8 XCDs (private L2) gets a CONTIGUOUS run of tiles,
 //     ordered so that the operand with more unique bytes is split across XCDs and read from HBM once.
 // SPEC = 1: 512 threads -- waves 4..7 only issue the DMA loads, waves 0..3 only do ds_read + MFMA + epilogue (see osg_conv3x3.hip)
-template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0, bool LN = false>
+// LN = 1: LayerNorm over K folded in, row statistics accumulated beside the MFMAs; LN = 2: ... row statistics emitted by the producer of A
+// (rs_in), prefetched into registers before the first tile is requested and combined right before the epilogue
+template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0, int LN = 0, int NCH = 5>
 __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm2_kernel(GemmParams p) {
     constexpr int ROWB = 128;                       // bytes per tile row (BK = 64 halves)
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
@@ -349,6 +351,20 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm2_kernel(GemmParams p) {
     const int a_rd = (wm0 + frow) * ROWB + fsw;
     const int b_rd = A_BYTES + (wn0 + frow) * ROWB + fsw;
 
+    // LN == 2: the producer's partial row statistics, [M][rs_np][2] floats = rs_np/2 16-byte chunks per row.  Lane l of a wave owns row
+    // (l & 15) + 16 ((l >> 4) % TM) of the wave's rows and requests ALL chunks of that row -- BEFORE the first tile (vector-memory
+    // results return in order: they are home by the time tile 0 is, at no extra wait).  NCH = chunks per row (template: K <= 64 NCH).
+    f32x4 pst[LN == 2 ? NCH : 1];
+    if constexpr (LN == 2) {
+        const int m = min(m0 + wm0 + (lane & 15) + 16 * ((lane >> 4) % TM), p.M - 1);
+        const float* src = p.rs_in + (long)m * p.rs_np * 2;
+        const int nch = p.rs_np >> 1;
+#pragma unroll
+        for (int c = 0; c < NCH; c++)   // unconditional, clamped (a predicated load makes the compiler wait for it on the spot); masked when consumed
+            pst[c] = *reinterpret_cast<const f32x4*>(src + 4 * min(c, nch - 1));
+        asm volatile("" ::: "memory");
+    }
+
     if (loads) {
 #pragma unroll
         for (int s2 = 0; s2 < NST - 1; s2++) issue_tile(s2);
@@ -376,14 +392,29 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm2_kernel(GemmParams p) {
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
-            if constexpr (LN) ln_accumulate<TM>(a, ls, lq);
+            if constexpr (LN == 1) ln_accumulate<TM>(a, ls, lq);
         }
         cur = cur + 1 == NST ? 0 : cur + 1;
         nxt = nxt + 1 == NST ? 0 : nxt + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the dummy tail loads before the LDS is released
     if (loader) return;
-    if constexpr (LN) ln_apply<TM, TN>(p, acc, ls, lq, n0, wn0, lane);
+    if constexpr (LN == 2) {
+        const int nch = p.rs_np >> 1;
+        float S = 0.f, Q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            // (the empty asm pins the additions AFTER the k loop: hoisted, they would wait for the prefetch before the first tile request)
+            asm volatile("" : "+v"(pst[c]));
+            if (c < nch) { S += pst[c][0] + pst[c][2]; Q += pst[c][1] + pst[c][3]; }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++) {   // row (lane & 15) + 16 i lives in lane (lane & 15) + 16 i
+            ls[i] = __shfl(S, (lane & 15) + 16 * i, 64);
+            lq[i] = __shfl(Q, (lane & 15) + 16 * i, 64);
+        }
+    }
+    if constexpr (LN != 0) ln_apply<TM, TN, LN == 1>(p, acc, ls, lq, n0, wn0, lane);
     if (p.act == OSG_ACT_GEGLU) {
         if constexpr (TN % 2 == 0) gemm_epilogue_geglu<TM, TN>(p, acc, m0, n0, wm0, wn0, lane, zb);
         return;
@@ -447,10 +478,10 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm2_kernel(GemmParams p) {
     }
 }
 
-template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0, bool LN = false>
+template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0, int LN = 0, int NCH = 5>
 int launch_v2(osg_ctx* ctx, GemmParams& p, int batch) {
     constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
-    auto kern = gemm2_kernel<BM, BN, NST, CONV, MODE, SPEC, LN>;
+    auto kern = gemm2_kernel<BM, BN, NST, CONV, MODE, SPEC, LN, NCH>;
     static bool attr_set = false;
     if (!attr_set) {
         OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -740,7 +771,7 @@ static osg_tune::Key tune_key(const osg_ctx* ctx, int kind, const GemmParams& p,
     k.kind = kind; k.device = ctx->device; k.M = p.M; k.N = p.N; k.K = p.K; k.batch = batch;
     if (kind != 0) { k.H = p.H; k.W = p.W; k.Cin = p.Cin; k.KW = p.KW; k.sh = p.sh; k.sw = p.sw; }
     else k.H = p.lda;
-    k.flags = (int)p.act | (p.residual ? 16 : 0) | (p.rowbias ? 32 : 0) | (p.bias_f32 ? 64 : 0) | (p.ln_c1 ? 128 : 0);
+    k.flags = (int)p.act | (p.residual ? 16 : 0) | (p.rowbias ? 32 : 0) | (p.bias_f32 ? 64 : 0) | (p.ln_c1 ? 128 : 0) | (p.rs_in ? 256 : 0) | (p.rs_out ? 512 : 0);
     return k;
 }
 // a launch may be repeated for timing only when it does not consume its own output
@@ -769,10 +800,24 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
     p.n_major = (double)p.N * p.K * 2.0 > a_unique;
     int rc;
     if constexpr (!CONV) {
-        if (p.ln_c1) {   // LayerNorm folded into the GEMM: the variants that accumulate row statistics beside the MFMAs
-            if (ch.cfg == 0) rc = ch.nst == 4 ? launch_v2<128, 128, 4, false, 0, 0, true>(ctx, p, batch) : launch_v2<128, 128, 2, false, 0, 0, true>(ctx, p, batch);
-            else if (ch.cfg == 1) rc = ch.nst == 4 ? launch_v2<128, 64, 4, false, 0, 0, true>(ctx, p, batch) : launch_v2<128, 64, 2, false, 0, 0, true>(ctx, p, batch);
-            else rc = ch.nst == 4 ? launch_v2<64, 64, 4, false, 0, 0, true>(ctx, p, batch) : launch_v2<64, 64, 2, false, 0, 0, true>(ctx, p, batch);
+        if (p.ln_c1 && p.rs_in) {   // LayerNorm folded into the GEMM, row statistics handed over by the producer of A
+            const int nch = p.rs_np >> 1;
+#define OSG_LN2(NCH_)                                                                                                                                \
+    do {                                                                                                                                             \
+        if (ch.cfg == 0) rc = ch.nst == 4 ? launch_v2<128, 128, 4, false, 0, 0, 2, NCH_>(ctx, p, batch) : launch_v2<128, 128, 2, false, 0, 0, 2, NCH_>(ctx, p, batch); \
+        else if (ch.cfg == 1) rc = ch.nst == 4 ? launch_v2<128, 64, 4, false, 0, 0, 2, NCH_>(ctx, p, batch) : launch_v2<128, 64, 2, false, 0, 0, 2, NCH_>(ctx, p, batch); \
+        else rc = ch.nst == 4 ? launch_v2<64, 64, 4, false, 0, 0, 2, NCH_>(ctx, p, batch) : launch_v2<64, 64, 2, false, 0, 0, 2, NCH_>(ctx, p, batch);   \
+    } while (0)
+            if (nch <= 5) OSG_LN2(5);
+            else if (nch <= 10) OSG_LN2(10);
+            else OSG_LN2(20);
+#undef OSG_LN2
+            return rc;
+        }
+        if (p.ln_c1) {   // ... row statistics accumulated beside the MFMAs
+            if (ch.cfg == 0) rc = ch.nst == 4 ? launch_v2<128, 128, 4, false, 0, 0, 1>(ctx, p, batch) : launch_v2<128, 128, 2, false, 0, 0, 1>(ctx, p, batch);
+            else if (ch.cfg == 1) rc = ch.nst == 4 ? launch_v2<128, 64, 4, false, 0, 0, 1>(ctx, p, batch) : launch_v2<128, 64, 2, false, 0, 0, 1>(ctx, p, batch);
+            else rc = ch.nst == 4 ? launch_v2<64, 64, 4, false, 0, 0, 1>(ctx, p, batch) : launch_v2<64, 64, 2, false, 0, 0, 1>(ctx, p, batch);
             return rc;
         }
     }
@@ -792,7 +837,7 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
 
 template <bool CONV>
 int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced) {
-    const bool allow_split = p.act != OSG_ACT_GEGLU && !p.ln_c1;   // the GEGLU pairing / the folded LayerNorm live in the tile epilogue
+    const bool allow_split = p.act != OSG_ACT_GEGLU && !p.ln_c1 && !p.rs_out;   // GEGLU pairing / folded LayerNorm / row statistics live in the tile epilogue
     V2Choice ch;
     const bool env_forced = getenv("OSG_GEMM_CFG") || getenv("OSG_GEMM_SPLITS") || getenv("OSG_GEMM_NST") || getenv("OSG_GEMM_DBG");
     if (forced) {
@@ -839,7 +884,7 @@ int run_gemm(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced = nul
             return run_gemm_v2<CONV>(ctx, p, batch, forced);
         }
         if (p.act == OSG_ACT_GEGLU) OSG_FAIL(ctx, "osg_gemm: GEGLU epilogue needs 16-byte aligned operands (direct-to-LDS kernel only)");
-        if (p.ln_c1) OSG_FAIL(ctx, "osg_gemm_ln: needs K % 64 == 0 and 16-byte aligned operands (direct-to-LDS kernel only)");
+        if (p.ln_c1 || p.rs_out) OSG_FAIL(ctx, "osg_gemm_ln / osg_gemm_rowstats: need K % 64 == 0 and 16-byte aligned operands (direct-to-LDS kernel only)");
     }
     const bool vec = CONV ? (p.Cin % 8 == 0) : (p.K % 8 == 0 && p.lda % 8 == 0);
     // ---- tile / split-K selection -------------------------------------------------------------------------
@@ -954,8 +999,21 @@ int osg_gemm(osg_ctx* ctx, osg_dtype dtype, const void* A, const void* B, int b_
     return run_gemm<false>(ctx, p, batch);
 }
 
-int osg_gemm_ln(osg_ctx* ctx, const void* x, const void* w_nk_folded, const float* c1, const float* c2, float eps, const void* residual, void* y,
-                int M, int N, int K, osg_act act) {
+int osg_gemm_rowstats(osg_ctx* ctx, const void* A, const void* B_nk, const void* bias, osg_dtype bias_dtype, const void* residual, void* C, int M, int N,
+                      int K, osg_act act, float* rowstats) {
+    if (M <= 0 || N <= 0 || K <= 0) OSG_FAIL(ctx, "osg_gemm_rowstats: invalid shape of inputs");
+    if (!rowstats || N % 32 || K % 64 || act == OSG_ACT_GEGLU) OSG_FAIL(ctx, "osg_gemm_rowstats: needs N % 32 == 0, K % 64 == 0, a plain activation");
+    if (bias && bias_dtype != OSG_F16 && bias_dtype != OSG_F32) OSG_FAIL(ctx, "osg_gemm_rowstats: invalid bias dtype");
+    GemmParams p{};
+    p.A = (const f16*)A; p.Bt = (const f16*)B_nk; p.C = (f16*)C; p.bias = bias; p.residual = (const f16*)residual;
+    p.M = M; p.N = N; p.K = K; p.lda = K;
+    p.bias_f32 = bias_dtype == OSG_F32; p.act = act;
+    p.rs_out = rowstats; p.rs_np = N / 32;
+    return run_gemm<false>(ctx, p, 1);
+}
+
+int osg_gemm_ln(osg_ctx* ctx, const void* x, const void* w_nk_folded, const float* c1, const float* c2, float eps, const float* rowstats,
+                const void* residual, void* y, int M, int N, int K, osg_act act) {
     if (M <= 0 || N <= 0 || K <= 0) OSG_FAIL(ctx, "osg_gemm_ln: invalid shape of inputs");
     if (!c1 || !c2) OSG_FAIL(ctx, "osg_gemm_ln: c1 and c2 are required");
     if (K % 64 || N % 4) OSG_FAIL(ctx, "osg_gemm_ln: needs K % 64 == 0, N % 4 == 0");
@@ -965,6 +1023,10 @@ int osg_gemm_ln(osg_ctx* ctx, const void* x, const void* w_nk_folded, const floa
     p.M = M; p.N = N; p.K = K; p.lda = K;
     p.bias_f32 = 1; p.act = act;
     p.ln_c1 = c1; p.ln_eps = eps;
+    if (rowstats) {
+        if (K % 32 || K > 1280) OSG_FAIL(ctx, "osg_gemm_ln: handed-over row statistics need K % 32 == 0, K <= 1280");
+        p.rs_in = rowstats; p.rs_np = K / 32;
+    }
     return run_gemm<false>(ctx, p, 1);
 }
 

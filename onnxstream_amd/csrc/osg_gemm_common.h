@@ -34,6 +34,9 @@ struct GemmParams {
     int w_zp;
     const float* ln_c1;          // osg_gemm_ln: LayerNorm over K folded into this GEMM -- c1[n] = sum_k W'[n][k]; bias holds c2 (f32)
     float ln_eps;
+    const float* rs_in;          //   row statistics of A emitted by the GEMM that produced it: [M][K/32][2] (sum, sum of squares) per 32 columns
+    float* rs_out;               // osg_gemm_rowstats: this GEMM's epilogue also emits [M][rs_np][2] partial row statistics of its f16 output
+    int rs_np;                   //   = N / 32
 };
 
 // ---- LayerNorm folded into the consuming GEMM (osg_gemm_ln) ----------------------------------------------------------------
@@ -55,18 +58,22 @@ __device__ __forceinline__ void ln_accumulate(const f16x8 (&a)[TM], float (&ls)[
         }
 }
 // acc <- rstd_m * (acc - mean_m * c1[n]): what the GEMM of the NORMALISED rows with the gamma-folded weight would have accumulated
-template <int TM, int TN>
+template <int TM, int TN, bool PARTIAL>
 __device__ __forceinline__ void ln_apply(const GemmParams& p, f32x4 (&acc)[TM][TN], float (&ls)[TM], float (&lq)[TM], int n0, int wn0, int lane) {
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         float s = ls[i], q = lq[i];
-        s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
-        s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
-        const double mean_d = (double)s / (double)p.K;
-        double var = (double)q / (double)p.K - mean_d * mean_d;
-        if (var < 0) var = 0;
+        if (PARTIAL) {   // the four 16-lane groups hold different k-chunks of the row
+            s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+            s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+        }
+        // E[x^2] - mean^2 in f64 (two fma-rate operations; the f32 subtraction would cancel), everything else in f32: an f64 divide
+        // or square root costs hundreds of instructions per row here
+        const double ik = (double)(1.0f / (float)p.K);
+        const double mean_d = (double)s * ik;
+        const float var = fmaxf((float)((double)q * ik - mean_d * mean_d), 0.f);
         const float mean = (float)mean_d;
-        const float rstd = (float)(1.0 / sqrt(var + (double)p.ln_eps));
+        const float rstd = 1.0f / sqrtf(var + p.ln_eps);
 #pragma unroll
         for (int j = 0; j < TN; j++) {
             const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
@@ -93,6 +100,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         for (int i = 0; i < TM; i++) {
             const int m = m0 + wm0 + i * 16 + (lane & 15);
             if (m >= p.M) continue;
+            float rs_s[(TN + 1) / 2], rs_q[(TN + 1) / 2];   // rs_out: sums over this wave's 32-column slots of row m (of the ROUNDED outputs)
+#pragma unroll
+            for (int h = 0; h < (TN + 1) / 2; h++) rs_s[h] = rs_q[h] = 0.f;
 #pragma unroll
             for (int j = 0; j < TN; j++) {
                 const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
@@ -124,6 +134,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 #pragma unroll
                     for (int r = 0; r < 4; r++) o[r] = (f16)osg_apply_act(v[r], p.act);
                     *reinterpret_cast<f16x4*>(C + (long)m * N + n) = o;
+                    if (p.rs_out) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const float f = (float)o[r];
+                            rs_s[j >> 1] += f;
+                            rs_q[j >> 1] = fmaf(f, f, rs_q[j >> 1]);
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
@@ -133,6 +151,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                         if (p.rowbias) x += (float)p.rowbias[(long)(m / p.rb_rows) * p.rb_ld + n + r];
                         if (R) x += (float)R[(long)m * N + n + r];
                         C[(long)m * N + n + r] = (f16)osg_apply_act(x, p.act);
+                    }
+                }
+            }
+            if (p.rs_out) {
+                // the four 16-lane groups of a row hold different columns of the same slot pair: 2-step butterfly, one lane group stores
+#pragma unroll
+                for (int h = 0; h < TN / 2; h++) {
+                    float s = rs_s[h], q = rs_q[h];
+                    s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+                    s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+                    const int slot = ((n0 + wn0) >> 5) + h;
+                    if ((lane >> 4) == 0 && slot < p.rs_np) {
+                        float* d = p.rs_out + ((long)m * p.rs_np + slot) * 2;
+                        d[0] = s;
+                        d[1] = q;
                     }
                 }
             }

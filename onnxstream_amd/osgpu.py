@@ -24,7 +24,7 @@ EXPORTS = [
     "osg_device_count", "osg_init", "osg_destroy", "osg_last_error", "osg_device_name", "osg_stream", "osg_set_autotune",
     "osg_malloc", "osg_free", "osg_upload", "osg_upload_sync", "osg_host_register", "osg_host_unregister", "osg_upload_pinned", "osg_download", "osg_copy", "osg_memset", "osg_sync",
     "osg_graph_begin", "osg_graph_end", "osg_graph_launch", "osg_graph_destroy", "osg_timer_start", "osg_timer_stop",
-    "osg_conv2d_nhwc", "osg_conv2d_nhwc_rb", "osg_gemm", "osg_gemm_ln", "osg_gemm_w8", "osg_conv2d_nhwc_w8", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided",
+    "osg_conv2d_nhwc", "osg_conv2d_nhwc_rb", "osg_gemm", "osg_gemm_ln", "osg_gemm_rowstats", "osg_gemm_w8", "osg_conv2d_nhwc_w8", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided",
     "osg_instance_norm", "osg_group_norm_nhwc", "osg_group_norm_conv3x3_supported", "osg_group_norm_conv3x3", "osg_layer_norm", "osg_reduce_mean_last", "osg_softmax_last",
     "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_resize_nearest", "osg_gather_rows",
     "osg_maxpool_nhwc", "osg_convert", "osg_sampler_prepare", "osg_sampler_cfg_euler_a",
@@ -89,7 +89,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_gather_rows.argtypes = [vp, ci, vp, vp, vp, cl, cl, cl]
     lib.osg_maxpool_nhwc.argtypes = [vp, ci, vp, vp] + [ci] * 12
     lib.osg_convert.argtypes = [vp, ci, ci, vp, vp, cl, cf, ci]
-    lib.osg_gemm_ln.argtypes = [vp, vp, vp, vp, vp, cf, vp, vp, ci, ci, ci, ci]
+    lib.osg_gemm_ln.argtypes = [vp, vp, vp, vp, vp, cf, vp, vp, vp, ci, ci, ci, ci]
+    lib.osg_gemm_rowstats.argtypes = [vp, vp, vp, vp, ci, vp, vp, ci, ci, ci, ci, vp]
     lib.osg_sampler_prepare.argtypes = [vp, vp, vp, vp, ci, cl, cf, cf, cl]
     lib.osg_sampler_cfg_euler_a.argtypes = [vp, vp, vp, vp, ci, cl, cf, cf, cf, cf, cf]
     return lib
@@ -211,7 +212,18 @@ class Gpu:
                                    n, k, batch, m * k if batch > 1 else 0, sb, m * n if batch > 1 else 0, act))
         return c
 
-    def gemm_ln(self, x: DevBuf, w_nk: np.ndarray, gamma: np.ndarray, beta: np.ndarray, bias=None, eps: float = 1e-5, residual=None, act=ACT_NONE):
+    def gemm_rowstats(self, a: DevBuf, b_nk: DevBuf, bias=None, residual=None, act=ACT_NONE):
+        """osg_gemm_rowstats: returns (C, rowstats[M, N/32, 2])."""
+        m, k = a.shape
+        n = b_nk.shape[0]
+        c = self.empty((m, n), a.dtype)
+        rs = self.empty((m, n // 32, 2), np.dtype(np.float32))
+        bdt = _NP2DT[bias.dtype] if bias is not None else F16
+        self._ck(self.lib.osg_gemm_rowstats(self.ctx, a.ptr, b_nk.ptr, self._p(bias), bdt, self._p(residual), c.ptr, m, n, k, act, rs.ptr))
+        return c, rs
+
+    def gemm_ln(self, x: DevBuf, w_nk: np.ndarray, gamma: np.ndarray, beta: np.ndarray, bias=None, eps: float = 1e-5, residual=None, act=ACT_NONE,
+                rowstats=None):
         """LayerNorm(x; gamma, beta, eps) . w_nk^T + bias through osg_gemm_ln: folds gamma into the [N,K] weight and builds c1 / c2 on the
         host exactly as the planner does (plan.cpp ln_fold_weight).  x:[M,K] device f16; w_nk, gamma, beta, bias: host f16 arrays."""
         m, k = x.shape
@@ -221,7 +233,7 @@ class Gpu:
         c2 = (w_nk.astype(np.float64) @ beta.astype(np.float64) + (bias.astype(np.float64) if bias is not None else 0.0)).astype(np.float32)
         dw, d1, d2 = self.to_dev(wf), self.to_dev(c1), self.to_dev(c2)
         y = self.empty((m, n // 2 if act == 3 else n), x.dtype)
-        self._ck(self.lib.osg_gemm_ln(self.ctx, x.ptr, dw.ptr, d1.ptr, d2.ptr, eps, self._p(residual), y.ptr, m, n, k, act))
+        self._ck(self.lib.osg_gemm_ln(self.ctx, x.ptr, dw.ptr, d1.ptr, d2.ptr, eps, self._p(rowstats), self._p(residual), y.ptr, m, n, k, act))
         return y
 
     def transpose_kn_to_nk(self, w: DevBuf):

@@ -105,10 +105,14 @@ def test_restatement_group_norm_and_layer_norm():
 
 # ---- the product path -------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("fusion", [2, 0])
+@pytest.mark.parametrize("fusion", [2, 0, "2+lnfold"])
 @pytest.mark.parametrize("name", gc.all_case_names())
 def test_hip_backend_vs_golden(name, fusion):
+    """fusion 2 = the default plan, 0 = one kernel per graph op (the reference's rounding points), "2+lnfold" = fusion 2 with every
+    LayerNorm folded into its consuming GEMM (hip_fuse_ln_gemm: osg_gemm_ln + osg_gemm_rowstats, opt-in)."""
     from onnxstream_amd import build as b
+    lnfold = fusion == "2+lnfold"
+    fusion = 2 if lnfold else fusion
     from onnxstream_amd.bindings import Model
     ins, oname, r16, r32 = load(name)
     with tempfile.TemporaryDirectory() as d:
@@ -121,6 +125,8 @@ def test_hip_backend_vs_golden(name, fusion):
         m.set_use_fp16_arithmetic(True)
         m.set_fuse_ops_in_attention(True)
         m._set_option("hip_fusion_level", fusion)
+        if lnfold:
+            m._set_option("hip_fuse_ln_gemm", 1)
         m.run()
         got, shape = m.get_tensor(oname)
         m.close()

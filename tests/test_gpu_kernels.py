@@ -96,6 +96,17 @@ def test_gemm_ln_folded_layer_norm(gpu, M, K, N, geglu):
             bk[32 * k + 16:32 * k + 32] = bias[C + 16 * k:C + 16 * k + 16]
     got = gpu.gemm_ln(gpu.to_dev(x), wk, gamma, beta, bk, 1e-5, act=3 if geglu else 0).numpy()
     assert rel_max(got, want) <= 1e-3
+    if K % 32 == 0 and K <= 1280:
+        # hand-over variant: x = the output of a GEMM that also emits partial row statistics (osg_gemm_rowstats); the consumer does no
+        # statistics work of its own.  x = x0 . I + 0 reproduces x exactly, so `want` still applies.
+        eye = gpu.to_dev(np.eye(K, dtype=f16))
+        xd, rs = gpu.gemm_rowstats(gpu.to_dev(x), eye)
+        assert np.array_equal(xd.numpy(), x)
+        rsn = rs.numpy()
+        x3 = x.astype(np.float64).reshape(M, K // 32, 32)
+        assert np.allclose(rsn[..., 0], x3.sum(-1), rtol=1e-5, atol=1e-3) and np.allclose(rsn[..., 1], (x3 ** 2).sum(-1), rtol=1e-5, atol=1e-3)
+        got2 = gpu.gemm_ln(xd, wk, gamma, beta, bk, 1e-5, act=3 if geglu else 0, rowstats=rs).numpy()
+        assert rel_max(got2, want) <= 1e-3
     # against the unfused device sequence (LayerNorm rounds to f16 first): within the two paths' roundings
     if not geglu:
         lnd = gpu.layer_norm(gpu.to_dev(x), gpu.to_dev(gamma), gpu.to_dev(beta), 1e-5)
