@@ -2,8 +2,10 @@
 # Dev tool (GPU box): HBM-side traffic of every kernel of a UNet step -- FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes
 # (MI355X_MICROARCH.md: FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2; never combined with sys/hip traces).  Output: gpurun_out/traffic_<tag>.json
 export TMPDIR=/tmp
+export OSG_TUNE_CACHE=/tmp/osg_tune_cache.txt   # the priming run below tunes; the counter passes reuse its choices (no timing launches in the counters)
 TAG=${1:-r1}
 cd $GRAFT_REPO_ROOT
+python bench.py --mode replay --steps 2 --warmup 1 --cpu-passes 0 --profile-reps 1 > /tmp/pmc_prime.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- python bench.py --mode replay --steps 4 --warmup 1 --cpu-passes 0 --profile-reps 1 > /tmp/pmc_$c.log 2>&1
