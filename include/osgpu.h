@@ -216,6 +216,9 @@ int osg_transpose(osg_ctx* ctx, int elem_size, const void* x, void* y, int rank,
  * (element units).  Implements Concat (:4140), Split (:5999), Slice (:6499) along any axis. */
 int osg_copy_2d(osg_ctx* ctx, int elem_size, const void* src, long src_pitch, long src_off, void* dst, long dst_pitch,
                 long dst_off, long outer, long inner);
+/* Two-input Concat along the innermost run in ONE launch: dst[o][0:inner_a) = a[o][:], dst[o][inner_a:inner_a+inner_b) = b[o][:] for
+ * o < outer; a, b dense (element units).  The UNet's 12 skip-connection concatenations (onnxstream.cpp:4140). */
+int osg_concat2(osg_ctx* ctx, int elem_size, const void* a, long inner_a, const void* b, long inner_b, void* dst, long outer);
 /* Nearest/asymmetric/floor resize of [N,H,W,C] (nhwc=1) or [N,C,H,W] (nhwc=0) by integer-or-not scales (onnxstream.cpp:6120-6315). */
 int osg_resize_nearest(osg_ctx* ctx, int elem_size, const void* x, void* y, int N, int C, int H, int W, int Ho, int Wo, int nhwc);
 /* Gather rows along axis 0: y[i,:] = x[idx[i],:] (onnxstream.cpp:6316). idx is a DEVICE int64 array. */

@@ -22,7 +22,7 @@ struct OsgApi {
     OSG_FN(osg_graph_destroy) OSG_FN(osg_timer_start) OSG_FN(osg_timer_stop) OSG_FN(osg_conv2d_nhwc) OSG_FN(osg_conv2d_nhwc_rb) OSG_FN(osg_gemm) OSG_FN(osg_gemm_ln) OSG_FN(osg_gemm_rowstats) OSG_FN(osg_gemm_w8) OSG_FN(osg_conv2d_nhwc_w8)
     OSG_FN(osg_transpose_kn_to_nk) OSG_FN(osg_attention) OSG_FN(osg_attention_strided) OSG_FN(osg_instance_norm)
     OSG_FN(osg_group_norm_nhwc) OSG_FN(osg_group_norm_conv3x3_supported) OSG_FN(osg_group_norm_conv3x3) OSG_FN(osg_layer_norm) OSG_FN(osg_reduce_mean_last) OSG_FN(osg_softmax_last) OSG_FN(osg_unary)
-    OSG_FN(osg_binary) OSG_FN(osg_geglu) OSG_FN(osg_transpose) OSG_FN(osg_copy_2d) OSG_FN(osg_resize_nearest)
+    OSG_FN(osg_binary) OSG_FN(osg_geglu) OSG_FN(osg_transpose) OSG_FN(osg_copy_2d) OSG_FN(osg_concat2) OSG_FN(osg_resize_nearest)
     OSG_FN(osg_gather_rows) OSG_FN(osg_maxpool_nhwc) OSG_FN(osg_convert) OSG_FN(osg_sampler_prepare) OSG_FN(osg_sampler_cfg_euler_a)
 #undef OSG_FN
 };
@@ -56,7 +56,7 @@ public:
         OSG_FN(osg_graph_destroy) OSG_FN(osg_timer_start) OSG_FN(osg_timer_stop) OSG_FN(osg_conv2d_nhwc) OSG_FN(osg_conv2d_nhwc_rb) OSG_FN(osg_gemm) OSG_FN(osg_gemm_ln) OSG_FN(osg_gemm_rowstats) OSG_FN(osg_gemm_w8) OSG_FN(osg_conv2d_nhwc_w8)
         OSG_FN(osg_transpose_kn_to_nk) OSG_FN(osg_attention) OSG_FN(osg_attention_strided) OSG_FN(osg_instance_norm)
         OSG_FN(osg_group_norm_nhwc) OSG_FN(osg_group_norm_conv3x3_supported) OSG_FN(osg_group_norm_conv3x3) OSG_FN(osg_layer_norm) OSG_FN(osg_reduce_mean_last) OSG_FN(osg_softmax_last) OSG_FN(osg_unary)
-        OSG_FN(osg_binary) OSG_FN(osg_geglu) OSG_FN(osg_transpose) OSG_FN(osg_copy_2d) OSG_FN(osg_resize_nearest)
+        OSG_FN(osg_binary) OSG_FN(osg_geglu) OSG_FN(osg_transpose) OSG_FN(osg_copy_2d) OSG_FN(osg_concat2) OSG_FN(osg_resize_nearest)
         OSG_FN(osg_gather_rows) OSG_FN(osg_maxpool_nhwc) OSG_FN(osg_convert) OSG_FN(osg_sampler_prepare) OSG_FN(osg_sampler_cfg_euler_a)
 #undef OSG_FN
         if (api.osg_device_count() <= 0)

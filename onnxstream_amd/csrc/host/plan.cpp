@@ -1885,6 +1885,12 @@ struct Lowering {
         long outer, dst_pitch, off = 0;
         if (all_nhwc) { outer = os[2] * os[3] * (batched ? N : 1); dst_pitch = os[1]; }
         else { outer = prod(os, 0, axis) * (batched ? N : 1); dst_pitch = prod(os, axis); }
+        if (xs.size() == 2 && V(xs[0]).ld == 0 && V(xs[1]).ld == 0) {   // the skip-connection shape: both sources in one launch
+            const int xa = xs[0], xb = xs[1];
+            const long ia = all_nhwc ? V(xa).shape[1] : prod(V(xa).shape, axis), ib = all_nhwc ? V(xb).shape[1] : prod(V(xb).shape, axis);
+            P.add_step("Concat " + op.m_name, {xa, xb}, {y}, [=, this] { be.check(be.api.osg_concat2(be.ctx, es, P.ptr(xa), ia, P.ptr(xb), ib, P.ptr(y), outer), "Concat"); });
+            return;
+        }
         for (int x : xs) {
             const long inner = all_nhwc ? V(x).shape[1] : prod(V(x).shape, axis);
             const long o = off;

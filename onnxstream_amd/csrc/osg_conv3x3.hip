@@ -443,8 +443,8 @@ std::vector<std::pair<double, std::pair<int, int>>> osg_conv3x3_rank(const osg_c
         const double tiles = (double)mt * ((p.N + bn - 1) / bn);
         const double mfma = 128.0 * bn * 128.0 / 4069.0;
         const double tload = (bn * 128.0 + pp * 128.0 / 9.0) / 23.0;
-        for (int s = 1; s <= 8; s++) {
-            if (s > 1 && slabs / s < 2) break;
+        for (int s = 1; s <= (ctx->autotune ? 12 : 8); s++) {
+            if (s > 1 && slabs / s < (ctx->autotune ? 1 : 2)) break;   // measured choice: let finer splits compete too
             const int sl = (slabs + s - 1) / s;
             if (s > 1 && sl * (s - 1) >= slabs) continue;
             const double blocks = tiles * s;

@@ -746,7 +746,7 @@ static std::vector<std::pair<double, V2Choice>> rank_v2(const osg_ctx* ctx, int 
             const int smem = nst * (kV2BM[c] + kV2BN[c]) * 128;
             const int bpc = std::min(4, 163840 / smem);
             for (int s = 1; s <= (allow_split ? 16 : 1); s++) {
-                if (s > 1 && (kt / s < 8)) break;
+                if (s > 1 && (kt / s < (ctx->autotune ? 3 : 8))) break;   // measured choice: let shorter slices compete too
                 const int kts = (kt + s - 1) / s;
                 if (s > 1 && (kts * (s - 1) >= kt)) continue;   // an empty split
                 const double blocks = tiles * s;

@@ -57,6 +57,17 @@ __global__ __launch_bounds__(256) void copy_2d_kernel(const E* __restrict__ src,
     }
 }
 
+// dst[o][0:ia) = a[o][:], dst[o][ia:ia+ib) = b[o][:]  (both sources dense): the UNet's skip-connection Concat in ONE launch
+template <typename E>
+__global__ __launch_bounds__(256) void concat2_kernel(const E* __restrict__ a, long ia, const E* __restrict__ b, long ib, E* __restrict__ dst, long outer) {
+    const long w = ia + ib, n = outer * w;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const long o = i / w, k = i - o * w;
+        dst[i] = k < ia ? a[o * ia + k] : b[o * ib + (k - ia)];
+    }
+}
+
 template <typename E>
 __global__ __launch_bounds__(256) void resize_nearest_kernel(const E* __restrict__ x, E* __restrict__ y, int N, int C, int H, int W, int Ho,
                                                              int Wo, int nhwc, float sh_inv, float sw_inv) {
@@ -228,6 +239,27 @@ int osg_copy_2d(osg_ctx* ctx, int elem_size, const void* src, long src_pitch, lo
     else if (w == 2) OSG_CP(uint16_t);
     else OSG_CP(uint8_t);
 #undef OSG_CP
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int osg_concat2(osg_ctx* ctx, int elem_size, const void* a, long inner_a, const void* b, long inner_b, void* dst, long outer) {
+    if (outer <= 0 || inner_a <= 0 || inner_b <= 0) OSG_FAIL(ctx, "osg_concat2: invalid argument");
+    const long es = elem_size;
+    auto all_mult = [&](long m) {
+        return (inner_a * es) % m == 0 && (inner_b * es) % m == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)dst) % m) == 0;
+    };
+    long w = all_mult(16) ? 16 : all_mult(8) ? 8 : all_mult(4) ? 4 : all_mult(2) ? 2 : 1;
+    if (w < es) w = es;
+    const long f = w / es, ia = inner_a / f, ib = inner_b / f;
+    const unsigned g = grid_for(outer * (ia + ib));
+#define OSG_CC(E) hipLaunchKernelGGL(concat2_kernel<E>, dim3(g), dim3(256), 0, ctx->compute, (const E*)a, ia, (const E*)b, ib, (E*)dst, outer)
+    if (w == 16) OSG_CC(uint4);
+    else if (w == 8) OSG_CC(uint64_t);
+    else if (w == 4) OSG_CC(uint32_t);
+    else if (w == 2) OSG_CC(uint16_t);
+    else OSG_CC(uint8_t);
+#undef OSG_CC
     OSG_LAUNCH_CHECK(ctx);
     return 0;
 }

@@ -26,7 +26,7 @@ EXPORTS = [
     "osg_graph_begin", "osg_graph_end", "osg_graph_launch", "osg_graph_destroy", "osg_timer_start", "osg_timer_stop",
     "osg_conv2d_nhwc", "osg_conv2d_nhwc_rb", "osg_gemm", "osg_gemm_ln", "osg_gemm_rowstats", "osg_gemm_w8", "osg_conv2d_nhwc_w8", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided",
     "osg_instance_norm", "osg_group_norm_nhwc", "osg_group_norm_conv3x3_supported", "osg_group_norm_conv3x3", "osg_layer_norm", "osg_reduce_mean_last", "osg_softmax_last",
-    "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_resize_nearest", "osg_gather_rows",
+    "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_concat2", "osg_resize_nearest", "osg_gather_rows",
     "osg_maxpool_nhwc", "osg_convert", "osg_sampler_prepare", "osg_sampler_cfg_euler_a",
 ]
 
@@ -89,6 +89,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_gather_rows.argtypes = [vp, ci, vp, vp, vp, cl, cl, cl]
     lib.osg_maxpool_nhwc.argtypes = [vp, ci, vp, vp] + [ci] * 12
     lib.osg_convert.argtypes = [vp, ci, ci, vp, vp, cl, cf, ci]
+    lib.osg_concat2.argtypes = [vp, ci, vp, cl, vp, cl, vp, cl]
     lib.osg_gemm_ln.argtypes = [vp, vp, vp, vp, vp, cf, vp, vp, vp, ci, ci, ci, ci]
     lib.osg_gemm_rowstats.argtypes = [vp, vp, vp, vp, ci, vp, vp, ci, ci, ci, ci, vp]
     lib.osg_sampler_prepare.argtypes = [vp, vp, vp, vp, ci, cl, cf, cf, cl]
@@ -322,6 +323,13 @@ class Gpu:
 
     def copy_2d(self, src: DevBuf, src_pitch, src_off, dst: DevBuf, dst_pitch, dst_off, outer, inner):
         self._ck(self.lib.osg_copy_2d(self.ctx, src.dtype.itemsize, src.ptr, src_pitch, src_off, dst.ptr, dst_pitch, dst_off, outer, inner))
+
+    def concat2(self, a: DevBuf, b: DevBuf):
+        """Concat of two dense tensors along the last axis in one launch."""
+        outer = int(np.prod(a.shape[:-1]))
+        y = self.empty(a.shape[:-1] + (a.shape[-1] + b.shape[-1],), a.dtype)
+        self._ck(self.lib.osg_concat2(self.ctx, a.dtype.itemsize, a.ptr, a.shape[-1], b.ptr, b.shape[-1], y.ptr, outer))
+        return y
 
     def resize_nearest(self, x: DevBuf, ho: int, wo: int, nhwc: bool):
         if nhwc:

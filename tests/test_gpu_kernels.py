@@ -447,3 +447,13 @@ def test_upload_staged_roundtrip(gpu):
     x = rng.integers(0, 255, size=(150 << 20) + 13, dtype=np.uint8)   # > 2 staging chunks, ragged tail
     d = gpu.to_dev(x, staged=True)
     assert np.array_equal(d.numpy(), x)
+
+
+@pytest.mark.parametrize("outer,ia,ib,dt", [(8192, 320, 320, f16), (2048, 1280, 640, f16), (7, 5, 3, f16), (3, 160, 160, f32), (1, 1, 9, np.uint8), (64, 8, 24, f16)])
+def test_concat2_single_launch(gpu, outer, ia, ib, dt):
+    """The skip-connection Concat as ONE launch (osg_concat2) == numpy.concatenate, bit for bit, for 16-byte and odd-sized runs."""
+    rng = np.random.default_rng(outer + ia + ib)
+    a = (rng.standard_normal((outer, ia)) * 50).astype(dt)
+    b = (rng.standard_normal((outer, ib)) * 50).astype(dt)
+    got = gpu.concat2(gpu.to_dev(a), gpu.to_dev(b)).numpy()
+    assert np.array_equal(got, np.concatenate([a, b], axis=-1))
