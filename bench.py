@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--cpu-passes", type=int, default=4, help="reference CPU passes in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--profile-reps", type=int, default=3)
     ap.add_argument("--steps-per-image", type=int, default=0, help="denoising steps per image (default 20; BASELINE config 4 = SDXL uses 10)")
+    ap.add_argument("--side-stream", action="store_true", help="shortcut convolutions etc. on a second stream beside the main chain (parallel hipGraph branches; measured slower)")
     ap.add_argument("--ln-fold", action="store_true", help="fold every LayerNorm into the GEMM that consumes it (osg_gemm_ln; 48 launches less, measured time-neutral)")
     ap.add_argument("--no-autotune", action="store_true", help="tile / split-K configurations from the cost model only (no measured choice in the first pass)")
     ap.add_argument("--host-loop", action="store_true", help="pipeline mode: CFG + Euler-A on the host with one round trip per step (the reference app's shape) instead of the device loop")
@@ -182,6 +183,8 @@ def main():
         m._set_option("hip_w8_resident", 1)
     if args.ln_fold:
         m._set_option("hip_fuse_ln_gemm", 1)
+    if args.side_stream:
+        m._set_option("hip_side_stream", 1)
     L = cfg.latent
     P = max(1, args.prompts_per_gpu if args.mode == "pipeline" and not cfg.sdxl_add_embed else 1)
     lat_shape = (P, cfg.in_ch, L, L)

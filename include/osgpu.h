@@ -196,6 +196,15 @@ int osg_binary(osg_ctx* ctx, osg_dtype dtype, osg_binary_kind kind, const void* 
 /* GEGLU: x:[rows,2C] -> y:[rows,C] = x[:, :C] * gelu_erf(x[:, C:]) (Slice,Slice,Div,Erf,Add,Mul,Mul,Mul). */
 int osg_geglu(osg_ctx* ctx, osg_dtype dtype, const void* x, void* y, long rows, long C);
 
+/* ---- side branch (new): independent launches beside the main chain ------------------------------------------------------ */
+/* Between osg_side_begin and osg_side_end every launch of this context goes to a second stream (with its own split-K workspace) that
+ * starts after everything enqueued so far; osg_side_join makes the main stream wait for all side work enqueued so far.  Inside a
+ * capture the fork / join become parallel branches of the hipGraph.  Sections do not nest; the caller guarantees that the main chain
+ * neither overwrites a side launch's operands nor reads its results before the join. */
+int osg_side_begin(osg_ctx* ctx);
+int osg_side_end(osg_ctx* ctx);
+int osg_side_join(osg_ctx* ctx);
+
 /* ---- denoising-loop glue on the device -------------------------------------------------------- */
 /* CFGDenoiser input side (src/sd.cpp:1427-1470): sample[2p] = sample[2p+1] = x[p] * c_in for p < prompts (L floats each, fp32);
  * timestep[0 .. 2*prompts*t_per_sample) = t.  x, sample, timestep are DEVICE fp32 buffers (the plan's input staging). */

@@ -19,7 +19,7 @@ struct OsgApi {
     OSG_FN(osg_device_count) OSG_FN(osg_init) OSG_FN(osg_destroy) OSG_FN(osg_last_error) OSG_FN(osg_device_name) OSG_FN(osg_stream) OSG_FN(osg_set_autotune)
     OSG_FN(osg_malloc) OSG_FN(osg_free) OSG_FN(osg_upload) OSG_FN(osg_upload_sync) OSG_FN(osg_host_register) OSG_FN(osg_host_unregister) OSG_FN(osg_upload_pinned) OSG_FN(osg_download) OSG_FN(osg_copy)
     OSG_FN(osg_memset) OSG_FN(osg_sync) OSG_FN(osg_graph_begin) OSG_FN(osg_graph_end) OSG_FN(osg_graph_launch)
-    OSG_FN(osg_graph_destroy) OSG_FN(osg_timer_start) OSG_FN(osg_timer_stop) OSG_FN(osg_conv2d_nhwc) OSG_FN(osg_conv2d_nhwc_rb) OSG_FN(osg_gemm) OSG_FN(osg_gemm_ln) OSG_FN(osg_gemm_rowstats) OSG_FN(osg_gemm_w8) OSG_FN(osg_conv2d_nhwc_w8)
+    OSG_FN(osg_graph_destroy) OSG_FN(osg_side_begin) OSG_FN(osg_side_end) OSG_FN(osg_side_join) OSG_FN(osg_timer_start) OSG_FN(osg_timer_stop) OSG_FN(osg_conv2d_nhwc) OSG_FN(osg_conv2d_nhwc_rb) OSG_FN(osg_gemm) OSG_FN(osg_gemm_ln) OSG_FN(osg_gemm_rowstats) OSG_FN(osg_gemm_w8) OSG_FN(osg_conv2d_nhwc_w8)
     OSG_FN(osg_transpose_kn_to_nk) OSG_FN(osg_attention) OSG_FN(osg_attention_strided) OSG_FN(osg_instance_norm)
     OSG_FN(osg_group_norm_nhwc) OSG_FN(osg_group_norm_conv3x3_supported) OSG_FN(osg_group_norm_conv3x3) OSG_FN(osg_layer_norm) OSG_FN(osg_reduce_mean_last) OSG_FN(osg_softmax_last) OSG_FN(osg_unary)
     OSG_FN(osg_binary) OSG_FN(osg_geglu) OSG_FN(osg_transpose) OSG_FN(osg_copy_2d) OSG_FN(osg_concat2) OSG_FN(osg_resize_nearest)
@@ -53,7 +53,7 @@ public:
         OSG_FN(osg_device_count) OSG_FN(osg_init) OSG_FN(osg_destroy) OSG_FN(osg_last_error) OSG_FN(osg_device_name) OSG_FN(osg_stream) OSG_FN(osg_set_autotune)
         OSG_FN(osg_malloc) OSG_FN(osg_free) OSG_FN(osg_upload) OSG_FN(osg_upload_sync) OSG_FN(osg_host_register) OSG_FN(osg_host_unregister) OSG_FN(osg_upload_pinned) OSG_FN(osg_download) OSG_FN(osg_copy)
         OSG_FN(osg_memset) OSG_FN(osg_sync) OSG_FN(osg_graph_begin) OSG_FN(osg_graph_end) OSG_FN(osg_graph_launch)
-        OSG_FN(osg_graph_destroy) OSG_FN(osg_timer_start) OSG_FN(osg_timer_stop) OSG_FN(osg_conv2d_nhwc) OSG_FN(osg_conv2d_nhwc_rb) OSG_FN(osg_gemm) OSG_FN(osg_gemm_ln) OSG_FN(osg_gemm_rowstats) OSG_FN(osg_gemm_w8) OSG_FN(osg_conv2d_nhwc_w8)
+        OSG_FN(osg_graph_destroy) OSG_FN(osg_side_begin) OSG_FN(osg_side_end) OSG_FN(osg_side_join) OSG_FN(osg_timer_start) OSG_FN(osg_timer_stop) OSG_FN(osg_conv2d_nhwc) OSG_FN(osg_conv2d_nhwc_rb) OSG_FN(osg_gemm) OSG_FN(osg_gemm_ln) OSG_FN(osg_gemm_rowstats) OSG_FN(osg_gemm_w8) OSG_FN(osg_conv2d_nhwc_w8)
         OSG_FN(osg_transpose_kn_to_nk) OSG_FN(osg_attention) OSG_FN(osg_attention_strided) OSG_FN(osg_instance_norm)
         OSG_FN(osg_group_norm_nhwc) OSG_FN(osg_group_norm_conv3x3_supported) OSG_FN(osg_group_norm_conv3x3) OSG_FN(osg_layer_norm) OSG_FN(osg_reduce_mean_last) OSG_FN(osg_softmax_last) OSG_FN(osg_unary)
         OSG_FN(osg_binary) OSG_FN(osg_geglu) OSG_FN(osg_transpose) OSG_FN(osg_copy_2d) OSG_FN(osg_concat2) OSG_FN(osg_resize_nearest)

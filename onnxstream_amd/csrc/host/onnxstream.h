@@ -550,6 +550,8 @@ public:
     bool m_hip_use_graph = true;   // replay a pass as one hipGraph from the third run on
     bool m_hip_fuse_ln_gemm = false; // fusion level 2: a LayerNorm whose only consumers are Linear ops is folded into their GEMM (osg_gemm_ln, row
                                      // statistics handed over by the producing GEMM): 48 launches less in the SD 1.5 UNet, measured time-neutral => opt-in
+    bool m_hip_side_stream = false; // contraction launches whose result is first read >= 3 steps later (a resnet's 1x1 shortcut convolution) run on a second
+                                    // stream beside the main chain (parallel branches of the captured hipGraph); measured +0.25 ms per pass => opt-in
     bool m_hip_autotune = true;    // the first (eager) pass times the legal tile / split-K configurations of every GEMM / convolution shape (osg_set_autotune)
     bool m_hip_w8_resident = false;     // true: uint8 weights of Conv/MatMul/Gemm stay uint8 in HBM (half the footprint and weight traffic) and are
                                         // dequantised on chip by the osg_*_w8 kernels -- same VALUES as the reference's load-time dequantisation

@@ -92,11 +92,12 @@ Plan::Plan(Model& model, HipBackend& backend, size_t batch) : m(model), be(backe
     w8_resident = m.m_hip_w8_resident && !m.m_hip_stream_weights;
     fuse_gn_conv = m.m_hip_fuse_gn_conv;
     fuse_ln_gemm = m.m_hip_fuse_ln_gemm;
+    side_stream = m.m_hip_side_stream && !m.m_hip_stream_weights;
     extra_outputs = m.m_extra_outputs;
 }
 
 bool Plan::compatible(Model& mm, size_t batch) const {
-    return (long)batch == N && mm.m_use_fp16_arithmetic == fp16 && mm.m_hip_fusion_level == fusion && mm.m_hip_stream_weights == stream_weights && mm.m_hip_fuse_gn_conv == fuse_gn_conv && mm.m_hip_fuse_ln_gemm == fuse_ln_gemm &&
+    return (long)batch == N && mm.m_use_fp16_arithmetic == fp16 && mm.m_hip_fusion_level == fusion && mm.m_hip_stream_weights == stream_weights && mm.m_hip_fuse_gn_conv == fuse_gn_conv && mm.m_hip_fuse_ln_gemm == fuse_ln_gemm && (mm.m_hip_side_stream && !mm.m_hip_stream_weights) == side_stream &&
            (mm.m_hip_w8_resident && !mm.m_hip_stream_weights) == w8_resident &&
            mm.m_extra_outputs == extra_outputs;
 }
@@ -2122,6 +2123,26 @@ void Plan::build() {
         }
     }
 
+    // ---- side branch: a contraction whose result is first read three or more steps later (a resnet's 1x1 shortcut convolution: GroupNorm,
+    // conv1, GroupNorm sit between it and conv2's residual input) runs on the second stream, joined right before that reader ------------
+    if (side_stream && fusion >= 2) {
+        std::vector<int> first_read(vals.size(), 1 << 30), writers(vals.size(), 0);
+        for (size_t si = 0; si < steps.size(); si++) {
+            for (int v : steps[si].reads) { int r = root_of(v); first_read[r] = std::min(first_read[r], (int)si); }
+            for (int v : steps[si].writes) writers[root_of(v)]++;
+        }
+        for (size_t si = 0; si < steps.size(); si++) {
+            Step& s = steps[si];
+            if (s.flops <= 0 || s.writes.size() != 1) continue;
+            const int w = root_of(s.writes[0]);
+            if (vals[w].pinned || vals[w].dptr || writers[w] != 1) continue;
+            const int j = first_read[w];
+            if (j >= (int)steps.size() || j - (int)si < 3) continue;
+            s.side_join = j;
+            steps[j].join_before = true;
+        }
+    }
+
     // ---- liveness + arena packing -----------------------------------------------------------------------------------
     for (size_t si = 0; si < steps.size(); si++)
         for (auto* lst : {&steps[si].reads, &steps[si].writes})
@@ -2129,6 +2150,8 @@ void Plan::build() {
                 Val& r = vals[root_of(v)];
                 r.first = std::min(r.first, (int)si);
                 r.last = std::max(r.last, (int)si);
+                // a side launch may still be running until its join: its operands and result stay untouched (and unreused) until then
+                if (steps[si].side_join >= 0) r.last = std::max(r.last, steps[si].side_join);
             }
     struct Block { size_t off, size; };
     std::vector<Block> free_list;
@@ -2178,6 +2201,24 @@ void Plan::build() {
     be.check(be.api.osg_sync(be.ctx), "osg_sync");
 }
 
+void Plan::run_steps() {
+    for (auto& s : steps) {
+        if (s.join_before) be.check(be.api.osg_side_join(be.ctx), "osg_side_join");
+        if (s.side_join >= 0) {
+            be.check(be.api.osg_side_begin(be.ctx), "osg_side_begin");
+            try {
+                s.run();
+            } catch (...) {
+                be.api.osg_side_end(be.ctx);
+                throw;
+            }
+            be.check(be.api.osg_side_end(be.ctx), "osg_side_end");
+        } else
+            s.run();
+    }
+    be.check(be.api.osg_side_join(be.ctx), "osg_side_join");
+}
+
 void Plan::execute() {
     // ---- stage the inputs (host fp32, N samples stacked) -------------------------------------------------------------
     for (auto& in : inputs) {
@@ -2224,7 +2265,7 @@ void Plan::execute() {
     } else if (runs >= 1 && m.m_hip_use_graph && !print && !graph) {
         be.check(be.api.osg_graph_begin(be.ctx), "osg_graph_begin");
         try {
-            for (auto& s : steps) s.run();
+            run_steps();
         } catch (...) {
             osg_graph* g = nullptr;
             be.api.osg_graph_end(be.ctx, &g);
@@ -2233,10 +2274,12 @@ void Plan::execute() {
         }
         be.check(be.api.osg_graph_end(be.ctx, &graph), "osg_graph_end");
         be.check(be.api.osg_graph_launch(be.ctx, graph), "osg_graph_launch");
+    } else if (!print) {
+        run_steps();
     } else {
         int idx = 0;
         for (auto& s : steps) {
-            if (print) printf("#%i) %s\n", idx++, s.what.c_str());
+            printf("#%i) %s\n", idx++, s.what.c_str());
             s.run();
         }
     }
@@ -2380,7 +2423,7 @@ double Plan::sampler_loop(const std::string& sample_name, const std::string& tim
         be.check(be.api.osg_sampler_prepare(be.ctx, (const float*)samp_x, (float*)ptr(in_s->staging), (float*)ptr(in_t->staging), prompts, L, c_in[i], t[i], TL),
                  "osg_sampler_prepare");
         if (graph) be.check(be.api.osg_graph_launch(be.ctx, graph), "osg_graph_launch");
-        else for (auto& s : steps) s.run();
+        else run_steps();
         const bool with_noise = noise != nullptr;
         be.check(be.api.osg_sampler_cfg_euler_a(be.ctx, (float*)samp_x, (const float*)ptr(out->f32val),
                                                with_noise ? (const float*)samp_noise + (size_t)i * prompts * L : nullptr, prompts, L, c_out[i], guidance,

@@ -52,6 +52,8 @@ struct Step {
     std::function<void()> run;
     std::vector<int> reads, writes;
     double flops = 0;             // algorithmic 2*MAC count of a contraction step (0 for memory-bound steps)
+    int side_join = -1;           // >= 0: runs on the side stream; index of the first step that reads its result (joined right before)
+    bool join_before = false;     // the main stream waits for the side stream before this step
 };
 
 struct Lowering;
@@ -125,6 +127,8 @@ struct Plan {
     bool stream_weights = false;
     bool fuse_gn_conv = false;
     bool fuse_ln_gemm = false;
+    bool side_stream = false;      // contraction steps whose result is not needed by the next steps run on a second stream (m_hip_side_stream)
+    void run_steps();              // one pass over `steps` honouring the side-stream marks
     bool w8_resident = false;      // uint8 Conv/MatMul/Gemm weights kept as codes, dequantised inside the kernels (osg_*_w8)   // m_hip_stream_weights: weights are re-pulled from the WeightsProvider and re-streamed H2D every pass
     int fusion = 2;
     std::vector<std::string> extra_outputs;

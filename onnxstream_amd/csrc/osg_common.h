@@ -12,6 +12,15 @@ struct osg_ctx {
     int device = 0;
     hipStream_t compute = nullptr;
     hipStream_t copy = nullptr;
+    // side branch (osg_side_begin/end/join): a second compute stream with its own split-K workspace.  While a side section is open,
+    // `compute`/`ws`/`ws2` ARE the side stream's (the fields are swapped), so every launch site works unchanged.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    void* ws_s = nullptr;
+    size_t ws_s_bytes = 0;
+    void* ws2_s = nullptr;
+    size_t ws2_s_bytes = 0;
+    bool in_side = false, side_dirty = false;
     hipEvent_t ev_copy = nullptr;       // copy stream -> compute stream dependency
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     // pinned double-buffered staging for host->device streaming (weights provider path)

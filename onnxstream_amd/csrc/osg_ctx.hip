@@ -1,6 +1,7 @@
 // libosgpu: context, memory, transfers, graph capture, timing.  (C ABI: include/osgpu.h)
 #include "osg_common.h"
 #include "osg_tune.h"
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -72,6 +73,9 @@ int osg_init(int device, osg_ctx** out) {
     }
     bool ok = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) == hipSuccess &&
               hipEventCreate(&c->ev_t0) == hipSuccess && hipEventCreate(&c->ev_t1) == hipSuccess &&
               hipEventCreate(&c->ev_a0) == hipSuccess && hipEventCreate(&c->ev_a1) == hipSuccess;
@@ -101,6 +105,11 @@ void osg_destroy(osg_ctx* c) {
     if (c->tickets) hipFree(c->tickets);
     if (c->ws) hipFree(c->ws);
     if (c->ws2) hipFree(c->ws2);
+    if (c->ws_s) hipFree(c->ws_s);
+    if (c->ws2_s) hipFree(c->ws2_s);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->side) hipStreamDestroy(c->side);
     if (c->ev_copy) hipEventDestroy(c->ev_copy);
     if (c->ev_t0) hipEventDestroy(c->ev_t0);
     if (c->ev_t1) hipEventDestroy(c->ev_t1);
@@ -203,6 +212,39 @@ int osg_memset(osg_ctx* c, void* dst, int value, size_t bytes) {
 int osg_sync(osg_ctx* c) {
     OSG_HIP(c, hipStreamSynchronize(c->copy));
     OSG_HIP(c, hipStreamSynchronize(c->compute));
+    OSG_HIP(c, hipStreamSynchronize(c->side));
+    return 0;
+}
+
+// ---- side branch: independent work (a resnet's 1x1 shortcut convolution, projections of the text context) runs on a second stream
+// beside the main chain; inside a capture the fork/join events become parallel branches of the hipGraph.
+int osg_side_begin(osg_ctx* c) {
+    if (c->in_side) OSG_FAIL(c, "osg_side_begin: a side section is already open");
+    OSG_HIP(c, hipEventRecord(c->ev_fork, c->compute));
+    OSG_HIP(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    std::swap(c->compute, c->side);
+    std::swap(c->ws, c->ws_s); std::swap(c->ws_bytes, c->ws_s_bytes);
+    std::swap(c->ws2, c->ws2_s); std::swap(c->ws2_bytes, c->ws2_s_bytes);
+    c->in_side = true;
+    c->side_dirty = true;
+    return 0;
+}
+
+int osg_side_end(osg_ctx* c) {
+    if (!c->in_side) OSG_FAIL(c, "osg_side_end: no side section is open");
+    std::swap(c->compute, c->side);
+    std::swap(c->ws, c->ws_s); std::swap(c->ws_bytes, c->ws_s_bytes);
+    std::swap(c->ws2, c->ws2_s); std::swap(c->ws2_bytes, c->ws2_s_bytes);
+    c->in_side = false;
+    return 0;
+}
+
+int osg_side_join(osg_ctx* c) {
+    if (c->in_side) OSG_FAIL(c, "osg_side_join: close the side section first");
+    if (!c->side_dirty) return 0;
+    OSG_HIP(c, hipEventRecord(c->ev_join, c->side));
+    OSG_HIP(c, hipStreamWaitEvent(c->compute, c->ev_join, 0));
+    c->side_dirty = false;
     return 0;
 }
 
@@ -216,6 +258,8 @@ int osg_graph_begin(osg_ctx* c) {
 
 int osg_graph_end(osg_ctx* c, osg_graph** out) {
     if (!c->capturing) OSG_FAIL(c, "not capturing");
+    if (c->in_side) osg_side_end(c);
+    if (osg_side_join(c)) return 1;     // every forked branch must be back before the capture ends
     c->capturing = false;
     hipGraph_t g = nullptr;
     OSG_HIP(c, hipStreamEndCapture(c->compute, &g));

@@ -23,7 +23,7 @@ BIN = dict(add=0, sub=1, mul=2, div=3)
 EXPORTS = [
     "osg_device_count", "osg_init", "osg_destroy", "osg_last_error", "osg_device_name", "osg_stream", "osg_set_autotune",
     "osg_malloc", "osg_free", "osg_upload", "osg_upload_sync", "osg_host_register", "osg_host_unregister", "osg_upload_pinned", "osg_download", "osg_copy", "osg_memset", "osg_sync",
-    "osg_graph_begin", "osg_graph_end", "osg_graph_launch", "osg_graph_destroy", "osg_timer_start", "osg_timer_stop",
+    "osg_graph_begin", "osg_graph_end", "osg_graph_launch", "osg_graph_destroy", "osg_side_begin", "osg_side_end", "osg_side_join", "osg_timer_start", "osg_timer_stop",
     "osg_conv2d_nhwc", "osg_conv2d_nhwc_rb", "osg_gemm", "osg_gemm_ln", "osg_gemm_rowstats", "osg_gemm_w8", "osg_conv2d_nhwc_w8", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided",
     "osg_instance_norm", "osg_group_norm_nhwc", "osg_group_norm_conv3x3_supported", "osg_group_norm_conv3x3", "osg_layer_norm", "osg_reduce_mean_last", "osg_softmax_last",
     "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_concat2", "osg_resize_nearest", "osg_gather_rows",

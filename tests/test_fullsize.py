@@ -62,6 +62,11 @@ def test_sd15_unet_properties_and_reference_parity(sd15_dir):
     # same result up to the f16 rounding of the normalised activation it no longer materialises
     folded = _run(b.LIB_HOST, sd15_dir, [a, c], options=(("hip_fuse_ln_gemm", 1),))[0]
     assert float(np.abs(folded[0] - both[0][0]).max()) / mx <= 5e-3 and float(np.abs(folded[1] - both[0][1]).max()) / float(np.abs(both[0][1]).max()) <= 5e-3
+    # opt-in side stream (the 14 shortcut convolutions as parallel branches of the captured graph): same kernels, same operands => same bits,
+    # eager, captured and replayed -- a race between the branches would show up here
+    side = _run(b.LIB_HOST, sd15_dir, [a, c], runs=3, options=(("hip_side_stream", 1),))
+    for o in side:
+        assert np.array_equal(both[0][0], o[0]) and np.array_equal(both[0][1], o[1])
     if not oref.available():
         pytest.skip("oracle/_ref not present: properties checked, reference parity skipped")
     r16 = oref.run_model(sd15_dir, a, fp16=True)["out_sample"]
