@@ -739,7 +739,9 @@ static std::vector<std::pair<double, V2Choice>> rank_v2(const osg_ctx* ctx, int 
     const int kt = K / 64;
     std::vector<std::pair<double, V2Choice>> out;
     for (int c = 0; c < 3; c++)
-        for (int nst = 4; nst >= 2; nst -= 2) {
+        for (int nst = 6; nst >= 2; nst -= 2) {
+            // 6 stages (every tile of a K <= 384 GEMM in flight at once): only as a measured candidate, only where the ring fits the LDS
+            if (nst == 6 && (!ctx->autotune || c == 0)) continue;
             const double tiles = (double)((M + kV2BM[c] - 1) / kV2BM[c]) * ((N + kV2BN[c] - 1) / kV2BN[c]) * batch;
             const double mfma = kV2BM[c] * kV2BN[c] * 128.0 / 4069.0;
             const double tload = (kV2BM[c] + kV2BN[c]) * 128.0 / 23.0;
@@ -828,8 +830,8 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
     else if (dbg == 2) rc = launch_v2<128, 128, 3, CONV>(ctx, p, batch);
     else if (dbg == 5) rc = launch_v2<128, 128, 2, CONV>(ctx, p, batch);
     else if (ch.cfg == 0) rc = ch.nst == 4 ? launch_v2<128, 128, 4, CONV>(ctx, p, batch) : launch_v2<128, 128, 2, CONV>(ctx, p, batch);
-    else if (ch.cfg == 1) rc = ch.nst == 4 ? launch_v2<128, 64, 4, CONV>(ctx, p, batch) : launch_v2<128, 64, 2, CONV>(ctx, p, batch);
-    else rc = ch.nst == 4 ? launch_v2<64, 64, 4, CONV>(ctx, p, batch) : launch_v2<64, 64, 2, CONV>(ctx, p, batch);
+    else if (ch.cfg == 1) rc = ch.nst == 6 ? launch_v2<128, 64, 6, CONV>(ctx, p, batch) : ch.nst == 4 ? launch_v2<128, 64, 4, CONV>(ctx, p, batch) : launch_v2<128, 64, 2, CONV>(ctx, p, batch);
+    else rc = ch.nst == 6 ? launch_v2<64, 64, 6, CONV>(ctx, p, batch) : ch.nst == 4 ? launch_v2<64, 64, 4, CONV>(ctx, p, batch) : launch_v2<64, 64, 2, CONV>(ctx, p, batch);
     if (rc) return rc;
     if (p.splits > 1 && !p.tickets) return launch_splitk_reduce(ctx, p, batch);
     return 0;
