@@ -732,13 +732,13 @@ int launch_cfg(osg_ctx* ctx, const GemmParams& p, int batch) {
 // max(MFMA, bytes / 23) (+ ~450 exposed cycles when a block is alone on its CU), whole rounds of tiles over the CU slots,
 // a fixed fill + epilogue per round, and the extra pass of a split-K reduce.
 struct V2Choice { int cfg, nst, splits; };
-static const int kV2BM[3] = {128, 128, 64}, kV2BN[3] = {128, 64, 64};
+static const int kV2BM[4] = {128, 128, 64, 64}, kV2BN[4] = {128, 64, 64, 128};   // (the 64x128 tile: measured candidate only)
 // every legal (tile, stages, splits) with its modelled cost in cycles, cheapest first
 static std::vector<std::pair<double, V2Choice>> rank_v2(const osg_ctx* ctx, int M, int N, int K, int batch, bool allow_split) {
     const double cus = ctx->num_cu;
     const int kt = K / 64;
     std::vector<std::pair<double, V2Choice>> out;
-    for (int c = 0; c < 3; c++)
+    for (int c = 0; c < (ctx->autotune ? 4 : 3); c++)
         for (int nst = 6; nst >= 2; nst -= 2) {
             // 6 stages (every tile of a K <= 384 GEMM in flight at once): only as a measured candidate, only where the ring fits the LDS
             if (nst == 6 && (!ctx->autotune || c == 0)) continue;
@@ -801,6 +801,7 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
     const double a_unique = CONV ? (double)p.a_bytes : (double)p.M * p.K * 2.0;
     p.n_major = (double)p.N * p.K * 2.0 > a_unique;
     int rc;
+    if (p.ln_c1 && ch.cfg == 3) ch.cfg = 2;   // (the folded-LayerNorm variants exist for the first three tiles only)
     if constexpr (!CONV) {
         if (p.ln_c1 && p.rs_in) {   // LayerNorm folded into the GEMM, row statistics handed over by the producer of A
             const int nch = p.rs_np >> 1;
@@ -831,6 +832,7 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
     else if (dbg == 5) rc = launch_v2<128, 128, 2, CONV>(ctx, p, batch);
     else if (ch.cfg == 0) rc = ch.nst == 4 ? launch_v2<128, 128, 4, CONV>(ctx, p, batch) : launch_v2<128, 128, 2, CONV>(ctx, p, batch);
     else if (ch.cfg == 1) rc = ch.nst == 6 ? launch_v2<128, 64, 6, CONV>(ctx, p, batch) : ch.nst == 4 ? launch_v2<128, 64, 4, CONV>(ctx, p, batch) : launch_v2<128, 64, 2, CONV>(ctx, p, batch);
+    else if (ch.cfg == 3) rc = ch.nst == 6 ? launch_v2<64, 128, 6, CONV>(ctx, p, batch) : ch.nst == 4 ? launch_v2<64, 128, 4, CONV>(ctx, p, batch) : launch_v2<64, 128, 2, CONV>(ctx, p, batch);
     else rc = ch.nst == 6 ? launch_v2<64, 64, 6, CONV>(ctx, p, batch) : ch.nst == 4 ? launch_v2<64, 64, 4, CONV>(ctx, p, batch) : launch_v2<64, 64, 2, CONV>(ctx, p, batch);
     if (rc) return rc;
     if (p.splits > 1 && !p.tickets) return launch_splitk_reduce(ctx, p, batch);
