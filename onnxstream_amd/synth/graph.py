@@ -81,10 +81,13 @@ def quantize_u8(w: np.ndarray) -> Tuple[np.ndarray, float, int]:
 
 
 class GraphBuilder:
-    def __init__(self, sink, wdtype: str = "float16", seed: int = 1234, quant_weights: bool = False):
+    def __init__(self, sink, wdtype: str = "float16", seed: int = 1234, quant_weights: bool = False, quant_all: bool = False):
         self.sink = sink
         self.wdtype = wdtype
-        self.quant = quant_weights
+        self.quant = quant_weights or quant_all
+        # quant_all: the reference exporter's full uint8 model (onnx2txt.ipynb ``quantize``: EVERY float initializer except Conv biases,
+        # InstanceNormalization scale/bias and Resize scales) -- what ``m_use_uint8_arithmetic`` needs (the vae_decoder_qu8 directory)
+        self.quant_all = quant_all
         self.rng = np.random.default_rng(seed)
         self.lines: List[str] = []
         self._uid = 0
@@ -103,9 +106,11 @@ class GraphBuilder:
         return f"{mangle(base)}_{self._uid}"
 
     def weight(self, name: str, arr: np.ndarray, dtype: Optional[str] = None, conv: bool = False,
-               allow_quant: bool = True) -> T:
+               allow_quant: bool = True, q8_exempt: bool = False) -> T:
         """Write ``arr`` (given in the ONNX initializer layout: OIHW for conv, [K,N] for matmul) and return its token."""
         dtype = dtype or self.wdtype
+        if self.quant_all and q8_exempt and dtype == "float16":
+            dtype = "float32"      # the exporter leaves what it does not quantise in the ONNX file's own fp32 (the qu8 Conv wants an fp32 bias)
         base = mangle(name)
         assert base not in self._wnames, base
         self._wnames.add(base)
@@ -117,7 +122,7 @@ class GraphBuilder:
             fname_ref, fname_disk = base + "_nchw.bin", base + "_nhwc.bin"
         else:
             fname_ref = fname_disk = base + ".bin"
-        if self.quant and allow_quant and dtype in ("float16", "float32") and arr.size >= 1024:
+        if dtype in ("float16", "float32") and ((self.quant and allow_quant and arr.size >= 1024) or (self.quant_all and not q8_exempt)):
             q, scale, zp = quantize_u8(data)
             self.sink.write(fname_disk, q)
             tystr = f"uint8[{scale!r},{zp}]"
@@ -166,7 +171,7 @@ class GraphBuilder:
         wt = self.weight(f"{name}.weight", self.randn((cout, cin, k, k), std), conv=True)
         ins = [x, wt]
         if bias:
-            ins.append(self.weight(f"{name}.bias", self.randn((cout,), 0.02), allow_quant=False))
+            ins.append(self.weight(f"{name}.bias", self.randn((cout,), 0.02), allow_quant=False, q8_exempt=True))
         ho = (h + 2 * pad - k) // stride + 1
         wo = (w + 2 * pad - k) // stride + 1
         return self.op(name, "Conv", ins, (n, cout, ho, wo),
@@ -237,8 +242,8 @@ class GraphBuilder:
     def group_norm(self, name, x: T, groups: int = 32, eps: float = 1e-5) -> T:
         n, c, h, w = x.shape
         r = self.reshape(name + "/Reshape", x, (1, groups, c * h * w // groups))
-        ones = self.weight(f"{name}.in_scale", np.ones((groups,), np.float32), allow_quant=False)
-        zeros = self.weight(f"{name}.in_bias", np.zeros((groups,), np.float32), allow_quant=False)
+        ones = self.weight(f"{name}.in_scale", np.ones((groups,), np.float32), allow_quant=False, q8_exempt=True)
+        zeros = self.weight(f"{name}.in_bias", np.zeros((groups,), np.float32), allow_quant=False, q8_exempt=True)
         i = self.op(name + "/InstanceNormalization", "InstanceNormalization", [r, ones, zeros], r.shape,
                     {"epsilon": repr(float(eps))})
         r2 = self.reshape(name + "/Reshape_1", i, (n, c, h, w))

@@ -186,7 +186,7 @@ class _UNet:
     def upsample(self, name, x: T) -> T:
         g = self.g
         n, c, h, w = x.shape
-        sc = g.weight(f"{name}.scales", np.asarray([1, 1, 2, 2], np.float32), dtype="float32", allow_quant=False)
+        sc = g.weight(f"{name}.scales", np.asarray([1, 1, 2, 2], np.float32), dtype="float32", allow_quant=False, q8_exempt=True)
         r = g.op(name + "/Resize", "Resize", [x, None, sc], (n, c, 2 * h, 2 * w),
                  {"coordinate_transformation_mode": "asymmetric", "cubic_coeff_a": "-0.75", "mode": "nearest",
                   "nearest_mode": "floor"})
@@ -243,7 +243,7 @@ class _UNet:
         # last op: give the graph output a stable name
         n, c, h, w = x.shape
         wt = g.weight("/conv_out.weight", g.randn((cfg.out_ch, c, 3, 3), 1.0 / math.sqrt(c * 9)), conv=True)
-        b = g.weight("/conv_out.bias", g.randn((cfg.out_ch,), 0.02), allow_quant=False)
+        b = g.weight("/conv_out.bias", g.randn((cfg.out_ch,), 0.02), allow_quant=False, q8_exempt=True)
         out = g.op("/conv_out", "Conv", [x, wt, b], (1, cfg.out_ch, h, w),
                    {"dilations": "1,1", "group": "1", "kernel_shape": "3,3", "pads": "1,1,1,1", "strides": "1,1"},
                    out_names=["out_sample"])

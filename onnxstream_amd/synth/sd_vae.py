@@ -76,7 +76,7 @@ class _Decoder:
     def upsample(self, name, x: T) -> T:
         g = self.g
         n, c, h, w = x.shape
-        sc = g.weight(f"{name}.scales", np.asarray([1, 1, 2, 2], np.float32), dtype="float32", allow_quant=False)
+        sc = g.weight(f"{name}.scales", np.asarray([1, 1, 2, 2], np.float32), dtype="float32", allow_quant=False, q8_exempt=True)
         r = g.op(name + "/Resize", "Resize", [x, None, sc], (n, c, 2 * h, 2 * w),
                  {"coordinate_transformation_mode": "asymmetric", "cubic_coeff_a": "-0.75", "mode": "nearest",
                   "nearest_mode": "floor"})
@@ -102,14 +102,15 @@ class _Decoder:
         x = g.silu("/decoder/conv_act", x)
         n, c, h, w = x.shape
         wt = g.weight("/decoder/conv_out.weight", g.randn((cfg.out_ch, c, 3, 3), 1.0 / math.sqrt(c * 9)), conv=True)
-        b = g.weight("/decoder/conv_out.bias", g.randn((cfg.out_ch,), 0.02), allow_quant=False)
+        b = g.weight("/decoder/conv_out.bias", g.randn((cfg.out_ch,), 0.02), allow_quant=False, q8_exempt=True)
         return g.op("/decoder/conv_out", "Conv", [x, wt, b], (1, cfg.out_ch, h, w),
                     {"dilations": "1,1", "group": "1", "kernel_shape": "3,3", "pads": "1,1,1,1", "strides": "1,1"},
                     out_names=["out_image"])
 
 
-def build_vae_decoder(sink, cfg: VAEConfig = SD_VAE, wdtype: str = "float16", seed: int = 4321, quant_weights: bool = False):
-    g = GraphBuilder(sink, wdtype=wdtype, seed=seed, quant_weights=quant_weights)
+def build_vae_decoder(sink, cfg: VAEConfig = SD_VAE, wdtype: str = "float16", seed: int = 4321, quant_weights: bool = False,
+                      quant_all: bool = False):
+    g = GraphBuilder(sink, wdtype=wdtype, seed=seed, quant_weights=quant_weights, quant_all=quant_all)
     out = _Decoder(g, cfg).build()
     g.finish()
     return g, out

@@ -69,3 +69,69 @@ def run_model(model_dir: str, inputs: Dict[str, np.ndarray], fp16: bool = True, 
         m.clear_tensors()
     m.close()
     return (outs, times) if return_times else outs
+
+
+# ---- uint8 arithmetic (the reference's m_use_uint8_arithmetic: the vae_decoder_qu8 path of `sd --rpi-lowmem`, src/sd.cpp:1212-1222) ----------
+def _extra(lib):
+    for f in ("ref_read_range_data", "ref_write_range_data"):
+        getattr(lib, f).argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        getattr(lib, f).restype = ctypes.c_char_p
+    lib.ref_set_range_data_calibrate.argtypes = [ctypes.c_void_p, ctypes.c_uint]
+    lib.ref_push_tensor_f32.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_float)]
+    lib.ref_push_tensor_f32.restype = ctypes.c_char_p
+
+
+def calibrate_ranges(model_dir: str, inputs: Dict[str, np.ndarray], threads: int = 1) -> str:
+    """One fp32 pass with m_range_data_calibrate (what `sd --decoder-calibrate` does): the text of range_data.txt."""
+    import sys
+    import tempfile
+    sys.path.insert(0, os.path.dirname(_HERE))
+    from onnxstream_amd.bindings import Model
+    m = Model(REF_LIB, threads, "ram+nocache")
+    _extra(m.lib)
+    m.read_file(os.path.join(model_dir, "model.txt"))
+    m.lib.ref_set_range_data_calibrate(m.handle, 1)
+    for k, v in inputs.items():
+        m.add_tensor(k, np.ascontiguousarray(v, np.float32))
+    m.run()
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, "range_data.txt")
+        err = m.lib.ref_write_range_data(m.handle, fn.encode())
+        if err:
+            raise RuntimeError(err.decode())
+        text = open(fn, newline="").read()
+    m.close()
+    return text
+
+
+def run_model_u8(model_dir: str, inputs: Dict[str, np.ndarray], range_text: str, threads: int = 1) -> Dict[str, np.ndarray]:
+    """The reference with m_use_uint8_arithmetic on a fully uint8 model (synth ``quant_all``) and a calibrated range_data.txt.  Inputs go
+    through Model::push_tensor with their real data (it quantises them dynamically, as the app's push of the VAE latents does)."""
+    import sys
+    import tempfile
+    sys.path.insert(0, os.path.dirname(_HERE))
+    from onnxstream_amd.bindings import Model
+    m = Model(REF_LIB, threads, "ram+nocache")
+    _extra(m.lib)
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, "range_data.txt")
+        open(fn, "w", newline="").write(range_text)
+        err = m.lib.ref_read_range_data(m.handle, fn.encode())
+        if err:
+            raise RuntimeError(err.decode())
+    m._set_option("use_uint8_arithmetic", 1)
+    m.read_file(os.path.join(model_dir, "model.txt"))
+    for k, v in inputs.items():
+        a = np.ascontiguousarray(v, np.float32)
+        dims = (ctypes.c_uint * a.ndim)(*a.shape)
+        err = m.lib.ref_push_tensor_f32(m.handle, m._name(k), a.ndim, dims, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+        if err:
+            raise RuntimeError(err.decode())
+    m.run()
+    outs = {}
+    for name in m.get_all_tensor_names():
+        got = m.get_tensor(name)
+        if got is not None:
+            outs[name] = got[0]
+    m.close()
+    return outs

@@ -58,4 +58,20 @@ size_t ref_get_tensor_any(void* ctx, const char* name, int* dtype, size_t* rank,
     return 0;
 }
 
+// Push a filled fp32 tensor through Model::push_tensor, as the reference app does for the VAE latents (src/sd.cpp:1228-1236): with
+// m_use_uint8_arithmetic set, push_tensor quantises the REAL data (model_add_tensor pushes an empty tensor first and cannot be used).
+const char* ref_push_tensor_f32(void* ctx, const char* name, unsigned dims_num, const unsigned* dims, const float* data) {
+    static thread_local std::string err;
+    try {
+        onnxstream::Tensor t;
+        t.m_name = name;
+        size_t n = 1;
+        for (unsigned i = 0; i < dims_num; i++) { t.m_shape.push_back(dims[i]); n *= dims[i]; }
+        onnxstream::tensor_vector<float> v(data, data + n);
+        t.set_vector(std::move(v));
+        as_model(ctx)->push_tensor(std::move(t));
+        return nullptr;
+    } catch (const std::exception& e) { err = e.what(); return err.c_str(); }
+}
+
 }  // extern "C"

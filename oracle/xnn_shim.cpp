@@ -20,7 +20,8 @@
 //    the un-rounded values, and the output is e * (1/sum) with the reciprocal rounded to the output
 //    precision first.  Differences to the pinned XNNPACK build are of 1-fp16-ulp class (polynomial exp).
 //  * transpose_nd is a plain N-d index walk, parallelised over the outermost output dimension.
-//  * SDPA / nchw-conv / qu8 softmax are not on the SD hot path: they report xnn_status_unsupported_hardware
+//  * SDPA / nchw-conv are not on the SD hot path: they report xnn_status_unsupported_hardware; qu8 softmax (the W8A8 VAE's attention)
+//    restates XNNPACK's lookup-table operator
 //    so that the reference throws its normal "failed to create ..." exception.
 #include <xnnpack.h>
 #include <pthreadpool.h>
@@ -38,13 +39,15 @@ namespace {
 const unsigned char kMagic[16] = {0x4f, 0x53, 0x47, 0x53, 0x48, 0x49, 0x4d, 0x21,
                                   0x9a, 0x17, 0xc3, 0x5e, 0x00, 0xd1, 0x7b, 0xe2};
 
-enum class Kind { softmax_f16, softmax_f32, dynfc_f16, dynfc_f32 };
+enum class Kind { softmax_f16, softmax_f32, softmax_qu8, dynfc_f16, dynfc_f32 };
 
 struct FakeOp {
     unsigned char magic[16];
     Kind kind;
     // softmax
     size_t channels = 0, in_stride = 0, out_stride = 0, batch = 0;
+    float qu8_in_scale = 0.f;           // qu8: lookup table of scaled exp((i - 255) * input_scale), built at reshape (depends on channels)
+    uint32_t lut[256] = {};
     const void* in = nullptr;
     void* out = nullptr;
     // dynamic fc
@@ -80,6 +83,26 @@ inline float h2f(uint16_t h) { return _cvtsh_ss(h); }
 inline uint16_t f2h(float f) { return _cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC); }
 
 struct SoftmaxCtx { FakeOp* op; };
+
+// qu8 softmax, restating XNNPACK's operator (src/operators/softmax-nc.c + u8-rmax + u8-lut32norm scalar microkernel, pinned commit
+// google/XNNPACK@5671db05): t[i] = lrint(qscale * exp((i - 255) * input_scale)), qscale = min(UINT32_MAX / channels, 2^23 - 1);
+// per row: m = max(x); sum = SUM t[x + 255 - m]; y = min(255, ((t[x + 255 - m] << 8) + (sum >> 1)) / sum).  Output scale is 1/256 with
+// zero point 0 (the only combination XNNPACK accepts).  Integer arithmetic after the table: bit-exact by construction.
+void softmax_row_qu8(void* vctx, size_t row) {
+    FakeOp* f = ((SoftmaxCtx*)vctx)->op;
+    const uint8_t* x = (const uint8_t*)f->in + row * f->in_stride;
+    uint8_t* y = (uint8_t*)f->out + row * f->out_stride;
+    uint8_t m = 0;
+    for (size_t i = 0; i < f->channels; i++) m = x[i] > m ? x[i] : m;
+    const uint32_t* t = f->lut + (255 - m);
+    uint32_t sum = 0;
+    for (size_t i = 0; i < f->channels; i++) sum += t[x[i]];
+    const uint32_t rounding = sum >> 1;
+    for (size_t i = 0; i < f->channels; i++) {
+        const uint32_t q = (uint32_t)((((uint64_t)t[x[i]] << 8) + rounding) / sum);
+        y[i] = q > 255 ? 255 : (uint8_t)q;
+    }
+}
 
 void softmax_row_f16(void* vctx, size_t row) {
     FakeOp* op = ((SoftmaxCtx*)vctx)->op;
@@ -217,6 +240,11 @@ enum xnn_status xnn_run_operator(xnn_operator_t op, pthreadpool_t tp) {
             pthreadpool_parallelize_1d(tp, softmax_row_f32, &c, f->batch, 0);
             return xnn_status_success;
         }
+        case Kind::softmax_qu8: {
+            SoftmaxCtx c{f};
+            pthreadpool_parallelize_1d(tp, softmax_row_qu8, &c, f->batch, 0);
+            return xnn_status_success;
+        }
         case Kind::dynfc_f16:
         case Kind::dynfc_f32:
             return run_dynfc(f, tp);
@@ -257,14 +285,23 @@ enum xnn_status xnn_setup_softmax_nc_f16(xnn_operator_t op, const void* in, void
 enum xnn_status xnn_setup_softmax_nc_f32(xnn_operator_t op, const float* in, float* out) {
     FakeOp* f = (FakeOp*)op; f->in = in; f->out = out; return xnn_status_success;
 }
-enum xnn_status xnn_create_softmax_nc_qu8(float, uint8_t, float, uint32_t, xnn_operator_t* out) {
-    *out = nullptr; return xnn_status_unsupported_hardware;
+enum xnn_status xnn_create_softmax_nc_qu8(float input_scale, uint8_t output_zero_point, float output_scale, uint32_t, xnn_operator_t* out) {
+    *out = nullptr;
+    if (!(input_scale > 0.f) || output_zero_point != 0 || output_scale != 0x1.0p-8f) return xnn_status_unsupported_parameter;   // XNNPACK's own gate
+    FakeOp* f = make_fake(Kind::softmax_qu8);
+    f->qu8_in_scale = input_scale;
+    *out = (xnn_operator_t)f;
+    return xnn_status_success;
 }
-enum xnn_status xnn_reshape_softmax_nc_qu8(xnn_operator_t, size_t, size_t, size_t, size_t, pthreadpool_t) {
-    return xnn_status_unsupported_hardware;
+enum xnn_status xnn_reshape_softmax_nc_qu8(xnn_operator_t op, size_t c, size_t is, size_t os, size_t b, pthreadpool_t) {
+    if (!is_fake(op) || c == 0) return xnn_status_invalid_parameter;
+    FakeOp* f = (FakeOp*)op;
+    const double qscale = std::fmin(((double)UINT32_MAX) / (double)c, 8388607.0);
+    for (int i = 0; i < 256; i++) f->lut[i] = (uint32_t)std::lrint(qscale * std::exp((double)(i - 255) * (double)f->qu8_in_scale));
+    return reshape_softmax(op, c, is, os, b);
 }
-enum xnn_status xnn_setup_softmax_nc_qu8(xnn_operator_t, const uint8_t*, uint8_t*) {
-    return xnn_status_unsupported_hardware;
+enum xnn_status xnn_setup_softmax_nc_qu8(xnn_operator_t op, const uint8_t* in, uint8_t* out) {
+    FakeOp* f = (FakeOp*)op; f->in = in; f->out = out; return xnn_status_success;
 }
 
 // ---- dynamic fully connected -------------------------------------------------------------------
