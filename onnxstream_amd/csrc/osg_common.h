@@ -89,6 +89,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float osg_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
 }
+// 0.5 g (1 + erf(g / sqrt 2)) for the fused GEGLU paths: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7 + fp32 evaluation, i.e. far
+// below the f16 rounding of the product) on v_rcp_f32 / v_exp_f32 -- a dozen instructions where libm's erff takes ~50; the GEGLU
+// epilogue evaluates it for every output element of the largest GEMMs of the net.  The standalone Erf op keeps erff (the reference
+// rounds std::erf's result, onnxstream.cpp:4001-4139).
+__device__ __forceinline__ float osg_gelu_erf(float g) {
+    const float xs = g * 0.70710678118654752440f, ax = fabsf(xs);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float e = __builtin_amdgcn_exp2f(ax * ax * -1.44269504088896341f);
+    const float er = copysignf(fmaf(-poly, e, 1.0f), xs);
+    return 0.5f * g * (1.0f + er);
+}
 __device__ __forceinline__ float osg_apply_act(float v, int act) {
     if (act == OSG_ACT_SILU) return v * osg_sigmoid(v);
     if (act == OSG_ACT_SIGMOID) return osg_sigmoid(v);

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void geglu_kernel(const T* __restrict__ x, T* 
         vec_t o;
 #pragma unroll
         for (int e = 0; e < V; e++)
-            o[e] = from_f32<T>(to_f32<T>(val[e]) * apply_unary(to_f32<T>(gate[e]), OSG_UN_GELU_ERF, 0.f));
+            o[e] = from_f32<T>(to_f32<T>(val[e]) * osg_gelu_erf(to_f32<T>(gate[e])));   // same expression as the GEMM's GEGLU epilogue
         *reinterpret_cast<vec_t*>(y + r * C + c) = o;
     }
 }

@@ -219,7 +219,7 @@ __device__ __forceinline__ void gemm_epilogue_geglu(const GemmParams& p, f32x4 (
                     v += p.bias_f32 ? ((const float*)p.bias)[n + r] : (float)((const f16*)p.bias)[n + r];
                     g += p.bias_f32 ? ((const float*)p.bias)[n + 16 + r] : (float)((const f16*)p.bias)[n + 16 + r];
                 }
-                o[r] = (f16)(v * (0.5f * g * (1.0f + erff(g * 0.70710678118654752440f))));
+                o[r] = (f16)(v * osg_gelu_erf(g));
             }
             *reinterpret_cast<f16x4*>(C + (long)m * No + c) = o;
         }
