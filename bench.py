@@ -320,8 +320,8 @@ def main():
             nd = sum(v["dispatches"] for v in sel)
             if nd:
                 traffic = (sum(2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0) for v in sel) * 1024.0) / nd
-        roofline = {"bound": "mfma", "kernel": "gemm_kernel (implicit-GEMM Conv + Linear/MatMul/Gemm)", "achieved": round(achieved, 2),
-                    "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC, corrected)",
+        roofline = {"bound": "mfma", "kernel": "gemm2_kernel + conv3x3_kernel (implicit-GEMM / halo-reuse Conv, Linear/MatMul/Gemm)", "achieved": round(achieved, 2),
+                    "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of profiles/r01_pmc_traffic.json, gfx950-corrected; collected on the v5 kernel generation)",
                     "launches_per_step": g_n, "flop_per_launch": g_fl / max(g_n, 1), "avg_launch_us": g_ms * 1e3 / max(g_n, 1),
                     "step_flop": tot_fl, "step_frac": round(tot_fl / (ms_per_step * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4),
                     "sum_of_kernels_ms": round(tot_ms, 4)}
