@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 __device__ __forceinline__ void gn_fold_stats(const float* __restrict__ part, float* stat, int n, long HW, int cpg, int G, int S, float eps) {
     int tpg = 1;
     while (tpg * 2 * G <= 256 && tpg < 64) tpg *= 2;
-    const double cnt = (double)HW * cpg;
+    const double icnt = (double)(1.0f / ((float)HW * (float)cpg));
     for (int g0 = 0; g0 < G; g0 += 256 / tpg) {
         const int g = g0 + threadIdx.x / tpg, l = threadIdx.x % tpg;
         double sm = 0, q = 0;
@@ -154,11 +154,12 @@ __device__ __forceinline__ void gn_fold_stats(const float* __restrict__ part, fl
             q += __shfl_xor(q, o, 64);
         }
         if (g < G && l == 0) {
-            double mean = sm / cnt;
-            double var = q / cnt - mean * mean;
-            if (var < 0) var = 0;
+            // E[x^2] - mean^2 in f64 (fma-rate operations; the f32 subtraction would cancel); the reciprocal count, the square root and the
+            // final reciprocal in f32 -- an f64 divide / sqrt is ~100 instructions each, on the critical path of every block that folds
+            const double mean = sm * icnt;
+            const float var = fmaxf((float)(q * icnt - mean * mean), 0.f);
             stat[g * 2 + 0] = (float)mean;
-            stat[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+            stat[g * 2 + 1] = 1.0f / sqrtf(var + eps);
         }
     }
     __syncthreads();
@@ -295,12 +296,11 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const f16* __restrict__ x
     if (t < gb) {
         double s = 0, q = 0;
         for (int w = 0; w < nw; w++) { s += red[t][w][0]; q += red[t][w][1]; }
-        const double cnt = (double)HW * cpg;
-        const double mean = s / cnt;
-        double var = q / cnt - mean * mean;
-        if (var < 0) var = 0;
+        const double icnt = (double)(1.0f / ((float)HW * (float)cpg));   // (f64 only where the cancellation is; see gn_fold_stats)
+        const double mean = s * icnt;
+        const float var = fmaxf((float)(q * icnt - mean * mean), 0.f);
         stat[t][0] = (float)mean;
-        stat[t][1] = (float)(1.0 / sqrt(var + (double)eps));
+        stat[t][1] = 1.0f / sqrtf(var + eps);
     }
     __syncthreads();
     if (!active) return;
