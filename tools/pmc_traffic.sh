@@ -5,10 +5,11 @@ export TMPDIR=/tmp
 export OSG_TUNE_CACHE=/tmp/osg_tune_cache.txt   # the priming run below tunes; the counter passes reuse its choices (no timing launches in the counters)
 TAG=${1:-r1}
 cd $GRAFT_REPO_ROOT
-python bench.py --mode replay --steps 2 --warmup 1 --cpu-passes 0 --profile-reps 1 > /tmp/pmc_prime.log 2>&1
+timeout 120 python bench.py --mode replay --steps 2 --warmup 1 --cpu-passes 0 --profile-reps 1 > /tmp/pmc_prime.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- python bench.py --mode replay --steps 4 --warmup 1 --cpu-passes 0 --profile-reps 1 > /tmp/pmc_$c.log 2>&1
+  # bounded: late in round 1 a --pmc pass of this very command sat until its timeout (rocprofv3 aborted with signal 6) where it took ~30 s before
+  timeout 240 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$c -o pmc -- python bench.py --mode replay --steps 4 --warmup 1 --cpu-passes 0 --profile-reps 1 > /tmp/pmc_$c.log 2>&1
 done
 python - $TAG <<'PY'
 import csv, glob, json, sys, collections
