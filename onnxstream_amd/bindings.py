@@ -202,6 +202,17 @@ class Model:
                     clip.ctypes.data_as(fp) if clip is not None else None, ctypes.byref(ms)))
         return ms.value
 
+    def hip_plan_info(self) -> str:
+        """Steps (reads / writes / side-stream marks) and arena placement of the current plan, as text (Plan::info)."""
+        f = self._lib.model_hip_plan_info
+        f.argtypes = [ctypes.c_void_p]; f.restype = ctypes.c_void_p
+        p = f(self._h)
+        text = ctypes.cast(p, ctypes.c_char_p).value.decode("utf-8", "replace")
+        self._lib.model_free_buffer(p)
+        if text.startswith("ERROR: "):
+            raise OnnxStreamError(text[7:])
+        return text
+
     def hip_profile(self, reps: int = 1):
         """Eager pass with HIP events around every step -> list of (ms, flops, bytes, what)."""
         f = self._lib.model_hip_profile

@@ -286,6 +286,14 @@ char* model_hip_sampler_loop(Handle* h, char* sample_name, char* timestep_name, 
         return dup_cstr(e.what());
     }
 }
+// steps and arena placement of the current plan (malloc'ed text, free with model_free_buffer); "ERROR: ..." on error
+char* model_hip_plan_info(Handle* h) {
+    try {
+        return dup_cstr(h->model.hip_plan_info());
+    } catch (const std::exception& e) {
+        return dup_cstr(std::string("ERROR: ") + e.what());
+    }
+}
 // per-step timing report (malloc'ed text, free with model_free_buffer); on error the text starts with "ERROR: "
 char* model_hip_profile(Handle* h, int reps) {
     try {

@@ -232,6 +232,11 @@ double Model::hip_sampler_loop(const std::string& sample_name, const std::string
     return ms;
 }
 
+std::string Model::hip_plan_info() const {
+    if (!m_plan) throw std::runtime_error("Model::hip_plan_info: no plan (call run() first).");
+    return m_plan->info();
+}
+
 std::string Model::hip_profile(int reps) {
     if (!m_plan) throw std::runtime_error("Model::hip_profile: no plan (call run() first).");
     return m_plan->profile(reps);

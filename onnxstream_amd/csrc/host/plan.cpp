@@ -2438,6 +2438,28 @@ double Plan::sampler_loop(const std::string& sample_name, const std::string& tim
     return ms;
 }
 
+std::string Plan::info() const {
+    std::string out;
+    char buf[128];
+    for (size_t i = 0; i < steps.size(); i++) {
+        const Step& s = steps[i];
+        snprintf(buf, sizeof buf, "step %zu side_join=%d join_before=%d reads=", i, s.side_join, s.join_before ? 1 : 0);
+        out += buf;
+        for (size_t k = 0; k < s.reads.size(); k++) out += (k ? "," : "") + std::to_string(root_of(s.reads[k]));
+        out += " writes=";
+        for (size_t k = 0; k < s.writes.size(); k++) out += (k ? "," : "") + std::to_string(root_of(s.writes[k]));
+        out += " | " + s.what + "\n";
+    }
+    for (size_t v = 0; v < vals.size(); v++) {
+        const Val& r = vals[v];
+        if (r.root >= 0 || r.dptr || r.is_const || r.last < 0) continue;
+        snprintf(buf, sizeof buf, "val %zu offset=%zu bytes=%zu first=%d last=%d\n", v, r.offset, val_bytes((int)v), r.first, r.last);
+        out += buf;
+    }
+    out += "arena " + std::to_string(arena_bytes) + "\n";
+    return out;
+}
+
 std::string Plan::profile(int reps) {
     if (runs < 1) throw std::runtime_error("Model::hip_profile: run() once first (inputs must be resident).");
     std::vector<double> acc(steps.size(), 0.0);

@@ -77,6 +77,10 @@ struct Plan {
                         const float* k_up, float guidance, const float* clip);
     // eager pass with HIP events around every step, `reps` times; "ms<TAB>flops<TAB>bytes<TAB>what" per line (ms = mean)
     std::string profile(int reps);
+    // plan introspection for the CPU tests of the host logic (tests/test_planner_cpu.py): one line per step
+    //   "step <i> side_join=<j> join_before=<0|1> reads=<v,...> writes=<v,...> | <what>"   (val ids are ROOT vals)
+    // and per arena val  "val <id> offset=<o> bytes=<b> first=<f> last=<l>", then "arena <bytes>".
+    std::string info() const;
     bool compatible(Model& m, size_t batch) const;
     size_t kernel_count() const { return steps.size(); }
     double last_ms() const { return m_last_ms; }
