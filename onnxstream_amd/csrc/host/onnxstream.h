@@ -246,6 +246,7 @@ class DiskPrefetchWeightsProvider : public WeightsProvider {
         std::deque<std::pair<Item, Blob>> ready;  // loaded, in order
         size_t ready_bytes = 0;
         size_t next = 0;                          // index into `order` of the next file to read
+        size_t done = 0;                          // files read AND published in `ready` so far (the file `next` points past may still be loading)
         bool stop = false;
         std::string error;
     };
@@ -299,6 +300,7 @@ class DiskPrefetchWeightsProvider : public WeightsProvider {
                     std::lock_guard<std::mutex> lk(sh->mu);
                     sh->ready_bytes += it.bytes;
                     sh->ready.emplace_back(std::move(it), std::move(b));
+                    sh->done++;
                 }
                 sh->cv.notify_all();
             }
@@ -317,7 +319,8 @@ class DiskPrefetchWeightsProvider : public WeightsProvider {
             m_thread = std::thread(&DiskPrefetchWeightsProvider::worker, this, m_sh, m_path, m_order);
         }
         std::unique_lock<std::mutex> lk(m_sh->mu);
-        m_sh->cv.wait(lk, [&] { return !m_sh->ready.empty() || !m_sh->error.empty() || (m_sh->next >= m_order.size() && m_sh->ready.empty()); });
+        // (exhausted = everything PUBLISHED and consumed; `next` alone runs ahead of the file the worker is still reading)
+        m_sh->cv.wait(lk, [&] { return !m_sh->ready.empty() || !m_sh->error.empty() || m_sh->done >= m_order.size(); });
         if (!m_sh->error.empty())
             throw std::invalid_argument("DiskPrefetchWeightsProvider::provide: fatal error in worker thread: \"" + m_sh->error + "\".");
         if (m_sh->ready.empty()) throw std::invalid_argument("DiskPrefetchWeightsProvider::provide: vector is empty.");
