@@ -273,3 +273,51 @@ def test_device_sampler_loop_plumbing(stub_backend):
         with pytest.raises(OnnxStreamError, match="not found"):
             m.hip_sampler_loop("sample", "timestep", "nope", x, None, *sc)
         m.close()
+
+
+def test_input_contract_errors(stub_backend):
+    """The caller contract of Model::run (reference src/onnxstream.cpp:3817-3842, :2618): missing input, inconsistent pushes, a shape that
+    changed after the plan was built -- reference-style messages, no crash; and a plan survives clear_tensors / re-push."""
+    from onnxstream_amd import build as b
+    from onnxstream_amd.bindings import Model, OnnxStreamError
+    ins = sd_unet.unet_inputs(sd_unet.TINY, 42)
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        sd_unet.build_unet(DirSink(d), sd_unet.TINY)
+        m = Model(b.LIB_HOST, 0, "ram+nocache")
+        m.read_file(d + "model.txt")
+        m.set_use_fp16_arithmetic(True)
+        m.set_fuse_ops_in_attention(True)
+        m.add_tensor("sample", ins["sample"])
+        m.add_tensor("timestep", ins["timestep"])
+        with pytest.raises(OnnxStreamError, match="not found"):
+            m.run()                                             # encoder_hidden_states was never pushed
+        m.clear_tensors()
+        for k, v in ins.items():
+            m.add_tensor(k, v)
+        m.add_tensor("sample", ins["sample"])                   # a second sample but no second context: inconsistent batch
+        with pytest.raises(OnnxStreamError, match="inconsistent"):
+            m.run()
+        m.clear_tensors()
+        for k, v in ins.items():
+            m.add_tensor(k, v)
+        m.run()
+        n1 = m.hip_last_kernel_count()
+        assert m.get_tensor("out_sample") is not None and m.get_tensor("no_such_tensor") is None
+        m.clear_tensors()
+        for k, v in ins.items():
+            m.add_tensor(k, v)
+        m.run()                                                 # same plan, second pass (this one captures the graph)
+        assert m.hip_last_kernel_count() == n1
+        m.clear_tensors()
+        bad = dict(ins)
+        bad["sample"] = np.zeros((1, 4, 8, 8), np.float32)
+        for k, v in bad.items():
+            m.add_tensor(k, v)
+        with pytest.raises(OnnxStreamError):
+            m.run()
+        m.close()
+    m = Model(b.LIB_HOST, 0, "ram+nocache")
+    with pytest.raises(OnnxStreamError):
+        m.read_file("/nonexistent/model.txt")
+    m.close()
