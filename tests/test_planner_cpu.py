@@ -321,3 +321,40 @@ def test_input_contract_errors(stub_backend):
     with pytest.raises(OnnxStreamError):
         m.read_file("/nonexistent/model.txt")
     m.close()
+
+
+_SWEEP = [
+    sd_unet.UNetConfig(block_out=(32, 64), transformer_depth=(1, 1), heads=1, ctx_dim=16, ctx_len=7, latent=8, name="s0"),
+    sd_unet.UNetConfig(block_out=(64, 64, 128), transformer_depth=(1, 0, 1), heads=4, ctx_dim=24, ctx_len=3, latent=16, name="s1"),
+    sd_unet.UNetConfig(block_out=(32, 96, 96, 32), transformer_depth=(0, 1, 1, 0), heads=2, ctx_dim=40, ctx_len=77, latent=24, name="s2"),   # odd sizes: no halo kernel
+    sd_unet.UNetConfig(block_out=(64, 128), transformer_depth=(2, 3), mid_depth=2, head_dim=32, ctx_dim=64, ctx_len=5, latent=8, linear_proj=True,
+                       sdxl_add_embed=True, name="s3"),
+    sd_unet.UNetConfig(block_out=(128,), transformer_depth=(1,), heads=8, ctx_dim=32, ctx_len=9, latent=32, layers_per_block=1, name="s4"),
+    sd_unet.UNetConfig(block_out=(32, 32, 32, 32, 32), transformer_depth=(1, 1, 1, 1, 0), heads=2, ctx_dim=8, ctx_len=2, latent=32, name="s5"),
+]
+
+
+@pytest.mark.parametrize("cfg", _SWEEP, ids=[c.name for c in _SWEEP])
+@pytest.mark.parametrize("pushes", [1, 3])
+def test_planner_invariants_over_a_sweep_of_unet_shapes(stub_backend, cfg, pushes):
+    """Structure fuzz: UNets of other depths / widths / head counts / odd spatial sizes, single and batched passes, every opt-in variant --
+    the plan must build, keep the arena and side-stream invariants, and stay consistent across variants."""
+    ins = sd_unet.unet_inputs(cfg, 7)
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        sd_unet.build_unet(DirSink(d), cfg)
+        base = None
+        for opts in ((), (("hip_fuse_ln_gemm", 1), ("hip_side_stream", 1)), (("hip_fusion_level", 0),), (("hip_fuse_gn_conv", 1),)):
+            m, info = _plan(d, ins, opts, pushes=pushes)
+            steps, vals, arena = _parse(info)
+            _check_arena(steps, vals, arena)
+            _check_side(steps, vals)
+            out = m.get_tensor("out_sample")
+            assert out is not None and list(out[0].shape) == [1, cfg.out_ch, cfg.latent, cfg.latent]
+            if not opts:
+                base = len(steps)
+            elif opts[0][0] == "hip_fusion_level":
+                assert len(steps) > base
+            else:
+                assert len(steps) <= base
+            m.close()
