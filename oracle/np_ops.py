@@ -217,10 +217,13 @@ def attention_exact(q, k, v, scale):
 
 # ---- quantisation (integer path: bit-exact contracts) -----------------------------------------------------
 def range_to_scale(lo, hi):
-    """Model::range_to_scale (:3234): range forced to include 0, scale=(hi-lo)/255.0 (double -> float), zp truncated."""
+    """Model::range_to_scale (:3234): range forced to include 0; scale = (float)((hi - lo) / 255.0) where hi - lo is a FLOAT subtraction
+    (rounded) and only the division runs in double; zp = (uint8_t)(|lo| / scale), a float division, truncated.  (Pinned against the
+    reference's push_tensor quantisation in tests/test_qu8_oracle.py: the double subtraction differs by an ulp of the scale on some ranges.)"""
     lo, hi = min(float(lo), 0.0), max(float(hi), 0.0)
-    scale = np.float32((np.float64(np.float32(hi)) - np.float64(np.float32(lo))) / 255.0)
-    zp = int(np.uint8(int(abs(np.float32(lo)) / scale)))
+    d = np.float32(np.float32(hi) - np.float32(lo))
+    scale = np.float32(np.float64(d) / 255.0)
+    zp = int(np.uint8(int(np.float32(abs(np.float32(lo))) / scale)))
     return scale, zp
 
 

@@ -122,3 +122,39 @@ def resize_nearest_u8(q, scale_h, scale_w):
     hi = np.minimum((np.arange(int(h * scale_h)) / scale_h).astype(np.int64), h - 1)
     wi = np.minimum((np.arange(int(w * scale_w)) / scale_w).astype(np.int64), w - 1)
     return q[:, :, hi][:, :, :, wi]
+
+
+def percentiles(x, from_left=0.001, from_right=0.001, threads=1, chunk=16384):
+    """Model::get_percentiles on fp32 data (onnxstream.cpp:3104-3231, FloatAsUInt::get_percentiles :2300-2386): the tensor is split evenly
+    over `threads` workers (get_start_and_end :3091), each worker walks its span in chunks of 16 K elements (the 64 KiB per-thread buffer),
+    sorts a chunk and takes the element (size_t)(n * from_left) from the bottom and (size_t)(n * from_right) from the top of its FINITE
+    values; the result is the min of the lows and the max of the highs over all chunks -- so it depends on the thread count and the chunk
+    size, exactly like the reference's.  Returns (lo, hi) or None."""
+    flat = np.asarray(x, f32).ravel()
+    size = flat.size
+    per = max(size // threads, 1)
+    lo, hi, found = np.inf, -np.inf, False
+    for i in range(threads):
+        start = i * per
+        end = size if i >= threads - 1 else (i + 1) * per
+        if start >= end or start >= size or end > size:
+            continue
+        for j in range(start, end, chunk):
+            c = np.sort(flat[j:min(end, j + chunk)])
+            n = c.size
+            c = c[np.isfinite(c)]
+            kl, kr = int(f32(n) * f32(from_left)), int(f32(n) * f32(from_right))
+            if kl >= c.size or kr >= c.size:
+                continue
+            lo, hi, found = min(lo, float(c[kl])), max(hi, float(c[c.size - 1 - kr])), True
+    if not found or not np.isfinite(lo) or not np.isfinite(hi) or lo >= hi:
+        return None
+    return f32(lo), f32(hi)
+
+
+def quantize_dynamic(x, threads=1):
+    """Model::quantize (onnxstream.cpp:3247-3352) = what push_tensor does to a pushed fp32 input under uint8 arithmetic (:3024-3028): 0.1 %
+    percentiles from each end -> range_to_scale -> f32 -> u8.  Returns (codes, scale, zero_point)."""
+    lo, hi = percentiles(x, 0.001, 0.001, threads)
+    scale, zp = range_to_scale(lo, hi)
+    return quantize_u8(x, scale, zp), scale, zp

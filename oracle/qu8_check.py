@@ -71,8 +71,24 @@ def run_u8_all(model_dir, inputs, ranges):
         a = np.ascontiguousarray(v, np.float32)
         dims = (ctypes.c_uint * a.ndim)(*a.shape)
         assert not lib.ref_push_tensor_f32(m.handle, m._name(k), a.ndim, dims, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
-    m.run()
     vals = {}
+
+    def grab(nm):
+        dt, rank, scale, zp, ptr = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_float(), ctypes.c_int(), ctypes.c_void_p()
+        shape = (ctypes.c_size_t * 8)()
+        n = lib.ref_get_tensor_any(m.handle, nm.encode(), ctypes.byref(dt), ctypes.byref(rank), shape, ctypes.byref(scale), ctypes.byref(zp), ctypes.byref(ptr))
+        if not n:
+            return None
+        npdt = {1: np.uint8, 2: np.uint16, 3: np.float32, 4: np.int64}[dt.value]
+        arr = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(np.ctypeslib.as_ctypes_type(npdt))), shape=(n,)).copy()
+        return dict(data=arr.reshape([shape[i] for i in range(rank.value)]), scale=np.float32(scale.value), zp=int(zp.value), dtype=dt.value)
+
+    for k in inputs:          # the pushed inputs, as push_tensor quantised them (they are consumed by the pass)
+        nm = m._name(k).decode()
+        v = grab(nm)
+        if v is not None:
+            vals[nm] = v
+    m.run()
     for op in ops:
         for o in op["outputs"] + op["inputs"]:
             nm = tname(o)

@@ -35,3 +35,32 @@ def test_uint8_add_multiplier_construction_matches_known_case():
     out = Q.add_u8(a, 0.5, 128, b, 0.25, 128, 1.0, 128)
     # (a-128)*0.5 + (b-128)*0.25 = [-32.25, -88.5, 0, 31.5]; rounded half up in the fixed-point domain, + 128
     assert out.tolist() == [96, 40, 128, 160]
+
+
+@pytest.mark.skipif(not oref.available(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("shape,threads", [((1, 4, 64, 64), 1), ((1, 4, 64, 64), 4), ((1, 4, 128, 128), 7), ((1, 3, 7, 5), 4)])
+def test_dynamic_input_quantisation_matches_push_tensor(shape, threads):
+    """What push_tensor does to a pushed fp32 input under uint8 arithmetic (0.1 % percentiles per 16 K chunk per worker thread -> scale /
+    zero point -> codes): the restatement reproduces the reference's codes AND its scale bit for bit, for several thread counts."""
+    import ctypes
+    from onnxstream_amd.bindings import Model
+    from oracle import np_qu8 as Q
+    z = (np.random.default_rng(sum(shape) + threads).standard_normal(shape) * 3).astype(np.float32)
+    m = Model(oref.REF_LIB, threads, "ram+nocache")
+    oref._extra(m.lib)
+    lib = m.lib
+    lib.ref_get_tensor_any.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_size_t),
+                                       ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int),
+                                       ctypes.POINTER(ctypes.c_void_p)]
+    lib.ref_get_tensor_any.restype = ctypes.c_size_t
+    m._set_option("use_uint8_arithmetic", 1)
+    dims = (ctypes.c_uint * z.ndim)(*z.shape)
+    assert not lib.ref_push_tensor_f32(m.handle, b"x", z.ndim, dims, z.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    dt, rank, scale, zp, ptr = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_float(), ctypes.c_int(), ctypes.c_void_p()
+    shp = (ctypes.c_size_t * 8)()
+    n = lib.ref_get_tensor_any(m.handle, b"x", ctypes.byref(dt), ctypes.byref(rank), shp, ctypes.byref(scale), ctypes.byref(zp), ctypes.byref(ptr))
+    ref_codes = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(n,)).copy()
+    m.close()
+    q, s, z0 = Q.quantize_dynamic(z, threads=threads)
+    assert np.float32(s) == np.float32(scale.value) and z0 == zp.value
+    assert np.array_equal(q.ravel(), ref_codes)
