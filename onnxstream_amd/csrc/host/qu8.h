@@ -1,0 +1,174 @@
+// qu8.h -- host-side parameter construction for the reference's uint8 arithmetic (m_use_uint8_arithmetic, reference src/onnxstream.cpp), the
+// part of the W8A8 VAE path that is pure host logic: quantisation parameters, the dynamic quantisation of pushed inputs, and the tables /
+// integer multipliers the device kernels will consume.  Every function restates the reference (cited) or XNNPACK's qu8 operators (pinned commit
+// google/XNNPACK@5671db05, as used through src/onnxstream.cpp) and is pinned bit for bit against oracle/np_qu8.py -- itself pinned against the
+// reference's own intermediates -- by tests/test_qu8_host.py.  Header-only; not wired into the planner yet (the HIP backend still rejects
+// uint8 activations): DESIGN.md section 9.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <optional>
+#include <utility>
+#include <vector>
+
+namespace onnxstream {
+namespace qu8 {
+
+struct QParams {
+    float scale;
+    uint8_t zero_point;
+};
+
+// Model::range_to_scale (reference :3234-3245): the range is forced to include 0; (hi - lo) is a FLOAT subtraction, the division by 255.0 runs
+// in double and is rounded to float; the zero point is the truncated float quotient |lo| / scale.
+inline QParams range_to_scale(float lo, float hi) {
+    if (lo > 0 && hi > 0) lo = 0;
+    else if (lo < 0 && hi < 0) hi = 0;
+    const float scale = (float)((double)(hi - lo) / 255.0);
+    const uint8_t zp = (uint8_t)(std::abs(lo) / scale);
+    return {scale, zp};
+}
+
+// XnnPack::convert_qu8<float, uint8_t> (reference :802-834 -> XNNPACK f32->qu8 convert): clamp(rne(x * (1.0f / scale)) + zp, 0, 255).
+inline uint8_t quantize(float x, QParams q) {
+    const float inv = 1.0f / q.scale;
+    float r = std::nearbyintf(x * inv) + (float)q.zero_point;      // default rounding mode: to nearest even
+    r = std::min(std::max(r, 0.0f), 255.0f);
+    return (uint8_t)r;
+}
+// XnnPack::convert_qu8<uint8_t, float>: (float)((int)q - zp) * scale.
+inline float dequantize(uint8_t q, QParams p) { return (float)((int)q - (int)p.zero_point) * p.scale; }
+
+// Model::get_percentiles on fp32 data (reference :3104-3231 + FloatAsUInt::get_percentiles :2300-2386): the tensor is split evenly over
+// `threads` workers (get_start_and_end :3091), each walks its span in chunks of 16 K elements, sorts a chunk and takes the element
+// (size_t)(n * from_left) from the bottom and (size_t)(n * from_right) from the top of its finite values; min of the lows, max of the highs.
+inline std::optional<std::pair<float, float>> percentiles(const float* x, size_t size, float from_left, float from_right, size_t threads) {
+    const size_t chunk = 64 * 1024 / sizeof(float);
+    if (!threads) threads = 1;
+    size_t per = size / threads;
+    if (!per) per = 1;
+    float lo = std::numeric_limits<float>::infinity(), hi = -std::numeric_limits<float>::infinity();
+    bool found = false;
+    std::vector<float> buf(chunk);
+    for (size_t i = 0; i < threads; i++) {
+        const size_t start = i * per, end = i >= threads - 1 ? size : (i + 1) * per;
+        if (start >= end || start >= size || end > size) continue;
+        for (size_t j = start; j < end; j += chunk) {
+            const size_t n = std::min(end - j, chunk);
+            size_t m = 0;
+            for (size_t k = 0; k < n; k++)
+                if (std::isfinite(x[j + k])) buf[m++] = x[j + k];
+            std::sort(buf.begin(), buf.begin() + m);
+            const size_t kl = (size_t)((float)n * from_left), kr = (size_t)((float)n * from_right);
+            if (kl >= m || kr >= m) continue;
+            lo = std::min(lo, buf[kl]);
+            hi = std::max(hi, buf[m - 1 - kr]);
+            found = true;
+        }
+    }
+    if (!found || !std::isfinite(lo) || !std::isfinite(hi) || lo >= hi) return std::nullopt;
+    return std::make_pair(lo, hi);
+}
+
+// Model::quantize (reference :3247-3352) = push_tensor's treatment of a pushed fp32 input under uint8 arithmetic (:3024-3028)
+inline bool quantize_dynamic(const float* x, size_t size, size_t threads, uint8_t* out, QParams* qp) {
+    auto r = percentiles(x, size, 0.001f, 0.001f, threads);
+    if (!r) return false;
+    *qp = range_to_scale(r->first, r->second);
+    for (size_t i = 0; i < size; i++) out[i] = quantize(x[i], *qp);
+    return true;
+}
+
+// Sigmoid, uint8 branch (reference :4412-4481): per code, dequantise, 1 / (1 + std::exp(-x)) in float, requantise.  The op becomes a
+// 256-entry table built HERE, with the host's expf -- the very function the reference calls -- so the device lookup is exact by construction.
+inline void sigmoid_lut(QParams in, QParams out, uint8_t lut[256]) {
+    for (int c = 0; c < 256; c++) {
+        const float x = dequantize((uint8_t)c, in);
+        lut[c] = quantize(1 / (1 + std::exp(-x)), out);
+    }
+}
+
+// fp32 requantisation scale of the qu8 GEMM / convolution / multiply microkernels: (a_scale * b_scale) / out_scale, all float
+inline float requant_scale(float a_scale, float b_scale, float out_scale) { return (a_scale * b_scale) / out_scale; }
+// float(acc) * scale, clamp to [0 - zp, 255 - zp] as float, round to nearest even, + zero point  (gemm/igemm/vmul "minmax fp32")
+inline uint8_t requant_fp32(int32_t acc, float scale, uint8_t out_zp) {
+    float v = (float)acc * scale;
+    v = std::min(std::max(v, (float)(0 - (int)out_zp)), (float)(255 - (int)out_zp));
+    return (uint8_t)((int)std::nearbyintf(v) + (int)out_zp);
+}
+// Conv, uint8 branch: the fp32 bias becomes (int32_t)(b / (x_scale * w_scale)) (reference :4639-4660)
+inline int32_t conv_bias_i32(float b, float x_scale, float w_scale) { return (int32_t)(b / (x_scale * w_scale)); }
+
+// XNNPACK qu8 add (fixed point): multipliers with 20 bits for the larger of the two scale ratios, rounding folded into the bias:
+//   out = clamp(((bias + a * a_mult + b * b_mult) >> shift) + out_zp, 0, 255)
+struct AddParams {
+    int32_t a_mult, b_mult, bias;
+    uint32_t shift;
+    uint8_t out_zp;
+};
+inline AddParams add_params(QParams a, QParams b, QParams out) {
+    const float a_os = a.scale / out.scale, b_os = b.scale / out.scale;
+    const float mx = std::max(a_os, b_os);
+    uint32_t bits;
+    std::memcpy(&bits, &mx, 4);
+    const int32_t exponent = (int32_t)(bits >> 23) - 127;
+    const uint32_t shift = (uint32_t)(20 - exponent);
+    AddParams p;
+    p.a_mult = (int32_t)std::lrintf(std::ldexp(a_os, (int)shift));
+    p.b_mult = (int32_t)std::lrintf(std::ldexp(b_os, (int)shift));
+    p.shift = shift;
+    p.bias = (int32_t)((1u << (shift - 1)) - (uint32_t)(p.a_mult * (int32_t)a.zero_point) - (uint32_t)(p.b_mult * (int32_t)b.zero_point));
+    p.out_zp = out.zero_point;
+    return p;
+}
+inline uint8_t add(uint8_t a, uint8_t b, const AddParams& p) {
+    const int32_t acc = p.bias + (int32_t)a * p.a_mult + (int32_t)b * p.b_mult;
+    const int32_t o = (acc >> p.shift) + (int32_t)p.out_zp;
+    return (uint8_t)std::min(std::max(o, 0), 255);
+}
+
+// XNNPACK qu8 softmax: table t[i] = lrint(min(UINT32_MAX / channels, 2^23 - 1) * exp((i - 255) * in_scale)) (double exp); per row
+// y = min(255, ((t[x + 255 - max] << 8) + (sum >> 1)) / sum); output scale 1/256, zero point 0.
+inline void softmax_lut(float in_scale, size_t channels, uint32_t lut[256]) {
+    const double qscale = std::fmin(((double)UINT32_MAX) / (double)channels, 8388607.0);
+    for (int i = 0; i < 256; i++) lut[i] = (uint32_t)std::lrint(qscale * std::exp((double)(i - 255) * (double)in_scale));
+}
+inline void softmax_row(const uint8_t* x, size_t channels, const uint32_t lut[256], uint8_t* y) {
+    uint8_t m = 0;
+    for (size_t i = 0; i < channels; i++) m = std::max(m, x[i]);
+    const uint32_t* t = lut + (255 - m);
+    uint32_t sum = 0;
+    for (size_t i = 0; i < channels; i++) sum += t[x[i]];
+    for (size_t i = 0; i < channels; i++) {
+        const uint32_t q = (uint32_t)((((uint64_t)t[x[i]] << 8) + (sum >> 1)) / sum);
+        y[i] = q > 255 ? 255 : (uint8_t)q;
+    }
+}
+
+// InstanceNormalization, uint8 branch (reference :4987-5043), per channel of L elements, from the channel's CODE HISTOGRAM: the dequantised
+// values are 256 distinct floats, sums of them in double are exact in any order, so mean / variance / the output code of every input code
+// follow from the histogram alone -- the device kernel is a histogram pass and a table lookup.
+inline void instance_norm_lut(const uint32_t hist[256], size_t L, QParams in, float scale, float bias, float eps, QParams out, uint8_t lut[256]) {
+    float deq[256];
+    double mean = 0;
+    for (int c = 0; c < 256; c++) {
+        deq[c] = dequantize((uint8_t)c, in);
+        mean += (double)hist[c] * (double)deq[c];
+    }
+    mean /= (double)L;
+    double var = 0;
+    for (int c = 0; c < 256; c++) {
+        const float dev = (float)((double)deq[c] - mean);     // float dev = buffer[k] - mean
+        var += (double)hist[c] * (double)(dev * dev);
+    }
+    var /= (double)L;
+    const double sr = std::sqrt(var + (double)eps);
+    for (int c = 0; c < 256; c++) lut[c] = quantize((float)((double)scale * ((double)deq[c] - mean) / sr + (double)bias), out);
+}
+
+}  // namespace qu8
+}  // namespace onnxstream
