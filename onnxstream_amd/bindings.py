@@ -11,7 +11,7 @@ Additions over the reference binding (all optional, feature-probed with ``hasatt
 """
 import ctypes
 import re
-from typing import List, Tuple
+from typing import List
 
 import numpy
 

@@ -9,8 +9,8 @@ app pushes: ``timestep``[1], ``sample``[1,4,H,W], ``encoder_hidden_states``[1,77
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
-from typing import List, Tuple
+from dataclasses import dataclass
+from typing import Tuple
 
 import numpy as np
 

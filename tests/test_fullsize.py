@@ -5,7 +5,6 @@
 * size-independent properties: bitwise reproducibility over eager / captured / replayed passes, and batch invariance --
   a sample's result does not depend on what else shares the batched pass (cond alone == cond next to uncond)."""
 import os
-import tempfile
 
 import numpy as np
 import pytest

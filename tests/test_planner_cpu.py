@@ -3,7 +3,6 @@ opt-in plan variants (LayerNorm folding, side stream), error paths -- exercised 
 (tests/stub/make_stub.py: every C-ABI entry point exists, nothing is computed, outputs stay zero; reachable only through OSGPU_LIB, which
 only this module sets).  What is checked is structure and invariants of the plan (Model.hip_plan_info), never numbers."""
 import os
-import re
 import sys
 import tempfile
 

@@ -1,7 +1,6 @@
 """Dev tool (GPU box): the streamed-weights mode on the full SD 1.5 UNet -- every pass re-pulls the 1.72 GB of weights through the
 WeightsProvider and streams them H2D against compute.  Reports ms per pass and GB/s against the PCIe Gen5 x16 figure (63 GB/s)."""
 import os, sys, time
-import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from onnxstream_amd import build as b

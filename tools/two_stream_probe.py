@@ -1,7 +1,6 @@
 """Dev tool (GPU box): does running cond and uncond as two CONCURRENT batch-1 graphs (two contexts, two streams) beat one batch-2
 graph?  (per-launch fill/drain of one chain would overlap the other chain's math)"""
 import os, sys, threading, time
-import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from onnxstream_amd import build as b
