@@ -1,0 +1,43 @@
+#!/bin/bash
+# Dev tool (GPU box): per-kernel counters of the CURRENT kernels over eager SD 1.5 UNet passes (tools/pmc_pass.py), each counter set in its
+# own bounded rocprofv3 pass (MI355X_MICROARCH.md: FETCH_SIZE 3 TCC slots, WRITE_SIZE 2 -- never together; --kernel-trace only, no other trace domain).
+#   gpurun_out/pmc_<tag>.json : per kernel name -> {dispatches, SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, GRBM_GUI_ACTIVE, FETCH_SIZE, WRITE_SIZE, ...} (sums)
+export TMPDIR=/tmp
+TAG=${1:-r2}
+PASSES=${PMC_PASSES:-2}
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 300 python tools/pmc_pass.py > /tmp/pmc_prime.log 2>&1; tail -1 /tmp/pmc_prime.log
+i=0
+for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"; do
+  i=$((i+1))
+  rm -rf /tmp/pmc_$i
+  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_$i -o pmc -- python tools/pmc_pass.py > /tmp/pmc_$i.log 2>&1
+  echo "pmc pass $i ($set): exit $?"; tail -2 /tmp/pmc_$i.log
+done
+python - $TAG $PASSES <<'PY'
+import csv, glob, json, sys, collections
+out = collections.defaultdict(lambda: collections.defaultdict(float))
+for i in (1, 2, 3, 4):
+    fs = glob.glob(f"/tmp/pmc_{i}/**/*counter_collection.csv", recursive=True)
+    if not fs:
+        print("pass", i, "produced no counter file"); continue
+    seen = collections.Counter()
+    for r in csv.DictReader(open(fs[0])):
+        k = r["Kernel_Name"]
+        out[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        seen[(k, r["Counter_Name"])] += 1
+    for (k, c), n in seen.items():
+        out[k]["dispatches"] = max(out[k]["dispatches"], n)
+res = {"note": f"sums over {sys.argv[2]} eager SD1.5 batch-2 UNet passes (tools/pmc_pass.py, hip_use_graph=0, autotune off); FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 "
+               "reports them (gfx950: FETCH_SIZE x2 for wide coalesced reads, MI355X_MICROARCH.md); SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs; "
+               "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs)", "passes": int(sys.argv[2]), "kernels": {k: dict(v) for k, v in out.items()}}
+json.dump(res, open(f"gpurun_out/pmc_{sys.argv[1]}.json", "w"), indent=1)
+rows = []
+for k, v in out.items():
+    g = v.get("GRBM_GUI_ACTIVE", 0.0)
+    util = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (g * 1024.0) if g else 0.0
+    rows.append((g, k[:70], int(v["dispatches"]), util, 2 * v.get("FETCH_SIZE", 0.0) * 1024 / 1e6, v.get("WRITE_SIZE", 0.0) * 1024 / 1e6))
+for g, k, n, u, f, w in sorted(rows, reverse=True)[:24]:
+    print(f"{k:70s} n={n:5d} gui_cycles={g:12.0f} mfma_util={u:6.3f} fetch(MB,x2)={f:9.1f} write(MB)={w:9.1f}")
+PY
