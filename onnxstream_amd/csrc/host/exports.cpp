@@ -95,21 +95,21 @@ char* model_get_weights_names(Handle* h) {
     return dup_cstr(out);
 }
 
-void* model_add_weights_file(Handle* h, char* type, char* name, unsigned int size) {
+// 64-bit size variant (bindings that pass size_t need not truncate: a buffer of 4 GiB or more handed to the 32-bit entry point would
+// be allocated short and overrun by the caller); the reference's 32-bit entry point (src/exports.cpp:139) forwards to it
+void* model_hip_add_weights_file(Handle* h, const char* type, const char* name, unsigned long long size) {
     if (h->provider != "ram") return nullptr;
     auto& wp = h->model.get_weights_provider<RamWeightsProvider<WeightsProvider>>();
     const std::string t = type;
-    if (t == "uint8") return wp.add_empty_and_return_ptr<uint8_t>(name, size / sizeof(uint8_t));
-    if (t == "float16") return wp.add_empty_and_return_ptr<uint16_t>(name, size / sizeof(uint16_t));
-    if (t == "float32") return wp.add_empty_and_return_ptr<float>(name, size / sizeof(float));
-    if (t == "int64") return wp.add_empty_and_return_ptr<int64_t>(name, size / sizeof(int64_t));
+    if (t == "uint8") return wp.add_empty_and_return_ptr<uint8_t>(name, (size_t)size / sizeof(uint8_t));
+    if (t == "float16") return wp.add_empty_and_return_ptr<uint16_t>(name, (size_t)size / sizeof(uint16_t));
+    if (t == "float32") return wp.add_empty_and_return_ptr<float>(name, (size_t)size / sizeof(float));
+    if (t == "int64") return wp.add_empty_and_return_ptr<int64_t>(name, (size_t)size / sizeof(int64_t));
     throw std::invalid_argument("Unsupported tensor data format.");
 }
 
-// 64-bit size variant (a 2560->1280 3x3 conv weight alone is 59 MB; whole models exceed 4 GiB only in aggregate, but
-// bindings that pass size_t need not truncate)
-void* model_hip_add_weights_file(Handle* h, const char* type, const char* name, unsigned long long size) {
-    return model_add_weights_file(h, (char*)type, (char*)name, (unsigned int)size);
+void* model_add_weights_file(Handle* h, char* type, char* name, unsigned int size) {
+    return model_hip_add_weights_file(h, type, name, (unsigned long long)size);
 }
 
 void* model_add_tensor(Handle* h, char* type, char* name, unsigned int dims_num, unsigned int* dims) {

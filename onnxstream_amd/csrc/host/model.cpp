@@ -43,6 +43,8 @@ Model::Model(int threads_count) { m_backend_wanted = threads_count >= 0; }
 
 Model::~Model() {
     delete m_plan;
+    if (m_pool && m_backend) m_pool->clear(*m_backend);
+    delete m_pool;
     delete m_backend;
 }
 
@@ -57,6 +59,7 @@ void Model::read_file(const char* filename) {
     m_ops_parsed = false;
     m_init_done = false;
     hip_invalidate_plan();
+    if (m_pool && m_backend) m_pool->clear(*m_backend);   // another model: its resident weights go with the old one
 }
 
 void Model::read_string(const char* string, const char* path_with_slash) {
@@ -66,6 +69,7 @@ void Model::read_string(const char* string, const char* path_with_slash) {
     m_ops_parsed = false;
     m_init_done = false;
     hip_invalidate_plan();
+    if (m_pool && m_backend) m_pool->clear(*m_backend);
 }
 
 std::string Model::next_line() {
@@ -263,8 +267,14 @@ void Model::run() {
     }
     if (m_plan && !m_plan->compatible(*this, batch)) hip_invalidate_plan();
     if (!m_plan) {
-        m_plan = new Plan(*this, *m_backend, batch);
-        m_plan->build();
+        if (!m_pool) m_pool = new ConstPool();
+        m_plan = new Plan(*this, *m_backend, *m_pool, batch);
+        try {
+            m_plan->build();
+        } catch (...) {
+            hip_invalidate_plan();
+            throw;
+        }
     }
     m_plan->execute();
     m_last_kernels = m_plan->kernel_count();

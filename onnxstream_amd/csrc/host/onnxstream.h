@@ -247,6 +247,7 @@ class DiskPrefetchWeightsProvider : public WeightsProvider {
         size_t ready_bytes = 0;
         size_t next = 0;                          // index into `order` of the next file to read
         size_t done = 0;                          // files read AND published in `ready` so far (the file `next` points past may still be loading)
+        size_t total = 0;                         // length of the order snapshot the worker runs on (m_order shrinks under remove() DURING a pass)
         bool stop = false;
         std::string error;
     };
@@ -316,11 +317,12 @@ class DiskPrefetchWeightsProvider : public WeightsProvider {
         if (!m_sh) {
             m_order_frozen = true;
             m_sh = std::make_shared<Shared>();
+            m_sh->total = m_order.size();
             m_thread = std::thread(&DiskPrefetchWeightsProvider::worker, this, m_sh, m_path, m_order);
         }
         std::unique_lock<std::mutex> lk(m_sh->mu);
         // (exhausted = everything PUBLISHED and consumed; `next` alone runs ahead of the file the worker is still reading)
-        m_sh->cv.wait(lk, [&] { return !m_sh->ready.empty() || !m_sh->error.empty() || m_sh->done >= m_order.size(); });
+        m_sh->cv.wait(lk, [&] { return !m_sh->ready.empty() || !m_sh->error.empty() || m_sh->done >= m_sh->total; });
         if (!m_sh->error.empty())
             throw std::invalid_argument("DiskPrefetchWeightsProvider::provide: fatal error in worker thread: \"" + m_sh->error + "\".");
         if (m_sh->ready.empty()) throw std::invalid_argument("DiskPrefetchWeightsProvider::provide: vector is empty.");
@@ -483,6 +485,7 @@ class XnnPack;  // kept only so that code naming the type still compiles; the de
 class HipBackend;
 struct Plan;
 struct Lowering;
+struct ConstPool;
 
 // The reference's CudaOptions (:904-911) -- accepted and mapped onto the HIP backend: vram budget => how many bytes of
 // weights may stay resident before the runtime falls back to streaming them every pass.
@@ -555,7 +558,9 @@ public:
                                      // statistics handed over by the producing GEMM): 48 launches less in the SD 1.5 UNet, measured time-neutral => opt-in
     bool m_hip_side_stream = false; // contraction launches whose result is first read >= 3 steps later (a resnet's 1x1 shortcut convolution) run on a second
                                     // stream beside the main chain (parallel branches of the captured hipGraph); measured +0.25 ms per pass => opt-in
-    bool m_hip_autotune = true;    // the first (eager) pass times the legal tile / split-K configurations of every GEMM / convolution shape (osg_set_autotune)
+    bool m_hip_autotune = false;   // true: the first (eager) pass TIMES the legal tile / split-K configurations of every GEMM / convolution shape
+                                   // (osg_set_autotune) -- faster, but the choice (hence the fp32 summation order, hence the last bits) depends on a
+                                   // timer unless OSG_TUNE_CACHE seeds it; default: the deterministic cost-model choice
     bool m_hip_w8_resident = false;     // true: uint8 weights of Conv/MatMul/Gemm stay uint8 in HBM (half the footprint and weight traffic) and are
                                         // dequantised on chip by the osg_*_w8 kernels -- same VALUES as the reference's load-time dequantisation
                                         // (:2887-2891); false (default, currently the faster path: halo conv + merged projections): dequantise once at load
@@ -605,6 +610,7 @@ private:
     HipBackend* m_backend = nullptr;       // takes the seat of `XnnPack* m_xnnpack` (reference :1036)
     bool m_backend_wanted = true;
     Plan* m_plan = nullptr;
+    ConstPool* m_pool = nullptr;           // device-resident weights, kept across plan rebuilds (plan.h)
     size_t m_last_kernels = 0;
     double m_last_ms = 0;
 };

@@ -85,21 +85,34 @@ bool is_const_tensor(const Tensor& t) { return !t.m_name.empty() && t.m_type != 
 }  // namespace
 
 // ======================================================================================================================
-Plan::Plan(Model& model, HipBackend& backend, size_t batch) : m(model), be(backend), N((long)batch) {
+Plan::Plan(Model& model, HipBackend& backend, ConstPool& cpool, size_t batch) : m(model), be(backend), pool(cpool), N((long)batch) {
     fp16 = m.m_use_fp16_arithmetic;
     fusion = m.m_hip_fusion_level;
     stream_weights = m.m_hip_stream_weights;
     w8_resident = m.m_hip_w8_resident && !m.m_hip_stream_weights;
     fuse_gn_conv = m.m_hip_fuse_gn_conv;
     fuse_ln_gemm = m.m_hip_fuse_ln_gemm;
+    u8 = m.m_use_uint8_arithmetic;
+    u8_qdq = m.m_use_uint8_qdq;
+    autotune = m.m_hip_autotune;
+    calibrate = m.m_range_data_calibrate;
+    outputs_convert_set = m.m_outputs_convert_set;
     side_stream = m.m_hip_side_stream && !m.m_hip_stream_weights;
     extra_outputs = m.m_extra_outputs;
 }
 
 bool Plan::compatible(Model& mm, size_t batch) const {
-    return (long)batch == N && mm.m_use_fp16_arithmetic == fp16 && mm.m_hip_fusion_level == fusion && mm.m_hip_stream_weights == stream_weights && mm.m_hip_fuse_gn_conv == fuse_gn_conv && mm.m_hip_fuse_ln_gemm == fuse_ln_gemm && (mm.m_hip_side_stream && !mm.m_hip_stream_weights) == side_stream &&
-           (mm.m_hip_w8_resident && !mm.m_hip_stream_weights) == w8_resident &&
-           mm.m_extra_outputs == extra_outputs;
+    if ((long)batch != N || mm.m_use_fp16_arithmetic != fp16 || mm.m_hip_fusion_level != fusion || mm.m_hip_stream_weights != stream_weights ||
+        mm.m_hip_fuse_gn_conv != fuse_gn_conv || mm.m_hip_fuse_ln_gemm != fuse_ln_gemm || (mm.m_hip_side_stream && !mm.m_hip_stream_weights) != side_stream ||
+        (mm.m_hip_w8_resident && !mm.m_hip_stream_weights) != w8_resident || mm.m_extra_outputs != extra_outputs ||
+        mm.m_use_uint8_arithmetic != u8 || mm.m_use_uint8_qdq != u8_qdq || mm.m_hip_autotune != autotune || mm.m_outputs_convert_set != outputs_convert_set ||
+        mm.m_range_data_calibrate != calibrate)
+        return false;
+    // a pushed input with another shape / type (dynamic-shape models) re-plans, the way the reference simply re-executes (:3550)
+    for (auto& in : inputs)
+        for (auto& t : mm.m_data)
+            if (t.m_name == in.name && (t.m_type != in.host_type || t.m_shape != in.shape)) return false;
+    return true;
 }
 
 int Plan::new_val(const std::string& name, const Shape& shape, osg_dtype dt, Lay lay, bool batched) {
@@ -150,6 +163,29 @@ void* Plan::ptr(int v) const {
     const Val& r = vals[v];
     if (r.dptr) return (char*)r.dptr + off;
     return (char*)arena + r.offset + off;
+}
+
+void* Plan::const_alloc(const std::string& tag, size_t bytes, bool* fresh) {
+    if (stream_weights || tag.empty()) {
+        void* p = be.malloc(bytes);
+        owned.push_back(p);
+        *fresh = true;
+        return p;
+    }
+    auto it = pool.derived.find(tag);
+    if (it != pool.derived.end() && it->second.second == bytes) {
+        *fresh = false;
+        return it->second.first;
+    }
+    if (it != pool.derived.end()) {   // same tag, other size: a different model behind the same names -- replace
+        be.free(it->second.first);
+        pool.bytes -= it->second.second;
+    }
+    void* p = be.malloc(bytes);
+    pool.derived[tag] = {p, bytes};
+    pool.bytes += bytes;
+    *fresh = true;
+    return p;
 }
 
 int Plan::ensure_dense(int v) {
@@ -254,38 +290,104 @@ struct Lowering {
         else return wp->get_int64(fn);
     }
 
+    // what one weight occurrence resolves to: the file actually read, its layout / shape, the dtype it is kept in on the device
+    struct Occ { std::string fn, key; Shape shape; Lay lay; osg_dtype want; long count; };
+    Occ resolve(const Operation& op, size_t i, const Tensor& t, TensorDataType ty) const {
+        Occ o;
+        o.fn = t.m_name;
+        o.shape = to_shape(t.m_shape);
+        o.lay = Lay::plain;
+        auto pos = o.fn.find("_nchw.bin");
+        if (pos != std::string::npos) {
+            // conv weight: model.txt names the OIHW file, the runtime loads the OHWI twin (reference :2666-2692)
+            if (o.shape.size() == 3) o.shape.push_back(1);  // Conv1D lifted to 2-D
+            if (o.shape.size() != 4) throw std::invalid_argument("Model::get_tensor_data: layout is nhwc but invalid shape.");
+            o.fn = o.fn.substr(0, pos) + "_nhwc.bin";
+            o.lay = Lay::nhwc;
+        }
+        const bool f32 = wants_f32(op, i) || !P.fp16;
+        // W8A16: the weight operand of a contraction stays uint8 when the on-chip dequantising kernels take its shape;
+        // W8A8 (m_use_uint8_arithmetic): every uint8 weight stays uint8 -- the integer kernels consume the codes
+        bool keep_u8 = false;
+        if (ty == TensorDataType::uint8 && !f32) {
+            if (P.u8) keep_u8 = true;
+            else if (P.w8_resident && i == 1) {
+                if (op.m_type == "Conv") keep_u8 = o.shape.size() == 4 && o.shape[1] % 64 == 0;                      // [O,I,kh,kw]: Cin % 64
+                else if (op.m_type == "MatMul" || op.m_type == "Gemm") keep_u8 = o.shape.size() == 2 && o.shape[0] % 64 == 0;   // [K,N]
+            }
+        }
+        o.want = keep_u8 ? OSG_U8 : ty == TensorDataType::int64 ? OSG_I64 : (f32 ? OSG_F32 : OSG_F16);
+        o.key = o.fn + (o.want == OSG_F32 ? "|f32" : o.want == OSG_F16 ? "|f16" : o.want == OSG_U8 ? "|u8" : "|i64");
+        o.count = prod(o.shape);
+        return o;
+    }
+
     void load_weights() {
         WeightsProvider* wp = m.get_wp();
+        ConstPool& pool = P.pool;
+        const bool use_pool = !P.stream_weights;
+        // a rebuilt plan (other batch size / input shapes / options) is served from the Model's pool: the provider is not touched
+        // again -- it is exhausted by now and, with m_use_ops_cache, no longer holds the weights.  Only when a different device format
+        // is wanted (fp16 arithmetic / hip_w8_resident toggled) the whole sequence is pulled once more, from a restarted provider.
+        bool fetch_all = true;
+        if (use_pool && pool.complete) {
+            fetch_all = false;
+            size_t occ = 0;
+            for (auto& op : ops())
+                for (size_t i = 0; i < op.m_input.size() && !fetch_all; i++) {
+                    const Tensor& t = op.m_input[i];
+                    if (!is_const_tensor(t)) continue;
+                    if (occ >= pool.occ_types.size() || !pool.base.count(resolve(op, i, t, pool.occ_types[occ]).key)) fetch_all = true;
+                    occ++;
+                }
+            if (fetch_all) {
+                wp->on_restart();
+                pool.occ_types.clear();
+                pool.complete = false;
+            }
+        }
+        size_t occ = 0;
         for (auto& op : ops())
             for (size_t i = 0; i < op.m_input.size(); i++) {
                 Tensor& t = op.m_input[i];
                 if (!is_const_tensor(t)) continue;
-                std::string fn = t.m_name;
-                Shape shape = to_shape(t.m_shape);
-                Lay lay = Lay::plain;
-                auto pos = fn.find("_nchw.bin");
-                if (pos != std::string::npos) {
-                    // conv weight: model.txt names the OIHW file, the runtime loads the OHWI twin (reference :2666-2692)
-                    if (shape.size() == 3) shape.push_back(1);  // Conv1D lifted to 2-D
-                    if (shape.size() != 4) throw std::invalid_argument("Model::get_tensor_data: layout is nhwc but invalid shape.");
-                    fn = fn.substr(0, pos) + "_nhwc.bin";
-                    lay = Lay::nhwc;
-                }
                 TensorDataType ty = t.m_type;
-                TensorDataType nt = wp->get_type_of_next();
-                if (nt != TensorDataType::none) ty = nt;
-                const bool f32 = wants_f32(op, i) || !P.fp16;
-                // W8A16: the weight operand of a contraction stays uint8 when the on-chip dequantising kernels take its shape
-                bool keep_u8 = false;
-                if (P.w8_resident && ty == TensorDataType::uint8 && !f32 && i == 1) {
-                    if (op.m_type == "Conv") keep_u8 = shape.size() == 4 && shape[1] % 64 == 0;                      // [O,I,kh,kw]: Cin % 64
-                    else if (op.m_type == "MatMul" || op.m_type == "Gemm") keep_u8 = shape.size() == 2 && shape[0] % 64 == 0;   // [K,N]
-                }
-                const osg_dtype want = keep_u8 ? OSG_U8 : ty == TensorDataType::int64 ? OSG_I64 : (f32 ? OSG_F32 : OSG_F16);
-                const std::string key = fn + (want == OSG_F32 ? "|f32" : want == OSG_F16 ? "|f16" : want == OSG_U8 ? "|u8" : "|i64");
-                const long count = prod(shape);
+                if (fetch_all) {
+                    TensorDataType nt = wp->get_type_of_next();
+                    if (nt != TensorDataType::none) ty = nt;
+                    if (use_pool) pool.occ_types.push_back(ty);
+                } else
+                    ty = pool.occ_types[occ];
+                occ++;
+                const Occ o = resolve(op, i, t, ty);
+                const std::string& fn = o.fn;
+                const osg_dtype want = o.want;
+                const long count = o.count;
                 int v = -1;
-                auto it = const_cache.find(key);
+                auto it = const_cache.find(o.key);
+                auto new_const = [&](void* dptr) {
+                    v = P.new_val("", o.shape, want, o.lay, false);
+                    Val& val = V(v);
+                    val.is_const = true;
+                    val.name = fn;
+                    val.qscale = t.m_scale;
+                    val.qzp = (int)t.m_zero_point;
+                    val.dptr = dptr;
+                    const_cache[o.key] = v;
+                };
+                if (!fetch_all) {
+                    if (it != const_cache.end()) v = it->second;
+                    else {
+                        const ConstPool::Base& b = pool.base.at(o.key);
+                        new_const(b.dptr);
+                        V(v).host_f = b.host_f;
+                        V(v).host_i = b.host_i;
+                        V(v).host_valid = b.host_valid;
+                        P.weight_bytes += b.bytes;
+                    }
+                    t.m_name = "#" + std::to_string(v);
+                    continue;
+                }
                 detail::dispatch_dtype(ty, [&](auto tag) {
                     using T = typename decltype(tag)::type;
                     tensor_vector<T> data = fetch<T>(wp, fn);  // always fetched: providers serve strictly in order
@@ -299,47 +401,57 @@ struct Lowering {
                         }
                         return;
                     }
-                    v = P.new_val("", shape, want, lay, false);
-                    Val& val = V(v);
-                    val.is_const = true;
-                    val.name = fn;
-                    val.qscale = t.m_scale;
-                    val.qzp = (int)t.m_zero_point;
-                    size_t bytes = (size_t)count * esize(want);
-                    val.dptr = be.malloc(bytes);
-                    P.owned.push_back(val.dptr);
-                    P.weight_bytes += bytes;
+                    const size_t bytes = (size_t)count * esize(want);
+                    // small constants stay readable on the host for the planner (shapes, axes, eps, scales ...)
                     constexpr osg_dtype have = std::is_same_v<T, uint8_t> ? OSG_U8 : std::is_same_v<T, uint16_t> ? OSG_F16
                                                : std::is_same_v<T, float> ? OSG_F32 : OSG_I64;
-                    Plan::WRecipe rec;
-                    rec.val = v; rec.fn = fn; rec.ty = ty; rec.have = have; rec.want = want; rec.count = count;
-                    rec.scale = t.m_scale; rec.zp = (int)t.m_zero_point;
-                    if (have == want) {
-                        be.check(be.api.osg_upload(be.ctx, val.dptr, data.data(), bytes), "osg_upload");
-                    } else {
-                        if (have == OSG_I64 || want == OSG_I64) throw std::invalid_argument("Model::get_tensor_data: unsupported tensor data format.");
-                        void* tmp = be.malloc((size_t)count * sizeof(T));
-                        be.check(be.api.osg_upload(be.ctx, tmp, data.data(), (size_t)count * sizeof(T)), "osg_upload");
-                        be.check(be.api.osg_convert(be.ctx, have, want, tmp, val.dptr, count, t.m_scale, (int)t.m_zero_point), "osg_convert");
-                        be.check(be.api.osg_sync(be.ctx), "osg_sync");
-                        if (P.stream_weights) { rec.raw = tmp; P.owned.push_back(tmp); }
-                        else be.free(tmp);
-                    }
-                    if (P.stream_weights) P.recipes.push_back(rec);
-                    // small constants stay readable on the host for the planner (shapes, axes, eps, scales ...)
+                    std::vector<float> host_f;
+                    std::vector<int64_t> host_i;
+                    bool host_valid = false;
                     if (have == OSG_I64) {
-                        val.host_i.assign((const int64_t*)data.data(), (const int64_t*)data.data() + count);
-                        val.host_valid = true;
+                        host_i.assign((const int64_t*)data.data(), (const int64_t*)data.data() + count);
+                        host_valid = true;
                     } else if (count <= 4096 && want != OSG_U8) {
-                        val.host_f.resize(count);
+                        host_f.resize(count);
                         for (long k = 0; k < count; k++) {
-                            if constexpr (std::is_same_v<T, uint8_t>) val.host_f[k] = (float)((int)data[k] - (int)t.m_zero_point) * t.m_scale;
-                            else if constexpr (std::is_same_v<T, uint16_t>) val.host_f[k] = half_to_float(data[k]);
-                            else if constexpr (std::is_same_v<T, float>) val.host_f[k] = data[k];
+                            if constexpr (std::is_same_v<T, uint8_t>) host_f[k] = (float)((int)data[k] - (int)t.m_zero_point) * t.m_scale;
+                            else if constexpr (std::is_same_v<T, uint16_t>) host_f[k] = half_to_float(data[k]);
+                            else if constexpr (std::is_same_v<T, float>) host_f[k] = data[k];
                         }
-                        val.host_valid = true;
+                        host_valid = true;
                     }
-                    const_cache[key] = v;
+                    auto pit = use_pool ? pool.base.find(o.key) : pool.base.end();
+                    if (pit != pool.base.end()) {   // (a partial reload: this format is resident already)
+                        new_const(pit->second.dptr);
+                    } else {
+                        new_const(be.malloc(bytes));
+                        if (use_pool) {
+                            ConstPool::Base b;
+                            b.dptr = V(v).dptr; b.bytes = bytes; b.host_f = host_f; b.host_i = host_i; b.host_valid = host_valid;
+                            pool.base[o.key] = std::move(b);
+                            pool.bytes += bytes;
+                        } else
+                            P.owned.push_back(V(v).dptr);
+                        Plan::WRecipe rec;
+                        rec.val = v; rec.fn = fn; rec.ty = ty; rec.have = have; rec.want = want; rec.count = count;
+                        rec.scale = t.m_scale; rec.zp = (int)t.m_zero_point;
+                        if (have == want) {
+                            be.check(be.api.osg_upload(be.ctx, V(v).dptr, data.data(), bytes), "osg_upload");
+                        } else {
+                            if (have == OSG_I64 || want == OSG_I64) throw std::invalid_argument("Model::get_tensor_data: unsupported tensor data format.");
+                            void* tmp = be.malloc((size_t)count * sizeof(T));
+                            be.check(be.api.osg_upload(be.ctx, tmp, data.data(), (size_t)count * sizeof(T)), "osg_upload");
+                            be.check(be.api.osg_convert(be.ctx, have, want, tmp, V(v).dptr, count, t.m_scale, (int)t.m_zero_point), "osg_convert");
+                            be.check(be.api.osg_sync(be.ctx), "osg_sync");
+                            if (P.stream_weights) { rec.raw = tmp; P.owned.push_back(tmp); }
+                            else be.free(tmp);
+                        }
+                        if (P.stream_weights) P.recipes.push_back(rec);
+                    }
+                    P.weight_bytes += bytes;
+                    V(v).host_f = std::move(host_f);
+                    V(v).host_i = std::move(host_i);
+                    V(v).host_valid = host_valid;
                 });
                 if (m.m_use_ops_cache && !P.stream_weights && !m.m_weights_exclusion_set.count(fn)) {
                     // resident from now on: drop the provider's host copy, like the reference's ops cache does (:4556-4569)
@@ -349,6 +461,7 @@ struct Lowering {
                 t.m_name = "#" + std::to_string(v);  // from here on the tensor names its resident val
             }
         be.check(be.api.osg_sync(be.ctx), "osg_sync");
+        if (use_pool) pool.complete = true;
     }
 
     int const_val(const Tensor& t) const { return std::stoi(t.m_name.substr(1)); }
@@ -504,6 +617,19 @@ struct Lowering {
             Operation& rm = ops()[i];
             if (rm.m_input.size() != 1 || !act(rm.m_input[0])) continue;
             const Tensor x = rm.m_input[0];
+            // both reductions must run over the LAST axis with keepdims = 1 (anything else is not a LayerNorm over the channels)
+            auto last_axis_keepdims = [&](const Operation& r) {
+                bool ax_ok = false, kd_ok = true;
+                for (auto& a : r.m_attributes) {
+                    if (a.first == "axes") {
+                        auto ax = int_list(a.second);
+                        ax_ok = ax.size() == 1 && !r.m_input.empty() && (ax[0] == -1 || ax[0] == (int)r.m_input[0].m_shape.size() - 1);
+                    } else if (a.first == "keepdims") kd_ok = std::stoi(a.second) == 1;
+                    else return false;
+                }
+                return ax_ok && kd_ok;
+            };
+            if (!last_axis_keepdims(rm)) continue;
             int sub = sole_consumer(rm.m_output[0]);
             if (!is(sub, "Sub") || ops()[sub].m_input[0].m_name != x.m_name || ops()[sub].m_input[1].m_name != rm.m_output[0].m_name) continue;
             const std::string d = ops()[sub].m_output[0].m_name;
@@ -515,7 +641,7 @@ struct Lowering {
             float p = 0;
             if (!const_scalar(ops()[pw].m_input[1], &p) || p != 2.0f) continue;
             int rm2 = sole_consumer(ops()[pw].m_output[0]);
-            if (!is(rm2, "ReduceMean")) continue;
+            if (!is(rm2, "ReduceMean") || !last_axis_keepdims(ops()[rm2])) continue;
             int ae = sole_consumer(ops()[rm2].m_output[0]);
             if (!is(ae, "Add")) continue;
             float eps = 0;
@@ -1093,9 +1219,9 @@ struct Lowering {
         tv.is_const = true;
         tv.name = V(w).name + "|nk";
         size_t bytes = (size_t)K * Nn * 2;
-        tv.dptr = be.malloc(bytes);
-        P.owned.push_back(tv.dptr);
-        be.check(be.api.osg_transpose_kn_to_nk(be.ctx, OSG_F16, P.ptr(w), tv.dptr, (int)K, (int)Nn), "osg_transpose_kn_to_nk");
+        bool fresh;
+        tv.dptr = P.const_alloc(tv.name, bytes, &fresh);
+        if (fresh) be.check(be.api.osg_transpose_kn_to_nk(be.ctx, OSG_F16, P.ptr(w), tv.dptr, (int)K, (int)Nn), "osg_transpose_kn_to_nk");
         V(w).as_nhwc = t;
         return t;
     }
@@ -1106,15 +1232,17 @@ struct Lowering {
         const long K = V(w).shape[0], Nn = V(w).shape[1];
         int t = P.new_val("", {Nn, K}, OSG_U8, Lay::plain, false);
         V(t).is_const = true;
-        V(t).name = V(w).name + "|nk";
+        V(t).name = V(w).name + "|nk_u8";
         V(t).qscale = V(w).qscale;
         V(t).qzp = V(w).qzp;
-        V(t).dptr = be.malloc((size_t)K * Nn);
-        P.owned.push_back(V(t).dptr);
-        long shape[2] = {K, Nn};
-        int perm[2] = {1, 0};
-        be.check(be.api.osg_transpose(be.ctx, 1, P.ptr(w), V(t).dptr, 2, shape, perm), "osg_transpose");
-        be.check(be.api.osg_sync(be.ctx), "osg_sync");
+        bool fresh;
+        V(t).dptr = P.const_alloc(V(t).name, (size_t)K * Nn, &fresh);
+        if (fresh) {
+            long shape[2] = {K, Nn};
+            int perm[2] = {1, 0};
+            be.check(be.api.osg_transpose(be.ctx, 1, P.ptr(w), V(t).dptr, 2, shape, perm), "osg_transpose");
+            be.check(be.api.osg_sync(be.ctx), "osg_sync");
+        }
         V(w).as_nk_u8 = t;
         return t;
     }
@@ -1220,18 +1348,17 @@ struct Lowering {
             // concatenated [ntot, K] weight and [ntot] bias, built once from the resident per-op tensors
             int wcat = P.new_val("", {g.ntot, K}, OSG_F16, Lay::plain, false);
             V(wcat).is_const = true;
-            V(wcat).name = "merged|" + op.m_input[0].m_name;
-            V(wcat).dptr = be.malloc((size_t)g.ntot * K * 2);
-            P.owned.push_back(V(wcat).dptr);
+            V(wcat).name = "merged|" + op.m_input[0].m_name + "|" + ops()[g.members[0]].m_name + "|" + std::to_string(g.members.size()) + (lnf ? "|ln" : "");
+            bool fresh_w, fresh_b = false;
+            V(wcat).dptr = P.const_alloc(V(wcat).name, (size_t)g.ntot * K * 2, &fresh_w);
             const bool has_bias = op.m_input.size() > 2 && !op.m_input[2].m_name.empty();
             int bcat = -1;
             if (has_bias) {
                 bcat = P.new_val("", {g.ntot}, OSG_F16, Lay::plain, false);
                 V(bcat).is_const = true;
-                V(bcat).dptr = be.malloc((size_t)g.ntot * 2);
-                P.owned.push_back(V(bcat).dptr);
+                V(bcat).dptr = P.const_alloc(V(wcat).name + "|bias", (size_t)g.ntot * 2, &fresh_b);
             }
-            for (size_t s2 = 0; s2 < g.members.size(); s2++) {
+            for (size_t s2 = 0; (fresh_w || fresh_b) && s2 < g.members.size(); s2++) {
                 const Operation& mo = ops()[g.members[s2]];
                 int wnk = weight_nk(in_val(mo.m_input[1]));
                 const long Ni = V(wnk).shape[0];
@@ -1248,7 +1375,7 @@ struct Lowering {
             g.y = P.new_val("", ys, OSG_F16, Lay::plain, V(a).batched);
             const long M = prod(as) / K * B(a);
             if (lnf) {
-                auto [c1, c2] = ln_fold_weight(*lnf, wcat, bcat, P.ptr(wcat));   // the concatenated copy is private: fold in place
+                auto [c1, c2] = ln_fold_weight(*lnf, wcat, bcat, P.ptr(wcat), V(wcat).name);   // the concatenated copy is private: fold in place
                 emit_gemm_ln("Linear ln+ merged(" + std::to_string(g.members.size()) + ") " + op.m_name, *lnf, wcat, c1, c2, -1, g.y, M, g.ntot, K, OSG_ACT_NONE);
             } else
             emit_gemm("Linear merged(" + std::to_string(g.members.size()) + ") " + op.m_name, a, wcat, bcat, -1, g.y, M, g.ntot, K, 1, 0, 0, 0, 1);
@@ -1266,23 +1393,26 @@ struct Lowering {
     // MatMul with a static 2-D weight, optional fused bias / residual
     // [N,K] weight (and bias) re-ordered so that rows 32k..32k+15 are value columns 16k.. and rows 32k+16..32k+31 the matching gate
     // columns (N = 2C): what the GEGLU GEMM epilogue expects
-    std::pair<int, int> geglu_interleave(int wnk, int bias) {
+    std::pair<int, int> geglu_interleave(int wnk, int bias, const std::string& suffix) {
         const long Nn = V(wnk).shape[0], K = V(wnk).shape[1], C = Nn / 2;
         int wi = P.new_val("", {Nn, K}, OSG_F16, Lay::plain, false);
         V(wi).is_const = true;
-        V(wi).name = V(wnk).name + "|geglu";
-        V(wi).dptr = be.malloc((size_t)Nn * K * 2);
-        P.owned.push_back(V(wi).dptr);
-        be.check(be.api.osg_copy_2d(be.ctx, 2, P.ptr(wnk), 16 * K, 0, V(wi).dptr, 32 * K, 0, C / 16, 16 * K), "osg_copy_2d");
-        be.check(be.api.osg_copy_2d(be.ctx, 2, P.ptr(wnk), 16 * K, C * K, V(wi).dptr, 32 * K, 16 * K, C / 16, 16 * K), "osg_copy_2d");
+        V(wi).name = V(wnk).name + "|geglu" + suffix;
+        bool fresh;
+        V(wi).dptr = P.const_alloc(V(wi).name, (size_t)Nn * K * 2, &fresh);
+        if (fresh) {
+            be.check(be.api.osg_copy_2d(be.ctx, 2, P.ptr(wnk), 16 * K, 0, V(wi).dptr, 32 * K, 0, C / 16, 16 * K), "osg_copy_2d");
+            be.check(be.api.osg_copy_2d(be.ctx, 2, P.ptr(wnk), 16 * K, C * K, V(wi).dptr, 32 * K, 16 * K, C / 16, 16 * K), "osg_copy_2d");
+        }
         int bi = -1;
         if (bias >= 0) {
             bi = P.new_val("", {Nn}, OSG_F16, Lay::plain, false);
             V(bi).is_const = true;
-            V(bi).dptr = be.malloc((size_t)Nn * 2);
-            P.owned.push_back(V(bi).dptr);
-            be.check(be.api.osg_copy_2d(be.ctx, 2, P.ptr(bias), 16, 0, V(bi).dptr, 32, 0, C / 16, 16), "osg_copy_2d");
-            be.check(be.api.osg_copy_2d(be.ctx, 2, P.ptr(bias), 16, C, V(bi).dptr, 32, 16, C / 16, 16), "osg_copy_2d");
+            V(bi).dptr = P.const_alloc(V(wi).name + "|bias", (size_t)Nn * 2, &fresh);
+            if (fresh) {
+                be.check(be.api.osg_copy_2d(be.ctx, 2, P.ptr(bias), 16, 0, V(bi).dptr, 32, 0, C / 16, 16), "osg_copy_2d");
+                be.check(be.api.osg_copy_2d(be.ctx, 2, P.ptr(bias), 16, C, V(bi).dptr, 32, 16, C / 16, 16), "osg_copy_2d");
+            }
         }
         be.check(be.api.osg_sync(be.ctx), "osg_sync");
         return {wi, bi};
@@ -1298,13 +1428,13 @@ struct Lowering {
             const long K = V(w).shape[0], Nn = V(w).shape[1];
             need(op, !as.empty() && as.back() == K, "invalid shape of inputs.");
             int bias = op.m_input.size() > 2 && !op.m_input[2].m_name.empty() ? in_val(op.m_input[2]) : -1;
-            auto [wi, bi] = geglu_interleave(weight_nk(w), bias);
+            auto [wi, bi] = geglu_interleave(weight_nk(w), bias, lnf ? "|ln" : "");
             Shape os = as;
             os.back() = Nn / 2;
             int y = out_val(op, os, Lay::plain, V(a).batched);
             const long M = prod(as) / K * B(a);
             if (lnf) {
-                auto [c1, c2] = ln_fold_weight(*lnf, wi, bi, P.ptr(wi));   // the interleaved copy is private: fold in place
+                auto [c1, c2] = ln_fold_weight(*lnf, wi, bi, P.ptr(wi), V(wi).name);   // the interleaved copy is private: fold in place
                 emit_gemm_ln("Linear+GEGLU ln+ " + op.m_name, *lnf, wi, c1, c2, -1, y, M, Nn, K, OSG_ACT_GEGLU);
                 return;
             }
@@ -1334,7 +1464,7 @@ struct Lowering {
         if (lnf) {
             const int wnk = weight_nk(w);
             const int wf = private_copy(wnk, "|ln");
-            auto [c1, c2] = ln_fold_weight(*lnf, wnk, bias, P.ptr(wf));
+            auto [c1, c2] = ln_fold_weight(*lnf, wnk, bias, P.ptr(wf), V(wf).name);
             emit_gemm_ln("Linear ln+ " + op.m_name, *lnf, wf, c1, c2, res, y, M, Nn, K, OSG_ACT_NONE);
             return;
         }
@@ -1547,8 +1677,14 @@ struct Lowering {
 
     // W[N,K] (device, f16) -> W' = f16(gamma[k] * W[n][k]) in place; returns the fp32 device vectors (c1, c2):
     // c1[n] = sum_k W'[n][k], c2[n] = sum_k beta[k] * W[n][k] + bias[n]
-    std::pair<int, int> ln_fold_weight(const LnFold& f, int wnk, int bias, void* w_dst) {
+    std::pair<int, int> ln_fold_weight(const LnFold& f, int wnk, int bias, void* w_dst, const std::string& tag) {
         const long Nn = V(wnk).shape[0], K = V(wnk).shape[1];
+        bool fresh1, fresh2;
+        int v1 = P.new_val("", {Nn}, OSG_F32, Lay::plain, false), v2 = P.new_val("", {Nn}, OSG_F32, Lay::plain, false);
+        V(v1).is_const = V(v2).is_const = true;
+        V(v1).dptr = P.const_alloc(tag + "|c1", (size_t)Nn * 4, &fresh1);
+        V(v2).dptr = P.const_alloc(tag + "|c2", (size_t)Nn * 4, &fresh2);
+        if (!fresh1 && !fresh2) return {v1, v2};   // folded by an earlier plan of this Model (w_dst is the same pooled buffer)
         std::vector<uint16_t> w((size_t)Nn * K);
         be.check(be.api.osg_sync(be.ctx), "osg_sync");
         be.check(be.api.osg_download(be.ctx, w.data(), P.ptr(wnk), w.size() * 2), "osg_download");
@@ -1574,12 +1710,6 @@ struct Lowering {
             c2[n] = (float)(s2 + (bias >= 0 ? (double)half_to_float(bh[n]) : 0.0));
         }
         be.check(be.api.osg_upload_sync(be.ctx, w_dst, w.data(), w.size() * 2), "osg_upload_sync");
-        int v1 = P.new_val("", {Nn}, OSG_F32, Lay::plain, false), v2 = P.new_val("", {Nn}, OSG_F32, Lay::plain, false);
-        for (int v : {v1, v2}) {
-            V(v).is_const = true;
-            V(v).dptr = be.malloc((size_t)Nn * 4);
-            P.owned.push_back(V(v).dptr);
-        }
         be.check(be.api.osg_upload_sync(be.ctx, V(v1).dptr, c1.data(), c1.size() * 4), "osg_upload_sync");
         be.check(be.api.osg_upload_sync(be.ctx, V(v2).dptr, c2.data(), c2.size() * 4), "osg_upload_sync");
         return {v1, v2};
@@ -1591,8 +1721,8 @@ struct Lowering {
         int t = P.new_val("", {Nn, K}, OSG_F16, Lay::plain, false);
         V(t).is_const = true;
         V(t).name = V(wnk).name + tag;
-        V(t).dptr = be.malloc((size_t)Nn * K * 2);
-        P.owned.push_back(V(t).dptr);
+        bool fresh;
+        V(t).dptr = P.const_alloc(V(t).name, (size_t)Nn * K * 2, &fresh);
         return t;
     }
 
@@ -1687,10 +1817,10 @@ struct Lowering {
             if (scale != 1.0f) {
                 int sc = P.new_val("", {1}, OSG_F16, Lay::plain, false);
                 V(sc).is_const = true;
-                V(sc).dptr = be.malloc(256);
-                P.owned.push_back(V(sc).dptr);
+                bool fresh;
+                V(sc).dptr = P.const_alloc("scale|" + op.m_name, 256, &fresh);
                 const uint16_t hbits = float_to_half(scale);
-                be.check(be.api.osg_upload_sync(be.ctx, V(sc).dptr, &hbits, 2), "osg_upload_sync");
+                if (fresh) be.check(be.api.osg_upload_sync(be.ctx, V(sc).dptr, &hbits, 2), "osg_upload_sync");
                 const long tot = heads * Tq * Tk;
                 P.add_step("Mul " + op.m_name + "/scale", {sv, sc}, {sv}, [=, this] {
                     long as[1] = {tot}, bs[1] = {1};

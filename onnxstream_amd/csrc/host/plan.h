@@ -12,6 +12,7 @@
 
 #include <functional>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -58,8 +59,34 @@ struct Step {
 
 struct Lowering;
 
+// Device-resident constants that outlive a Plan (owned by the Model, next to the backend): a plan is rebuilt when the number of pushed
+// samples, the input shapes or a hip_* option change, and a rebuild must not go back to the WeightsProvider -- by then a strictly
+// sequential provider is exhausted and, with m_use_ops_cache, the host copies were remove()d (reference: the ops cache keeps the packed
+// weights across runs, src/onnxstream.cpp:4556-4569).  `base` = weights as pulled through the provider ("file|dtype"), `derived` = the
+// re-laid-out / merged / folded copies the lowering makes of them, by tag.  Not used in streamed-weights mode.
+struct ConstPool {
+    struct Base {
+        void* dptr = nullptr;
+        size_t bytes = 0;
+        std::vector<float> host_f;
+        std::vector<int64_t> host_i;
+        bool host_valid = false;
+    };
+    std::map<std::string, Base> base;
+    std::map<std::string, std::pair<void*, size_t>> derived;
+    std::vector<TensorDataType> occ_types;   // resolved storage type of every weight occurrence, model order
+    bool complete = false;                   // every occurrence of the graph went through the provider once
+    size_t bytes = 0;
+    void clear(HipBackend& be) {
+        for (auto& kv : base) be.free(kv.second.dptr);
+        for (auto& kv : derived) be.free(kv.second.first);
+        base.clear(); derived.clear(); occ_types.clear();
+        complete = false; bytes = 0;
+    }
+};
+
 struct Plan {
-    Plan(Model& m, HipBackend& be, size_t batch);
+    Plan(Model& m, HipBackend& be, ConstPool& pool, size_t batch);
     ~Plan();
     void build();
     void execute();
@@ -87,6 +114,7 @@ struct Plan {
 
     Model& m;
     HipBackend& be;
+    ConstPool& pool;
     long N;  // batch (number of samples pushed under each input name)
 
     std::vector<Operation> ops;  // working copy of the graph (mutated by the fusion passes)
@@ -128,6 +156,9 @@ struct Plan {
     double m_last_ms = 0;
     // options the plan was built with
     bool fp16 = true;
+    bool u8_qdq = false, autotune = false, calibrate = false;
+    std::set<std::string> outputs_convert_set;
+    bool u8 = false;               // m_use_uint8_arithmetic: uint8 activations (the reference's W8A8 path, VAE decoder)
     bool stream_weights = false;
     bool fuse_gn_conv = false;
     bool fuse_ln_gemm = false;
@@ -147,6 +178,9 @@ struct Plan {
     void add_step(const std::string& what, std::vector<int> reads, std::vector<int> writes, std::function<void()> fn);
     int ensure_plain(int v);
     int ensure_nhwc(int v);
+    // a device constant that survives this plan (ConstPool::derived) -- *fresh tells the caller to fill it; plan-owned (always fresh) in
+    // streamed-weights mode or with an empty tag
+    void* const_alloc(const std::string& tag, size_t bytes, bool* fresh);
     int ensure_dense(int v);   // materialise a strided column view as a dense tensor (for consumers that cannot take a leading dimension)
 };
 

@@ -770,7 +770,7 @@ static V2Choice choose_v2(const osg_ctx* ctx, int M, int N, int K, int batch) {
 
 static osg_tune::Key tune_key(const osg_ctx* ctx, int kind, const GemmParams& p, int batch) {
     osg_tune::Key k{};
-    k.kind = kind; k.device = ctx->device; k.M = p.M; k.N = p.N; k.K = p.K; k.batch = batch;
+    k.kind = kind; k.device = 0;   /* (one table for every MI355X of a node: ranks seeded from one file make identical choices) */ k.M = p.M; k.N = p.N; k.K = p.K; k.batch = batch;
     if (kind != 0) { k.H = p.H; k.W = p.W; k.Cin = p.Cin; k.KW = p.KW; k.sh = p.sh; k.sw = p.sw; }
     else k.H = p.lda;
     k.flags = (int)p.act | (p.residual ? 16 : 0) | (p.rowbias ? 32 : 0) | (p.bias_f32 ? 64 : 0) | (p.ln_c1 ? 128 : 0) | (p.rs_in ? 256 : 0) | (p.rs_out ? 512 : 0);

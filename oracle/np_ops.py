@@ -6,7 +6,7 @@ product (``onnxstream_amd``) never does and has no CPU fallback.
 Each function restates what the reference computes for ONE graph op when ``m_use_fp16_arithmetic`` is on: f16 storage,
 f32 (or double) math inside the op, one round-to-nearest-even to f16 on the op's output.  Citations are
 ``/root/reference/src/onnxstream.cpp`` line numbers.  The restatement is pinned against the real reference (built
-unmodified into ``oracle/_ref``) by ``tests/test_oracle_cpu.py`` and the committed fixtures in ``tests/golden``.
+unmodified into ``oracle/_ref``) by ``tests/test_golden.py (test_restatement_*)`` and the committed fixtures in ``tests/golden``.
 """
 from __future__ import annotations
 

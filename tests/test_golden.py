@@ -6,10 +6,12 @@ CPU (-m "not gpu"):  * the fixtures exist for every case;
                      * the numpy restatement (oracle/np_ops.py) agrees with them -> the restatement is pinned.
 GPU (-m gpu):        * the HIP backend, driven through the model_* C API, against the same fixtures.
 
-Tolerance (north_star: <= 1e-3 relative for fp16 activations): err = max|got - ref16| / max|ref32|.  A case passes when
-err <= 1e-3, or -- for multi-op graphs, where the reference itself rounds to fp16 after EVERY op while the fused HIP kernels
-round once per fused group -- when the result is as close to the fp32 reference as the reference's own fp16 path is:
-max|got - ref32| <= 1.5 * max|ref16 - ref32| + 1e-3 * max|ref32|  (SURVEY.md section 8(c) triangulation).
+Tolerance (north_star: <= 1e-3 relative for fp16 activations): err16 = max|got - ref16| / max|ref32|.
+  * the 16 single-pattern cases: err16 <= 1e-3 outright, at every fusion level (three named 2-ulp exceptions at 1.1e-3, see TWO_ULP);
+  * the 4 whole miniature networks, where the reference itself moves by 3e-3 between hosts: err16 <= 1e-3 against either host's
+    reference, or as close to the fp32 reference as the reference's own fp16 path:  max|got - ref32| <= 1.5 * max|ref16 - ref32| +
+    1e-3 * max|ref32|  (SURVEY.md section 8(c) triangulation; the smaller of the two hosts' drifts).
+Every parity run uses hip_autotune = 0 (deterministic plan); the measured plan choice is covered through a fixed tune table.
 """
 import os
 import tempfile
@@ -104,17 +106,20 @@ def test_restatement_group_norm_and_layer_norm():
 
 
 # ---- the product path -------------------------------------------------------------------------------------------------
-@pytest.mark.gpu
-@pytest.mark.parametrize("fusion", [2, 0, "2+lnfold"])
-@pytest.mark.parametrize("name", gc.all_case_names())
-def test_hip_backend_vs_golden(name, fusion):
-    """fusion 2 = the default plan, 0 = one kernel per graph op (the reference's rounding points), "2+lnfold" = fusion 2 with every
-    LayerNorm folded into its consuming GEMM (hip_fuse_ln_gemm: osg_gemm_ln + osg_gemm_rowstats, opt-in)."""
+SINGLE = [c.__name__ for c in gc.CASES]          # one hot-path pattern each
+NETS = list(gc.UNETS)                            # whole miniature networks
+# Single-pattern cases must sit ON the fp16 reference: err16 <= 1e-3, no second leg.  Measured on MI355X with the deterministic plan
+# (hip_autotune = 0; profiles/r02_golden_table.txt): every case at fusion 0 (the reference's rounding points) is <= 8.4e-4.  The three
+# entries below are the ones that cannot at fusion >= 1, with their measured err16: the output's top binade has an f16 ulp of
+# 4.9e-4 ... 9.8e-4 of max, the reference rounds to f16 after each of the 5 (GroupNorm+SiLU), 9 (LayerNorm) or 3 (S, S*s, P of the sliced
+# attention, src/onnxstream.cpp:6837-6929) ops where the fused kernel rounds once, and the two results land 2 ulp apart on one element.
+# For them the bound is 1.1e-3 AND the result must be closer to the fp32 reference than the reference's own fp16 path is.
+TWO_ULP = {"group_norm_silu": 1.03e-3, "layer_norm": 1.04e-3, "self_attention": 1.00e-3}
+
+
+def _run_hip(name, ins, oname, fusion, lnfold=False, options=()):
     from onnxstream_amd import build as b
-    lnfold = fusion == "2+lnfold"
-    fusion = 2 if lnfold else fusion
     from onnxstream_amd.bindings import Model
-    ins, oname, r16, r32 = load(name)
     with tempfile.TemporaryDirectory() as d:
         d += "/"
         gc.emit(gc.by_name(name), DirSink(d))
@@ -125,21 +130,86 @@ def test_hip_backend_vs_golden(name, fusion):
         m.set_use_fp16_arithmetic(True)
         m.set_fuse_ops_in_attention(True)
         m._set_option("hip_fusion_level", fusion)
+        m._set_option("hip_autotune", 0)          # deterministic: tile / split-K from the cost model, never from a timer
         if lnfold:
             m._set_option("hip_fuse_ln_gemm", 1)
+        for k, v in options:
+            m._set_option(k, v)
         m.run()
         got, shape = m.get_tensor(oname)
         m.close()
+    return got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fusion", [0, 1, 2, "2+lnfold"])
+@pytest.mark.parametrize("name", SINGLE)
+def test_hip_backend_vs_golden_single_pattern(name, fusion):
+    """fusion 0 = one kernel per graph op (the reference's rounding points), 1 = + elementwise / norm fusions, 2 = the default plan,
+    "2+lnfold" = fusion 2 with every LayerNorm folded into its consuming GEMM (opt-in).  Strict: err16 <= 1e-3 (see TWO_ULP)."""
+    lnfold = fusion == "2+lnfold"
+    fusion = 2 if lnfold else fusion
+    ins, oname, r16, r32 = load(name)
+    got = _run_hip(name, ins, oname, fusion, lnfold)
     assert list(got.shape) == list(r16.shape)
     mx = float(np.abs(r32).max())
     err16 = float(np.abs(got - r16).max()) / mx
     err32 = float(np.abs(got - r32).max()) / mx
     noise = float(np.abs(r16 - r32).max()) / mx
-    # triangulated bound: either on top of the fp16 reference, or as close to the fp32 reference as fp16 arithmetic gets.  The second leg is
-    # 2 x the reference's own fp16-vs-fp32 drift: on the random-weight miniature UNets the device result moves by +-1e-3 of max with the
-    # (measured, run-dependent) tile / split-K choice alone -- err32 4.6e-3 ... 6.2e-3 across plans, 5.1e-3 at fusion 0, i.e. at the
-    # reference's own rounding points (tools/golden_err.py) -- against a drift of 3.4e-3
-    assert err16 <= 1e-3 or err32 <= 2.0 * noise + 1e-3, (name, fusion, err16, err32, noise)
+    if fusion >= 1 and name in TWO_ULP:
+        assert err16 <= 1.1e-3 and err32 < noise, (name, fusion, err16, err32, noise)
+    else:
+        assert err16 <= 1e-3, (name, fusion, err16, err32, noise)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fusion", [0, 1, 2, "2+lnfold"])
+@pytest.mark.parametrize("name", NETS)
+def test_hip_backend_vs_golden_whole_nets(name, fusion):
+    """Whole miniature networks (hundreds of ops): the reference itself is not reproducible to 1e-3 across hosts -- XNNPACK selects its
+    micro-kernels per CPU, and the SAME oracle build gives, for unet_tiny, |ref16(Xeon, fixture) - ref16(GPU box host)| = 3.3e-3 of max and
+    an fp16-vs-fp32 drift of 3.4e-3 on one host, 6.2e-3 on the other (tests/golden/ref16_host2.npz = the second host's outputs, written
+    by tools/golden_table.py; every single-pattern case agrees between the hosts to <= 4.9e-4).  So a whole net passes when it is on
+    either host's fp16 reference (<= 1e-3) or as close to the fp32 reference as the reference's own fp16 path gets:
+    err32 <= 1.5 x (the SMALLER of the two hosts' drifts) + 1e-3.  Deterministic plans (hip_autotune = 0): the same numbers every run."""
+    lnfold = fusion == "2+lnfold"
+    fusion = 2 if lnfold else fusion
+    ins, oname, r16, r32 = load(name)
+    r16b = np.load(os.path.join(GOLD, "ref16_host2.npz"))[name]
+    got = _run_hip(name, ins, oname, fusion, lnfold)
+    assert list(got.shape) == list(r16.shape)
+    mx = float(np.abs(r32).max())
+    err16 = min(float(np.abs(got - r16).max()), float(np.abs(got - r16b).max())) / mx
+    err32 = float(np.abs(got - r32).max()) / mx
+    noise = min(float(np.abs(r16 - r32).max()), float(np.abs(r16b - r32).max())) / mx
+    assert err16 <= 1e-3 or err32 <= 1.5 * noise + 1e-3, (name, fusion, err16, err32, noise)
+
+
+@pytest.mark.gpu
+def test_measured_plan_choice_is_reproducible_from_a_tune_table(tmp_path, monkeypatch):
+    """hip_autotune picks tile / split-K by timing, so two tuning runs may differ in the last bits; a tune table (OSG_TUNE_CACHE) pins the
+    choice: a process seeded from the table issues no timing launches and reproduces the tuning run's output bit for bit -- and that
+    output meets the same bound as the deterministic plan."""
+    import subprocess
+    import sys
+    table = str(tmp_path / "tune.txt")
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_golden as t; "
+            "ins, oname, r16, r32 = t.load('unet_tiny'); got = t._run_hip('unet_tiny', ins, oname, 2, options=(('hip_autotune', 1),)); np.save(sys.argv[1], got)"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for i in range(2):
+        out = str(tmp_path / f"o{i}.npy")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, OSG_TUNE_CACHE=table))
+        outs.append(np.load(out))
+        if i == 0:
+            rows = open(table).read().strip().splitlines()
+            assert len(rows) > 10
+        else:
+            assert open(table).read().strip().splitlines() == rows       # the seeded process measured nothing new
+    assert np.array_equal(outs[0], outs[1])
+    ins, oname, r16, r32 = load("unet_tiny")
+    mx = float(np.abs(r32).max())
+    assert float(np.abs(outs[0] - r32).max()) / mx <= 1.5 * float(np.abs(r16 - r32).max()) / mx + 1e-3
 
 
 @pytest.mark.gpu
@@ -229,7 +299,7 @@ def test_w8_resident_equals_load_time_dequant():
     mx = float(np.abs(r32).max())
     noise = float(np.abs(r16 - r32).max()) / mx
     for mode in (1, 0):
-        assert float(np.abs(outs[mode] - r32).max()) / mx <= 2.0 * noise + 1e-3      # same leg as test_hip_backend_vs_golden
+        assert float(np.abs(outs[mode] - r32).max()) / mx <= 1.5 * noise + 1e-3      # same leg as test_hip_backend_vs_golden_whole_nets
     assert float(np.abs(outs[1] - outs[0]).max()) / mx <= 5e-3
 
 

@@ -236,6 +236,40 @@ def test_streamed_weights_mode_respects_the_provider_contract(stub_backend, wp):
     assert streamed[0] == 0 and streamed[1] == streamed[2] > 0      # pass 1 makes the plan (resident upload), later passes re-stream everything
 
 
+@pytest.mark.parametrize("ops_cache", [0, 1])
+@pytest.mark.parametrize("wp", ["ram+nocache", "nocache", "prefetch", "ram+prefetch"])
+def test_plan_rebuild_never_goes_back_to_the_provider(stub_backend, wp, ops_cache):
+    """A plan is rebuilt when the number of pushed samples or a hip_* option changes (the reference allows the batch size to change
+    between runs).  By then a strictly sequential provider is exhausted and, with m_use_ops_cache, the host copies were remove()d: the
+    rebuild is served from the Model's pool of resident constants.  Also the round-1 advisor case: DiskPrefetch + use_ops_cache, where
+    remove() shrinks the order DURING the first pass while the worker runs on its own snapshot."""
+    from onnxstream_amd import build as b
+    from onnxstream_amd.bindings import Model
+    ins = sd_unet.unet_inputs(sd_unet.TINY, 42)
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        sd_unet.build_unet(DirSink(d), sd_unet.TINY)
+        m = Model(b.LIB_HOST, 0, wp)
+        m.read_file(d + "model.txt")
+        m.set_use_ops_cache(bool(ops_cache))
+        counts = []
+        for pushes, opts in ((1, ()), (2, ()), (2, (("hip_fuse_ln_gemm", 1),)), (1, (("hip_fusion_level", 0),)), (3, (("hip_fusion_level", 2), ("hip_fuse_ln_gemm", 0)))):
+            for k, v in opts:
+                m._set_option(k, v)
+            for _ in range(pushes):
+                for k, v in ins.items():
+                    m.add_tensor(k, v)
+            m.set_use_fp16_arithmetic(True)
+            m.set_fuse_ops_in_attention(True)
+            m.run()
+            counts.append(m.hip_last_kernel_count())
+            out = m.get_tensor("out_sample", pushes - 1)
+            assert out is not None
+            m.clear_tensors()
+        m.close()
+    assert counts[0] == counts[1] == counts[4] and counts[2] < counts[1] < counts[3]
+
+
 def test_device_sampler_loop_plumbing(stub_backend):
     """model_hip_sampler_loop / model_hip_set_input: argument checking and the 2-samples-per-prompt contract (no numbers: the stub computes nothing)."""
     from onnxstream_amd import build as b
