@@ -517,6 +517,7 @@ struct Lowering {
             index_graph(); fuse_attention(true);
             index_graph(); fuse_linear();
             index_graph(); fuse_residual();
+            index_graph(); fuse_conv_act();
             index_graph(); fuse_linear_geglu();
             index_graph(); cse_silu();
             index_graph(); fuse_image_bias();
@@ -857,7 +858,7 @@ struct Lowering {
             int ci = sole_consumer(gn.m_output[0]);
             if (!is(ci, "Conv")) continue;
             Operation& cv = ops()[ci];
-            if (cv.m_input.empty() || cv.m_input[0].m_name != gn.m_output[0].m_name) continue;
+            if (cv.m_input.empty() || cv.m_input[0].m_name != gn.m_output[0].m_name || attr(cv, "osg_act")) continue;
             bool other_use = false;   // the normalised tensor must not also be the residual / image bias of the same conv
             for (size_t k = 1; k < cv.m_input.size(); k++) other_use |= cv.m_input[k].m_name == gn.m_output[0].m_name;
             if (other_use) continue;
@@ -1009,6 +1010,23 @@ struct Lowering {
         }
     }
 
+    // Conv(..) -> osg.SiLU  ==> the activation rides in the convolution's epilogue (the Conv -> Sigmoid -> Mul triple of every block of
+    // the exported YOLOv8 graphs; in the SD UNet SiLU follows the GroupNorms instead)
+    void fuse_conv_act() {
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (!is((int)i, "Conv")) continue;
+            Operation& op = ops()[i];
+            if (op.m_output.size() != 1 || attr(op, "osg_act")) continue;
+            int sl = sole_consumer(op.m_output[0]);
+            if (!is(sl, "osg.SiLU") || ops()[sl].m_input.size() != 1) continue;
+            Operation f = op;
+            f.m_attributes.emplace_back("osg_act", "silu");
+            f.m_output = {ops()[sl].m_output[0]};
+            dead[i] = 1;
+            ops()[sl] = std::move(f);
+        }
+    }
+
     // ------------------------------------------------------------------------------------------------------------------
     // lowering
     // ------------------------------------------------------------------------------------------------------------------
@@ -1016,8 +1034,219 @@ struct Lowering {
         if (is_const_tensor(t)) return const_val(t);
         auto it = P.by_name.find(t.m_name);
         if (it == P.by_name.end()) throw std::invalid_argument("Model::get_tensor_data: input tensor not found: " + t.m_name);
+        const int r = P.root_of(it->second);
+        if (V(r).host_only && !V(r).dptr) {   // a plan-time value that a launch wants to read after all: give it device storage now
+            const size_t bytes = std::max<size_t>(P.val_bytes(r), 8);
+            V(r).dptr = be.malloc(bytes);
+            P.owned.push_back(V(r).dptr);
+            if (V(r).dtype == OSG_I64) be.check(be.api.osg_upload_sync(be.ctx, V(r).dptr, V(r).host_i.data(), V(r).host_i.size() * 8), "osg_upload_sync");
+            else if (V(r).dtype == OSG_F32) be.check(be.api.osg_upload_sync(be.ctx, V(r).dptr, V(r).host_f.data(), V(r).host_f.size() * 4), "osg_upload_sync");
+            else throw std::invalid_argument("Model::get_tensor_data: unsupported tensor data format.");
+        }
         return it->second;
     }
+    // a constant, or an activation whose VALUE is known at plan time (the Shape -> Gather -> Concat -> Reshape chains exporters leave behind)
+    const Val* hval(const Tensor& t) const {
+        if (is_const_tensor(t)) return &P.vals[const_val(t)];
+        auto it = P.by_name.find(t.m_name);
+        if (it == P.by_name.end()) return nullptr;
+        const Val& v = P.vals[it->second];
+        return v.host_valid && v.host_only ? &v : nullptr;
+    }
+    int host_val(const Operation& op, const Shape& shape, std::vector<int64_t> ints, std::vector<float> floats = {}) {
+        const bool is_int = floats.empty();
+        check_out(op, shape);
+        int v = P.new_val(op.m_output[0].m_name, shape, is_int ? OSG_I64 : OSG_F32, Lay::plain, false);
+        V(v).is_const = true;
+        V(v).host_valid = V(v).host_only = true;
+        V(v).host_i = std::move(ints);
+        V(v).host_f = std::move(floats);
+        return v;
+    }
+
+    // Ops evaluated on the host while the plan is built: Shape (reference :7003) always, and Gather (:6316) / Cast (:7352) / Concat (:4140) /
+    // Unsqueeze / Squeeze / Reshape / Slice / Add / Sub / Mul / Div whose operands are all int64 values known at plan time.  Tensor shapes
+    // are static per plan (a pushed input with another shape re-plans), so these chains fold to constants.  Returns false when the op
+    // has to run on the device.
+    bool try_host_eval(const Operation& op) {
+        const std::string& t = op.m_type;
+        if (t == "Shape") {
+            need(op, op.m_input.size() == 1, "wrong number of inputs.");
+            need(op, op.m_output.size() == 1, "wrong number of outputs.");
+            need(op, op.m_attributes.empty(), "unrecognized attribute (not implemented).");
+            const int x = in_val_raw(op.m_input[0]);
+            const Shape xs = V(x).shape;
+            need(op, !xs.empty(), "shape of input not available.");
+            host_val(op, {(long)xs.size()}, std::vector<int64_t>(xs.begin(), xs.end()));
+            return true;
+        }
+        if (t != "Gather" && t != "Cast" && t != "Concat" && t != "Unsqueeze" && t != "Squeeze" && t != "Reshape" && t != "Slice" && t != "Add" && t != "Sub" &&
+            t != "Mul" && t != "Div")
+            return false;
+        if (op.m_input.empty() || op.m_output.size() != 1) return false;
+        std::vector<const Val*> in;
+        for (auto& ti : op.m_input) {
+            if (ti.m_name.empty()) { in.push_back(nullptr); continue; }
+            const Val* v = hval(ti);
+            if (!v || !v->host_valid) return false;
+            in.push_back(v);
+        }
+        // the data operand must be a plan-time VALUE (not merely a small weight): weights stay on the device path
+        if (!in[0] || !in[0]->host_only) {
+            if (!(t == "Add" || t == "Sub" || t == "Mul" || t == "Div") || !in[1] || !in[1]->host_only) return false;
+        }
+        auto ints = [](const Val* v) { return v->dtype == OSG_I64; };
+        if (t == "Cast") {
+            int to = -1;
+            for (auto& a : op.m_attributes) {
+                if (a.first == "to") to = std::stoi(a.second);
+                else throw std::invalid_argument(op.m_type + ": unrecognized attribute (not implemented).");
+            }
+            need(op, to != -1, "'to' attribute not found.");
+            if (to == 1) {
+                need(op, ints(in[0]), "wrong data type of input (not implemented).");
+                std::vector<float> f(in[0]->host_i.begin(), in[0]->host_i.end());
+                if (f.empty()) return false;
+                host_val(op, in[0]->shape, {}, std::move(f));
+            } else if (to == 9 || to == 7 || to == 6) {
+                std::vector<int64_t> o;
+                if (ints(in[0])) o = in[0]->host_i;
+                else for (float f : in[0]->host_f) o.push_back((int64_t)f);
+                host_val(op, in[0]->shape, std::move(o));
+            } else
+                throw std::invalid_argument(op.m_type + ": requested cast not implemented.");
+            return true;
+        }
+        for (auto* v : in)
+            if (v && !ints(v)) return false;
+        const std::vector<int64_t>& x = in[0]->host_i;
+        if (t == "Gather") {
+            need(op, op.m_input.size() == 2, "wrong number of inputs.");
+            int axis = 0;
+            for (auto& a : op.m_attributes) {
+                if (a.first == "axis") axis = std::stoi(a.second);
+                else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
+            }
+            need(op, in[0]->shape.size() == 1 && (axis == 0 || axis == -1), "axis must be 0 (not implemented).");
+            std::vector<int64_t> o;
+            for (int64_t i : in[1]->host_i) {
+                if (i < 0) i += (int64_t)x.size();
+                need(op, i >= 0 && i < (int64_t)x.size(), "invalid index in indices.");
+                o.push_back(x[i]);
+            }
+            host_val(op, in[1]->shape, std::move(o));   // 0-d indices -> 0-d output, 1-d -> 1-d (reference :6391-6394)
+            return true;
+        }
+        if (t == "Concat") {
+            std::vector<int64_t> o;
+            for (auto* v : in) {
+                need(op, v && v->shape.size() <= 1, "invalid shape of inputs.");
+                o.insert(o.end(), v->host_i.begin(), v->host_i.end());
+            }
+            const long no = (long)o.size();
+            host_val(op, {no}, std::move(o));
+            return true;
+        }
+        if (t == "Unsqueeze" || t == "Squeeze" || t == "Reshape") {
+            Shape os;
+            for (auto& d : op.m_output[0].m_shape) os.push_back((long)d);
+            need(op, prod(os) == (long)x.size(), "invalid shape.");
+            host_val(op, os, x);
+            return true;
+        }
+        if (t == "Slice") {
+            need(op, op.m_input.size() >= 3 && in[0]->shape.size() == 1 && in[1]->host_i.size() == 1 && in[2]->host_i.size() == 1, "unsupported slice of a shape vector (not implemented).");
+            if (op.m_input.size() > 4 && in[4]) need(op, in[4]->host_i.size() == 1 && in[4]->host_i[0] == 1, "unsupported steps value(s) (not implemented).");
+            int64_t b = in[1]->host_i[0], e = in[2]->host_i[0];
+            const int64_t n = (int64_t)x.size();
+            if (b < 0) b += n;
+            if (e < 0) e += n;
+            b = std::min(std::max<int64_t>(b, 0), n);
+            e = std::min(std::max<int64_t>(e, 0), n);
+            need(op, b < e, "invalid value(s) in starts and/or ends.");
+            host_val(op, {(long)(e - b)}, std::vector<int64_t>(x.begin() + b, x.begin() + e));
+            return true;
+        }
+        // Add / Sub / Mul / Div on int64 (scalar broadcast or equal length)
+        const std::vector<int64_t>& y = in[1]->host_i;
+        need(op, x.size() == y.size() || x.size() == 1 || y.size() == 1, "shapes are not broadcastable.");
+        const size_t n = std::max(x.size(), y.size());
+        std::vector<int64_t> o(n);
+        for (size_t i = 0; i < n; i++) {
+            const int64_t a = x[x.size() == 1 ? 0 : i], b = y[y.size() == 1 ? 0 : i];
+            if (t == "Div") need(op, b != 0, "division by zero.");
+            o[i] = t == "Add" ? a + b : t == "Sub" ? a - b : t == "Mul" ? a * b : a / b;
+        }
+        host_val(op, x.size() >= y.size() ? in[0]->shape : in[1]->shape, std::move(o));
+        return true;
+    }
+
+    // Gather on the device (reference :6316-6498): rows of a [rows, els] view along axis 0 (leading 1-dims stripped), static int64 indices
+    void lower_gather(const Operation& op) {
+        need(op, op.m_input.size() == 2, "wrong number of inputs.");
+        need(op, op.m_output.size() == 1, "wrong number of outputs.");
+        int axis = 0;
+        for (auto& a : op.m_attributes) {
+            if (a.first == "axis") axis = std::stoi(a.second);
+            else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
+        }
+        const Val* iv = hval(op.m_input[1]);
+        need(op, iv && iv->dtype == OSG_I64 && iv->host_valid, "wrong data type of indices.");
+        int x = P.ensure_plain(in_val(op.m_input[0]));
+        Shape xs = V(x).shape;
+        if (axis < 0) axis += (int)xs.size();
+        const int prev_axis = axis;
+        while (axis > 0 && !xs.empty() && xs[0] == 1) { xs.erase(xs.begin()); axis--; }
+        need(op, axis == 0, "axis must be 0 (not implemented).");
+        const bool in1d = xs.size() == 1;
+        if (in1d) xs.insert(xs.begin(), 1);
+        Shape is = iv->shape;
+        const bool idx0d = is.empty();
+        if (idx0d) is.push_back(1);
+        const bool idx1d = is.size() == 1;
+        if (idx1d) is.insert(is.begin(), 1);
+        need(op, is.size() == 2 && is[0] == 1, "shape of indices must be (1,D) (not implemented).");
+        Shape over;
+        if (xs.size() > 2) {
+            over.assign(xs.begin() + 1, xs.end());
+            xs = {xs[0], prod(over)};
+        }
+        need(op, xs.size() == 2, "input must be 2D or more.");
+        Shape os = {1, is[1], xs[1]};
+        if (in1d && idx0d) os.clear();
+        else if (idx1d) os.erase(os.begin());
+        for (int i = 0; i < prev_axis; i++) os.insert(os.begin(), 1);
+        if (!over.empty()) os = over;
+        const long dim = in1d ? xs[1] : xs[0], els = in1d ? 1 : xs[1];
+        std::vector<int64_t> idx = iv->host_i;
+        for (auto& i : idx) {
+            if (i < 0) i += dim;
+            need(op, i >= 0 && i < dim, "invalid index in indices.");
+        }
+        const int idev = P.new_val("", {(long)idx.size()}, OSG_I64, Lay::plain, false);
+        V(idev).is_const = true;
+        bool fresh;
+        std::string tag = "gather|" + op.m_name;
+        V(idev).dptr = P.const_alloc(tag, std::max<size_t>(idx.size() * 8, 8), &fresh);
+        be.check(be.api.osg_upload_sync(be.ctx, V(idev).dptr, idx.data(), idx.size() * 8), "osg_upload_sync");
+        int y = out_val(op, os, Lay::plain, V(x).batched, V(x).dtype);
+        const int es = (int)esize(V(x).dtype);
+        const long nb = B(x), n_idx = (long)idx.size(), per_in = V(x).numel(), per_out = n_idx * els;
+        P.add_step("Gather " + op.m_name, {x, idev}, {y}, [=, this] {
+            for (long b = 0; b < nb; b++)
+                be.check(be.api.osg_gather_rows(be.ctx, es, (const char*)P.ptr(x) + b * per_in * es, (const int64_t*)P.ptr(idev), (char*)P.ptr(y) + b * per_out * es, n_idx,
+                                                els, dim),
+                         "Gather");
+        });
+    }
+
+    // Cast on the device (reference :7352-7423): the device keeps f16 activations only, so FLOAT -> FLOAT16 / FLOAT are relabelings there
+    void lower_cast(const Operation& op) {
+        need(op, op.m_input.size() == 1, "wrong number of inputs.");
+        need(op, op.m_output.size() == 1, "wrong number of outputs.");
+        throw std::invalid_argument(op.m_type + ": requested cast not implemented (only casts of plan-time integer values are supported on the HIP backend).");
+    }
+
     int in_val(const Tensor& t) { return P.ensure_dense(in_val_raw(t)); }
 
     void check_out(const Operation& op, const Shape& got, size_t idx = 0) {
@@ -1046,6 +1275,9 @@ struct Lowering {
 
     void lower(const Operation& op) {
         const std::string& t = op.m_type;
+        if (try_host_eval(op)) return;
+        if (t == "Gather") return lower_gather(op);
+        if (t == "Cast") return lower_cast(op);
         if (t == "Conv") return lower_conv(op);
         if (t == "MatMul") return lower_matmul(op);
         if (t == "osg.Linear") return lower_linear(op);
@@ -1113,6 +1345,7 @@ struct Lowering {
         const bool has_res = attr(op, "osg_residual") != nullptr;
         const bool has_ib = attr(op, "osg_image_bias") != nullptr;
         const bool has_pre = attr(op, "osg_prenorm") != nullptr;
+        const osg_act cact = attr(op, "osg_act") ? OSG_ACT_SILU : OSG_ACT_NONE;
         const size_t nin = has_pre ? (op.m_input.size() == 7 ? (has_ib ? 5 : has_res ? 4 : !op.m_input[2].m_name.empty() ? 3 : 2) : 0) : op.m_input.size();
         need(op, nin == 2 || nin == 3 || (has_res && nin == 4) || (has_ib && nin == 5), "wrong number of inputs.");
         need(op, op.m_output.size() == 1, "wrong number of outputs.");
@@ -1125,7 +1358,7 @@ struct Lowering {
             else if (a.first == "pads") pads = int_list(a.second);
             else if (a.first == "strides") strides = int_list(a.second);
             else if (a.first == "osg_residual" || a.first == "osg_image_bias" || a.first == "osg_prenorm" || a.first == "osg_pre_groups" ||
-                     a.first == "osg_pre_eps") {}
+                     a.first == "osg_pre_eps" || a.first == "osg_act") {}
             else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
         }
         int x = in_val(op.m_input[0]);
@@ -1191,7 +1424,7 @@ struct Lowering {
                 be.check(be.api.osg_conv2d_nhwc_w8(be.ctx, P.ptr(x), P.ptr(w), qs, qz, bias >= 0 ? P.ptr(bias) : nullptr,
                                                    bias >= 0 ? P.vals[bias].dtype : OSG_F16, ib >= 0 ? P.ptr(ib) : nullptr, ib_ld,
                                                    res >= 0 ? P.ptr(res) : nullptr, P.ptr(y), (int)nb, (int)H, (int)W, (int)Cin, (int)Cout,
-                                                   (int)KH, (int)KW, sh, sw, pt, pl, pb, pr, OSG_ACT_NONE),
+                                                   (int)KH, (int)KW, sh, sw, pt, pl, pb, pr, cact),
                          "Conv");
             });
             P.steps.back().flops = 2.0 * nb * Ho * Wo * Cout * KH * KW * Cin;
@@ -1201,11 +1434,11 @@ struct Lowering {
             be.check(be.api.osg_conv2d_nhwc_rb(be.ctx, OSG_F16, P.ptr(x), P.ptr(w), bias >= 0 ? P.ptr(bias) : nullptr,
                                                bias >= 0 ? P.vals[bias].dtype : OSG_F16, ib >= 0 ? P.ptr(ib) : nullptr, ib_ld,
                                                res >= 0 ? P.ptr(res) : nullptr, P.ptr(y), (int)nb, (int)H, (int)W, (int)Cin, (int)Cout,
-                                               (int)KH, (int)KW, sh, sw, pt, pl, pb, pr, OSG_ACT_NONE),
+                                               (int)KH, (int)KW, sh, sw, pt, pl, pb, pr, cact),
                      "Conv");
         });
         P.steps.back().flops = 2.0 * nb * Ho * Wo * Cout * KH * KW * Cin;
-        if (KH == 1 && KW == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && ib < 0)   // a 1x1 convolution IS a GEMM over the pixels (OHWI == [N,K])
+        if (KH == 1 && KW == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && ib < 0 && cact == OSG_ACT_NONE)   // a 1x1 convolution IS a GEMM over the pixels (OHWI == [N,K])
             note_rs_producer(x, w, bias, res, y, nb * Ho * Wo, Cout, Cin);
     }
 
@@ -1901,7 +2134,7 @@ struct Lowering {
             else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
         }
         int x = in_val(op.m_input[0]);
-        const Val* sv = cval(op.m_input[1]);
+        const Val* sv = hval(op.m_input[1]);
         need(op, sv && sv->dtype == OSG_I64 && sv->host_valid, "wrong data type of shape.");
         const long total = V(x).numel();
         Shape os;
@@ -1937,7 +2170,7 @@ struct Lowering {
     void lower_squeeze(const Operation& op, bool unsq) {
         need(op, op.m_input.size() == 2, "wrong number of inputs.");
         int x = P.ensure_plain(in_val(op.m_input[0]));
-        const Val* ax = cval(op.m_input[1]);
+        const Val* ax = hval(op.m_input[1]);
         need(op, ax && ax->dtype == OSG_I64 && ax->host_valid, "wrong data type of axes.");
         Shape os = V(x).shape;
         std::vector<long> axes(ax->host_i.begin(), ax->host_i.end());
@@ -2034,7 +2267,7 @@ struct Lowering {
     void lower_split(const Operation& op) {
         need(op, op.m_input.size() == 2, "wrong number of inputs.");
         int x = in_val(op.m_input[0]);
-        const Val* sz = cval(op.m_input[1]);
+        const Val* sz = hval(op.m_input[1]);
         need(op, sz && sz->dtype == OSG_I64 && sz->host_valid && sz->host_i.size() == op.m_output.size(), "invalid split tensor.");
         int axis = 0;
         if (auto* a = attr(op, "axis")) axis = std::stoi(*a);
@@ -2065,10 +2298,10 @@ struct Lowering {
         need(op, op.m_input.size() >= 3 && op.m_input.size() <= 5, "wrong number of inputs.");
         need(op, op.m_attributes.empty(), "unrecognized attribute (not implemented).");
         int x = P.ensure_plain(in_val(op.m_input[0]));
-        const Val* st = cval(op.m_input[1]);
-        const Val* en = cval(op.m_input[2]);
-        const Val* ax = op.m_input.size() > 3 ? cval(op.m_input[3]) : nullptr;
-        const Val* sp = op.m_input.size() > 4 ? cval(op.m_input[4]) : nullptr;
+        const Val* st = hval(op.m_input[1]);
+        const Val* en = hval(op.m_input[2]);
+        const Val* ax = op.m_input.size() > 3 ? hval(op.m_input[3]) : nullptr;
+        const Val* sp = op.m_input.size() > 4 ? hval(op.m_input[4]) : nullptr;
         need(op, st && en && st->dtype == OSG_I64 && en->dtype == OSG_I64, "wrong data type of starts.");
         const size_t na = st->host_i.size();
         need(op, (na == 1 || na == 2) && en->host_i.size() == na, "unsupported shape of starts (not implemented).");
@@ -2114,11 +2347,11 @@ struct Lowering {
         need(op, s.size() == 4 && s[0] == 1, "input must be [1,C,H,W] (not implemented).");
         Shape os = s;
         if (op.m_input.size() == 4 && !op.m_input[3].m_name.empty()) {
-            const Val* sz = cval(op.m_input[3]);
+            const Val* sz = hval(op.m_input[3]);
             need(op, sz && sz->host_i.size() == 4, "invalid sizes.");
             for (int i = 0; i < 4; i++) os[i] = sz->host_i[i];
         } else {
-            const Val* sc = cval(op.m_input[2]);
+            const Val* sc = hval(op.m_input[2]);
             need(op, sc && sc->host_valid && sc->host_f.size() == 4, "invalid scales.");
             need(op, sc->host_f[0] == 1.f && sc->host_f[1] == 1.f, "scales for N and C must be 1 (not implemented).");
             for (int i = 2; i < 4; i++) os[i] = (long)std::floor((float)s[i] * sc->host_f[i]);

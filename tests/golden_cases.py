@@ -130,8 +130,28 @@ def time_embedding(g):
     return {"timestep": np.asarray([999.0], f32)}
 
 
+def shape_gather_chain(g):
+    """what exporters leave around a `view(b, -1, h, d)`: Shape -> Gather (0-d and 1-d indices) -> Unsqueeze -> Cast -> Concat -> Reshape
+    (folded to constants at plan time on the device backend), plus an embedding-style Gather of weight rows (reference :6316, :7003, :7352)"""
+    x = g.input("x", (1, 6, 32))
+    tab = g.weight("/emb.weight", g.randn((10, 32), 1.0))
+    idx = g.weight("/emb.idx", np.asarray([[3, 0, 9, 9, 1, 7]], np.int64), dtype="int64")
+    e = g.op("/emb/Gather", "Gather", [tab, idx], (1, 6, 32), {"axis": "0"})
+    y = g.binary("/add", "Add", x, e)
+    sh = g.op("/Shape", "Shape", [y], (3,))
+    b0 = g.op("/Gather_b", "Gather", [sh, g.weight("/c0", np.asarray(0, np.int64), dtype="int64")], [()], {"axis": "0"})[0]
+    b = g.unsqueeze("/Unsq_b", b0, 0)
+    t = g.op("/Gather_t", "Gather", [sh, g.weight("/c1", np.asarray(1, np.int64), dtype="int64")], [()], {"axis": "0"})[0]
+    t1 = g.unsqueeze("/Unsq_t", t, 0)
+    c = g.op("/Cast", "Cast", [t1], (1,), {"to": "7"})
+    tgt = g.concat("/Concat", [b, c, g.const_i64("/hd", [4, 8])], 0)
+    r = g.op("/Reshape", "Reshape", [y, tgt], (1, 6, 4, 8), {"allowzero": "0"})
+    g.transpose("/T", r, (0, 2, 1, 3))
+    return {"x": _rn(20, (1, 6, 32))}
+
+
 CASES = [conv3x3, conv3x3_stride2, conv1x1_nobias, conv_in_4ch, conv_ragged, linear_bias, gemm_temb, group_norm_silu, layer_norm,
-         self_attention, cross_attention, geglu_ff, resnet_block, transformer_block, upsample_concat, time_embedding]
+         self_attention, cross_attention, geglu_ff, resnet_block, transformer_block, upsample_concat, time_embedding, shape_gather_chain]
 # whole (miniature) networks: SD1.5-shaped and SDXL-shaped UNets, the VAE decoder (single 32-wide attention head + 3 resolutions)
 UNETS = {"unet_tiny": sd_unet.TINY, "unet_tinyxl": sd_unet.TINY_XL, "vae_tiny": sd_vae.TINY_VAE,
          # W8A16 (BASELINE config 3, UNet half): uint8 weights + per-tensor scale/zero-point in model.txt, dequantised at load
