@@ -231,7 +231,7 @@ def main():
                 x = state["x"]
                 den = pipe.denoise(x, float(sig[i]), ctx_cs, ctx_us, extra_cond=ex_c, extra_uncond=ex_u)
                 dev += m.hip_last_pass_ms()
-                x = ((x - den) * scal[3][i] + den + rng.standard_normal(lat_shape, dtype=np.float32) * scal[4][i]).astype(np.float32)
+                x = (x + ((x - den) / scal[3][i]) * scal[4][i] + rng.standard_normal(lat_shape, dtype=np.float32) * scal[5][i]).astype(np.float32)
                 x = np.clip(x, -clip[i], clip[i])
                 n = 1
             else:

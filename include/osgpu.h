@@ -210,13 +210,14 @@ int osg_side_join(osg_ctx* ctx);
  * timestep[0 .. 2*prompts*t_per_sample) = t.  x, sample, timestep are DEVICE fp32 buffers (the plan's input staging). */
 int osg_sampler_prepare(osg_ctx* ctx, const float* x, float* sample, float* timestep, int prompts, long L, float c_in, float t,
                         long t_per_sample);
-/* One Euler-Ancestral step with the CFG combine (src/sd.cpp:1545-1556, src/samplers.h:1430-1472), in place on x:[prompts,L]:
+/* One Euler-Ancestral step with the CFG combine (src/sd.cpp:1545-1556, src/samplers.h:1430-1449), in place on x:[prompts,L]:
  *   den_c = eps[2p]*c_out + x;  den_u = eps[2p+1]*c_out + x;  den = den_u + guidance*(den_c - den_u);
- *   x = (x - den)*k_down + den + noise*k_up        (k_down = sigma_down/sigma_i, k_up = sigma_up; noise may be NULL: term skipped)
+ *   x = x + ((x - den) / sigma) * d_sigma + noise*sigma_up      (the branch `#define ORIGINAL_SAMPLER_ALGORITHMS 1`, samplers.h:66, selects, :1431-1449;
+ *                                                                 sigma = sigma_i, d_sigma = sigma_down - sigma_i; noise may be NULL: term skipped)
  * every product and sum rounded separately to fp32, i.e. bit-identical to the host loop.  clip > 0 additionally clamps the new x to
  * [-clip, clip] (not in the reference; used with random-weight synthetic UNets, which do not denoise, to keep the trajectory finite). */
 int osg_sampler_cfg_euler_a(osg_ctx* ctx, float* x, const float* eps, const float* noise, int prompts, long L, float c_out,
-                            float guidance, float k_down, float k_up, float clip);
+                            float guidance, float sigma, float d_sigma, float sigma_up, float clip);
 
 /* ---- data movement ------------------------------------------------------------------------------------------ */
 /* N-d transpose (XnnPack::transpose, onnxstream.cpp:1748): out.shape[i] = shape[perm[i]]. elem_size in {1,2,4,8}. */

@@ -177,18 +177,18 @@ class Model:
         a = np.ascontiguousarray(data, np.float32)
         self._err(f(self._h, self._name(name), index, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), a.size))
 
-    def hip_sampler_loop(self, sample: str, timestep: str, out: str, x, noise, c_in, c_out, t, k_down, k_up, guidance: float = 7.0, clip=None) -> float:
+    def hip_sampler_loop(self, sample: str, timestep: str, out: str, x, noise, c_in, c_out, t, sigma, d_sigma, sigma_up, guidance: float = 7.0, clip=None) -> float:
         """The denoising loop (CFG combine + Euler-Ancestral update) enqueued on the device, one host sync at the end.
         x: float32 [prompts, ...] (updated IN PLACE); noise: float32 [steps, prompts, ...] or None; the per-step scalar arrays have
         `steps` float32 entries.  The plan must have been built by a run() with 2*prompts pushes.  Returns the loop's device ms."""
         import numpy as np
         f = self._lib.model_hip_sampler_loop
         fp = ctypes.POINTER(ctypes.c_float)
-        f.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp, fp, fp,
+        f.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, fp, fp, fp, fp, fp, fp, fp, fp,
                       ctypes.c_float, fp, ctypes.POINTER(ctypes.c_double)]
         f.restype = ctypes.c_void_p
         assert x.dtype == np.float32 and x.flags.c_contiguous
-        arrs = [np.ascontiguousarray(a, np.float32) for a in (c_in, c_out, t, k_down, k_up)]
+        arrs = [np.ascontiguousarray(a, np.float32) for a in (c_in, c_out, t, sigma, d_sigma, sigma_up)]
         steps = len(arrs[0])
         if noise is not None:
             noise = np.ascontiguousarray(noise, np.float32)

@@ -276,10 +276,10 @@ char* model_hip_set_input(Handle* h, char* name, long long index, const float* d
 // without per-step host round trips.  x:[prompts,L] fp32 is updated in place; noise:[steps,prompts,L]; the five per-step scalar arrays
 // have `steps` entries; clip (may be NULL) is a sixth: per-step clamp of the new latents, 0 = none.  *ms (may be NULL) receives the device time of the loop.
 char* model_hip_sampler_loop(Handle* h, char* sample_name, char* timestep_name, char* out_name, int steps, int prompts, float* x, const float* noise,
-                             const float* c_in, const float* c_out, const float* t, const float* k_down, const float* k_up, float guidance, const float* clip,
+                             const float* c_in, const float* c_out, const float* t, const float* sigma, const float* d_sigma, const float* sigma_up, float guidance, const float* clip,
                              double* ms) {
     try {
-        const double v = h->model.hip_sampler_loop(sample_name, timestep_name, out_name, steps, prompts, x, noise, c_in, c_out, t, k_down, k_up, guidance, clip);
+        const double v = h->model.hip_sampler_loop(sample_name, timestep_name, out_name, steps, prompts, x, noise, c_in, c_out, t, sigma, d_sigma, sigma_up, guidance, clip);
         if (ms) *ms = v;
         return nullptr;
     } catch (const std::exception& e) {

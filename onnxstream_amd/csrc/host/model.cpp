@@ -228,10 +228,10 @@ void Model::hip_set_input(const std::string& name, long index, const float* data
 }
 
 double Model::hip_sampler_loop(const std::string& sample_name, const std::string& timestep_name, const std::string& out_name, int steps, int prompts,
-                               float* x, const float* noise, const float* c_in, const float* c_out, const float* t, const float* k_down,
-                               const float* k_up, float guidance, const float* clip) {
+                               float* x, const float* noise, const float* c_in, const float* c_out, const float* t, const float* sigma, const float* d_sigma,
+                               const float* sigma_up, float guidance, const float* clip) {
     if (!m_plan) throw std::runtime_error("Model::hip_sampler_loop: no plan (call run() first).");
-    const double ms = m_plan->sampler_loop(sample_name, timestep_name, out_name, steps, prompts, x, noise, c_in, c_out, t, k_down, k_up, guidance, clip);
+    const double ms = m_plan->sampler_loop(sample_name, timestep_name, out_name, steps, prompts, x, noise, c_in, c_out, t, sigma, d_sigma, sigma_up, guidance, clip);
     m_last_ms = m_plan->last_ms();
     return ms;
 }

@@ -575,8 +575,8 @@ public:
     void hip_set_input(const std::string& name, long index, const float* data, size_t count);   // refresh one pushed sample of a resident input
     // the denoising loop with CFG + Euler-Ancestral on the device (see Plan::sampler_loop); returns the loop's device time in ms
     double hip_sampler_loop(const std::string& sample_name, const std::string& timestep_name, const std::string& out_name, int steps, int prompts,
-                            float* x, const float* noise, const float* c_in, const float* c_out, const float* t, const float* k_down,
-                            const float* k_up, float guidance, const float* clip);
+                            float* x, const float* noise, const float* c_in, const float* c_out, const float* t, const float* sigma, const float* d_sigma,
+                            const float* sigma_up, float guidance, const float* clip);
     std::string hip_plan_info() const;         // steps / arena placement of the current plan (see Plan::info)
     std::string hip_profile(int reps);         // per-step HIP-event timing report of an eager pass
 

@@ -2751,8 +2751,8 @@ void Plan::set_input(const std::string& name, long index, const float* data, siz
 }
 
 double Plan::sampler_loop(const std::string& sample_name, const std::string& timestep_name, const std::string& out_name, int n_steps, int prompts,
-                          float* x, const float* noise, const float* c_in, const float* c_out, const float* t, const float* k_down,
-                          const float* k_up, float guidance, const float* clip) {
+                          float* x, const float* noise, const float* c_in, const float* c_out, const float* t, const float* sigma, const float* d_sigma,
+                          const float* sigma_up, float guidance, const float* clip) {
     if (runs < 1) throw std::runtime_error("Model::hip_sampler_loop: run() once first (the context inputs must be resident).");
     if (stream_weights) throw std::runtime_error("Model::hip_sampler_loop: not available in streamed-weights mode.");
     if (prompts <= 0 || 2L * prompts != N) throw std::invalid_argument("Model::hip_sampler_loop: the plan's batch must be 2 * prompts (cond, uncond per prompt).");
@@ -2790,7 +2790,7 @@ double Plan::sampler_loop(const std::string& sample_name, const std::string& tim
         const bool with_noise = noise != nullptr;
         be.check(be.api.osg_sampler_cfg_euler_a(be.ctx, (float*)samp_x, (const float*)ptr(out->f32val),
                                                with_noise ? (const float*)samp_noise + (size_t)i * prompts * L : nullptr, prompts, L, c_out[i], guidance,
-                                               k_down[i], k_up[i], clip ? clip[i] : 0.f),
+                                               sigma[i], d_sigma[i], sigma_up[i], clip ? clip[i] : 0.f),
                  "osg_sampler_cfg_euler_a");
     }
     float ms = 0;

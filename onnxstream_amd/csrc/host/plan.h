@@ -96,13 +96,13 @@ struct Plan {
     // the reference app's denoising loop with the CFG combine and the Euler-Ancestral update on the device: `steps`
     // passes enqueued back to back, one host sync at the end.  The plan's batch must be 2*prompts (push 2p = cond, 2p+1 = uncond of
     // prompt p) and every other input (context, ...) must already be resident from an earlier run().  Per-step scalars come from the
-    // caller (who owns the schedule): c_in, c_out, t, k_down = sigma_down/sigma, k_up = sigma_up, clip (NULL or per-step clamp of the new latents, 0 = none).  x: [prompts, L] fp32 host, updated
+    // caller (who owns the schedule): c_in, c_out, t, sigma = sigma_i, d_sigma = sigma_down - sigma_i, sigma_up, clip (NULL or per-step clamp of the new latents, 0 = none).  x: [prompts, L] fp32 host, updated
     // in place; noise: [steps, prompts, L] fp32 host.  Returns the device time of the whole loop in ms.
     // overwrite sample `index` of a graph input in its device staging (what run() does for every pushed tensor) without running a pass
     void set_input(const std::string& name, long index, const float* data, size_t count);
     double sampler_loop(const std::string& sample_name, const std::string& timestep_name, const std::string& out_name, int n_steps, int prompts,
-                        float* x, const float* noise, const float* c_in, const float* c_out, const float* t, const float* k_down,
-                        const float* k_up, float guidance, const float* clip);
+                        float* x, const float* noise, const float* c_in, const float* c_out, const float* t, const float* sigma, const float* d_sigma,
+                        const float* sigma_up, float guidance, const float* clip);
     // eager pass with HIP events around every step, `reps` times; "ms<TAB>flops<TAB>bytes<TAB>what" per line (ms = mean)
     std::string profile(int reps);
     // plan introspection for the CPU tests of the host logic (tests/test_planner_cpu.py): one line per step

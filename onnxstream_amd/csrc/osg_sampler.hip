@@ -2,7 +2,8 @@
 // enqueued without one host round trip:
 //   osg_sampler_prepare     <- CFGDenoiser_CompVisDenoiser's input scaling  x * c_in  and the timestep broadcast (reference src/sd.cpp:1427-1470)
 //   osg_sampler_cfg_euler_a <- eps -> denoised (x + eps * c_out), the CFG combine (uncond + g * (cond - uncond), src/sd.cpp:1545-1556) and
-//                              the Euler-Ancestral update (src/samplers.h:1430-1472)
+//                              the Euler-Ancestral update (src/samplers.h:1430-1449: the branch the shipped `#define ORIGINAL_SAMPLER_ALGORITHMS 1`,
+//                              samplers.h:66, selects:  x = x + ((x - d) / sigma_i) * (sigma_down - sigma_i) + r * sigma_up)
 // fp32 throughout, in the reference's operation order with every multiply and add rounded separately (no fma contraction), so the device
 // loop reproduces the host loop bit for bit (tests/test_pipeline.py).
 #include "osg_common.h"
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(256) void sampler_prepare_kernel(const float* __res
 }
 
 __global__ __launch_bounds__(256) void sampler_cfg_euler_a_kernel(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
-                                                                  int prompts, long L, float c_out, float guidance, float k_down, float k_up, float clip) {
+                                                                  int prompts, long L, float c_out, float guidance, float sigma, float d_sigma, float sigma_up, float clip) {
 #pragma clang fp contract(off)
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)prompts * L) return;
@@ -38,10 +39,11 @@ __global__ __launch_bounds__(256) void sampler_cfg_euler_a_kernel(float* __restr
     const float den_u = pu + xv;
     const float gd = guidance * (den_c - den_u);
     const float den = den_u + gd;
-    const float sc = (xv - den) * k_down;
-    float nx = sc + den;
+    const float dd = (xv - den) / sigma;          // IEEE division (hipcc keeps fp32 divides correctly rounded), one rounding per operation
+    const float st = dd * d_sigma;
+    float nx = xv + st;
     if (noise) {
-        const float nz = noise[i] * k_up;
+        const float nz = noise[i] * sigma_up;
         nx = nx + nz;
     }
     if (clip > 0.f) nx = fminf(fmaxf(nx, -clip), clip);
@@ -63,11 +65,11 @@ int osg_sampler_prepare(osg_ctx* ctx, const float* x, float* sample, float* time
 }
 
 int osg_sampler_cfg_euler_a(osg_ctx* ctx, float* x, const float* eps, const float* noise, int prompts, long L, float c_out, float guidance,
-                            float k_down, float k_up, float clip) {
+                            float sigma, float d_sigma, float sigma_up, float clip) {
     if (prompts <= 0 || L <= 0) return 0;
     const long total = (long)prompts * L;
     hipLaunchKernelGGL(sampler_cfg_euler_a_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->compute, x, eps, noise, prompts, L, c_out,
-                       guidance, k_down, k_up, clip);
+                       guidance, sigma, d_sigma, sigma_up, clip);
     OSG_LAUNCH_CHECK(ctx);
     return 0;
 }

@@ -93,7 +93,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_gemm_ln.argtypes = [vp, vp, vp, vp, vp, cf, vp, vp, vp, ci, ci, ci, ci]
     lib.osg_gemm_rowstats.argtypes = [vp, vp, vp, vp, ci, vp, vp, ci, ci, ci, ci, vp]
     lib.osg_sampler_prepare.argtypes = [vp, vp, vp, vp, ci, cl, cf, cf, cl]
-    lib.osg_sampler_cfg_euler_a.argtypes = [vp, vp, vp, vp, ci, cl, cf, cf, cf, cf, cf]
+    lib.osg_sampler_cfg_euler_a.argtypes = [vp, vp, vp, vp, ci, cl, cf, cf, cf, cf, cf, cf]
     return lib
 
 

@@ -20,36 +20,59 @@ from .bindings import Model
 f32 = np.float32
 
 
+def _libm_float_fn(name):
+    """The reference app computes its schedule with the C library's FLOAT functions (std::exp / std::log on float: expf / logf, src/sd.cpp:1402,
+    :1608).  numpy's float32 exp / log are its own SIMD kernels and differ from glibc's in the last bit for a third of the table
+    (sigma[0] = 14.614644 vs 14.614643) -- one ulp of sigma flips f16 roundings of the UNet input and moves a whole pass by 1e-3.  So the
+    harness calls the same libm; without one, the correctly rounded value (double function, rounded once) stands in."""
+    import ctypes
+    import ctypes.util
+    import math
+    try:
+        fn = getattr(ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6"), name + "f")
+        fn.restype, fn.argtypes = ctypes.c_float, [ctypes.c_float]
+        return lambda v: f32(fn(float(v)))
+    except (OSError, AttributeError):
+        dbl = getattr(math, name)
+        return lambda v: f32(dbl(float(v)))
+
+
+expf, logf = _libm_float_fn("exp"), _libm_float_fn("log")
+
+
 def log_sigmas_table() -> np.ndarray:
     """The 1000-entry table hard-coded at src/sd.cpp:1591: log(sqrt((1-acp)/acp)) of SD's scaled-linear beta schedule
-    (beta 0.00085 -> 0.012 over 1000 steps), here recomputed in float64 (agrees with the table to ~1e-6)."""
+    (beta 0.00085 -> 0.012 over 1000 steps), recomputed the way it was made -- alphas_cumprod in float64, stored as float32, sigma and log
+    in float32.  The reference's literals are the float32 results of whatever libm produced them: this recomputation hits 827 of the
+    1000 entries exactly and is 1 float32 ulp (<= 2.4e-7) off in the others (tests/test_pipeline.py checks that against the source)."""
     betas = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=np.float64) ** 2
-    acp = np.cumprod(1.0 - betas)
-    return (0.5 * np.log((1.0 - acp) / acp)).astype(f32)
+    acp = np.cumprod(1.0 - betas).astype(f32)
+    return np.log(np.sqrt((f32(1) - acp) / acp)).astype(f32)
 
 
 def sigma_schedule(steps: int, log_sigmas: np.ndarray) -> np.ndarray:
     """t_to_sigma over linspace(999, 0, steps) + a trailing 0 (src/sd.cpp:1597-1612)."""
     sig = np.empty(steps + 1, f32)
-    delta = -999.0 / (steps - 1) if steps > 1 else 0.0
+    delta = f32(-999.0) / f32(steps - 1) if steps > 1 else f32(0)      # float delta = -999.0f / (step - 1)
     for i in range(steps):
-        t = f32(999.0 + i * delta)
+        t = f32(999.0 + float(f32(f32(i) * delta)))                   # float t = 999.0 + i * delta  (float product, double sum, one rounding)
         lo, hi = int(np.floor(t)), int(np.ceil(t))
         w = f32(t - lo)
-        sig[i] = np.exp((1 - w) * log_sigmas[lo] + w * log_sigmas[hi])
+        sig[i] = expf(f32(f32(f32(1) - w) * log_sigmas[lo]) + f32(w * log_sigmas[hi]))
     sig[steps] = 0.0
     return sig
 
 
 def sigma_to_t(sigma: float, log_sigmas: np.ndarray) -> float:
     """src/sd.cpp:1403-1425."""
-    ls = np.log(f32(sigma))
+    ls = logf(f32(sigma))
     dists = np.cumsum((ls - log_sigmas >= 0).astype(np.int64))
     low = min(int(np.argmax(dists)), 1000 - 2)
     high = low + 1
     lo, hi = log_sigmas[low], log_sigmas[high]
-    w = float(np.clip((lo - ls) / (lo - hi), 0.0, 1.0))
-    return (1 - w) * low + w * high
+    w = f32(f32(lo - ls) / f32(lo - hi))                      # float arithmetic throughout, as :1420-1422
+    w = max(f32(0), min(f32(1), w))
+    return float(f32(f32(f32(1) - w) * f32(low)) + f32(w * f32(high)))
 
 
 class Txt2Img:
@@ -139,28 +162,42 @@ class Txt2Img:
         den_u = eps_u * c_out + x
         return (den_u + f32(guidance) * (den_c - den_u)).astype(f32)
 
+    @staticmethod
+    def ancestral_step_scalars(s_i, s_n):
+        """(sigma_up, sigma_down) of one Euler-Ancestral step exactly as the reference's ACTIVE branch computes them -- samplers.h:66
+        ships `#define ORIGINAL_SAMPLER_ALGORITHMS 1`, i.e. src/samplers.h:1431-1433, all in float:
+            sigma_up   = min(s1, sqrt(s1 * s1 * (s0 * s0 - s1 * s1) / (s0 * s0)));   sigma_down = sqrt(s1 * s1 - sigma_up * sigma_up)"""
+        s0, s1 = f32(s_i), f32(s_n)
+        with np.errstate(invalid="ignore"):
+            sigma_up = min(s1, np.sqrt(f32(f32(f32(s1 * s1) * f32(f32(s0 * s0) - f32(s1 * s1))) / f32(s0 * s0))))
+            sigma_down = np.sqrt(f32(f32(s1 * s1) - f32(sigma_up * sigma_up)))
+        return f32(sigma_up), f32(sigma_down)
+
     def sample(self, cond: np.ndarray, uncond: np.ndarray, steps: int = 20, seed: int = 42, latent_shape=(1, 4, 64, 64),
-               on_step: Optional[Callable[[int, np.ndarray], None]] = None) -> np.ndarray:
-        """diffusion_solver with the default sampler (Euler Ancestral, src/samplers.h:1430-1472; non-original arithmetic branch)."""
+               on_step: Optional[Callable[[int, np.ndarray], None]] = None, init_latent: Optional[np.ndarray] = None,
+               step_noise: Optional[Callable[[int], np.ndarray]] = None) -> np.ndarray:
+        """diffusion_solver (src/sd.cpp:1574-1780) with the default sampler, Euler Ancestral as the shipped reference runs it
+        (src/samplers.h:1431-1449, ORIGINAL_SAMPLER_ALGORITHMS):  x += ((x - d) / sigma_i) * (sigma_down - sigma_i) + r * sigma_up,
+        every operation rounded to float on its own.  init_latent: N(0,1) start (default: numpy stream; the reference draws
+        randn_4_w_h(seed % 1000), :1595) -- it is scaled by sigma[0] here as :1611-1612 does; step_noise(i): the ancestral noise of step i."""
         sig = sigma_schedule(steps, self.log_sigmas)
         rng = np.random.default_rng(seed)     # the reference draws mt19937 normals; any N(0,1) stream is equivalent for the harness
-        x = rng.standard_normal(latent_shape, dtype=f32) * sig[0]
+        x0 = rng.standard_normal(latent_shape, dtype=f32) if init_latent is None else np.asarray(init_latent, f32).reshape(latent_shape)
+        x = (x0 * f32(sig[0])).astype(f32)
         for i in range(steps):
             den = self.denoise(x, float(sig[i]), cond, uncond)
-            s_i, s_n = np.float64(sig[i]), np.float64(sig[i + 1])
-            sigma_up = min(s_n, abs(s_n * np.sqrt(s_i * s_i - s_n * s_n) / s_i))
-            sigma_down = f32(np.sqrt(s_n * s_n - sigma_up * sigma_up))
-            noise = rng.standard_normal(latent_shape, dtype=f32)
-            x = ((x - den) * f32(sigma_down / f32(s_i)) + den + noise * f32(sigma_up)).astype(f32)
+            sigma_up, sigma_down = self.ancestral_step_scalars(sig[i], sig[i + 1])
+            noise = rng.standard_normal(latent_shape, dtype=f32) if step_noise is None else np.asarray(step_noise(i), f32).reshape(latent_shape)
+            x = (x + f32(f32(x - den) / f32(sig[i])) * f32(sigma_down - f32(sig[i])) + noise * sigma_up).astype(f32)
             if on_step:
                 on_step(i, x)
         return x
 
     def loop_scalars(self, sig: np.ndarray):
-        """Per-step fp32 scalars of the loop, computed exactly as denoise()/sample() do: c_in, c_out, t (sigma_to_t), k_down = sigma_down /
-        sigma_i and k_up = sigma_up of the Euler-Ancestral update."""
+        """Per-step fp32 scalars of the loop, computed exactly as denoise()/sample() do: c_in, c_out, t (sigma_to_t), sigma_i, d_sigma =
+        sigma_down - sigma_i and sigma_up of the Euler-Ancestral update."""
         steps = len(sig) - 1
-        c_in, c_out, ts, k_down, k_up = (np.empty(steps, f32) for _ in range(5))
+        c_in, c_out, ts, s_arr, d_sigma, s_up = (np.empty(steps, f32) for _ in range(6))
         for i in range(steps):
             sigma = float(sig[i])
             c_out[i] = f32(-1.0 * sigma)
@@ -168,14 +205,14 @@ class Txt2Img:
             if sigma not in self._t_cache:
                 self._t_cache[sigma] = sigma_to_t(sigma, self.log_sigmas)
             ts[i] = f32(self._t_cache[sigma])
-            s_i, s_n = np.float64(sig[i]), np.float64(sig[i + 1])
-            sigma_up = min(s_n, abs(s_n * np.sqrt(s_i * s_i - s_n * s_n) / s_i))
-            sigma_down = f32(np.sqrt(s_n * s_n - sigma_up * sigma_up))
-            k_down[i] = f32(sigma_down / f32(s_i))
-            k_up[i] = f32(sigma_up)
-        return c_in, c_out, ts, k_down, k_up
+            sigma_up, sigma_down = self.ancestral_step_scalars(sig[i], sig[i + 1])
+            s_arr[i] = f32(sig[i])
+            d_sigma[i] = f32(sigma_down - f32(sig[i]))
+            s_up[i] = sigma_up
+        return c_in, c_out, ts, s_arr, d_sigma, s_up
 
-    def sample_device(self, cond, uncond, steps: int = 20, seed: int = 42, latent_shape=(1, 4, 64, 64), guidance: float = 7.0) -> np.ndarray:
+    def sample_device(self, cond, uncond, steps: int = 20, seed: int = 42, latent_shape=(1, 4, 64, 64), guidance: float = 7.0,
+                      init_latent: Optional[np.ndarray] = None, step_noise: Optional[Callable[[int], np.ndarray]] = None) -> np.ndarray:
         """sample() with the whole loop enqueued on the GPU (HIP backend only): per step a scaling kernel fills the UNet's input staging,
         the captured pass is launched, and one kernel does eps -> denoised, the CFG combine and the Euler-Ancestral update -- no host
         round trip until the last step.  Same schedule, same random stream, same fp32 operation order as sample(): the two agree bit
@@ -187,11 +224,12 @@ class Txt2Img:
         unconds = list(uncond) if isinstance(uncond, (list, tuple)) else [uncond] * P
         sig = sigma_schedule(steps, self.log_sigmas)
         rng = np.random.default_rng(seed)
-        x = np.ascontiguousarray(rng.standard_normal(latent_shape, dtype=f32) * sig[0], f32)
+        x0 = rng.standard_normal(latent_shape, dtype=f32) if init_latent is None else np.asarray(init_latent, f32).reshape(latent_shape)
+        x = np.ascontiguousarray(x0 * f32(sig[0]), f32)
         noise = np.empty((steps,) + tuple(latent_shape), f32)
-        c_in, c_out, ts, k_down, k_up = self.loop_scalars(sig)
+        c_in, c_out, ts, s_arr, d_sigma, s_up = self.loop_scalars(sig)
         for i in range(steps):
-            noise[i] = rng.standard_normal(latent_shape, dtype=f32)
+            noise[i] = rng.standard_normal(latent_shape, dtype=f32) if step_noise is None else np.asarray(step_noise(i), f32).reshape(latent_shape)
         key = (id(self.unet), P)
         if self._dev_ready.get(key):
             for p in range(P):      # plan + captured pass exist: only the contexts change between images
@@ -204,7 +242,7 @@ class Txt2Img:
                 else:
                     self.denoise(x, float(sig[0]), conds[0], unconds[0], guidance)
             self._dev_ready[key] = True
-        self.last_loop_ms = self.unet.hip_sampler_loop(n["sample"], n["timestep"], n["out"], x, noise, c_in, c_out, ts, k_down, k_up, guidance)
+        self.last_loop_ms = self.unet.hip_sampler_loop(n["sample"], n["timestep"], n["out"], x, noise, c_in, c_out, ts, s_arr, d_sigma, s_up, guidance)
         return x
 
     def decode(self, latents: np.ndarray) -> np.ndarray:
