@@ -277,7 +277,7 @@ def test_device_sampler_loop_plumbing(stub_backend):
     ins = sd_unet.unet_inputs(sd_unet.TINY, 42)
     L = ins["sample"].shape
     steps = 3
-    sc = [np.full(steps, v, np.float32) for v in (0.5, -2.0, 900.0, 0.9, 0.1)]
+    sc = [np.full(steps, v, np.float32) for v in (0.5, -2.0, 900.0, 2.0, -0.3, 0.1)]
     with tempfile.TemporaryDirectory() as d:
         d += "/"
         sd_unet.build_unet(DirSink(d), sd_unet.TINY)
