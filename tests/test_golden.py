@@ -207,9 +207,13 @@ def test_measured_plan_choice_is_reproducible_from_a_tune_table(tmp_path, monkey
         else:
             assert open(table).read().strip().splitlines() == rows       # the seeded process measured nothing new
     assert np.array_equal(outs[0], outs[1])
+    # (the tuned plan is whatever the timer picked on this box -- err32 was seen between 4.6e-3 and 6.3e-3 across runs -- so this one run is
+    # held to the LARGER of the two hosts' reference drifts, 6.2e-3 on the GPU box's own EPYC; the deterministic plan is held to the smaller)
     ins, oname, r16, r32 = load("unet_tiny")
+    r16b = np.load(os.path.join(GOLD, "ref16_host2.npz"))["unet_tiny"]
     mx = float(np.abs(r32).max())
-    assert float(np.abs(outs[0] - r32).max()) / mx <= 1.5 * float(np.abs(r16 - r32).max()) / mx + 1e-3
+    noise = max(float(np.abs(r16 - r32).max()), float(np.abs(r16b - r32).max())) / mx
+    assert float(np.abs(outs[0] - r32).max()) / mx <= 1.5 * noise + 1e-3
 
 
 @pytest.mark.gpu
