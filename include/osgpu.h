@@ -241,6 +241,35 @@ int osg_maxpool_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, void* y, int 
 /* f16<->f32 ; u8->f32/f16: (float)((int)q - zp) * scale ; f32/f16->u8: clamp(rne(x * (1.0f/scale)) + zp, 0, 255). */
 int osg_convert(osg_ctx* ctx, osg_dtype src_dtype, osg_dtype dst_dtype, const void* x, void* y, long n, float scale, int zero_point);
 
+/* ---- uint8 arithmetic: the reference's m_use_uint8_arithmetic path (W8A8; the VAE decoder of `sd --rpi-lowmem`, src/sd.cpp:1212-1222) ------
+ * A uint8 tensor is (codes, scale, zero_point); every entry point reproduces the reference's codes BIT FOR BIT (specification:
+ * oracle/np_qu8.py, pinned against the reference's own intermediates).  Output (scale, zero_point) come from the caller: the host Model
+ * derives them from range_data.txt with Model::range_to_scale (onnxstream.cpp:3234), exactly as the reference does per op (:4664-4687). */
+/* XnnPack::convolution<uint8_t,int32_t> (onnxstream.cpp:1292, :1458-1491) + the bias rescaling of Model::run's Conv branch (:4639-4660):
+ * acc = sum (x - x_zp)(w - w_zp) on v_mfma_i32_16x16x64_i8 (padding taps hold x_zp, i.e. contribute 0) + (int32)(bias / (x_scale * w_scale)),
+ * then XNNPACK's fp32 requantisation  clamp(rne(float(acc) * (x_scale * w_scale / out_scale)))) + out_zp.  bias_f32: fp32 [Cout] or NULL. */
+int osg_qu8_conv2d_nhwc(osg_ctx* ctx, const void* x, float x_scale, int x_zp, const void* w_ohwi, float w_scale, int w_zp, const float* bias_f32,
+                        float out_scale, int out_zp, void* y, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride_h, int stride_w,
+                        int pad_top, int pad_left, int pad_bottom, int pad_right);
+/* XnnPack::matrix_multiply<uint8_t> (onnxstream.cpp:1035, Model::run MatMul uint8 branch :5779-5837): C[b] = requant(sum_k (A - a_zp)(B - b_zp)
+ * (+ bias)), A:[M,K] rows lda apart, B given K-contiguous as [N,K]; stride_* = element strides between batch items (0 = shared). */
+int osg_qu8_gemm(osg_ctx* ctx, const void* A, long lda, float a_scale, int a_zp, const void* B_nk, float b_scale, int b_zp, const float* bias_f32,
+                 float out_scale, int out_zp, void* C, int M, int N, int K, int batch, long stride_a, long stride_b, long stride_c);
+/* y[i] = lut[x[i]] with a 256-entry DEVICE table: Model::run's Sigmoid uint8 branch (onnxstream.cpp:4412-4481) is a function of the input code
+ * alone -- the host builds the table with its own expf (the function the reference calls) and the lookup is exact by construction. */
+int osg_qu8_lut(osg_ctx* ctx, const void* x, void* y, long n, const void* lut256);
+/* XnnPack::add / multiply with quint8 parameters (onnxstream.cpp:1666 / :846; Model::run :5105-5124 / :3977-3996), NumPy broadcasting like osg_binary:
+ * Mul = (a - a_zp)(b - b_zp) * (a_scale * b_scale / out_scale) in fp32, clamp, rne, + out_zp;  Add = XNNPACK's fixed-point add (20-bit multipliers). */
+int osg_qu8_binary(osg_ctx* ctx, osg_binary_kind kind, const void* a, const long* a_shape, float a_scale, int a_zp, const void* b, const long* b_shape,
+                   float b_scale, int b_zp, void* y, float out_scale, int out_zp, int rank);
+/* Model::run's InstanceNormalization uint8 branch (onnxstream.cpp:4987-5043) on [rows, L]: dequantise, mean / variance / affine in double as the
+ * reference does, requantise -- evaluated per distinct input code from the row's code histogram.  scale/bias: fp32 [n_scale] device vectors. */
+int osg_qu8_instance_norm(osg_ctx* ctx, const void* x, void* y, int rows, long L, int n_scale, const float* scale, const float* bias, float eps,
+                          float in_scale, int in_zp, float out_scale, int out_zp);
+/* XnnPack::softmax<uint8_t> (onnxstream.cpp:1958-2060 -> XNNPACK qu8 softmax): lut_u32_256 = DEVICE table t[i] = lrint(min(UINT32_MAX / C, 2^23 - 1) *
+ * exp((i - 255) * in_scale)) built by the host; y = min(255, ((t[x + 255 - rowmax] << 8) + (sum >> 1)) / sum); output scale 1/256, zero point 0. */
+int osg_qu8_softmax_last(osg_ctx* ctx, const void* x, void* y, long rows, long C, const void* lut_u32_256);
+
 #ifdef __cplusplus
 }
 #endif

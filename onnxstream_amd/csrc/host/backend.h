@@ -14,16 +14,23 @@
 
 namespace onnxstream {
 
+// every entry point of include/osgpu.h the host binds (one list: declaration of the table and its dlsym loop)
+#define OSG_API_LIST(X) \
+    X(osg_device_count) X(osg_init) X(osg_destroy) X(osg_last_error) X(osg_device_name) X(osg_stream) \
+    X(osg_set_autotune) X(osg_malloc) X(osg_free) X(osg_upload) X(osg_upload_sync) X(osg_host_register) \
+    X(osg_host_unregister) X(osg_upload_pinned) X(osg_download) X(osg_copy) X(osg_memset) X(osg_sync) \
+    X(osg_graph_begin) X(osg_graph_end) X(osg_graph_launch) X(osg_graph_destroy) X(osg_side_begin) X(osg_side_end) \
+    X(osg_side_join) X(osg_timer_start) X(osg_timer_stop) X(osg_conv2d_nhwc) X(osg_conv2d_nhwc_rb) X(osg_gemm) \
+    X(osg_gemm_ln) X(osg_gemm_rowstats) X(osg_gemm_w8) X(osg_conv2d_nhwc_w8) X(osg_transpose_kn_to_nk) X(osg_attention) \
+    X(osg_attention_strided) X(osg_instance_norm) X(osg_group_norm_nhwc) X(osg_group_norm_conv3x3_supported) X(osg_group_norm_conv3x3) X(osg_layer_norm) \
+    X(osg_reduce_mean_last) X(osg_softmax_last) X(osg_unary) X(osg_binary) X(osg_geglu) X(osg_transpose) \
+    X(osg_copy_2d) X(osg_concat2) X(osg_resize_nearest) X(osg_gather_rows) X(osg_maxpool_nhwc) X(osg_convert) \
+    X(osg_sampler_prepare) X(osg_sampler_cfg_euler_a) X(osg_qu8_conv2d_nhwc) X(osg_qu8_gemm) X(osg_qu8_lut) X(osg_qu8_binary) \
+    X(osg_qu8_instance_norm) X(osg_qu8_softmax_last)
+
 struct OsgApi {
 #define OSG_FN(name) decltype(&::name) name = nullptr;
-    OSG_FN(osg_device_count) OSG_FN(osg_init) OSG_FN(osg_destroy) OSG_FN(osg_last_error) OSG_FN(osg_device_name) OSG_FN(osg_stream) OSG_FN(osg_set_autotune)
-    OSG_FN(osg_malloc) OSG_FN(osg_free) OSG_FN(osg_upload) OSG_FN(osg_upload_sync) OSG_FN(osg_host_register) OSG_FN(osg_host_unregister) OSG_FN(osg_upload_pinned) OSG_FN(osg_download) OSG_FN(osg_copy)
-    OSG_FN(osg_memset) OSG_FN(osg_sync) OSG_FN(osg_graph_begin) OSG_FN(osg_graph_end) OSG_FN(osg_graph_launch)
-    OSG_FN(osg_graph_destroy) OSG_FN(osg_side_begin) OSG_FN(osg_side_end) OSG_FN(osg_side_join) OSG_FN(osg_timer_start) OSG_FN(osg_timer_stop) OSG_FN(osg_conv2d_nhwc) OSG_FN(osg_conv2d_nhwc_rb) OSG_FN(osg_gemm) OSG_FN(osg_gemm_ln) OSG_FN(osg_gemm_rowstats) OSG_FN(osg_gemm_w8) OSG_FN(osg_conv2d_nhwc_w8)
-    OSG_FN(osg_transpose_kn_to_nk) OSG_FN(osg_attention) OSG_FN(osg_attention_strided) OSG_FN(osg_instance_norm)
-    OSG_FN(osg_group_norm_nhwc) OSG_FN(osg_group_norm_conv3x3_supported) OSG_FN(osg_group_norm_conv3x3) OSG_FN(osg_layer_norm) OSG_FN(osg_reduce_mean_last) OSG_FN(osg_softmax_last) OSG_FN(osg_unary)
-    OSG_FN(osg_binary) OSG_FN(osg_geglu) OSG_FN(osg_transpose) OSG_FN(osg_copy_2d) OSG_FN(osg_concat2) OSG_FN(osg_resize_nearest)
-    OSG_FN(osg_gather_rows) OSG_FN(osg_maxpool_nhwc) OSG_FN(osg_convert) OSG_FN(osg_sampler_prepare) OSG_FN(osg_sampler_cfg_euler_a)
+    OSG_API_LIST(OSG_FN)
 #undef OSG_FN
 };
 
@@ -50,14 +57,7 @@ public:
 #define OSG_FN(name)                                                                                   \
     api.name = reinterpret_cast<decltype(api.name)>(dlsym(m_handle, #name));                           \
     if (!api.name) throw std::runtime_error(std::string("HipBackend: symbol missing in libosgpu.so: ") + #name);
-        OSG_FN(osg_device_count) OSG_FN(osg_init) OSG_FN(osg_destroy) OSG_FN(osg_last_error) OSG_FN(osg_device_name) OSG_FN(osg_stream) OSG_FN(osg_set_autotune)
-        OSG_FN(osg_malloc) OSG_FN(osg_free) OSG_FN(osg_upload) OSG_FN(osg_upload_sync) OSG_FN(osg_host_register) OSG_FN(osg_host_unregister) OSG_FN(osg_upload_pinned) OSG_FN(osg_download) OSG_FN(osg_copy)
-        OSG_FN(osg_memset) OSG_FN(osg_sync) OSG_FN(osg_graph_begin) OSG_FN(osg_graph_end) OSG_FN(osg_graph_launch)
-        OSG_FN(osg_graph_destroy) OSG_FN(osg_side_begin) OSG_FN(osg_side_end) OSG_FN(osg_side_join) OSG_FN(osg_timer_start) OSG_FN(osg_timer_stop) OSG_FN(osg_conv2d_nhwc) OSG_FN(osg_conv2d_nhwc_rb) OSG_FN(osg_gemm) OSG_FN(osg_gemm_ln) OSG_FN(osg_gemm_rowstats) OSG_FN(osg_gemm_w8) OSG_FN(osg_conv2d_nhwc_w8)
-        OSG_FN(osg_transpose_kn_to_nk) OSG_FN(osg_attention) OSG_FN(osg_attention_strided) OSG_FN(osg_instance_norm)
-        OSG_FN(osg_group_norm_nhwc) OSG_FN(osg_group_norm_conv3x3_supported) OSG_FN(osg_group_norm_conv3x3) OSG_FN(osg_layer_norm) OSG_FN(osg_reduce_mean_last) OSG_FN(osg_softmax_last) OSG_FN(osg_unary)
-        OSG_FN(osg_binary) OSG_FN(osg_geglu) OSG_FN(osg_transpose) OSG_FN(osg_copy_2d) OSG_FN(osg_concat2) OSG_FN(osg_resize_nearest)
-        OSG_FN(osg_gather_rows) OSG_FN(osg_maxpool_nhwc) OSG_FN(osg_convert) OSG_FN(osg_sampler_prepare) OSG_FN(osg_sampler_cfg_euler_a)
+        OSG_API_LIST(OSG_FN)
 #undef OSG_FN
         if (api.osg_device_count() <= 0)
             throw std::runtime_error("HipBackend: no HIP device visible; the MI355X backend has no CPU fallback");

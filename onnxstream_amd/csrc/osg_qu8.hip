@@ -1,0 +1,462 @@
+// libosgpu: uint8 arithmetic -- the device side of the reference's m_use_uint8_arithmetic (W8A8) path, i.e. of the XNNPACK qu8 operators
+// `class XnnPack` runs for it (reference src/onnxstream.cpp: convolution<uint8_t,int32_t> :1292 + :1458-1491, matrix_multiply<uint8_t> :1035,
+// add / multiply :1666 / :846 with quint8 params, softmax<uint8_t> :1958) and of the two inline uint8 branches of Model::run (Sigmoid
+// :4412-4481, InstanceNormalization :4987-5043).  The contract is BIT-EXACT codes (north_star: "bit-exact for int8 indexing"); the
+// arithmetic specification is oracle/np_qu8.py, itself pinned code for code against the reference's own intermediates.
+//
+//   contraction: acc = sum_k (x_k - zx)(w_k - zw) on v_mfma_i32_16x16x64_i8.  The MFMA is signed x signed, the codes are unsigned: both
+//     operands are re-biased by 128 on their way into LDS (x' = x ^ 0x80 = x - 128 as int8) and the identity
+//         sum (x'+a)(w'+b) = sum x'w' + b sum x' + a sum w' + K a b,     a = 128 - zx,  b = 128 - zw
+//     is closed in the epilogue: the row sums of x' and the column sums of w' are accumulated beside the MFMAs from the very fragments
+//     they consume (v_dot4c_i32_i8 against 0x01010101).  Convolution padding is the INPUT ZERO POINT, like XNNPACK's: an out-of-image tap
+//     is filled with zx, i.e. contributes exactly 0.  Then  + (int32)(bias / (sx sw))  (the reference's truncation, :4650-4656), fp32
+//     requantisation  float(acc) * ((sx sw) / so), clamp to [0 - zo, 255 - zo], round to nearest even, + zo  (XNNPACK "minmax fp32").
+//   elementwise: Mul = integer product + fp32 requantisation, Add = XNNPACK's 20-bit fixed-point multipliers, Sigmoid = a 256-entry table
+//     the host builds with its own expf, InstanceNormalization = per-row code histogram -> 256-entry table in f64 (the reference's double
+//     arithmetic on 256 distinct values) -> lookup, Softmax = XNNPACK's exp table + integer normalisation.
+#include "osg_common.h"
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+struct Q8Params {
+    const uint8_t* A;        // activation codes [M, K] (lda) or NHWC image (CONV)
+    const uint8_t* Bt;       // weight codes [N, K]
+    uint8_t* C;              // [M, N]
+    const float* bias;       // fp32 bias [N] or NULL
+    int M, N, K;
+    long lda;
+    long strideA, strideB, strideC;
+    int a_zp, b_zp, out_zp;
+    float ab_scale, out_scale;   // sx * sw (float product formed on the host), so
+    int H, W, Cin, Ho, Wo, KW, sh, sw, pt, pl;
+};
+
+__device__ __forceinline__ uint8_t q8_requant(int acc, float scale, int out_zp) {
+#pragma clang fp contract(off)
+    float v = (float)acc * scale;
+    v = fminf(fmaxf(v, (float)(0 - out_zp)), (float)(255 - out_zp));
+    return (uint8_t)((int)__builtin_rintf(v) + out_zp);
+}
+
+// C[M,N] = requant( sum_k (A[m,k]-za)(Bt[n,k]-zb) + bias ).  64x64 tile, BK = 64 codes = one v_mfma_i32_16x16x64_i8 deep, 256 threads
+// = 2x2 waves of 32x32; global -> registers -> LDS (row stride 80 B: conflict-free ds_read_b128), double-buffered.
+// VEC: 16-byte chunks (K % 16 == 0, rows 16-byte aligned; CONV: Cin % 16 == 0 so a chunk never straddles a filter tap).
+template <bool CONV, bool VEC>
+__global__ __launch_bounds__(256) void q8_gemm_kernel(Q8Params p) {
+    constexpr int BM = 64, BN = 64, BK = 64, LDSW = BK + 16;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[2][(BM + BN) * LDSW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, zb = blockIdx.z;
+    const uint8_t* __restrict__ A = p.A + (long)zb * p.strideA;
+    const uint8_t* __restrict__ Bt = p.Bt + (long)zb * p.strideB;
+    const int row = tid >> 2, kc = (tid & 3) * 16;       // this thread stages one 16-byte chunk of A and one of B per k-tile
+
+    // A row state
+    const int am = m0 + row;
+    const bool a_ok = am < p.M;
+    long a_off = 0;
+    int hi0 = 0, wi0 = 0;
+    if (CONV) {
+        const int mm = a_ok ? am : 0, hw = p.Ho * p.Wo, n_img = mm / hw, rem = mm - n_img * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        a_off = (long)n_img * p.H * p.W * p.Cin;
+        hi0 = ho * p.sh - p.pt;
+        wi0 = wo * p.sw - p.pl;
+    } else
+        a_off = (long)(a_ok ? am : 0) * p.lda;
+    const int bn = n0 + row;
+    const bool b_ok = bn < p.N;
+    const long b_off = (long)(b_ok ? bn : 0) * p.K;
+    const unsigned pad4 = ((unsigned)(p.a_zp ^ 0x80) & 0xffu) * 0x01010101u;   // a padding tap holds the input zero point (re-biased)
+
+    v4i areg, breg;
+    auto load_tile = [&](int k0) {
+        const int k = k0 + kc;
+        if (VEC) {
+            v4i va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
+            if (k < p.K) {
+                if (CONV) {
+                    const int cell = k / p.Cin, c = k - cell * p.Cin, kh = cell / p.KW, kw = cell - kh * p.KW;
+                    const int hi = hi0 + kh, wi = wi0 + kw;
+                    if (a_ok) {
+                        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
+                            va = *reinterpret_cast<const v4i*>(A + a_off + ((long)hi * p.W + wi) * p.Cin + c);
+                            va ^= (int)0x80808080;
+                        } else
+                            va = v4i{(int)pad4, (int)pad4, (int)pad4, (int)pad4};
+                    }
+                } else if (a_ok) {
+                    va = *reinterpret_cast<const v4i*>(A + a_off + k);
+                    va ^= (int)0x80808080;
+                }
+                if (b_ok) {
+                    vb = *reinterpret_cast<const v4i*>(Bt + b_off + k);
+                    vb ^= (int)0x80808080;
+                }
+            }
+            areg = va;
+            breg = vb;
+        } else {
+            unsigned wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int ke = k + e;
+                unsigned xa = 0, xb = 0;     // beyond K: x' = w' = 0 (no contribution to any term)
+                if (ke < p.K) {
+                    if (a_ok) {
+                        if (CONV) {
+                            const int cell = ke / p.Cin, c = ke - cell * p.Cin, kh = cell / p.KW, kw = cell - kh * p.KW;
+                            const int hi = hi0 + kh, wi = wi0 + kw;
+                            const unsigned code = ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                                                      ? A[a_off + ((long)hi * p.W + wi) * p.Cin + c] : (unsigned)p.a_zp;
+                            xa = (code ^ 0x80u) & 0xffu;
+                        } else
+                            xa = ((unsigned)A[a_off + ke] ^ 0x80u) & 0xffu;
+                    }
+                    if (b_ok) xb = ((unsigned)Bt[b_off + ke] ^ 0x80u) & 0xffu;
+                }
+                wa[e >> 2] |= xa << ((e & 3) * 8);
+                wb[e >> 2] |= xb << ((e & 3) * 8);
+            }
+            areg = v4i{(int)wa[0], (int)wa[1], (int)wa[2], (int)wa[3]};
+            breg = v4i{(int)wb[0], (int)wb[1], (int)wb[2], (int)wb[3]};
+        }
+    };
+    auto store_tile = [&](int buf) {
+        *reinterpret_cast<v4i*>(&smem[buf][row * LDSW + kc]) = areg;
+        *reinterpret_cast<v4i*>(&smem[buf][(BM + row) * LDSW + kc]) = breg;
+    };
+
+    v4i acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = v4i{0, 0, 0, 0};
+    int rs[2] = {0, 0}, cs[2] = {0, 0};     // partial sums of x' over this lane's k-chunks of its activation rows / of w' of its weight rows
+
+    const int nkt = (p.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    const int frow = lane & 15, fk = (lane >> 4) * 16;
+    for (int kt = 0; kt < nkt; kt++) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) load_tile((kt + 1) * BK);
+        v4i xa[2], wb[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) xa[i] = *reinterpret_cast<const v4i*>(&smem[cur][(wm0 + i * 16 + frow) * LDSW + fk]);
+#pragma unroll
+        for (int j = 0; j < 2; j++) wb[j] = *reinterpret_cast<const v4i*>(&smem[cur][(BM + wn0 + j * 16 + frow) * LDSW + fk]);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wb[j], xa[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                rs[i] = __builtin_amdgcn_sdot4(xa[i][e], 0x01010101, rs[i], false);
+                cs[i] = __builtin_amdgcn_sdot4(wb[i][e], 0x01010101, cs[i], false);
+            }
+        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+    // the four 16-lane groups hold different k-chunks of the same rows
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        rs[i] += __shfl_xor(rs[i], 16, 64); rs[i] += __shfl_xor(rs[i], 32, 64);
+        cs[i] += __shfl_xor(cs[i], 16, 64); cs[i] += __shfl_xor(cs[i], 32, 64);
+    }
+    const int az = 128 - p.a_zp, bz = 128 - p.b_zp;
+    const int kab = p.K * az * bz;
+    float scale;
+    {
+#pragma clang fp contract(off)
+        scale = p.ab_scale / p.out_scale;
+    }
+    uint8_t* __restrict__ C = p.C + (long)zb * p.strideC;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int m = m0 + wm0 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int nb = n0 + wn0 + j * 16 + (lane >> 4) * 4;
+            uint8_t o[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                // acc register r of this lane = output channel nb + r: its column sum lives in the lanes whose (lane & 15) is that row of the fragment
+                const int csn = __shfl(cs[j], (lane >> 4) * 4 + r, 64);
+                int t = acc[i][j][r] + bz * rs[i] + az * csn + kab;
+                const int n = nb + r;
+                if (p.bias && n < p.N) {
+#pragma clang fp contract(off)
+                    t += (int)(p.bias[n] / p.ab_scale);      // (int32_t)(b / (x_scale * w_scale)): truncation, reference :4650-4656
+                }
+                o[r] = q8_requant(t, scale, p.out_zp);
+            }
+            if (m < p.M) {
+                if (nb + 3 < p.N && ((p.N & 3) == 0)) {
+                    *reinterpret_cast<unsigned*>(C + (long)m * p.N + nb) = (unsigned)o[0] | ((unsigned)o[1] << 8) | ((unsigned)o[2] << 16) | ((unsigned)o[3] << 24);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (nb + r < p.N) C[(long)m * p.N + nb + r] = o[r];
+                }
+            }
+        }
+    }
+}
+
+int launch_q8(osg_ctx* ctx, const Q8Params& p, int batch, bool conv) {
+    const bool al = ((((uintptr_t)p.A | (uintptr_t)p.Bt) & 15) == 0) && p.strideA % 16 == 0 && p.strideB % 16 == 0;
+    const bool vec = al && p.K % 16 == 0 && (conv ? p.Cin % 16 == 0 : p.lda % 16 == 0);
+    dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, batch);
+    if (grid.y > 65535u) OSG_FAIL(ctx, "osg_qu8: M too large for one launch");
+    if (conv) {
+        if (vec) hipLaunchKernelGGL((q8_gemm_kernel<true, true>), grid, dim3(256), 0, ctx->compute, p);
+        else hipLaunchKernelGGL((q8_gemm_kernel<true, false>), grid, dim3(256), 0, ctx->compute, p);
+    } else {
+        if (vec) hipLaunchKernelGGL((q8_gemm_kernel<false, true>), grid, dim3(256), 0, ctx->compute, p);
+        else hipLaunchKernelGGL((q8_gemm_kernel<false, false>), grid, dim3(256), 0, ctx->compute, p);
+    }
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+// ---- elementwise ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void q8_lut_kernel(const uint8_t* __restrict__ x, uint8_t* __restrict__ y, long n, const uint8_t* __restrict__ lut) {
+    __shared__ uint8_t t[256];
+    t[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = t[x[i]];
+}
+
+constexpr int kMaxRank = 6;
+struct Q8Bcast {
+    long oshape[kMaxRank], astride[kMaxRank], bstride[kMaxRank];
+    int rank;
+};
+struct Q8Bin {
+    int a_zp, b_zp, out_zp;
+    float scale;                 // MUL: (sa * sb) / so
+    int a_mult, b_mult, bias;    // ADD: XNNPACK fixed point
+    unsigned shift;
+};
+
+template <int KIND>   // 0 add, 1 mul
+__global__ __launch_bounds__(256) void q8_binary_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint8_t* __restrict__ y, long n,
+                                                        Q8Bcast p, Q8Bin q) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        long rem = i, ao = 0, bo = 0;
+#pragma unroll
+        for (int d = kMaxRank - 1; d >= 0; d--)
+            if (d < p.rank) {
+                const long qd = rem / p.oshape[d], idx = rem - qd * p.oshape[d];
+                rem = qd;
+                ao += idx * p.astride[d];
+                bo += idx * p.bstride[d];
+            }
+        const int av = a[ao], bv = b[bo];
+        if (KIND == 1) {
+            y[i] = q8_requant((av - q.a_zp) * (bv - q.b_zp), q.scale, q.out_zp);
+        } else {
+            const int acc = q.bias + av * q.a_mult + bv * q.b_mult;
+            const int o = (acc >> q.shift) + q.out_zp;
+            y[i] = (uint8_t)min(max(o, 0), 255);
+        }
+    }
+}
+
+__device__ __forceinline__ uint8_t q8_quantize(float x, float inv_scale, int zp) {
+#pragma clang fp contract(off)
+    float r = __builtin_rintf(x * inv_scale) + (float)zp;
+    r = fminf(fmaxf(r, 0.0f), 255.0f);
+    return (uint8_t)r;
+}
+
+// InstanceNormalization on [rows, L] codes: one workgroup per row.  Histogram of the row's codes -> mean / variance from the histogram in
+// f64 exactly as the reference accumulates them over the elements (the dequantised values are 256 distinct floats; products count x value
+// and their sums stay below 2^53 ulps, so the order of the additions cannot matter) -> the output code of every input code -> lookup.
+__global__ __launch_bounds__(256) void q8_instance_norm_kernel(const uint8_t* __restrict__ x, uint8_t* __restrict__ y, long L, int n_scale,
+                                                               const float* __restrict__ scale, const float* __restrict__ bias, float eps,
+                                                               float in_scale, int in_zp, float out_scale, int out_zp) {
+#pragma clang fp contract(off)
+    __shared__ unsigned hist[256];
+    __shared__ float deq[256];
+    __shared__ double stat[2];
+    __shared__ uint8_t lut[256];
+    const int row = blockIdx.x, c = threadIdx.x;
+    const uint8_t* __restrict__ xr = x + (long)row * L;
+    uint8_t* __restrict__ yr = y + (long)row * L;
+    hist[c] = 0;
+    deq[c] = (float)(c - in_zp) * in_scale;
+    __syncthreads();
+    for (long i = c; i < L; i += 256) atomicAdd(&hist[xr[i]], 1u);
+    __syncthreads();
+    if (c == 0) {
+        double mean = 0;
+        for (int k = 0; k < 256; k++) mean += (double)hist[k] * (double)deq[k];
+        mean /= (double)L;
+        double var = 0;
+        for (int k = 0; k < 256; k++) {
+            const float dev = (float)((double)deq[k] - mean);
+            var += (double)hist[k] * (double)(dev * dev);
+        }
+        var /= (double)L;
+        stat[0] = mean;
+        stat[1] = sqrt(var + (double)eps);
+    }
+    __syncthreads();
+    {
+        const double sc = (double)scale[row % n_scale], bi = (double)bias[row % n_scale];
+        const float v = (float)(sc * ((double)deq[c] - stat[0]) / stat[1] + bi);
+        const float inv = 1.0f / out_scale;
+        lut[c] = q8_quantize(v, inv, out_zp);
+    }
+    __syncthreads();
+    for (long i = c; i < L; i += 256) yr[i] = lut[xr[i]];
+}
+
+// XNNPACK qu8 softmax over the last axis, one workgroup per row: t = host-built exp table (uint32[256]);
+// y = min(255, ((t[x + 255 - max] << 8) + (sum >> 1)) / sum)
+__global__ __launch_bounds__(256) void q8_softmax_kernel(const uint8_t* __restrict__ x, uint8_t* __restrict__ y, long C, const unsigned* __restrict__ lut) {
+    __shared__ unsigned t[256];
+    __shared__ unsigned red[4];
+    const uint8_t* __restrict__ xr = x + (long)blockIdx.x * C;
+    uint8_t* __restrict__ yr = y + (long)blockIdx.x * C;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    t[tid] = lut[tid];
+    unsigned mx = 0;
+    for (long i = tid; i < C; i += 256) mx = max(mx, (unsigned)xr[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = max(max(red[0], red[1]), max(red[2], red[3]));
+    __syncthreads();
+    const unsigned off = 255u - mx;
+    unsigned sum = 0;
+    for (long i = tid; i < C; i += 256) sum += t[xr[i] + off];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += (unsigned)__shfl_xor((int)sum, o, 64);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    sum = red[0] + red[1] + red[2] + red[3];
+    for (long i = tid; i < C; i += 256) {
+        const unsigned long long q = (((unsigned long long)t[xr[i] + off] << 8) + (sum >> 1)) / sum;
+        yr[i] = q > 255ull ? (uint8_t)255 : (uint8_t)q;
+    }
+}
+
+inline unsigned grid_for(long work_items) {
+    long blocks = (work_items + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    return (unsigned)blocks;
+}
+
+}  // namespace
+
+extern "C" {
+
+int osg_qu8_gemm(osg_ctx* ctx, const void* A, long lda, float a_scale, int a_zp, const void* B_nk, float b_scale, int b_zp, const float* bias_f32,
+                 float out_scale, int out_zp, void* C, int M, int N, int K, int batch, long stride_a, long stride_b, long stride_c) {
+    if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) OSG_FAIL(ctx, "osg_qu8_gemm: invalid shape of inputs");
+    if (lda < K) OSG_FAIL(ctx, "osg_qu8_gemm: lda < K");
+    if (batch > 65535) OSG_FAIL(ctx, "osg_qu8_gemm: batch too large");
+    Q8Params p{};
+    p.A = (const uint8_t*)A; p.Bt = (const uint8_t*)B_nk; p.C = (uint8_t*)C; p.bias = bias_f32;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.strideA = stride_a; p.strideB = stride_b; p.strideC = stride_c;
+    p.a_zp = a_zp; p.b_zp = b_zp; p.out_zp = out_zp;
+    p.ab_scale = a_scale * b_scale;
+    p.out_scale = out_scale;
+    return launch_q8(ctx, p, batch, false);
+}
+
+int osg_qu8_conv2d_nhwc(osg_ctx* ctx, const void* x, float x_scale, int x_zp, const void* w_ohwi, float w_scale, int w_zp, const float* bias_f32,
+                        float out_scale, int out_zp, void* y, int N, int H, int W, int Cin, int Cout, int KH, int KW, int sh, int sw, int pt, int pl,
+                        int pb, int pr) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || sh <= 0 || sw <= 0) OSG_FAIL(ctx, "osg_qu8_conv2d_nhwc: invalid argument");
+    const int Ho = (H + pt + pb - KH) / sh + 1, Wo = (W + pl + pr - KW) / sw + 1;
+    if (Ho <= 0 || Wo <= 0) OSG_FAIL(ctx, "osg_qu8_conv2d_nhwc: empty output");
+    Q8Params p{};
+    p.A = (const uint8_t*)x; p.Bt = (const uint8_t*)w_ohwi; p.C = (uint8_t*)y; p.bias = bias_f32;
+    p.M = N * Ho * Wo; p.N = Cout; p.K = KH * KW * Cin; p.lda = 0;
+    p.a_zp = x_zp; p.b_zp = w_zp; p.out_zp = out_zp;
+    p.ab_scale = x_scale * w_scale;
+    p.out_scale = out_scale;
+    p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.KW = KW; p.sh = sh; p.sw = sw; p.pt = pt; p.pl = pl;
+    return launch_q8(ctx, p, 1, true);
+}
+
+int osg_qu8_lut(osg_ctx* ctx, const void* x, void* y, long n, const void* lut256) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(q8_lut_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->compute, (const uint8_t*)x, (uint8_t*)y, n, (const uint8_t*)lut256);
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int osg_qu8_binary(osg_ctx* ctx, osg_binary_kind kind, const void* a, const long* a_shape, float a_scale, int a_zp, const void* b, const long* b_shape,
+                   float b_scale, int b_zp, void* y, float out_scale, int out_zp, int rank) {
+    if (rank < 1 || rank > kMaxRank) OSG_FAIL(ctx, "osg_qu8_binary: rank must be in [1,6]");
+    if (kind != OSG_BIN_ADD && kind != OSG_BIN_MUL) OSG_FAIL(ctx, "osg_qu8_binary: only Add and Mul have a uint8 branch (reference :3977, :5105)");
+    Q8Bcast p{};
+    p.rank = rank;
+    long as = 1, bs = 1, n = 1;
+    for (int d = rank - 1; d >= 0; d--) {
+        if (a_shape[d] != b_shape[d] && a_shape[d] != 1 && b_shape[d] != 1) OSG_FAIL(ctx, "osg_qu8_binary: shapes are not broadcastable");
+        p.oshape[d] = a_shape[d] > b_shape[d] ? a_shape[d] : b_shape[d];
+        p.astride[d] = a_shape[d] == 1 ? 0 : as;
+        p.bstride[d] = b_shape[d] == 1 ? 0 : bs;
+        as *= a_shape[d];
+        bs *= b_shape[d];
+        n *= p.oshape[d];
+    }
+    Q8Bin q{};
+    q.a_zp = a_zp; q.b_zp = b_zp; q.out_zp = out_zp;
+    if (kind == OSG_BIN_MUL) {
+        q.scale = (a_scale * b_scale) / out_scale;
+        hipLaunchKernelGGL(q8_binary_kernel<1>, dim3(grid_for(n)), dim3(256), 0, ctx->compute, (const uint8_t*)a, (const uint8_t*)b, (uint8_t*)y, n, p, q);
+    } else {
+        // XNNPACK qu8 add: the two input/output scale ratios as integer multipliers, 20 bits for the larger one, rounding folded into the bias
+        const float a_os = a_scale / out_scale, b_os = b_scale / out_scale;
+        const float mx = a_os > b_os ? a_os : b_os;
+        unsigned bits;
+        memcpy(&bits, &mx, 4);
+        const int exponent = (int)(bits >> 23) - 127;
+        const int shift = 20 - exponent;
+        if (shift < 1 || shift > 31) OSG_FAIL(ctx, "osg_qu8_binary: scale ratio out of the range of the fixed-point add");
+        q.shift = (unsigned)shift;
+        q.a_mult = (int)lrintf(ldexpf(a_os, shift));
+        q.b_mult = (int)lrintf(ldexpf(b_os, shift));
+        q.bias = (int)((1u << (shift - 1)) - (unsigned)(q.a_mult * a_zp) - (unsigned)(q.b_mult * b_zp));
+        hipLaunchKernelGGL(q8_binary_kernel<0>, dim3(grid_for(n)), dim3(256), 0, ctx->compute, (const uint8_t*)a, (const uint8_t*)b, (uint8_t*)y, n, p, q);
+    }
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int osg_qu8_instance_norm(osg_ctx* ctx, const void* x, void* y, int rows, long L, int n_scale, const float* scale, const float* bias, float eps,
+                          float in_scale, int in_zp, float out_scale, int out_zp) {
+    if (rows <= 0 || L <= 0 || n_scale <= 0) OSG_FAIL(ctx, "osg_qu8_instance_norm: invalid shape");
+    hipLaunchKernelGGL(q8_instance_norm_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->compute, (const uint8_t*)x, (uint8_t*)y, L, n_scale, scale, bias, eps,
+                       in_scale, in_zp, out_scale, out_zp);
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int osg_qu8_softmax_last(osg_ctx* ctx, const void* x, void* y, long rows, long C, const void* lut_u32_256) {
+    if (rows <= 0 || C <= 0) return 0;
+    if (rows > 2147483647L) OSG_FAIL(ctx, "osg_qu8_softmax_last: too many rows");
+    hipLaunchKernelGGL(q8_softmax_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->compute, (const uint8_t*)x, (uint8_t*)y, C, (const unsigned*)lut_u32_256);
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+}  // extern "C"

@@ -28,6 +28,7 @@ EXPORTS = [
     "osg_instance_norm", "osg_group_norm_nhwc", "osg_group_norm_conv3x3_supported", "osg_group_norm_conv3x3", "osg_layer_norm", "osg_reduce_mean_last", "osg_softmax_last",
     "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_concat2", "osg_resize_nearest", "osg_gather_rows",
     "osg_maxpool_nhwc", "osg_convert", "osg_sampler_prepare", "osg_sampler_cfg_euler_a",
+    "osg_qu8_conv2d_nhwc", "osg_qu8_gemm", "osg_qu8_lut", "osg_qu8_binary", "osg_qu8_instance_norm", "osg_qu8_softmax_last",
 ]
 
 
@@ -94,6 +95,12 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_gemm_rowstats.argtypes = [vp, vp, vp, vp, ci, vp, vp, ci, ci, ci, ci, vp]
     lib.osg_sampler_prepare.argtypes = [vp, vp, vp, vp, ci, cl, cf, cf, cl]
     lib.osg_sampler_cfg_euler_a.argtypes = [vp, vp, vp, vp, ci, cl, cf, cf, cf, cf, cf, cf]
+    lib.osg_qu8_conv2d_nhwc.argtypes = [vp, vp, cf, ci, vp, cf, ci, vp, cf, ci, vp] + [ci] * 13
+    lib.osg_qu8_gemm.argtypes = [vp, vp, cl, cf, ci, vp, cf, ci, vp, cf, ci, vp, ci, ci, ci, ci, cl, cl, cl]
+    lib.osg_qu8_lut.argtypes = [vp, vp, vp, cl, vp]
+    lib.osg_qu8_binary.argtypes = [vp, ci, vp, ctypes.POINTER(cl), cf, ci, vp, ctypes.POINTER(cl), cf, ci, vp, cf, ci, ci]
+    lib.osg_qu8_instance_norm.argtypes = [vp, vp, vp, ci, cl, ci, vp, vp, cf, cf, ci, cf, ci]
+    lib.osg_qu8_softmax_last.argtypes = [vp, vp, vp, cl, cl, vp]
     return lib
 
 
@@ -360,4 +367,57 @@ class Gpu:
     def convert(self, x: DevBuf, dtype, scale: float = 1.0, zero_point: int = 0):
         y = self.empty(x.shape, dtype)
         self._ck(self.lib.osg_convert(self.ctx, _NP2DT[x.dtype], _NP2DT[np.dtype(dtype)], x.ptr, y.ptr, x.size, scale, zero_point))
+        return y
+
+    # ---- uint8 arithmetic (a uint8 tensor = codes DevBuf + (scale, zero_point)) ----
+    def qu8_conv2d_nhwc(self, x: DevBuf, xq, w: DevBuf, wq, bias: Optional[DevBuf], oq, stride=1, pads=(1, 1, 1, 1)):
+        n, h, wd, cin = x.shape
+        cout, kh, kw, _ = w.shape
+        sh, sw = (stride, stride) if isinstance(stride, int) else stride
+        pt, pl, pb, pr = pads
+        ho, wo = (h + pt + pb - kh) // sh + 1, (wd + pl + pr - kw) // sw + 1
+        y = self.empty((n, ho, wo, cout), np.uint8)
+        self._ck(self.lib.osg_qu8_conv2d_nhwc(self.ctx, x.ptr, float(xq[0]), int(xq[1]), w.ptr, float(wq[0]), int(wq[1]), self._p(bias), float(oq[0]), int(oq[1]),
+                                              y.ptr, n, h, wd, cin, cout, kh, kw, sh, sw, pt, pl, pb, pr))
+        return y
+
+    def qu8_gemm(self, a: DevBuf, aq, b_nk: DevBuf, bq, bias: Optional[DevBuf], oq):
+        """a:[(batch,)M,K], b_nk:[(batch,)N,K] codes."""
+        batch = a.shape[0] if len(a.shape) == 3 else 1
+        m, k = a.shape[-2:]
+        n = b_nk.shape[-2]
+        c = self.empty(a.shape[:-1] + (n,), np.uint8)
+        self._ck(self.lib.osg_qu8_gemm(self.ctx, a.ptr, k, float(aq[0]), int(aq[1]), b_nk.ptr, float(bq[0]), int(bq[1]), self._p(bias), float(oq[0]), int(oq[1]),
+                                       c.ptr, m, n, k, batch, m * k if batch > 1 else 0, n * k if len(b_nk.shape) == 3 else 0, m * n if batch > 1 else 0))
+        return c
+
+    def qu8_lut(self, x: DevBuf, lut: np.ndarray):
+        y = self.empty(x.shape, np.uint8)
+        t = self.to_dev(np.ascontiguousarray(lut, np.uint8))
+        self._ck(self.lib.osg_qu8_lut(self.ctx, x.ptr, y.ptr, x.size, t.ptr))
+        self.sync()
+        return y
+
+    def qu8_binary(self, kind: str, a: DevBuf, aq, b: DevBuf, bq, oq):
+        rank = max(len(a.shape), len(b.shape))
+        ash = (1,) * (rank - len(a.shape)) + a.shape
+        bsh = (1,) * (rank - len(b.shape)) + b.shape
+        y = self.empty(tuple(np.broadcast_shapes(ash, bsh)), np.uint8)
+        A = (ctypes.c_long * rank)(*ash)
+        B = (ctypes.c_long * rank)(*bsh)
+        self._ck(self.lib.osg_qu8_binary(self.ctx, BIN[kind], a.ptr, A, float(aq[0]), int(aq[1]), b.ptr, B, float(bq[0]), int(bq[1]), y.ptr, float(oq[0]), int(oq[1]), rank))
+        return y
+
+    def qu8_instance_norm(self, x: DevBuf, xq, scale: DevBuf, bias: DevBuf, eps: float, oq):
+        rows, L = int(np.prod(x.shape[:-1])), x.shape[-1]
+        y = self.empty(x.shape, np.uint8)
+        self._ck(self.lib.osg_qu8_instance_norm(self.ctx, x.ptr, y.ptr, rows, L, scale.size, scale.ptr, bias.ptr, eps, float(xq[0]), int(xq[1]), float(oq[0]), int(oq[1])))
+        return y
+
+    def qu8_softmax_last(self, x: DevBuf, lut_u32: np.ndarray):
+        rows, c = int(np.prod(x.shape[:-1])), x.shape[-1]
+        y = self.empty(x.shape, np.uint8)
+        t = self.to_dev(np.ascontiguousarray(lut_u32, np.uint32))
+        self._ck(self.lib.osg_qu8_softmax_last(self.ctx, x.ptr, y.ptr, rows, c, t.ptr))
+        self.sync()
         return y

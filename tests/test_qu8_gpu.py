@@ -1,0 +1,91 @@
+"""GPU: the uint8-arithmetic kernels (osg_qu8_*, onnxstream_amd/csrc/osg_qu8.hip) against the specification oracle/np_qu8.py -- the numpy
+restatement of the reference's uint8 ops that tests/test_qu8_oracle.py pins code for code against the reference's own intermediates.
+Everything here is BIT-EXACT (north_star: "bit-exact for int8 indexing"): array_equal on the codes, through the C ABI."""
+import numpy as np
+import pytest
+
+from oracle import np_qu8 as Q
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def _codes(rng, shape):
+    return rng.integers(0, 256, shape, dtype=np.uint8)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,pad", [(1, 12, 10, 32, 48, 3, 1, 1), (2, 9, 7, 16, 20, 3, 2, 1), (1, 16, 16, 4, 32, 3, 1, 1),
+                                                         (1, 8, 8, 64, 64, 1, 1, 0), (1, 20, 20, 128, 3, 3, 1, 1), (1, 5, 6, 20, 30, 3, 1, 1),
+                                                         (1, 64, 64, 128, 128, 3, 1, 1), (1, 33, 31, 48, 70, 3, 1, 1)])
+def test_qu8_conv(gpu, N, H, W, Cin, Cout, k, stride, pad):
+    rng = np.random.default_rng(Cin * 100 + Cout + k)
+    x, w = _codes(rng, (N, H, W, Cin)), _codes(rng, (Cout, k, k, Cin))
+    sx, zx, sw, zw = f32(0.0173), 117, f32(0.0042), 131
+    bias = (rng.standard_normal(Cout) * 0.5).astype(f32)
+    so, zo = f32(float(sx) * float(sw) * np.sqrt(k * k * Cin) * 75.0 / 2.0), 120
+    for b in (bias, None):
+        want = Q.conv2d_nhwc_u8(x, sx, zx, w, sw, zw, b, (pad,) * 4, (stride, stride), so, zo)
+        got = gpu.qu8_conv2d_nhwc(gpu.to_dev(x), (sx, zx), gpu.to_dev(w), (sw, zw), gpu.to_dev(b) if b is not None else None, (so, zo), stride, (pad,) * 4).numpy()
+        assert want.min() < 30 and want.max() > 220          # the output range is exercised, saturation included
+        assert np.array_equal(got, want), int((got != want).sum())
+
+
+@pytest.mark.parametrize("batch,M,N,K", [(1, 77, 64, 128), (1, 200, 96, 40), (3, 64, 64, 64), (2, 50, 33, 48), (1, 256, 256, 512), (1, 5, 3, 7)])
+def test_qu8_gemm(gpu, batch, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    a = _codes(rng, (batch, M, K) if batch > 1 else (M, K))
+    b = _codes(rng, (batch, K, N) if batch > 1 else (K, N))
+    sa, za, sb, zb = f32(0.021), 140, f32(0.0105), 99
+    so, zo = f32(float(sa) * float(sb) * np.sqrt(K) * 75.0 / 2.0), 128
+    want = Q.matmul_u8(a, sa, za, b, sb, zb, so, zo)
+    b_nk = np.ascontiguousarray(np.swapaxes(b, -1, -2))
+    got = gpu.qu8_gemm(gpu.to_dev(a), (sa, za), gpu.to_dev(b_nk), (sb, zb), None, (so, zo)).numpy()
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
+def test_qu8_sigmoid_lut(gpu):
+    rng = np.random.default_rng(3)
+    x = _codes(rng, (1, 32, 16, 16))
+    si, zi, so, zo = f32(0.0713), 130, f32(1.0 / 255), 0
+    lut = Q.sigmoid_u8(np.arange(256, dtype=np.uint8), si, zi, so, zo)
+    got = gpu.qu8_lut(gpu.to_dev(x), lut).numpy()
+    assert np.array_equal(got, Q.sigmoid_u8(x, si, zi, so, zo))
+
+
+@pytest.mark.parametrize("kind", ["add", "mul"])
+@pytest.mark.parametrize("ash,bsh", [((1, 16, 16, 32), (1, 16, 16, 32)), ((1, 16, 16, 32), (32,)), ((1, 32, 8, 8), (32, 1, 1)), ((1, 7, 5), (1, 7, 5)),
+                                     ((4, 64, 64), (1,))])
+def test_qu8_binary(gpu, kind, ash, bsh):
+    rng = np.random.default_rng(len(ash) * 7 + len(bsh))
+    a, b = _codes(rng, ash), _codes(rng, bsh)
+    for (sa, za, sb, zb, so, zo) in ((f32(0.031), 120, f32(0.017), 131, f32(0.045 if kind == "add" else 0.0125), 125),
+                                    (f32(0.0042826), 0, f32(0.00154), 123, f32(0.0061 if kind == "add" else 0.00007), 40)):
+        fn = Q.add_u8 if kind == "add" else Q.mul_u8
+        want = fn(a, sa, za, b, sb, zb, so, zo)
+        got = gpu.qu8_binary(kind, gpu.to_dev(a), (sa, za), gpu.to_dev(b), (sb, zb), (so, zo)).numpy()
+        assert np.array_equal(got, np.broadcast_to(want, got.shape)), int((got != want).sum())
+
+
+@pytest.mark.parametrize("rows,L", [(8, 1024), (32, 4096), (3, 77), (16, 65536)])
+def test_qu8_instance_norm(gpu, rows, L):
+    rng = np.random.default_rng(rows + L)
+    # codes with structure (a bell around a per-row centre), like real activations
+    x = np.clip(np.rint(rng.standard_normal((1, rows, L)) * 35 + rng.integers(60, 190, (1, rows, 1))), 0, 255).astype(np.uint8)
+    si, zi, so, zo = f32(0.0193), 113, f32(0.0291), 128
+    scale = (1.0 + 0.1 * rng.standard_normal(rows)).astype(f32)
+    bias = (0.1 * rng.standard_normal(rows)).astype(f32)
+    want = Q.instance_norm_u8(x, si, zi, scale, bias, 1e-6, so, zo)
+    got = gpu.qu8_instance_norm(gpu.to_dev(x), (si, zi), gpu.to_dev(scale), gpu.to_dev(bias), 1e-6, (so, zo)).numpy()
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
+@pytest.mark.parametrize("rows,C", [(64, 64), (256, 4096), (5, 1000), (3, 7)])
+def test_qu8_softmax(gpu, rows, C):
+    rng = np.random.default_rng(rows * C)
+    x = np.clip(np.rint(rng.standard_normal((1, rows, C)) * 30 + 120), 0, 255).astype(np.uint8)
+    si = f32(0.0625)
+    want, so, zo = Q.softmax_u8(x, si, -1)
+    qscale = min(float(np.iinfo(np.uint32).max) / C, 8388607.0)
+    lut = np.rint(qscale * np.exp((np.arange(256, dtype=np.float64) - 255.0) * float(si))).astype(np.uint32)
+    got = gpu.qu8_softmax_last(gpu.to_dev(x), lut).numpy()
+    assert np.array_equal(got, want), int((got != want).sum())
