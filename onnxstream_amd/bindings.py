@@ -202,6 +202,16 @@ class Model:
                     clip.ctypes.data_as(fp) if clip is not None else None, ctypes.byref(ms)))
         return ms.value
 
+    def hip_read_range_data(self, filename: str):
+        f = self._lib.model_hip_read_range_data
+        f.argtypes = [ctypes.c_void_p, ctypes.c_char_p]; f.restype = ctypes.c_void_p
+        self._err(f(self._h, filename.encode()))
+
+    def hip_write_range_data(self, filename: str):
+        f = self._lib.model_hip_write_range_data
+        f.argtypes = [ctypes.c_void_p, ctypes.c_char_p]; f.restype = ctypes.c_void_p
+        self._err(f(self._h, filename.encode()))
+
     def hip_plan_info(self) -> str:
         """Steps (reads / writes / side-stream marks) and arena placement of the current plan, as text (Plan::info)."""
         f = self._lib.model_hip_plan_info

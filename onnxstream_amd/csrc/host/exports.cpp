@@ -226,6 +226,7 @@ void model_set_option(Handle* h, char* name, unsigned int value) {
     else if (n == "ops_printf") m.m_ops_printf = b;
     else if (n == "ops_times_printf") m.m_ops_times_printf = b;
     else if (n == "use_nchw_convs") m.m_use_nchw_convs = b;
+    else if (n == "range_data_calibrate") m.m_range_data_calibrate = b;
     // ---- backend additions ----
     else if (n == "attention_fused_ops_parts") m.m_attention_fused_ops_parts = value;
     else if (n == "hip_device") m.m_hip_device = (int)value;
@@ -300,6 +301,25 @@ char* model_hip_profile(Handle* h, int reps) {
         return dup_cstr(h->model.hip_profile(reps));
     } catch (const std::exception& e) {
         return dup_cstr(std::string("ERROR: ") + e.what());
+    }
+}
+
+// range_data.txt (per-op output ranges of a calibration run; src/sd.cpp:1214 reads it before the uint8 VAE decode, :1241 writes it after
+// --decoder-calibrate): Model::read_range_data / write_range_data have no export in the reference's C API (the app links the class)
+char* model_hip_read_range_data(Handle* h, const char* filename) {
+    try {
+        h->model.read_range_data(filename);
+        return nullptr;
+    } catch (const std::exception& e) {
+        return dup_cstr(e.what());
+    }
+}
+char* model_hip_write_range_data(Handle* h, const char* filename) {
+    try {
+        h->model.write_range_data(filename);
+        return nullptr;
+    } catch (const std::exception& e) {
+        return dup_cstr(e.what());
     }
 }
 

@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <cstring>
 
+#include <thread>
+
 #include "backend.h"
 #include "plan.h"
 
@@ -39,7 +41,11 @@ std::vector<std::string> split(const std::string& s, char delim) {
 
 }  // namespace
 
-Model::Model(int threads_count) { m_backend_wanted = threads_count >= 0; }
+Model::Model(int threads_count) {
+    m_backend_wanted = threads_count >= 0;
+    // XnnPack::XnnPack(threads): 0 = one worker per hardware thread (reference :678-687)
+    m_threads = threads_count > 0 ? (size_t)threads_count : std::max(1u, std::thread::hardware_concurrency());
+}
 
 Model::~Model() {
     delete m_plan;

@@ -609,6 +609,7 @@ private:
     CudaOptions m_cuda_options;
     HipBackend* m_backend = nullptr;       // takes the seat of `XnnPack* m_xnnpack` (reference :1036)
     bool m_backend_wanted = true;
+    size_t m_threads = 1;                  // the reference's pthreadpool size: only the chunking of get_percentiles depends on it (qu8.h)
     Plan* m_plan = nullptr;
     ConstPool* m_pool = nullptr;           // device-resident weights, kept across plan rebuilds (plan.h)
     size_t m_last_kernels = 0;

@@ -2,6 +2,7 @@
 // Per-op semantics follow the reference's Model::run branches (cited per function as reference src/onnxstream.cpp:LINE);
 // the error strings mirror the reference's so that callers matching on them keep working.
 #include "plan.h"
+#include "qu8.h"
 
 #include <algorithm>
 #include <cmath>
@@ -142,6 +143,9 @@ int Plan::alias(int v, const Shape& shape, Lay lay, const std::string& name) {
     a.batched = vals[v].batched;
     a.is_const = vals[v].is_const;
     a.root = v;
+    a.qscale = vals[v].qscale;
+    a.qzp = vals[v].qzp;
+    a.qdyn = vals[v].qdyn;
     a.host_f = vals[v].host_f;
     a.host_i = vals[v].host_i;
     a.host_valid = vals[v].host_valid;
@@ -149,6 +153,29 @@ int Plan::alias(int v, const Shape& shape, Lay lay, const std::string& name) {
     int id = (int)vals.size() - 1;
     if (!name.empty()) by_name[name] = id;
     return id;
+}
+
+const Val& Plan::qv(int v) const {
+    for (int guard = 0; guard < 64; guard++) {
+        if (vals[v].qsrc >= 0) v = vals[v].qsrc;
+        else if (vals[v].root >= 0) v = vals[v].root;
+        else break;
+    }
+    return vals[v];
+}
+
+void Plan::share_q(int dst, int src) {
+    if (vals[src].dtype != OSG_U8 || dst == src) return;
+    int s = src;
+    while (vals[s].qsrc < 0 && vals[s].root >= 0) s = vals[s].root;
+    if (vals[s].qsrc >= 0) s = vals[s].qsrc;
+    int d = dst;
+    while (vals[d].root >= 0) d = vals[d].root;
+    if (d == s) return;
+    vals[d].qsrc = s;
+    vals[d].qscale = vals[s].qscale;
+    vals[d].qzp = vals[s].qzp;
+    vals[d].qdyn = vals[s].qdyn;
 }
 
 long Plan::total_elems(int v) const { return vals[v].numel() * (vals[v].batched ? N : 1); }
@@ -199,6 +226,7 @@ int Plan::ensure_dense(int v) {
         be.check(be.api.osg_copy_2d(be.ctx, es, ptr(v), ld, 0, ptr(o), cols, 0, rows, cols), "osg_copy_2d");
     });
     vals[v].as_dense = o;
+    share_q(o, v);
     return o;
 }
 
@@ -225,6 +253,7 @@ int Plan::ensure_plain(int v) {
         be.check(be.api.osg_transpose(be.ctx, es, ptr(v), ptr(o), 3, shape, perm), "osg_transpose");
     });
     vals[v].as_plain = o;
+    share_q(o, v);
     return o;
 }
 
@@ -247,6 +276,7 @@ int Plan::ensure_nhwc(int v) {
         be.check(be.api.osg_transpose(be.ctx, es, ptr(v), ptr(o), 3, shape, perm), "osg_transpose");
     });
     vals[v].as_nhwc = o;
+    share_q(o, v);
     return o;
 }
 
@@ -305,13 +335,13 @@ struct Lowering {
             o.fn = o.fn.substr(0, pos) + "_nhwc.bin";
             o.lay = Lay::nhwc;
         }
-        const bool f32 = wants_f32(op, i) || !P.fp16;
+        const bool f32 = wants_f32(op, i) || !P.fp16 || P.u8;
         // W8A16: the weight operand of a contraction stays uint8 when the on-chip dequantising kernels take its shape;
         // W8A8 (m_use_uint8_arithmetic): every uint8 weight stays uint8 -- the integer kernels consume the codes
         bool keep_u8 = false;
-        if (ty == TensorDataType::uint8 && !f32) {
-            if (P.u8) keep_u8 = true;
-            else if (P.w8_resident && i == 1) {
+        if (ty == TensorDataType::uint8 && P.u8) keep_u8 = true;
+        else if (ty == TensorDataType::uint8 && !f32) {
+            if (P.w8_resident && i == 1) {
                 if (op.m_type == "Conv") keep_u8 = o.shape.size() == 4 && o.shape[1] % 64 == 0;                      // [O,I,kh,kw]: Cin % 64
                 else if (op.m_type == "MatMul" || op.m_type == "Gemm") keep_u8 = o.shape.size() == 2 && o.shape[0] % 64 == 0;   // [K,N]
             }
@@ -1181,6 +1211,299 @@ struct Lowering {
         return true;
     }
 
+    // ==================================================================================================================
+    // uint8 arithmetic (m_use_uint8_arithmetic; the reference's W8A8 path -- in practice the VAE decoder of `sd --rpi-lowmem`,
+    // src/sd.cpp:1212-1222).  One launch per graph op: every op re-quantises to its OWN (scale, zero point) -- derived from
+    // range_data.txt by Model::range_to_scale exactly where the reference derives them -- so nothing may be fused without changing
+    // codes.  Quantisation parameters are read from the vals at RUN time (a pushed input is quantised per run, reference :3024-3028).
+    // ==================================================================================================================
+    qu8::QParams out_q(const Operation& op) {
+        auto it = m.m_range_data.find(op.m_name);
+        if (it == m.m_range_data.end()) throw std::invalid_argument(op.m_type + ": range data not found.");
+        return qu8::range_to_scale(it->second.first, it->second.second);
+    }
+    int out_val_u8(const Operation& op, const Shape& shape, Lay lay, bool batched, qu8::QParams q) {
+        int y = out_val(op, shape, lay, batched, OSG_U8);
+        V(y).qscale = q.scale;
+        V(y).qzp = (int)q.zero_point;
+        return y;
+    }
+    void need_u8(const Operation& op, int v, const char* what) {
+        if (V(v).dtype != OSG_U8) throw std::invalid_argument(op.m_type + ": wrong data type of " + what + ".");
+    }
+    // a 256-byte device table that lives as long as the plan
+    void* lut_alloc(size_t bytes) {
+        void* p = be.malloc(bytes);
+        P.owned.push_back(p);
+        return p;
+    }
+
+    void lower_u8(const Operation& op) {
+        const std::string& t = op.m_type;
+        if (t == "Conv") return lower_conv_u8(op);
+        if (t == "MatMul") return lower_matmul_u8(op);
+        if (t == "Add" || t == "Mul") return lower_binary_u8(op);
+        if (t == "Sigmoid") return lower_sigmoid_u8(op);
+        if (t == "InstanceNormalization") return lower_instance_norm_u8(op);
+        if (t == "Softmax") return lower_softmax_u8(op);
+        if (t == "Reshape" || t == "Flatten" || t == "Unsqueeze" || t == "Squeeze" || t == "Transpose" || t == "Resize") {
+            // the codes are re-arranged, scale and zero point carried over (reference :4783, :5231, :6251)
+            const int x = in_val_raw(op.m_input[0]);
+            if (t == "Reshape") lower_reshape(op);
+            else if (t == "Flatten") lower_flatten(op);
+            else if (t == "Unsqueeze" || t == "Squeeze") lower_squeeze(op, t == "Unsqueeze");
+            else if (t == "Transpose") lower_transpose(op);
+            else lower_resize(op);
+            P.share_q(P.by_name.at(op.m_output[0].m_name), x);
+            return;
+        }
+        throw std::invalid_argument("Model::run: operation not implemented with uint8 arithmetic on the HIP backend: " + t);
+    }
+
+    // Conv, uint8 branch (reference :4629-4690 -> XnnPack::convolution<uint8_t,int32_t> :1292)
+    void lower_conv_u8(const Operation& op) {
+        need(op, op.m_input.size() == 2 || op.m_input.size() == 3, "wrong number of inputs.");
+        need(op, op.m_output.size() == 1, "wrong number of outputs.");
+        std::vector<int> dil = {1, 1}, ks, pads = {0, 0, 0, 0}, strides = {1, 1};
+        int group = 1;
+        for (auto& a : op.m_attributes) {
+            if (a.first == "dilations") dil = int_list(a.second);
+            else if (a.first == "group") group = std::stoi(a.second);
+            else if (a.first == "kernel_shape") ks = int_list(a.second);
+            else if (a.first == "pads") pads = int_list(a.second);
+            else if (a.first == "strides") strides = int_list(a.second);
+            else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
+        }
+        int x = in_val(op.m_input[0]);
+        need(op, V(x).shape.size() == 4, "Conv1D / non 4-D input not implemented on the HIP backend.");
+        for (int d : dil) need(op, d == 1, "dilations != 1 not supported (not implemented).");
+        need(op, group == 1, "group != 1 not supported (not implemented).");
+        need(op, pads.size() == 4 && strides.size() == 2, "invalid pads/strides.");
+        need_u8(op, x, "X");
+        x = P.ensure_nhwc(x);
+        const int w = in_val(op.m_input[1]);
+        need_u8(op, w, "W");
+        const Shape ws = V(w).shape, xs = V(x).shape;
+        need(op, V(w).is_const && V(w).lay == Lay::nhwc && ws.size() == 4, "weights must be a static *_nchw.bin tensor.");
+        need(op, xs[0] == 1 && N == 1, "uint8 arithmetic runs one sample per pass (every pushed sample has its own scale).");
+        const long Cin = xs[1], H = xs[2], W = xs[3], Cout = ws[0], KH = ws[2], KW = ws[3];
+        need(op, ws[1] == Cin, "invalid shape of weights.");
+        if (!ks.empty()) need(op, ks.size() == 2 && ks[0] == KH && ks[1] == KW, "kernel_shape does not match the weights.");
+        const int ph = pads[0] + pads[2], pw = pads[1] + pads[3];
+        const int pt = ph / 2, pb = ph - pt, pl = pw / 2, pr = pw - pl;
+        const long Ho = (H + ph - KH) / strides[0] + 1, Wo = (W + pw - KW) / strides[1] + 1;
+        int bias = -1;
+        if (op.m_input.size() == 3 && !op.m_input[2].m_name.empty()) {
+            bias = in_val(op.m_input[2]);
+            need(op, V(bias).numel() == Cout && V(bias).dtype == OSG_F32, "wrong data type of B.");
+        }
+        const qu8::QParams oq = out_q(op);
+        const int y = out_val_u8(op, {1, Cout, Ho, Wo}, Lay::nhwc, V(x).batched, oq);
+        const int sh = strides[0], sw = strides[1];
+        std::vector<int> reads = {x, w};
+        if (bias >= 0) reads.push_back(bias);
+        P.add_step("Conv qu8 " + op.m_name, reads, {y}, [=, this] {
+            const Val& qx = P.qv(x);
+            be.check(be.api.osg_qu8_conv2d_nhwc(be.ctx, P.ptr(x), qx.qscale, qx.qzp, P.ptr(w), P.vals[w].qscale, P.vals[w].qzp,
+                                                bias >= 0 ? (const float*)P.ptr(bias) : nullptr, oq.scale, (int)oq.zero_point, P.ptr(y), 1, (int)H, (int)W, (int)Cin,
+                                                (int)Cout, (int)KH, (int)KW, sh, sw, pt, pl, pb, pr),
+                     "Conv");
+        });
+        P.steps.back().flops = 2.0 * Ho * Wo * Cout * KH * KW * Cin;
+    }
+
+    // MatMul, uint8 branch (reference :5779-5837 -> XnnPack::matrix_multiply<uint8_t> :1035): [.., M,K] x [K,N] weight or batched [n,M,K] x [n,K,N]
+    void lower_matmul_u8(const Operation& op) {
+        need(op, op.m_input.size() == 2, "wrong number of inputs.");
+        need(op, op.m_output.size() == 1, "wrong number of outputs.");
+        need(op, N == 1, "uint8 arithmetic runs one sample per pass (every pushed sample has its own scale).");
+        int a = P.ensure_plain(in_val(op.m_input[0])), b = in_val(op.m_input[1]);
+        need_u8(op, a, "input");
+        need_u8(op, b, "input");
+        const qu8::QParams oq = out_q(op);
+        if (V(b).is_const && V(b).shape.size() == 2) {
+            const Shape as = V(a).shape;
+            const long K = V(b).shape[0], Nn = V(b).shape[1];
+            need(op, !as.empty() && as.back() == K, "invalid shape of inputs.");
+            const int wq = weight_nk_u8(b);
+            Shape os = as;
+            os.back() = Nn;
+            const int y = out_val_u8(op, os, Lay::plain, V(a).batched, oq);
+            const long M = prod(as) / K;
+            P.add_step("MatMul qu8 " + op.m_name, {a, wq}, {y}, [=, this] {
+                const Val& qa = P.qv(a);
+                be.check(be.api.osg_qu8_gemm(be.ctx, P.ptr(a), K, qa.qscale, qa.qzp, P.ptr(wq), P.vals[wq].qscale, P.vals[wq].qzp, nullptr, oq.scale,
+                                             (int)oq.zero_point, P.ptr(y), (int)M, (int)Nn, (int)K, 1, 0, 0, 0),
+                         "MatMul");
+            });
+            P.steps.back().flops = 2.0 * M * Nn * K;
+            return;
+        }
+        b = P.ensure_plain(b);
+        Shape as = V(a).shape, bs = V(b).shape;
+        bool lead1 = false;
+        if (as.size() == 4 && as[0] == 1) { as.erase(as.begin()); lead1 = true; }
+        if (bs.size() == 4 && bs[0] == 1) bs.erase(bs.begin());
+        need(op, as.size() == 3 && bs.size() == 3 && as[0] == bs[0] && as[2] == bs[1], "invalid shape of inputs.");
+        const long n = as[0], M = as[1], K = as[2], Nn = bs[2];
+        Shape os = {n, M, Nn};
+        if (lead1) os.insert(os.begin(), 1);
+        const int y = out_val_u8(op, os, Lay::plain, false, oq);
+        // the [K,N] operand is an activation: re-laid out to K-contiguous [N,K] by a transpose launch of its own
+        const int bt = P.new_val("", {n, Nn, K}, OSG_U8, Lay::plain, false);
+        P.add_step("MatMul qu8/T " + op.m_name, {b}, {bt}, [=, this] {
+            long sh[3] = {n, K, Nn};
+            int pm[3] = {0, 2, 1};
+            be.check(be.api.osg_transpose(be.ctx, 1, P.ptr(b), P.ptr(bt), 3, sh, pm), "MatMul");
+        });
+        P.add_step("MatMul qu8 " + op.m_name, {a, bt}, {y}, [=, this] {
+            const Val &qa = P.qv(a), &qb = P.qv(b);
+            be.check(be.api.osg_qu8_gemm(be.ctx, P.ptr(a), K, qa.qscale, qa.qzp, P.ptr(bt), qb.qscale, qb.qzp, nullptr, oq.scale, (int)oq.zero_point, P.ptr(y),
+                                         (int)M, (int)Nn, (int)K, (int)n, M * K, Nn * K, M * Nn),
+                     "MatMul");
+        });
+        P.steps.back().flops = 2.0 * n * M * Nn * K;
+    }
+
+    // Add / Mul, uint8 branches (reference :5105-5124, :3977-3996 -> XnnPack::add / multiply with quint8 parameters)
+    void lower_binary_u8(const Operation& op) {
+        need(op, op.m_input.size() == 2, "wrong number of inputs.");
+        need(op, op.m_output.size() == 1, "wrong number of outputs.");
+        int a = in_val(op.m_input[0]), b = in_val(op.m_input[1]);
+        need_u8(op, a, "inputs");
+        need_u8(op, b, "inputs");
+        const osg_binary_kind kind = op.m_type == "Add" ? OSG_BIN_ADD : OSG_BIN_MUL;
+        const Shape as = V(a).shape, bs = V(b).shape;
+        const size_t rank = std::max(as.size(), bs.size());
+        Shape os(rank);
+        for (size_t i = 0; i < rank; i++) {
+            long da = i + as.size() >= rank ? as[i + as.size() - rank] : 1;
+            long db = i + bs.size() >= rank ? bs[i + bs.size() - rank] : 1;
+            need(op, da == db || da == 1 || db == 1, "shapes are not broadcastable.");
+            os[i] = std::max(da, db);
+        }
+        auto per_channel = [&](int v, long C) {
+            const Shape& s = V(v).shape;
+            if (V(v).lay == Lay::nhwc) return false;
+            if (V(v).numel() == 1) return true;
+            if (V(v).numel() != C) return false;
+            return (s.size() == 3 && s[0] == C) || (s.size() == 4 && s[1] == C);
+        };
+        Lay olay = Lay::plain;
+        Shape pa, pb;
+        if (V(a).lay == Lay::nhwc || V(b).lay == Lay::nhwc) {
+            int x = V(a).lay == Lay::nhwc ? a : b, o = x == a ? b : a;
+            const Shape xs = V(x).shape;
+            const long C = xs[1], HW = xs[2] * xs[3];
+            if (V(o).lay == Lay::nhwc && V(o).shape == xs) {
+                olay = Lay::nhwc;
+                pa = pb = {HW, C};
+            } else if (per_channel(o, C) && os == xs) {
+                olay = Lay::nhwc;
+                Shape px = {HW, C}, po = {1, V(o).numel() == 1 ? 1 : C};
+                pa = x == a ? px : po;
+                pb = x == a ? po : px;
+            } else {
+                a = P.ensure_plain(a);
+                b = P.ensure_plain(b);
+            }
+        }
+        if (olay == Lay::plain) { pa = V(a).shape; pb = V(b).shape; }
+        const qu8::QParams oq = out_q(op);
+        const int y = out_val_u8(op, os, olay, V(a).batched || V(b).batched, oq);
+        const size_t prank = std::max(pa.size(), pb.size());
+        need(op, prank >= 1 || true, "");
+        const size_t pr = std::max<size_t>(prank, 1);
+        need(op, pr <= 6, "rank too large for the device broadcast kernel.");
+        std::vector<long> sa(pr, 1), sb(pr, 1);
+        for (size_t i = 0; i < pa.size(); i++) sa[pr - pa.size() + i] = pa[i];
+        for (size_t i = 0; i < pb.size(); i++) sb[pr - pb.size() + i] = pb[i];
+        P.add_step(op.m_type + " qu8 " + op.m_name, {a, b}, {y}, [=, this] {
+            const Val &qa = P.qv(a), &qb = P.qv(b);
+            be.check(be.api.osg_qu8_binary(be.ctx, kind, P.ptr(a), sa.data(), qa.qscale, qa.qzp, P.ptr(b), sb.data(), qb.qscale, qb.qzp, P.ptr(y), oq.scale,
+                                           (int)oq.zero_point, (int)pr),
+                     op.m_type.c_str());
+        });
+    }
+
+    // Sigmoid, uint8 branch (reference :4412-4481): a function of the input code -> 256-entry table built on the host with the host's expf
+    void lower_sigmoid_u8(const Operation& op) {
+        need(op, op.m_input.size() == 1, "wrong number of inputs.");
+        need(op, op.m_output.size() == 1, "wrong number of outputs.");
+        const int x = in_val(op.m_input[0]);
+        need_u8(op, x, "input");
+        const qu8::QParams oq = out_q(op);
+        const int y = out_val_u8(op, V(x).shape, V(x).lay, V(x).batched, oq);
+        const long n = P.total_elems(x);
+        void* lut = lut_alloc(256);
+        const bool dyn = P.qv(x).qdyn;
+        auto build = [=, this] {
+            const Val& qx = P.qv(x);
+            uint8_t t[256];
+            qu8::sigmoid_lut(qu8::QParams{qx.qscale, (uint8_t)qx.qzp}, oq, t);
+            be.check(be.api.osg_upload_sync(be.ctx, lut, t, 256), "osg_upload_sync");
+        };
+        if (!dyn) build();
+        P.add_step("Sigmoid qu8 " + op.m_name, {x}, {y}, [=, this] {
+            if (dyn) build();      // the input scale changes from run to run: rebuild (256 expf) before the lookup
+            be.check(be.api.osg_qu8_lut(be.ctx, P.ptr(x), P.ptr(y), n, lut), "Sigmoid");
+        });
+    }
+
+    // InstanceNormalization, uint8 branch (reference :4987-5043): input [1,G,L]
+    void lower_instance_norm_u8(const Operation& op) {
+        need(op, op.m_input.size() == 3, "wrong number of inputs.");
+        const int x = P.ensure_plain(in_val(op.m_input[0]));
+        need_u8(op, x, "input");
+        const int sc = in_val(op.m_input[1]), bi = in_val(op.m_input[2]);
+        const Shape s = V(x).shape;
+        need(op, s.size() == 3 && s[0] == 1, "input shape must be [1,G,L] (not implemented).");
+        need(op, V(sc).numel() == s[1] && V(bi).numel() == s[1] && V(sc).dtype == OSG_F32 && V(bi).dtype == OSG_F32, "invalid scale/bias.");
+        float eps = 1e-5f;
+        for (auto& a : op.m_attributes) {
+            if (a.first == "epsilon") eps = std::stof(a.second);
+            else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
+        }
+        const qu8::QParams oq = out_q(op);
+        const int y = out_val_u8(op, s, Lay::plain, V(x).batched, oq);
+        const long rows = s[1], L = s[2];
+        P.add_step("InstanceNorm qu8 " + op.m_name, {x, sc, bi}, {y}, [=, this] {
+            const Val& qx = P.qv(x);
+            be.check(be.api.osg_qu8_instance_norm(be.ctx, P.ptr(x), P.ptr(y), (int)rows, L, (int)rows, (const float*)P.ptr(sc), (const float*)P.ptr(bi), eps, qx.qscale,
+                                                  qx.qzp, oq.scale, (int)oq.zero_point),
+                     "InstanceNormalization");
+        });
+    }
+
+    // Softmax, uint8 branch (reference :5960-5975 -> XnnPack::softmax<uint8_t>): last axis; output scale 1/256, zero point 0
+    void lower_softmax_u8(const Operation& op) {
+        need(op, op.m_input.size() == 1, "wrong number of inputs.");
+        const int x = P.ensure_plain(in_val(op.m_input[0]));
+        need_u8(op, x, "input");
+        const Shape s = V(x).shape;
+        int axis = -1;
+        for (auto& a : op.m_attributes) {
+            if (a.first == "axis") axis = std::stoi(a.second);
+            else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
+        }
+        if (axis < 0) axis += (int)s.size();
+        need(op, axis == (int)s.size() - 1, "uint8 softmax over a non-last axis is not implemented on the HIP backend.");
+        const int y = out_val_u8(op, s, Lay::plain, V(x).batched, qu8::QParams{0x1.0p-8f, 0});
+        const long C = s.back(), rows = P.total_elems(x) / C;
+        void* lut = lut_alloc(256 * 4);
+        const bool dyn = P.qv(x).qdyn;
+        auto build = [=, this] {
+            uint32_t t[256];
+            qu8::softmax_lut(P.qv(x).qscale, (size_t)C, t);
+            be.check(be.api.osg_upload_sync(be.ctx, lut, t, sizeof t), "osg_upload_sync");
+        };
+        if (!dyn) build();
+        P.add_step("Softmax qu8 " + op.m_name, {x}, {y}, [=, this] {
+            if (dyn) build();
+            be.check(be.api.osg_qu8_softmax_last(be.ctx, P.ptr(x), P.ptr(y), rows, C, lut), "Softmax");
+        });
+    }
+
     // Gather on the device (reference :6316-6498): rows of a [rows, els] view along axis 0 (leading 1-dims stripped), static int64 indices
     void lower_gather(const Operation& op) {
         need(op, op.m_input.size() == 2, "wrong number of inputs.");
@@ -1276,6 +1599,7 @@ struct Lowering {
     void lower(const Operation& op) {
         const std::string& t = op.m_type;
         if (try_host_eval(op)) return;
+        if (P.u8) return lower_u8(op);
         if (t == "Gather") return lower_gather(op);
         if (t == "Cast") return lower_cast(op);
         if (t == "Conv") return lower_conv(op);
@@ -2244,7 +2568,7 @@ struct Lowering {
             for (int d = 0; d < rank; d++) need(op, d == axis || s[d] == V(xs[0]).shape[d], "invalid shape of inputs.");
             os[axis] += s[axis];
         }
-        int y = out_val(op, os, all_nhwc ? Lay::nhwc : Lay::plain, batched);
+        int y = out_val(op, os, all_nhwc ? Lay::nhwc : Lay::plain, batched, V(xs[0]).dtype);
         const int es = (int)esize(V(y).dtype);
         long outer, dst_pitch, off = 0;
         if (all_nhwc) { outer = os[2] * os[3] * (batched ? N : 1); dst_pitch = os[1]; }
@@ -2358,7 +2682,7 @@ struct Lowering {
         }
         need(op, os[0] == s[0] && os[1] == s[1], "resize of N/C not supported.");
         const bool nhwc = V(x).lay == Lay::nhwc;
-        int y = out_val(op, os, V(x).lay, V(x).batched);
+        int y = out_val(op, os, V(x).lay, V(x).batched, V(x).dtype);
         const int es = (int)esize(V(x).dtype);
         const long nb = B(x);
         P.add_step("Resize " + op.m_name, {x}, {y}, [=, this] {
@@ -2405,11 +2729,17 @@ Plan::~Plan() {
 }
 
 void Plan::build() {
-    if (!fp16)
-        throw std::runtime_error("Model::run: the HIP backend implements f16 arithmetic only; set m_use_fp16_arithmetic "
-                                 "(the configuration the reference uses for the SD UNet, src/sd.cpp:1633).");
-    if (m.m_use_uint8_arithmetic || m.m_use_uint8_qdq)
-        throw std::runtime_error("Model::run: uint8 activations (m_use_uint8_arithmetic / m_use_uint8_qdq) are not implemented on the HIP backend yet.");
+    if (!fp16 && !u8)
+        throw std::runtime_error("Model::run: the HIP backend implements f16 arithmetic (m_use_fp16_arithmetic, the configuration the reference uses for "
+                                 "the SD UNet, src/sd.cpp:1633) and uint8 arithmetic (m_use_uint8_arithmetic, src/sd.cpp:1218); fp32 arithmetic is not implemented.");
+    if (m.m_use_uint8_qdq)
+        throw std::runtime_error("Model::run: m_use_uint8_qdq (uint8 storage between fp32 ops) is not implemented on the HIP backend.");
+    if (m.m_requires_upcast)
+        throw std::runtime_error("Model::run: m_requires_upcast (per-op fp32 upcast, the LLM path of src/llm.cpp:385) is not implemented on the HIP backend.");
+    if (u8) {
+        if (N != 1) throw std::invalid_argument("Model::run: uint8 arithmetic runs one sample per pass on the HIP backend (every pushed sample is quantised with its own scale).");
+        fusion = 0;      // every op re-quantises to its own (scale, zero point): fusing ops would change codes
+    }
     be.check(be.api.osg_set_autotune(be.ctx, m.m_hip_autotune ? 1 : 0), "osg_set_autotune");
     ops = m.m_ops;
     vals.reserve(ops.size() * 12 + 1024);  // belt and braces: lowering code copies shapes, never holds Val& across new_val
@@ -2438,6 +2768,17 @@ void Plan::build() {
                 inp.name = in.m_name;
                 inp.host_type = src->m_type;
                 inp.shape = src->m_shape;
+                if (u8) {
+                    // a pushed fp32 input is quantised with the 0.1 % percentiles of ITS OWN data (push_tensor -> Model::quantize, reference
+                    // :3024-3028, :3247): done on the host in execute(), the codes are uploaded, scale / zero point live in the val
+                    inp.staging = inp.val = new_val(in.m_name, shape, OSG_U8, Lay::plain, true);
+                    vals[inp.val].dptr = be.malloc(val_bytes(inp.val));
+                    owned.push_back(vals[inp.val].dptr);
+                    vals[inp.val].pinned = true;
+                    vals[inp.val].qdyn = true;
+                    inputs.push_back(std::move(inp));
+                    continue;
+                }
                 inp.staging = new_val("", shape, OSG_F32, Lay::plain, true);
                 vals[inp.staging].dptr = be.malloc(val_bytes(inp.staging));
                 owned.push_back(vals[inp.staging].dptr);
@@ -2481,7 +2822,11 @@ void Plan::build() {
             const int s = v, d = o.f32val;
             const long n = total_elems(v);
             const osg_dtype sd = vals[v].dtype;
-            add_step("output " + nme, {s}, {d}, [this, s, d, n, sd] { be.check(be.api.osg_convert(be.ctx, sd, OSG_F32, ptr(s), ptr(d), n, 1.f, 0), "osg_convert"); });
+            // uint8 outputs are dequantised with the parameters their val carries at RUN time: (float)((int)q - zp) * scale (reference :8238 -> dequantize :3353)
+            add_step("output " + nme, {s}, {d}, [this, s, d, n, sd] {
+                const Val& q = qv(s);
+                be.check(be.api.osg_convert(be.ctx, sd, OSG_F32, ptr(s), ptr(d), n, sd == OSG_U8 ? q.qscale : 1.f, sd == OSG_U8 ? q.qzp : 0), "osg_convert");
+            });
             outputs.push_back(std::move(o));
         }
     }
@@ -2595,6 +2940,16 @@ void Plan::execute() {
         auto upload = [&](Tensor& t, long idx) {
             auto& vec = t.get_vector<float>();
             if (vec.size() * sizeof(float) != per) throw std::invalid_argument("Model::get_tensor_data: mismatch between tensor shape and data size.");
+            if (u8) {
+                std::vector<uint8_t> codes(vec.size());
+                qu8::QParams qp;
+                if (!qu8::quantize_dynamic(vec.data(), vec.size(), m.m_threads, codes.data(), &qp))
+                    throw std::invalid_argument("Model::quantize: unable to compute the percentiles of input '" + in.name + "'.");
+                vals[in.val].qscale = qp.scale;
+                vals[in.val].qzp = (int)qp.zero_point;
+                be.check(be.api.osg_upload(be.ctx, ptr(in.val), codes.data(), codes.size()), "osg_upload");
+                return;
+            }
             be.check(be.api.osg_upload(be.ctx, (char*)ptr(in.staging) + idx * per, vec.data(), per), "osg_upload");
         };
         upload(*src, 0);
@@ -2625,7 +2980,7 @@ void Plan::execute() {
     } else
     if (graph && !print) {
         be.check(be.api.osg_graph_launch(be.ctx, graph), "osg_graph_launch");
-    } else if (runs >= 1 && m.m_hip_use_graph && !print && !graph) {
+    } else if (runs >= 1 && m.m_hip_use_graph && !print && !graph && !u8) {   // (uint8 plans read per-run quantisation parameters on the host: no capture)
         be.check(be.api.osg_graph_begin(be.ctx), "osg_graph_begin");
         try {
             run_steps();
@@ -2739,6 +3094,7 @@ void Plan::replay(int n, float* ms_each) {
 }
 
 void Plan::set_input(const std::string& name, long index, const float* data, size_t count) {
+    if (u8) throw std::runtime_error("Model::hip_set_input: not available with uint8 arithmetic (inputs are quantised per run).");
     for (auto& in : inputs)
         if (in.name == name) {
             const size_t per = (size_t)vals[in.staging].numel();
@@ -2755,6 +3111,7 @@ double Plan::sampler_loop(const std::string& sample_name, const std::string& tim
                           const float* sigma_up, float guidance, const float* clip) {
     if (runs < 1) throw std::runtime_error("Model::hip_sampler_loop: run() once first (the context inputs must be resident).");
     if (stream_weights) throw std::runtime_error("Model::hip_sampler_loop: not available in streamed-weights mode.");
+    if (u8) throw std::runtime_error("Model::hip_sampler_loop: not available with uint8 arithmetic.");
     if (prompts <= 0 || 2L * prompts != N) throw std::invalid_argument("Model::hip_sampler_loop: the plan's batch must be 2 * prompts (cond, uncond per prompt).");
     const In *in_s = nullptr, *in_t = nullptr;
     for (auto& in : inputs) {

@@ -43,8 +43,10 @@ struct Val {
     // column-slice view of a wider 2-D buffer (merged projections): rows are `ld` elements apart, starting `view_off` bytes into the root
     long ld = 0;
     size_t view_off = 0;
-    float qscale = 1.f;           // dtype == OSG_U8 weights: w = (q - qzp) * qscale
-    int qzp = 0;
+    float qscale = 1.f;           // dtype == OSG_U8: value = (q - qzp) * qscale  (weights: from model.txt; uint8 activations: from range_data / the
+    int qzp = 0;                  //   dynamic quantisation of a pushed input)
+    int qsrc = -1;                // >= 0: the val whose (qscale, qzp) this one shares (Reshape / Transpose / Resize carry them over) -- read at RUN time
+    bool qdyn = false;            // parameters change from run to run (a pushed input and what merely re-arranges it)
     int as_nk_u8 = -1;            // [N,K] twin of a [K,N] uint8 matrix
     long numel() const { long n = 1; for (auto d : shape) n *= d; return n; }
 };
@@ -177,6 +179,8 @@ struct Plan {
     size_t val_bytes(int v) const;
     long total_elems(int v) const;
     void add_step(const std::string& what, std::vector<int> reads, std::vector<int> writes, std::function<void()> fn);
+    const Val& qv(int v) const;    // the val holding v's quantisation parameters
+    void share_q(int dst, int src); // dst carries src's quantisation parameters
     int ensure_plain(int v);
     int ensure_nhwc(int v);
     // a device constant that survives this plan (ConstPool::derived) -- *fresh tells the caller to fill it; plan-owned (always fresh) in

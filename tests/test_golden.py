@@ -337,7 +337,7 @@ def test_fused_group_norm_conv_option_is_bit_identical():
 def test_reference_reproduces_vae_qu8_golden():
     """W8A8 as the reference itself runs it (m_use_uint8_arithmetic on the exporter's fully-uint8 VAE layout, calibrated range_data.txt;
     src/sd.cpp:1212-1222): the oracle -- unmodified reference + the shim's qu8 softmax -- reproduces tests/golden/vae_tiny_qu8.npz bit for
-    bit, calibration text included.  (The HIP backend has no uint8 activations yet: this pins the oracle for the round that builds them.)"""
+    bit, calibration text included.  (The device side of it: tests/test_qu8_gpu.py.)"""
     from onnxstream_amd.synth import sd_vae
     z = np.load(os.path.join(GOLD, "vae_tiny_qu8.npz"))
     with tempfile.TemporaryDirectory() as d:
@@ -352,13 +352,60 @@ def test_reference_reproduces_vae_qu8_golden():
     assert float(np.abs(out - z["ref32"]).max() / np.abs(z["ref32"]).max()) < 0.5
 
 
-def test_hip_backend_rejects_uint8_arithmetic_loudly():
-    """No silent fallback: asking the HIP backend for uint8 activations must raise before anything runs (CPU: the option is accepted by
-    model_set_option, the error comes from Plan::build on the first run(), which needs a GPU -- so here only the option plumbing)."""
+def test_uint8_arithmetic_plans_on_cpu_and_qdq_is_rejected_loudly():
+    """host logic of the W8A8 path through the no-op stand-in for libosgpu (tests/stub): the fully uint8 VAE plans (one launch per op:
+    every op re-quantises to its own scale), range data is required op by op, m_use_uint8_qdq throws instead of silently running
+    something else.  (Numbers: tests/test_qu8_gpu.py, bit for bit against the reference.)"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub"))
+    import make_stub
     from onnxstream_amd import build as b
-    from onnxstream_amd.bindings import Model
+    from onnxstream_amd.bindings import Model, OnnxStreamError
+    from onnxstream_amd.synth import sd_vae
     if not os.path.exists(b.LIB_HOST):
         pytest.skip("host library not built")
-    m = Model(b.LIB_HOST, -1, "ram+nocache")
-    m._set_option("use_uint8_arithmetic", 1)
-    m.close()
+    z = np.load(os.path.join(GOLD, "vae_tiny_qu8.npz"))
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        old = os.environ.get("OSGPU_LIB")
+        os.environ["OSGPU_LIB"] = make_stub.build(d + "stub")
+        try:
+            sd_vae.build_vae_decoder(DirSink(d), sd_vae.TINY_VAE, quant_all=True)
+            open(d + "range_data.txt", "w", newline="").write(str(z["ranges"]))
+            m = Model(b.LIB_HOST, 1, "ram+nocache")
+            m.set_use_uint8_arithmetic(True)
+            m.read_file(d + "model.txt")
+            m.add_tensor("input.1", z["z"])
+            with pytest.raises(OnnxStreamError, match="range data not found"):
+                m.run()                                   # the reference's own error (src/onnxstream.cpp:4664)
+            m.close()
+            m = Model(b.LIB_HOST, 1, "ram+nocache")
+            m.hip_read_range_data(d + "range_data.txt")
+            m.hip_write_range_data(d + "range_data_2.txt")
+            assert len(open(d + "range_data_2.txt", newline="").read().split("\r\n")) == len(str(z["ranges"]).split("\r\n"))
+            m.set_use_uint8_arithmetic(True)
+            m.read_file(d + "model.txt")
+            m.add_tensor("input.1", z["z"])
+            m.run()
+            kinds = [r.split(" | ")[1] for r in m.hip_plan_info().splitlines() if r.startswith("step ")]
+            assert sum(k.startswith("Conv qu8") for k in kinds) == 22 and sum(k.startswith("InstanceNorm qu8") for k in kinds) == 18
+            assert list(m.get_tensor("out_image")[1]) == [1, 3, 64, 64]
+            m.clear_tensors()
+            m.add_tensor("input.1", z["z"])
+            m.add_tensor("input.1", z["z"])
+            with pytest.raises(OnnxStreamError, match="one sample per pass"):
+                m.run()
+            m.close()
+            m = Model(b.LIB_HOST, 1, "ram+nocache")
+            m.set_use_uint8_qdq(True)
+            m.set_use_fp16_arithmetic(True)
+            m.read_file(d + "model.txt")
+            m.add_tensor("input.1", z["z"])
+            with pytest.raises(OnnxStreamError, match="not implemented"):
+                m.run()
+            m.close()
+        finally:
+            if old is None:
+                os.environ.pop("OSGPU_LIB", None)
+            else:
+                os.environ["OSGPU_LIB"] = old

@@ -89,3 +89,82 @@ def test_qu8_softmax(gpu, rows, C):
     lut = np.rint(qscale * np.exp((np.arange(256, dtype=np.float64) - 255.0) * float(si))).astype(np.uint32)
     got = gpu.qu8_softmax_last(gpu.to_dev(x), lut).numpy()
     assert np.array_equal(got, want), int((got != want).sum())
+
+
+# ---- the whole W8A8 graph through the product: model_* C API -> planner (uint8 lowering) -> osg_qu8_* -----------------------------------
+def _run_vae_qu8(extra=()):
+    import os
+    import tempfile
+    from onnxstream_amd import build as b
+    from onnxstream_amd.bindings import Model
+    from onnxstream_amd.synth import sd_vae
+    from onnxstream_amd.synth.graph import DirSink
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vae_tiny_qu8.npz"))
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        sd_vae.build_vae_decoder(DirSink(d), sd_vae.TINY_VAE, quant_all=True)
+        open(d + "range_data.txt", "w", newline="").write(str(z["ranges"]))
+        m = Model(b.LIB_HOST, 1, "ram+nocache")          # threads = 1: the chunking of the input's percentiles follows the thread count (reference :3104)
+        m.hip_read_range_data(d + "range_data.txt")
+        m.set_use_uint8_arithmetic(True)
+        m.read_file(d + "model.txt")
+        m.mangle_tensor_names = False                     # names as they stand in model.txt
+        for e in extra:
+            m.add_extra_output(e)
+        outs = []
+        for _ in range(2):                                # the second pass re-quantises the input and must reproduce the first
+            m.add_tensor("input_2E_1", z["z"])
+            m.run()
+            got = {n: m.get_tensor(n) for n in ("out_5F_image",) + tuple(extra)}
+            outs.append({n: v[0] for n, v in got.items() if v is not None})
+            m.clear_tensors()
+        launches = m.hip_last_kernel_count()
+        m.close()
+        return z, d, outs, launches
+
+
+def test_hip_vae_qu8_reproduces_the_reference_bit_for_bit():
+    """BASELINE config 3's W8A8 half: the fully uint8 VAE decoder (exporter layout `quant_all`, calibrated range_data.txt) with
+    m_use_uint8_arithmetic, as `sd --rpi-lowmem` runs it (src/sd.cpp:1212-1222).  tests/golden/vae_tiny_qu8.npz is the reference's own
+    output (reproduced bit for bit by the oracle in tests/test_golden.py); the device must produce the same fp32 image, i.e. the same
+    final codes -- which requires every one of the 174 ops upstream to produce the reference's codes."""
+    z, _, outs, launches = _run_vae_qu8()
+    assert np.array_equal(outs[0]["out_5F_image"], z["ref_u8"]), int((outs[0]["out_5F_image"] != z["ref_u8"]).sum())
+    assert np.array_equal(outs[1]["out_5F_image"], z["ref_u8"])
+    assert launches > 100
+
+
+def test_hip_vae_qu8_every_op_matches_the_reference_intermediates():
+    """where oracle/_ref travelled: every op output of the uint8 VAE against the reference's own raw intermediates (oracle/qu8_check.py
+    keeps them: codes + scale + zero point), dequantised with the same formula on both sides -> identical floats = identical codes"""
+    import os
+    from oracle import qu8_check as qc
+    from oracle import ref as oref
+    if not oref.available():
+        pytest.skip("oracle/_ref not present")
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vae_tiny_qu8.npz"))
+    import tempfile
+    from onnxstream_amd.synth import sd_vae
+    from onnxstream_amd.synth.graph import DirSink
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        sd_vae.build_vae_decoder(DirSink(d), sd_vae.TINY_VAE, quant_all=True)
+        ops, vals = qc.run_u8_all(d, {"input.1": z["z"]}, str(z["ranges"]))
+    prod = {qc.tname(o): op["type"] for op in ops for o in op["outputs"]}
+    names = [qc.tname(op["outputs"][0]) for op in ops if qc.tname(op["outputs"][0]) in vals]
+    _, _, outs, _ = _run_vae_qu8(extra=names)
+    checked = 0
+    for n, pn in zip(names, names):
+        v = vals[n]
+        if v["dtype"] != 1:
+            continue
+        ref = ((v["data"].astype(np.int32) - v["zp"]).astype(np.float32) * v["scale"]).astype(np.float32)
+        if prod.get(n) == "Conv":
+            ref = ref.transpose(0, 3, 1, 2)
+        if pn not in outs[0]:
+            continue
+        got = outs[0][pn]
+        assert got.shape == ref.shape, (n, got.shape, ref.shape)
+        assert np.array_equal(got, ref), (n, prod.get(n), int((got != ref).sum()), got.size)
+        checked += 1
+    assert checked >= 150
