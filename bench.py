@@ -94,12 +94,116 @@ def cpu_baseline(model_dir, inputs_cond, inputs_uncond, passes):
                       f"({times[0]:.2f} s), W16A16, reference --ram plumbing, images/s = 1/(20 x 2 x {pass_s:.3f} s)"}
 
 
+PEAK_I8_TOPS = 3944.0                # MI355X dense int8 MFMA (16x16x64), MI355X_MICROARCH.md
+
+
+def bench_vae_qu8(args):
+    """BASELINE config 3, W8A8 half: the fully uint8 SD VAE decoder (exporter layout quant_all, [1,4,64,64] latents -> [1,3,512,512]) with
+    m_use_uint8_arithmetic, as `sd --rpi-lowmem` decodes (src/sd.cpp:1212-1222).  range_data.txt comes from a calibration pass of the
+    device itself (m_range_data_calibrate; cached beside the synthetic model).  A step = one decode: host quantisation of the pushed
+    latents (0.1 % percentiles), upload, the uint8 pass (one launch per graph op), dequantised fp32 image downloaded."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
+    from onnxstream_amd import build as b
+    from onnxstream_amd.bindings import Model
+    from onnxstream_amd.synth import sd_vae
+    from onnxstream_amd.synth.graph import DirSink
+    cfg = sd_vae.SD_VAE if args.config == "VAE_QU8" else sd_vae.TINY_VAE
+    d = os.path.join(os.environ.get("OSA_SYNTH_DIR", "/tmp/onnxstream_amd_synth"), cfg.name + "_qu8") + "/"
+    if not os.path.exists(d + ".complete"):
+        os.makedirs(d, exist_ok=True)
+        sd_vae.build_vae_decoder(DirSink(d), cfg, quant_all=True)
+        open(d + ".complete", "w").write("ok")
+    z = sd_vae.vae_inputs(cfg)[cfg.in_name]
+    shipped = os.path.join(REPO, "onnxstream_amd", "synth", "data", cfg.name + "_qu8_range_data.txt")   # a calibration pass of this very (seeded) model, kept
+    if os.path.exists(shipped) and not os.path.exists(d + "range_data.txt") and not os.environ.get("OSA_RECALIBRATE"):
+        import shutil
+        shutil.copy(shipped, d + "range_data.txt")
+    if not os.path.exists(d + "range_data.txt"):
+        t0 = time.time()
+        m = Model(b.LIB_HOST, 0, "ram+nocache")
+        m._set_option("range_data_calibrate", 1)
+        m.set_use_fp16_arithmetic(True)
+        m.read_file(d + "model.txt")
+        m.add_tensor(cfg.in_name, z)
+        m.run()
+        m.hip_write_range_data(d + "range_data.txt")
+        m.close()
+        log(f"[bench] calibration pass (f16 on the device, percentiles on the host): {time.time()-t0:.1f} s")
+        if os.path.isdir(os.path.join(REPO, "gpurun_out")):
+            import shutil
+            shutil.copy(d + "range_data.txt", os.path.join(REPO, "gpurun_out", cfg.name + "_qu8_range_data.txt"))
+    m = Model(b.LIB_HOST, 0, "ram+nocache")
+    m.hip_read_range_data(d + "range_data.txt")
+    m.set_use_uint8_arithmetic(True)
+    m.read_file(d + "model.txt")
+
+    def decode():
+        m.add_tensor(cfg.in_name, z)
+        m.run()
+        out = m.get_tensor("out_image")[0]
+        m.clear_tensors()
+        return out
+    for _ in range(max(args.warmup, 1)):
+        img = decode()
+    dev = 0.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        img = decode()
+        dev += m.hip_last_pass_ms()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    assert np.isfinite(img).all()
+    rows = m.hip_profile(args.profile_reps)
+    conv = [(ms, fl) for ms, fl, by, what in rows if what.startswith(("Conv qu8", "MatMul qu8 "))]
+    c_ms, c_fl = sum(r[0] for r in conv), sum(r[1] for r in conv)
+    by_kind = {}
+    for ms, fl, by, what in rows:
+        k = what.split(" ", 1)[0]
+        e = by_kind.setdefault(k, [0.0, 0])
+        e[0] += ms; e[1] += 1
+    if args.breakdown:
+        with open(args.breakdown, "w") as f:
+            for k, e in sorted(by_kind.items(), key=lambda kv: -kv[1][0]):
+                f.write(f"{k}\t{e[1]}\t{e[0]:.4f}\n")
+            for ms, fl, by, what in rows:
+                f.write(f"{ms:.5f}\t{fl:.0f}\t{by:.0f}\t{what}\n")
+    cpu = None
+    from oracle import ref as oref
+    if args.cpu_passes > 0 and oref.available():
+        try:
+            t0 = time.perf_counter()
+            oref.run_model_u8(d, {cfg.in_name: z}, open(d + "range_data.txt", newline="").read(), threads=oref.usable_cores())
+            s1 = time.perf_counter() - t0
+            cpu = {"value": 1.0 / s1, "unit": "decodes/s", "cores": oref.usable_cores(), "kind": "reference", "ms_per_step": s1 * 1e3,
+                   "sample": "1 decode of the same uint8 model + range data through the reference (m_use_uint8_arithmetic, XNNPACK qu8), model load included"}
+        except Exception as e:
+            log(f"[bench] cpu_baseline failed: {e!r}")
+    achieved = c_fl / (c_ms * 1e-3) / 1e12 if c_ms > 0 else 0.0
+    ms_step = wall * 1e3 / args.steps
+    line = {"metric": "sd15_vae_decoder_w8a8_decode_latency_ms+decodes_per_sec_512x512", "value": round(1e3 / ms_step, 4), "unit": "decodes/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{cfg.name} decoder, fully uint8 (W8A8, m_use_uint8_arithmetic): [1,4,{cfg.latent},{cfg.latent}] latents -> [1,3,{8*cfg.latent},{8*cfg.latent}], "
+                                   "range data from a device calibration pass; per decode: host quantisation of the input, uint8 pass, fp32 image back",
+                       "launches_per_step": m.hip_last_kernel_count(), "device_ms_per_step": round(dev / max(args.steps, 1), 4),
+                       "by_kind_ms": {k: round(e[0], 4) for k, e in sorted(by_kind.items(), key=lambda kv: -kv[1][0])}},
+            "roofline": {"bound": "mfma", "kernel": "q8_gemm_kernel (v_mfma_i32_16x16x64_i8: Conv / MatMul of the uint8 graph)", "achieved": round(achieved, 2),
+                         "peak": PEAK_I8_TOPS, "unit": "TOP/s", "frac": round(achieved / PEAK_I8_TOPS, 4), "traffic": None,
+                         "launches_per_step": len(conv), "avg_launch_us": c_ms * 1e3 / max(len(conv), 1)},
+            "cpu_baseline": cpu}
+    m.close()
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="SD15", help="SD15 (headline) | SDXL | TINY | TINY_XL")
+    ap.add_argument("--config", default="SD15", help="SD15 (headline) | SDXL | TINY | TINY_XL | VAE_QU8 (BASELINE config 3, W8A8 VAE decoder) | VAE_QU8_TINY")
     ap.add_argument("--fusion", type=int, default=2)
     ap.add_argument("--mode", default="pipeline", choices=["pipeline", "replay"],
                     help="pipeline: full txt2img loop (host CFG + Euler-A, VAE decode every 20 steps); replay: UNet graph replays only")
@@ -115,6 +219,8 @@ def main():
     ap.add_argument("--quant-weights", action="store_true", help="W8A16: uint8 weights + scale/zero-point in model.txt, dequantised at load")
     ap.add_argument("--breakdown", default="", help="write the per-step HIP-event profile to this file")
     args = ap.parse_args()
+    if args.config in ("VAE_QU8", "VAE_QU8_TINY"):
+        return bench_vae_qu8(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 
 namespace onnxstream {
 
@@ -1593,6 +1594,12 @@ struct Lowering {
         for (size_t i = 0; i < ops().size(); i++) {
             if (group_of.count((int)i)) lower_group_member(ops()[i], (int)i);
             else lower(ops()[i]);
+            if (P.calibrate)      // m_range_data_calibrate: every op output is measured right after the launch(es) that produce it
+                for (auto& o : ops()[i].m_output) {
+                    auto it = P.by_name.find(o.m_name);
+                    if (it != P.by_name.end() && V(it->second).dtype == OSG_F16 && !V(it->second).host_only)
+                        P.calib.push_back(Plan::Calib{(int)std::max<size_t>(P.steps.size(), 1) - 1, ops()[i].m_name, it->second});
+                }
         }
     }
 
@@ -2736,6 +2743,10 @@ void Plan::build() {
         throw std::runtime_error("Model::run: m_use_uint8_qdq (uint8 storage between fp32 ops) is not implemented on the HIP backend.");
     if (m.m_requires_upcast)
         throw std::runtime_error("Model::run: m_requires_upcast (per-op fp32 upcast, the LLM path of src/llm.cpp:385) is not implemented on the HIP backend.");
+    if (calibrate) {
+        if (u8) throw std::invalid_argument("Model::run: m_range_data_calibrate runs in floating-point arithmetic (src/sd.cpp:1216-1222), not with m_use_uint8_arithmetic.");
+        fusion = 0;      // one output per graph op, at the reference's rounding points
+    }
     if (u8) {
         if (N != 1) throw std::invalid_argument("Model::run: uint8 arithmetic runs one sample per pass on the HIP backend (every pushed sample is quantised with its own scale).");
         fusion = 0;      // every op re-quantises to its own (scale, zero point): fusing ops would change codes
@@ -2978,9 +2989,9 @@ void Plan::execute() {
         }
         while (ri < recipes.size()) restream(recipes[ri++]);   // keep the provider's sequence complete
     } else
-    if (graph && !print) {
+    if (graph && !print && !calibrate) {
         be.check(be.api.osg_graph_launch(be.ctx, graph), "osg_graph_launch");
-    } else if (runs >= 1 && m.m_hip_use_graph && !print && !graph && !u8) {   // (uint8 plans read per-run quantisation parameters on the host: no capture)
+    } else if (runs >= 1 && m.m_hip_use_graph && !print && !graph && !u8 && !calibrate) {   // (uint8 plans read per-run quantisation parameters on the host: no capture)
         be.check(be.api.osg_graph_begin(be.ctx), "osg_graph_begin");
         try {
             run_steps();
@@ -2992,6 +3003,38 @@ void Plan::execute() {
         }
         be.check(be.api.osg_graph_end(be.ctx, &graph), "osg_graph_end");
         be.check(be.api.osg_graph_launch(be.ctx, graph), "osg_graph_launch");
+    } else if (calibrate) {
+        // Model::push_tensor's calibration hook (reference :2983-3003): the 0.1 % percentiles of every tensor an op pushes widen the range
+        // recorded under the OP's name.  The tensors live on the device: each is read back right after its producer (the arena recycles
+        // it later) and measured by the host restatement of get_percentiles (qu8.h), chunked by the Model's thread count like the reference's.
+        size_t ci = 0;
+        std::vector<uint16_t> h16;
+        std::vector<float> h32;
+        static const std::vector<float> half_table = [] {
+            std::vector<float> t(65536);
+            for (unsigned k = 0; k < 65536; k++) t[k] = half_to_float((uint16_t)k);
+            return t;
+        }();
+        const size_t workers = std::max(1u, std::thread::hardware_concurrency());
+        for (size_t si = 0; si < steps.size(); si++) {
+            steps[si].run();
+            for (; ci < calib.size() && calib[ci].step <= (int)si; ci++) {
+                const Calib& c = calib[ci];
+                const size_t n = (size_t)total_elems(c.val);
+                h16.resize(n);
+                h32.resize(n);
+                be.check(be.api.osg_download(be.ctx, h16.data(), ptr(c.val), n * 2), "osg_download");
+                for (size_t k = 0; k < n; k++) h32[k] = half_table[h16[k]];
+                auto r = qu8::percentiles_fast(h32.data(), n, 0.001f, 0.001f, m.m_threads, workers);
+                if (!r) continue;
+                auto it = m.m_range_data.find(c.op);
+                if (it == m.m_range_data.end()) m.m_range_data[c.op] = *r;
+                else {
+                    if (r->first < it->second.first) it->second.first = r->first;
+                    if (r->second > it->second.second) it->second.second = r->second;
+                }
+            }
+        }
     } else if (!print) {
         run_steps();
     } else {

@@ -146,6 +146,8 @@ struct Plan {
 
     struct In { std::string name; int val; int staging; TensorDataType host_type; std::vector<size_t> shape; };
     struct Out { std::string name; int val; int f32val; std::vector<size_t> shape; };
+    struct Calib { int step; std::string op; int val; };   // m_range_data_calibrate: val is measured after `step`, range kept under the op's name
+    std::vector<Calib> calib;
     std::vector<In> inputs;
     std::vector<Out> outputs;
 

@@ -2,8 +2,8 @@
 // part of the W8A8 VAE path that is pure host logic: quantisation parameters, the dynamic quantisation of pushed inputs, and the tables /
 // integer multipliers the device kernels will consume.  Every function restates the reference (cited) or XNNPACK's qu8 operators (pinned commit
 // google/XNNPACK@5671db05, as used through src/onnxstream.cpp) and is pinned bit for bit against oracle/np_qu8.py -- itself pinned against the
-// reference's own intermediates -- by tests/test_qu8_host.py.  Header-only; not wired into the planner yet (the HIP backend still rejects
-// uint8 activations): DESIGN.md section 9.
+// reference's own intermediates -- by tests/test_qu8_host.py.  Header-only; used by the planner's uint8 lowering (plan.cpp, lower_*_u8) and by
+// the calibration pass (m_range_data_calibrate).
 #pragma once
 
 #include <algorithm>
@@ -12,6 +12,7 @@
 #include <cstring>
 #include <limits>
 #include <optional>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -70,6 +71,56 @@ inline std::optional<std::pair<float, float>> percentiles(const float* x, size_t
             found = true;
         }
     }
+    if (!found || !std::isfinite(lo) || !std::isfinite(hi) || lo >= hi) return std::nullopt;
+    return std::make_pair(lo, hi);
+}
+
+// The same result, for the calibration pass that measures EVERY op output of a network (hundreds of tensors of up to tens of millions of
+// elements): the chunks are independent, so they are spread over `workers` host threads, and only two order statistics of a chunk are
+// needed, so std::nth_element replaces the full sort.  min / max over the chunks is order-free => identical to percentiles().
+inline std::optional<std::pair<float, float>> percentiles_fast(const float* x, size_t size, float from_left, float from_right, size_t threads, size_t workers) {
+    const size_t chunk = 64 * 1024 / sizeof(float);
+    if (!threads) threads = 1;
+    size_t per = size / threads;
+    if (!per) per = 1;
+    std::vector<std::pair<size_t, size_t>> pieces;     // (begin, length) of every chunk, in the reference's order
+    for (size_t i = 0; i < threads; i++) {
+        const size_t start = i * per, end = i >= threads - 1 ? size : (i + 1) * per;
+        if (start >= end || start >= size || end > size) continue;
+        for (size_t j = start; j < end; j += chunk) pieces.emplace_back(j, std::min(end - j, chunk));
+    }
+    if (!workers) workers = 1;
+    workers = std::min(workers, std::max<size_t>(pieces.size(), 1));
+    std::vector<float> los(workers, std::numeric_limits<float>::infinity()), his(workers, -std::numeric_limits<float>::infinity());
+    std::vector<char> founds(workers, 0);
+    auto work = [&](size_t w) {
+        std::vector<float> buf(chunk);
+        for (size_t pi = w; pi < pieces.size(); pi += workers) {
+            const size_t j = pieces[pi].first, n = pieces[pi].second;
+            size_t m = 0;
+            for (size_t k = 0; k < n; k++)
+                if (std::isfinite(x[j + k])) buf[m++] = x[j + k];
+            const size_t kl = (size_t)((float)n * from_left), kr = (size_t)((float)n * from_right);
+            if (kl >= m || kr >= m) continue;
+            std::nth_element(buf.begin(), buf.begin() + kl, buf.begin() + m);
+            const float lo = buf[kl];
+            std::nth_element(buf.begin(), buf.begin() + (m - 1 - kr), buf.begin() + m);
+            const float hi = buf[m - 1 - kr];
+            los[w] = std::min(los[w], lo);
+            his[w] = std::max(his[w], hi);
+            founds[w] = 1;
+        }
+    };
+    if (workers == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (size_t w = 0; w < workers; w++) pool.emplace_back(work, w);
+        for (auto& t : pool) t.join();
+    }
+    float lo = std::numeric_limits<float>::infinity(), hi = -std::numeric_limits<float>::infinity();
+    bool found = false;
+    for (size_t w = 0; w < workers; w++)
+        if (founds[w]) { lo = std::min(lo, los[w]); hi = std::max(hi, his[w]); found = true; }
     if (!found || !std::isfinite(lo) || !std::isfinite(hi) || lo >= hi) return std::nullopt;
     return std::make_pair(lo, hi);
 }

@@ -17,6 +17,7 @@
 #include "osg_common.h"
 #include <cmath>
 #include <cstring>
+#include <utility>
 
 namespace {
 
@@ -273,6 +274,47 @@ __global__ __launch_bounds__(256) void q8_binary_kernel(const uint8_t* __restric
     }
 }
 
+template <int KIND>
+__device__ __forceinline__ uint8_t q8_bin_op(int av, int bv, const Q8Bin& q) {
+    if (KIND == 1) return q8_requant((av - q.a_zp) * (bv - q.b_zp), q.scale, q.out_zp);
+    const int acc = q.bias + av * q.a_mult + bv * q.b_mult;
+    const int o = (acc >> q.shift) + q.out_zp;
+    return (uint8_t)min(max(o, 0), 255);
+}
+
+// the two shapes the uint8 graphs are made of: a full tensor combined with (MODE 0) a tensor of the same shape or (MODE 1) an operand that
+// repeats with a period -- b[(i / inner) % period]: a scalar (period 1), a per-channel vector against NHWC (inner 1) or against NCHW
+// (inner H*W).  16 codes per thread, 16-byte loads and stores.
+template <int KIND, int MODE>
+__global__ __launch_bounds__(256) void q8_binary_fast_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint8_t* __restrict__ y, long n,
+                                                             long inner, long period, Q8Bin q) {
+    const long nv = n >> 4, stride = (long)gridDim.x * 256;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nv; v += stride) {
+        const long i0 = v << 4;
+        const v4i av = *reinterpret_cast<const v4i*>(a + i0);
+        v4i bv;
+        if (MODE == 0) bv = *reinterpret_cast<const v4i*>(b + i0);
+        v4i ov;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            unsigned o = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int ac = ((unsigned)av[w] >> (8 * e)) & 0xff;
+                int bc;
+                if (MODE == 0) bc = ((unsigned)bv[w] >> (8 * e)) & 0xff;
+                else bc = b[((i0 + w * 4 + e) / inner) % period];
+                o |= (unsigned)q8_bin_op<KIND>(ac, bc, q) << (8 * e);
+            }
+            ov[w] = (int)o;
+        }
+        *reinterpret_cast<v4i*>(y + i0) = ov;
+    }
+    // tail
+    for (long i = (nv << 4) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        y[i] = q8_bin_op<KIND>(a[i], MODE == 0 ? b[i] : b[(i / inner) % period], q);
+}
+
 __device__ __forceinline__ uint8_t q8_quantize(float x, float inv_scale, int zp) {
 #pragma clang fp contract(off)
     float r = __builtin_rintf(x * inv_scale) + (float)zp;
@@ -280,24 +322,48 @@ __device__ __forceinline__ uint8_t q8_quantize(float x, float inv_scale, int zp)
     return (uint8_t)r;
 }
 
-// InstanceNormalization on [rows, L] codes: one workgroup per row.  Histogram of the row's codes -> mean / variance from the histogram in
-// f64 exactly as the reference accumulates them over the elements (the dequantised values are 256 distinct floats; products count x value
-// and their sums stay below 2^53 ulps, so the order of the additions cannot matter) -> the output code of every input code -> lookup.
-__global__ __launch_bounds__(256) void q8_instance_norm_kernel(const uint8_t* __restrict__ x, uint8_t* __restrict__ y, long L, int n_scale,
-                                                               const float* __restrict__ scale, const float* __restrict__ bias, float eps,
-                                                               float in_scale, int in_zp, float out_scale, int out_zp) {
+// InstanceNormalization on [rows, L] codes in three launches that all fill the chip (a full-size VAE has 32 rows of a million codes):
+//   1. histogram of every row's codes (workgroups own 64 KiB pieces of a row: per-wave LDS histograms -> one global atomic per bin);
+//   2. per row: mean / variance from the histogram in f64 exactly as the reference accumulates them over the elements (the dequantised
+//      values are 256 distinct floats; count x value products and their sums stay below 2^53 ulps, so the order of the additions cannot
+//      matter), then the output code of every input code -> a 256-entry table;
+//   3. lookup.
+constexpr int kInPiece = 65536;
+__global__ __launch_bounds__(256) void q8_in_hist_kernel(const uint8_t* __restrict__ x, unsigned* __restrict__ hist, long L) {
+    __shared__ unsigned h[4][256];
+    const int tid = threadIdx.x, wave = tid >> 6, row = blockIdx.y;
+    for (int k = tid; k < 1024; k += 256) (&h[0][0])[k] = 0;
+    __syncthreads();
+    const uint8_t* __restrict__ xr = x + (long)row * L;
+    const long beg = (long)blockIdx.x * kInPiece, end = min(L, beg + kInPiece);
+    if (((uintptr_t)(xr + beg) & 15) == 0) {
+        const long nv = (end - beg) >> 4;
+        for (long v = tid; v < nv; v += 256) {
+            const v4i c = *reinterpret_cast<const v4i*>(xr + beg + (v << 4));
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) atomicAdd(&h[wave][((unsigned)c[w] >> (8 * e)) & 0xff], 1u);
+        }
+        for (long i = beg + (nv << 4) + tid; i < end; i += 256) atomicAdd(&h[wave][xr[i]], 1u);
+    } else {
+        for (long i = beg + tid; i < end; i += 256) atomicAdd(&h[wave][xr[i]], 1u);
+    }
+    __syncthreads();
+    const unsigned t = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+    if (t) atomicAdd(&hist[row * 256 + tid], t);
+}
+
+__global__ __launch_bounds__(256) void q8_in_lut_kernel(const unsigned* __restrict__ hist_g, uint8_t* __restrict__ lut_g, long L, int n_scale,
+                                                        const float* __restrict__ scale, const float* __restrict__ bias, float eps, float in_scale, int in_zp,
+                                                        float out_scale, int out_zp) {
 #pragma clang fp contract(off)
     __shared__ unsigned hist[256];
     __shared__ float deq[256];
     __shared__ double stat[2];
-    __shared__ uint8_t lut[256];
     const int row = blockIdx.x, c = threadIdx.x;
-    const uint8_t* __restrict__ xr = x + (long)row * L;
-    uint8_t* __restrict__ yr = y + (long)row * L;
-    hist[c] = 0;
+    hist[c] = hist_g[row * 256 + c];
     deq[c] = (float)(c - in_zp) * in_scale;
-    __syncthreads();
-    for (long i = c; i < L; i += 256) atomicAdd(&hist[xr[i]], 1u);
     __syncthreads();
     if (c == 0) {
         double mean = 0;
@@ -313,14 +379,38 @@ __global__ __launch_bounds__(256) void q8_instance_norm_kernel(const uint8_t* __
         stat[1] = sqrt(var + (double)eps);
     }
     __syncthreads();
-    {
-        const double sc = (double)scale[row % n_scale], bi = (double)bias[row % n_scale];
-        const float v = (float)(sc * ((double)deq[c] - stat[0]) / stat[1] + bi);
-        const float inv = 1.0f / out_scale;
-        lut[c] = q8_quantize(v, inv, out_zp);
-    }
+    const double sc = (double)scale[row % n_scale], bi = (double)bias[row % n_scale];
+    const float v = (float)(sc * ((double)deq[c] - stat[0]) / stat[1] + bi);
+    const float inv = 1.0f / out_scale;
+    lut_g[row * 256 + c] = q8_quantize(v, inv, out_zp);
+}
+
+__global__ __launch_bounds__(256) void q8_in_apply_kernel(const uint8_t* __restrict__ x, uint8_t* __restrict__ y, const uint8_t* __restrict__ lut_g, long L) {
+    __shared__ uint8_t lut[256];
+    const int tid = threadIdx.x, row = blockIdx.y;
+    lut[tid] = lut_g[row * 256 + tid];
     __syncthreads();
-    for (long i = c; i < L; i += 256) yr[i] = lut[xr[i]];
+    const uint8_t* __restrict__ xr = x + (long)row * L;
+    uint8_t* __restrict__ yr = y + (long)row * L;
+    const long beg = (long)blockIdx.x * kInPiece, end = min(L, beg + kInPiece);
+    if ((((uintptr_t)(xr + beg) | (uintptr_t)(yr + beg)) & 15) == 0) {
+        const long nv = (end - beg) >> 4;
+        for (long v = tid; v < nv; v += 256) {
+            const v4i c = *reinterpret_cast<const v4i*>(xr + beg + (v << 4));
+            v4i o;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                unsigned r = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) r |= (unsigned)lut[((unsigned)c[w] >> (8 * e)) & 0xff] << (8 * e);
+                o[w] = (int)r;
+            }
+            *reinterpret_cast<v4i*>(yr + beg + (v << 4)) = o;
+        }
+        for (long i = beg + (nv << 4) + tid; i < end; i += 256) yr[i] = lut[xr[i]];
+    } else {
+        for (long i = beg + tid; i < end; i += 256) yr[i] = lut[xr[i]];
+    }
 }
 
 // XNNPACK qu8 softmax over the last axis, one workgroup per row: t = host-built exp table (uint32[256]);
@@ -420,9 +510,40 @@ int osg_qu8_binary(osg_ctx* ctx, osg_binary_kind kind, const void* a, const long
     }
     Q8Bin q{};
     q.a_zp = a_zp; q.b_zp = b_zp; q.out_zp = out_zp;
+    // fast shapes: `full` operand x (same shape | operand repeating with a period)
+    long an = 1, bn = 1;
+    for (int d = 0; d < rank; d++) { an *= a_shape[d]; bn *= b_shape[d]; }
+    int mode = -1;             // 0: same shape, 1: b periodic, 2: a periodic (operands swapped below)
+    long inner = 1, period = 1;
+    auto periodic = [&](const long* sh, long cnt) {     // the non-1 dims of `sh` form one contiguous run matching the output there
+        int lo = -1, hi = -1;
+        for (int d = 0; d < rank; d++)
+            if (sh[d] != 1) { if (lo < 0) lo = d; hi = d; }
+        if (lo < 0) { inner = 1; period = 1; return true; }
+        long per = 1;
+        for (int d = lo; d <= hi; d++) { if (sh[d] != p.oshape[d]) return false; per *= sh[d]; }
+        long in = 1;
+        for (int d = hi + 1; d < rank; d++) in *= p.oshape[d];
+        inner = in; period = per;
+        return per == cnt;
+    };
+    const bool al = ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)y) & 15) == 0);
+    if (al && an == n && bn == n) mode = 0;
+    else if (al && an == n && periodic(b_shape, bn)) mode = 1;
+    else if (al && bn == n && periodic(a_shape, an)) mode = 2;
+    const uint8_t *pa = (const uint8_t*)a, *pb = (const uint8_t*)b;
+    if (mode == 2) {           // Add and Mul commute: swap the operands together with their parameters
+        std::swap(pa, pb);
+        std::swap(a_scale, b_scale);
+        std::swap(a_zp, b_zp);
+        q.a_zp = a_zp; q.b_zp = b_zp;
+        mode = 1;
+    }
     if (kind == OSG_BIN_MUL) {
         q.scale = (a_scale * b_scale) / out_scale;
-        hipLaunchKernelGGL(q8_binary_kernel<1>, dim3(grid_for(n)), dim3(256), 0, ctx->compute, (const uint8_t*)a, (const uint8_t*)b, (uint8_t*)y, n, p, q);
+        if (mode == 0) hipLaunchKernelGGL((q8_binary_fast_kernel<1, 0>), dim3(grid_for(n / 16 + 1)), dim3(256), 0, ctx->compute, pa, pb, (uint8_t*)y, n, inner, period, q);
+        else if (mode == 1) hipLaunchKernelGGL((q8_binary_fast_kernel<1, 1>), dim3(grid_for(n / 16 + 1)), dim3(256), 0, ctx->compute, pa, pb, (uint8_t*)y, n, inner, period, q);
+        else hipLaunchKernelGGL(q8_binary_kernel<1>, dim3(grid_for(n)), dim3(256), 0, ctx->compute, (const uint8_t*)a, (const uint8_t*)b, (uint8_t*)y, n, p, q);
     } else {
         // XNNPACK qu8 add: the two input/output scale ratios as integer multipliers, 20 bits for the larger one, rounding folded into the bias
         const float a_os = a_scale / out_scale, b_os = b_scale / out_scale;
@@ -436,7 +557,9 @@ int osg_qu8_binary(osg_ctx* ctx, osg_binary_kind kind, const void* a, const long
         q.a_mult = (int)lrintf(ldexpf(a_os, shift));
         q.b_mult = (int)lrintf(ldexpf(b_os, shift));
         q.bias = (int)((1u << (shift - 1)) - (unsigned)(q.a_mult * a_zp) - (unsigned)(q.b_mult * b_zp));
-        hipLaunchKernelGGL(q8_binary_kernel<0>, dim3(grid_for(n)), dim3(256), 0, ctx->compute, (const uint8_t*)a, (const uint8_t*)b, (uint8_t*)y, n, p, q);
+        if (mode == 0) hipLaunchKernelGGL((q8_binary_fast_kernel<0, 0>), dim3(grid_for(n / 16 + 1)), dim3(256), 0, ctx->compute, pa, pb, (uint8_t*)y, n, inner, period, q);
+        else if (mode == 1) hipLaunchKernelGGL((q8_binary_fast_kernel<0, 1>), dim3(grid_for(n / 16 + 1)), dim3(256), 0, ctx->compute, pa, pb, (uint8_t*)y, n, inner, period, q);
+        else hipLaunchKernelGGL(q8_binary_kernel<0>, dim3(grid_for(n)), dim3(256), 0, ctx->compute, (const uint8_t*)a, (const uint8_t*)b, (uint8_t*)y, n, p, q);
     }
     OSG_LAUNCH_CHECK(ctx);
     return 0;
@@ -445,8 +568,16 @@ int osg_qu8_binary(osg_ctx* ctx, osg_binary_kind kind, const void* a, const long
 int osg_qu8_instance_norm(osg_ctx* ctx, const void* x, void* y, int rows, long L, int n_scale, const float* scale, const float* bias, float eps,
                           float in_scale, int in_zp, float out_scale, int out_zp) {
     if (rows <= 0 || L <= 0 || n_scale <= 0) OSG_FAIL(ctx, "osg_qu8_instance_norm: invalid shape");
-    hipLaunchKernelGGL(q8_instance_norm_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->compute, (const uint8_t*)x, (uint8_t*)y, L, n_scale, scale, bias, eps,
-                       in_scale, in_zp, out_scale, out_zp);
+    if (rows > 65535) OSG_FAIL(ctx, "osg_qu8_instance_norm: too many rows");
+    const size_t hist_bytes = (size_t)rows * 256 * sizeof(unsigned), lut_bytes = (size_t)rows * 256;
+    if (osg_ensure_workspace(ctx, hist_bytes + lut_bytes)) return 1;
+    unsigned* hist = (unsigned*)ctx->ws;
+    uint8_t* lut = (uint8_t*)ctx->ws + hist_bytes;
+    OSG_HIP(ctx, hipMemsetAsync(hist, 0, hist_bytes, ctx->compute));
+    const unsigned pieces = (unsigned)((L + kInPiece - 1) / kInPiece);
+    hipLaunchKernelGGL(q8_in_hist_kernel, dim3(pieces, (unsigned)rows), dim3(256), 0, ctx->compute, (const uint8_t*)x, hist, L);
+    hipLaunchKernelGGL(q8_in_lut_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->compute, hist, lut, L, n_scale, scale, bias, eps, in_scale, in_zp, out_scale, out_zp);
+    hipLaunchKernelGGL(q8_in_apply_kernel, dim3(pieces, (unsigned)rows), dim3(256), 0, ctx->compute, (const uint8_t*)x, (uint8_t*)y, lut, L);
     OSG_LAUNCH_CHECK(ctx);
     return 0;
 }

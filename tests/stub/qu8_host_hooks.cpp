@@ -10,6 +10,12 @@ int h_quantize_dynamic(const float* x, size_t n, size_t threads, uint8_t* out, f
     *scale = q.scale; *zp = q.zero_point;
     return 0;
 }
+int h_percentiles(const float* x, size_t n, size_t threads, size_t workers, float* lo, float* hi) {
+    auto r = workers ? percentiles_fast(x, n, 0.001f, 0.001f, threads, workers) : percentiles(x, n, 0.001f, 0.001f, threads);
+    if (!r) return 1;
+    *lo = r->first; *hi = r->second;
+    return 0;
+}
 void h_sigmoid_lut(float si, int zi, float so, int zo, uint8_t* lut) { sigmoid_lut({si, (uint8_t)zi}, {so, (uint8_t)zo}, lut); }
 void h_add(const uint8_t* a, float sa, int za, const uint8_t* b, float sb, int zb, float so, int zo, size_t n, uint8_t* y) {
     const AddParams p = add_params({sa, (uint8_t)za}, {sb, (uint8_t)zb}, {so, (uint8_t)zo});

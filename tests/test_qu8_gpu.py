@@ -54,7 +54,7 @@ def test_qu8_sigmoid_lut(gpu):
 
 @pytest.mark.parametrize("kind", ["add", "mul"])
 @pytest.mark.parametrize("ash,bsh", [((1, 16, 16, 32), (1, 16, 16, 32)), ((1, 16, 16, 32), (32,)), ((1, 32, 8, 8), (32, 1, 1)), ((1, 7, 5), (1, 7, 5)),
-                                     ((4, 64, 64), (1,))])
+                                     ((4, 64, 64), (1,)), ((32, 1, 1), (1, 32, 9, 7)), ((1, 1, 1, 48), (2, 5, 7, 48)), ((3, 1, 5), (3, 4, 5)), ((1, 130, 130, 16), ())])
 def test_qu8_binary(gpu, kind, ash, bsh):
     rng = np.random.default_rng(len(ash) * 7 + len(bsh))
     a, b = _codes(rng, ash), _codes(rng, bsh)
@@ -168,3 +168,57 @@ def test_hip_vae_qu8_every_op_matches_the_reference_intermediates():
         assert np.array_equal(got, ref), (n, prod.get(n), int((got != ref).sum()), got.size)
         checked += 1
     assert checked >= 150
+
+
+def test_hip_calibration_run_writes_usable_range_data():
+    """m_range_data_calibrate on the device (`sd --rpi-lowmem --decoder-calibrate`, src/sd.cpp:1216-1241): a floating-point pass records the
+    0.1 % percentiles of every op output under the op's name (push_tensor hook, src/onnxstream.cpp:2983-3003) and write_range_data saves
+    them.  The reference calibrates in fp32 arithmetic, the device in f16, so the ranges agree to f16 accuracy, not bit for bit; the
+    uint8 pass driven by the device's own range_data must be as close to the fp32 image as the reference's uint8 pass is."""
+    import os
+    import tempfile
+    from onnxstream_amd import build as b
+    from onnxstream_amd.bindings import Model
+    from onnxstream_amd.synth import sd_vae
+    from onnxstream_amd.synth.graph import DirSink
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vae_tiny_qu8.npz"))
+    ref = {}
+    for line in str(z["ranges"]).split("\r\n"):
+        if line:
+            n, lo, hi = line.rsplit(",", 2)
+            ref[n] = (float(lo), float(hi))
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        sd_vae.build_vae_decoder(DirSink(d), sd_vae.TINY_VAE, quant_all=True)
+        m = Model(b.LIB_HOST, 1, "ram+nocache")
+        m._set_option("range_data_calibrate", 1)
+        m.set_use_fp16_arithmetic(True)
+        m.read_file(d + "model.txt")
+        m.add_tensor("input.1", z["z"])
+        m.run()
+        m.hip_write_range_data(d + "range_data.txt")
+        m.close()
+        ours = {}
+        for line in open(d + "range_data.txt", newline="").read().split("\r\n"):
+            if line:
+                n, lo, hi = line.rsplit(",", 2)
+                ours[n] = (float(lo), float(hi))
+        assert set(ours) == set(ref), (sorted(set(ref) - set(ours))[:5], sorted(set(ours) - set(ref))[:5])
+        worst = max(max(abs(ours[n][0] - ref[n][0]), abs(ours[n][1] - ref[n][1])) / (ref[n][1] - ref[n][0]) for n in ref)
+        devs = sorted(((max(abs(ours[n][0] - ref[n][0]), abs(ours[n][1] - ref[n][1])) / (ref[n][1] - ref[n][0]), n) for n in ref), reverse=True)
+        print(f"calibration: {len(ours)} ranges, worst deviation from the reference's fp32 calibration {worst:.2e} of the range; top:",
+              [(round(v, 4), n[-40:], ours[n], ref[n]) for v, n in devs[:4]], "median", devs[len(devs) // 2][0])
+        assert worst <= 5e-2
+        m = Model(b.LIB_HOST, 1, "ram+nocache")
+        m.hip_read_range_data(d + "range_data.txt")
+        m.set_use_uint8_arithmetic(True)
+        m.read_file(d + "model.txt")
+        m.add_tensor("input.1", z["z"])
+        m.run()
+        got = m.get_tensor("out_image")[0]
+        m.close()
+    mx = float(np.abs(z["ref32"]).max())
+    e_ref = float(np.abs(z["ref_u8"] - z["ref32"]).max()) / mx
+    e_own = float(np.abs(got - z["ref32"]).max()) / mx
+    print(f"uint8 pass on own calibration: {e_own:.3f} of max from the fp32 image (reference's uint8 pass: {e_ref:.3f})")
+    assert e_own <= 1.5 * e_ref + 0.02

@@ -94,3 +94,23 @@ def test_softmax_and_instance_norm_tables(hooks):
         hooks.h_instance_norm(_p(x, u8p), ctypes.c_size_t(C), ctypes.c_size_t(L), ctypes.c_float(si), zi, _p(sc, f32p), _p(bi, f32p),
                               ctypes.c_float(1e-5), ctypes.c_float(so), zo, _p(y, u8p))
         assert np.array_equal(y, Q.instance_norm_u8(x, si, zi, sc, bi, 1e-5, so, zo))
+
+
+def test_parallel_percentiles_equal_the_sequential_ones(hooks):
+    """percentiles_fast (chunks spread over host threads, nth_element instead of sort; used by the calibration pass) == percentiles"""
+    rng = np.random.default_rng(11)
+    hooks.h_percentiles.argtypes = [f32p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, f32p, f32p]
+    for n, threads in ((100, 1), (16384, 1), (50000, 3), (200001, 8), (1 << 20, 16), (7, 4)):
+        x = (rng.standard_normal(n) * rng.uniform(0.1, 30)).astype(np.float32)
+        if n > 1000:
+            x[rng.integers(0, n, 5)] = np.inf
+        want = Q.percentiles(x, 0.001, 0.001, threads)
+        res = []
+        for workers in (0, 1, 5):
+            lo, hi = ctypes.c_float(), ctypes.c_float()
+            rc = hooks.h_percentiles(_p(x, f32p), n, threads, workers, ctypes.byref(lo), ctypes.byref(hi))
+            res.append(None if rc else (lo.value, hi.value))
+        assert res[0] == res[1] == res[2]
+        assert (res[0] is None) == (want is None)
+        if want is not None:
+            assert res[0] == (float(want[0]), float(want[1]))
