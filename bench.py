@@ -283,7 +283,25 @@ def main():
             open(vae_dir + ".complete", "w").write("ok")
         barrier()
     t_build = time.time()
-    pipe = Txt2Img(b.LIB_HOST, model_dir, vae_dir, batched=True, device=local_rank, fusion=args.fusion, autotune=not args.no_autotune)
+
+    def make_pipe():
+        return Txt2Img(b.LIB_HOST, model_dir, vae_dir, batched=True, device=local_rank, fusion=args.fusion, autotune=not args.no_autotune)
+    pipe = None
+    if dist is not None and not args.no_autotune:
+        # N > 1: every rank must make the SAME measured tile / split-K choices (else the same prompt gives different last bits on different
+        # GPUs): rank 0 plans + tunes first, its table travels over RCCL, the other ranks start seeded from it and time nothing
+        def tune_on_rank0():
+            nonlocal pipe
+            pipe = make_pipe()
+            x0 = np.random.default_rng(7).standard_normal((1, cfg.in_ch, cfg.latent, cfg.latent), dtype=np.float32)
+            pipe.denoise(x0, 1.0, cond["encoder_hidden_states"], uncond["encoder_hidden_states"],
+                         extra_cond={k: cond[k] for k in ("text_embeds", "time_ids") if k in cond} or None,
+                         extra_uncond={k: uncond[k] for k in ("text_embeds", "time_ids") if k in uncond} or None)
+            if pipe.vae is not None:
+                pipe.decode(x0)
+        shard.share_tune_table(dist, rank, world, f"/tmp/osg_tune_shared_rank{rank}.txt", tune_on_rank0, device="cuda")
+    if pipe is None:
+        pipe = make_pipe()
     m = pipe.unet
     if args.w8_resident:
         m._set_option("hip_w8_resident", 1)

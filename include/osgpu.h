@@ -86,6 +86,12 @@ int osg_host_register(osg_ctx* ctx, void* host_ptr, size_t bytes);
 int osg_host_unregister(osg_ctx* ctx, void* host_ptr);
 int osg_upload_pinned(osg_ctx* ctx, void* dst, const void* pinned_host_src, size_t bytes);
 int osg_download(osg_ctx* ctx, void* host_dst, const void* src, size_t bytes);       /* D2H + wait == ensure_is_ready */
+/* VRAM-budgeted weight streaming (CudaOptions::m_vram_to_use, onnxstream.cpp:396-398): device buffers of the streaming ring are recycled, so
+ * an upload into one must not start before the LAUNCHES that read its previous occupant have finished.  osg_marker_record(slot) marks the
+ * current position of the COMPUTE stream; osg_copy_wait_marker(slot) makes the COPY stream (every later osg_upload*) wait for it.
+ * slot in [0, 256). */
+int osg_marker_record(osg_ctx* ctx, int slot);
+int osg_copy_wait_marker(osg_ctx* ctx, int slot);
 int osg_copy(osg_ctx* ctx, void* dst, const void* src, size_t bytes);                /* async D2D on compute stream */
 int osg_memset(osg_ctx* ctx, void* dst, int value, size_t bytes);
 int osg_sync(osg_ctx* ctx);
@@ -99,6 +105,12 @@ void osg_graph_destroy(osg_graph* g);
 /* ---- timing on the compute stream (HIP events) ------------------------------------------------------------ */
 int osg_timer_start(osg_ctx* ctx);
 int osg_timer_stop(osg_ctx* ctx, float* ms); /* waits for the stop event */
+
+/* ---- tracing: rocTX ranges around the launches of one graph op (visible in rocprofv3 --marker-trace timelines); no-ops when libroctx64 is absent.
+ * The host Model opens a range per step when m_ops_printf / m_ops_times_printf is set or OSG_ROCTX=1 (the reference's tracing is the two printf
+ * flags, onnxstream.cpp:3759-3762, :8199-8214). */
+void osg_range_push(const char* name);
+void osg_range_pop(void);
 
 /* ---- dense contractions ------------------------------------------------------------------------------------ */
 /* Convolution, NHWC in / OHWI weights / NHWC out, group 1, dilation 1, f32 accumulate.

@@ -202,6 +202,17 @@ class Model:
                     clip.ctypes.data_as(fp) if clip is not None else None, ctypes.byref(ms)))
         return ms.value
 
+    def hip_set_vram_budget(self, nbytes: int):
+        """CudaOptions.m_vram_to_use: weights (model order) stay resident until `nbytes` are spent, the rest stream every pass."""
+        f = self._lib.model_hip_set_vram_budget
+        f.argtypes = [ctypes.c_void_p, ctypes.c_ulonglong]; f.restype = None
+        f(self._h, int(nbytes))
+
+    def hip_resident_weight_bytes(self) -> int:
+        f = self._lib.model_hip_resident_weight_bytes
+        f.argtypes = [ctypes.c_void_p]; f.restype = ctypes.c_ulonglong
+        return int(f(self._h))
+
     def hip_read_range_data(self, filename: str):
         f = self._lib.model_hip_read_range_data
         f.argtypes = [ctypes.c_void_p, ctypes.c_char_p]; f.restype = ctypes.c_void_p

@@ -255,6 +255,9 @@ unsigned long long model_hip_last_kernel_count(Handle* h) { return h->model.hip_
 void model_hip_invalidate_plan(Handle* h) { h->model.hip_invalidate_plan(); }
 // bytes the last pass pulled through the WeightsProvider and streamed host->device (0 in resident mode)
 unsigned long long model_hip_streamed_bytes(Handle* h) { return h->model.hip_streamed_bytes(); }
+unsigned long long model_hip_resident_weight_bytes(Handle* h) { return h->model.hip_resident_weight_bytes(); }
+// CudaOptions::m_vram_to_use through the C API (the reference sets it from C++ only: src/llm.cpp set_cuda_options)
+void model_hip_set_vram_budget(Handle* h, unsigned long long bytes) { h->model.set_cuda_options(CudaOptions(bytes, false)); }
 // relaunch the captured pass n times on the resident inputs; ms_each (may be NULL) receives per-launch device times
 char* model_hip_replay(Handle* h, int n, float* ms_each) {
     try {

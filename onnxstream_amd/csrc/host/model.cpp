@@ -54,7 +54,7 @@ Model::~Model() {
     delete m_backend;
 }
 
-void Model::set_cuda_options(const CudaOptions& options) { m_cuda_options = options; }
+void Model::set_cuda_options(const CudaOptions& options) { m_cuda_options = options; }   // m_vram_to_use -> Plan's resident-weight budget; m_compute_fp32: accumulation is always fp32 here
 
 void Model::read_file(const char* filename) {
     m_model = onnxstream::read_file<std::vector<char>>(filename);
@@ -176,7 +176,7 @@ void Model::init() {
         m_init_done = true;
     } else {
         m_first_run = false;
-        if (m_hip_stream_weights) get_wp()->on_restart();
+        if (m_hip_stream_weights || m_cuda_options.m_vram_to_use > 0) get_wp()->on_restart();
     }
 }
 
@@ -253,6 +253,7 @@ std::string Model::hip_profile(int reps) {
 }
 
 size_t Model::hip_streamed_bytes() const { return m_plan ? m_plan->streamed_bytes : 0; }
+size_t Model::hip_resident_weight_bytes() const { return m_plan ? (m_plan->budgeted ? m_plan->resident_bytes + m_plan->ring_bytes : m_plan->weight_bytes) : 0; }
 
 size_t Model::hip_last_kernel_count() const { return m_last_kernels; }
 double Model::hip_last_pass_ms() const { return m_last_ms; }

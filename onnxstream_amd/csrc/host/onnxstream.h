@@ -571,6 +571,7 @@ public:
     double hip_last_pass_ms() const;   // device time of the last pass (HIP events on the compute stream)
     void hip_invalidate_plan();
     size_t hip_streamed_bytes() const;
+    size_t hip_resident_weight_bytes() const;   // device bytes held for weights: everything, or (VRAM budget) the resident part + the streaming ring
     void hip_replay(int n, float* ms_each);   // relaunch the captured pass on resident inputs (per-launch device ms)
     void hip_set_input(const std::string& name, long index, const float* data, size_t count);   // refresh one pushed sample of a resident input
     // the denoising loop with CFG + Euler-Ancestral on the device (see Plan::sampler_loop); returns the loop's device time in ms

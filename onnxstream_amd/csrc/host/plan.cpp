@@ -91,7 +91,12 @@ Plan::Plan(Model& model, HipBackend& backend, ConstPool& cpool, size_t batch) : 
     fp16 = m.m_use_fp16_arithmetic;
     fusion = m.m_hip_fusion_level;
     stream_weights = m.m_hip_stream_weights;
-    w8_resident = m.m_hip_w8_resident && !m.m_hip_stream_weights;
+    // CudaOptions::m_vram_to_use (reference :396-398: weights are placed on the GPU until the budget is spent, the rest stay off it): here the
+    // weights beyond the budget are streamed every pass through a device ring instead -- a budget switches the streamed-weights mode on
+    vram_budget = (size_t)m.m_cuda_options.m_vram_to_use;
+    budgeted = vram_budget > 0;
+    if (budgeted) stream_weights = true;
+    w8_resident = m.m_hip_w8_resident && !stream_weights;
     fuse_gn_conv = m.m_hip_fuse_gn_conv;
     fuse_ln_gemm = m.m_hip_fuse_ln_gemm;
     u8 = m.m_use_uint8_arithmetic;
@@ -99,14 +104,16 @@ Plan::Plan(Model& model, HipBackend& backend, ConstPool& cpool, size_t batch) : 
     autotune = m.m_hip_autotune;
     calibrate = m.m_range_data_calibrate;
     outputs_convert_set = m.m_outputs_convert_set;
-    side_stream = m.m_hip_side_stream && !m.m_hip_stream_weights;
+    side_stream = m.m_hip_side_stream && !stream_weights;
     extra_outputs = m.m_extra_outputs;
 }
 
 bool Plan::compatible(Model& mm, size_t batch) const {
-    if ((long)batch != N || mm.m_use_fp16_arithmetic != fp16 || mm.m_hip_fusion_level != fusion || mm.m_hip_stream_weights != stream_weights ||
-        mm.m_hip_fuse_gn_conv != fuse_gn_conv || mm.m_hip_fuse_ln_gemm != fuse_ln_gemm || (mm.m_hip_side_stream && !mm.m_hip_stream_weights) != side_stream ||
-        (mm.m_hip_w8_resident && !mm.m_hip_stream_weights) != w8_resident || mm.m_extra_outputs != extra_outputs ||
+    const bool want_stream = mm.m_hip_stream_weights || mm.m_cuda_options.m_vram_to_use > 0;
+    if ((long)batch != N || mm.m_use_fp16_arithmetic != fp16 || mm.m_hip_fusion_level != fusion || want_stream != stream_weights ||
+        (size_t)mm.m_cuda_options.m_vram_to_use != vram_budget ||
+        mm.m_hip_fuse_gn_conv != fuse_gn_conv || mm.m_hip_fuse_ln_gemm != fuse_ln_gemm || (mm.m_hip_side_stream && !want_stream) != side_stream ||
+        (mm.m_hip_w8_resident && !want_stream) != w8_resident || mm.m_extra_outputs != extra_outputs ||
         mm.m_use_uint8_arithmetic != u8 || mm.m_use_uint8_qdq != u8_qdq || mm.m_hip_autotune != autotune || mm.m_outputs_convert_set != outputs_convert_set ||
         mm.m_range_data_calibrate != calibrate)
         return false;
@@ -454,8 +461,19 @@ struct Lowering {
                     auto pit = use_pool ? pool.base.find(o.key) : pool.base.end();
                     if (pit != pool.base.end()) {   // (a partial reload: this format is resident already)
                         new_const(pit->second.dptr);
+                    } else if (P.budgeted && have == want && have != OSG_I64 && !host_valid && P.resident_bytes + bytes > P.vram_budget) {
+                        // over the VRAM budget: this weight gets no buffer of its own -- every pass (the first one included) it is pulled from
+                        // the provider again and lands in the streaming ring right before the step that reads it (Plan::restream)
+                        new_const(nullptr);
+                        Plan::WRecipe rec;
+                        rec.val = v; rec.fn = fn; rec.ty = ty; rec.have = have; rec.want = want; rec.count = count;
+                        rec.scale = t.m_scale; rec.zp = (int)t.m_zero_point;
+                        rec.ring = true;
+                        P.recipes.push_back(rec);
+                        P.ring_weight_bytes += bytes;
                     } else {
                         new_const(be.malloc(bytes));
+                        P.resident_bytes += bytes;
                         if (use_pool) {
                             ConstPool::Base b;
                             b.dptr = V(v).dptr; b.bytes = bytes; b.host_f = host_f; b.host_i = host_i; b.host_valid = host_valid;
@@ -477,6 +495,7 @@ struct Lowering {
                             if (P.stream_weights) { rec.raw = tmp; P.owned.push_back(tmp); }
                             else be.free(tmp);
                         }
+                        rec.resident = P.budgeted;     // budget mode: resident weights are fetched (providers serve strictly in order) but not re-sent
                         if (P.stream_weights) P.recipes.push_back(rec);
                     }
                     P.weight_bytes += bytes;
@@ -2730,6 +2749,7 @@ Plan::~Plan() {
     if (graph) be.api.osg_graph_destroy(graph);
     if (samp_x) be.api.osg_free(be.ctx, samp_x);
     if (samp_noise) be.api.osg_free(be.ctx, samp_noise);
+    if (ring) be.free(ring);
     delete lowering;
     for (void* p : owned) be.free(p);
     if (arena) be.free(arena);
@@ -2826,6 +2846,20 @@ void Plan::build() {
             o.name = nme;
             o.val = v;
             for (long d : vals[v].shape) o.shape.push_back((size_t)d);
+            if (!outputs_convert_set.empty() && !outputs_convert_set.count(nme) && vals[v].dtype == OSG_F16) {
+                // m_outputs_convert_set (reference :8234): only the listed outputs are converted back to fp32 at the end of run(); the others
+                // stay in the arithmetic type (f16 bits; here always in the logical layout).  A pinned f16 copy is what the caller reads.
+                o.f32val = new_val("", vals[v].shape, OSG_F16, Lay::plain, vals[v].batched);
+                vals[o.f32val].dptr = be.malloc(val_bytes(o.f32val));
+                owned.push_back(vals[o.f32val].dptr);
+                vals[o.f32val].pinned = true;
+                o.raw16 = true;
+                const int s0 = v, d0 = o.f32val;
+                const size_t nbytes = val_bytes(v);
+                add_step("output " + nme, {s0}, {d0}, [this, s0, d0, nbytes] { be.check(be.api.osg_copy(be.ctx, ptr(d0), ptr(s0), nbytes), "osg_copy"); });
+                outputs.push_back(std::move(o));
+                continue;
+            }
             o.f32val = new_val("", vals[v].shape, OSG_F32, Lay::plain, vals[v].batched);
             vals[o.f32val].dptr = be.malloc(val_bytes(o.f32val));
             owned.push_back(vals[o.f32val].dptr);
@@ -2915,13 +2949,55 @@ void Plan::build() {
         for (int v : born[si]) vals[v].offset = take(aligned(val_bytes(v)));
         for (int v : dies[si]) give(vals[v].offset, aligned(val_bytes(v)));
     }
+    if (budgeted && ring_weight_bytes) {
+        // the streaming ring: FIFO of the over-budget weights in the order the steps read them.  It must hold what ONE step reads plus what
+        // the next one is being sent (upload(i+1) overlaps compute(i)): twice the largest per-step demand, or a quarter of the streamed
+        // weights up to 32 MiB if that is more
+        std::vector<size_t> per_step(steps.size() + 1, 0);
+        size_t worst = 0;
+        for (auto& r : recipes)
+            if (r.ring && r.val >= 0 && vals[r.val].last >= 0)
+                for (int si = vals[r.val].first; si <= vals[r.val].last; si++) {
+                    per_step[si] += ((size_t)r.count * esize(r.want) + 255) & ~(size_t)255;
+                    worst = std::max(worst, per_step[si]);
+                }
+        ring_bytes = std::max<size_t>(2 * worst + 4096, std::min<size_t>((size_t)32 << 20, ring_weight_bytes / 4));
+        ring = be.malloc(ring_bytes);
+    }
     arena_bytes = top ? top : 256;
     arena = be.malloc(arena_bytes);
     be.check(be.api.osg_sync(be.ctx), "osg_sync");
 }
 
 void Plan::run_steps() {
+    // measurement aid (tools/skip_probe.sh): OSG_PLAN_SKIP=<prefix>[,<prefix>...] leaves out every step whose description starts with one of
+    // the prefixes -- the pass computes garbage, its captured-graph time shows what that class of launches really costs inside the chain
+    static const std::vector<std::string> skip = [] {
+        std::vector<std::string> v;
+        if (const char* e = std::getenv("OSG_PLAN_SKIP")) {
+            std::string t = e;
+            size_t b0 = 0;
+            while (b0 <= t.size()) {
+                size_t e0 = t.find(',', b0);
+                if (e0 == std::string::npos) e0 = t.size();
+                if (e0 > b0) v.push_back(t.substr(b0, e0 - b0));
+                b0 = e0 + 1;
+            }
+        }
+        return v;
+    }();
     for (auto& s : steps) {
+        if (!skip.empty()) {
+            bool sk = false;
+            for (auto& pre : skip) sk |= s.what.rfind(pre, 0) == 0;
+            if (sk) continue;
+        }
+        static const bool roctx_on = std::getenv("OSG_ROCTX") != nullptr;
+        struct Range {
+            HipBackend& b; bool on;
+            Range(HipBackend& b_, bool on_, const char* n) : b(b_), on(on_) { if (on) b.api.osg_range_push(n); }
+            ~Range() { if (on) b.api.osg_range_pop(); }
+        } range(be, roctx_on, s.what.c_str());
         if (s.join_before) be.check(be.api.osg_side_join(be.ctx), "osg_side_join");
         if (s.side_join >= 0) {
             be.check(be.api.osg_side_begin(be.ctx), "osg_side_begin");
@@ -2969,16 +3045,47 @@ void Plan::execute() {
         for (long i = 0; i < extra; i++) upload((*src->m_batch)[i], i + 1);
     }
     // ---- run the pass -------------------------------------------------------------------------------------------------
-    be.check(be.api.osg_timer_start(be.ctx), "osg_timer_start");
+    const bool stream_pass = stream_weights && (runs >= 1 || budgeted);
+    const bool times = m.m_ops_times_printf && !calibrate && !stream_pass;
+    if (!times) be.check(be.api.osg_timer_start(be.ctx), "osg_timer_start");
     const bool print = m.m_ops_printf;
-    if (stream_weights && runs >= 1) {
+    float times_total = 0;
+    if (times) {
+        // m_ops_times_printf (reference :3810-3815, :8199-8214: wall milliseconds per op TYPE, printed after the last op of the pass): here the
+        // DEVICE milliseconds (HIP events on the compute stream) of the launches each graph op type was lowered to, eager pass, same line format
+        std::map<std::string, double> per_type;
+        int idx = 0;
+        for (auto& s : steps) {
+            if (print) printf("#%i) %s\n", idx++, s.what.c_str());
+            be.api.osg_range_push(s.what.c_str());
+            be.check(be.api.osg_timer_start(be.ctx), "osg_timer_start");
+            s.run();
+            float ms1 = 0;
+            be.check(be.api.osg_timer_stop(be.ctx, &ms1), "osg_timer_stop");
+            be.api.osg_range_pop();
+            std::string ty = s.what.substr(0, s.what.find(' '));
+            const size_t plus = ty.find('+');
+            if (plus != std::string::npos) ty = ty.substr(0, plus);
+            per_type[ty] += ms1;
+            times_total += ms1;
+        }
+        printf("\033[7m > \033[0m");
+        for (auto& e : per_type) printf(" %s:%f,", e.first.c_str(), e.second);
+        printf("\n");
+        fflush(stdout);
+    } else
+    if (stream_pass) {
+        if (budgeted && runs == 0) m.get_wp()->on_restart();   // the plan build pulled the whole sequence once; the first pass pulls it again
         // ---- streamed-weights pass: every weight is pulled from the provider again, in model order, and sent H2D on the COPY stream
         // (pinned double-buffered staging, or straight out of a RAM provider's page-locked buffer) while the compute stream works on
         // the previous steps; a step is launched right after the uploads of ITS weights were enqueued (the compute stream waits on
         // their events), so upload(i+1) overlaps compute(i).  No hipGraph: host-side copies interleave with the launches.
         streamed_bytes = 0;
         size_t ri = 0;
+        ring_occ.clear();
+        ring_head = 0;
         for (size_t si = 0; si < steps.size(); si++) {
+            cur_step = (int)si;
             while (ri < recipes.size()) {
                 const WRecipe& r = recipes[ri];
                 if (r.val >= 0 && vals[r.val].first > (int)si && vals[r.val].last >= 0) break;
@@ -2986,7 +3093,15 @@ void Plan::execute() {
                 ri++;
             }
             steps[si].run();
+            // ring occupants whose last reader has just been enqueued: mark the compute stream here, the slot may be overwritten after it
+            for (auto& o : ring_occ)
+                if (o.marker < 0 && o.last <= (int)si) {
+                    o.marker = next_marker;
+                    next_marker = (next_marker + 1) % 256;
+                    be.check(be.api.osg_marker_record(be.ctx, o.marker), "osg_marker_record");
+                }
         }
+        cur_step = (int)steps.size();
         while (ri < recipes.size()) restream(recipes[ri++]);   // keep the provider's sequence complete
     } else
     if (graph && !print && !calibrate) {
@@ -3041,11 +3156,13 @@ void Plan::execute() {
         int idx = 0;
         for (auto& s : steps) {
             printf("#%i) %s\n", idx++, s.what.c_str());
+            be.api.osg_range_push(s.what.c_str());
             s.run();
+            be.api.osg_range_pop();
         }
     }
-    float ms = 0;
-    be.check(be.api.osg_timer_stop(be.ctx, &ms), "osg_timer_stop");
+    float ms = times_total;
+    if (!times) be.check(be.api.osg_timer_stop(be.ctx, &ms), "osg_timer_stop");
     m_last_ms = ms;
     runs++;
     // ---- consume the inputs, publish the outputs as fp32 host tensors in the logical (NCHW) layout (reference :8217-8263) --
@@ -3057,12 +3174,18 @@ void Plan::execute() {
         const long nb = vals[o.f32val].batched ? N : 1;
         Tensor first;
         for (long i = 0; i < nb; i++) {
-            tensor_vector<float> host(per_elems);
-            be.check(be.api.osg_download(be.ctx, host.data(), (char*)ptr(o.f32val) + i * per_elems * sizeof(float), per_elems * sizeof(float)), "osg_download");
             Tensor t;
             t.m_name = o.name;
             t.m_shape = o.shape;
-            t.set_vector(std::move(host));
+            if (o.raw16) {
+                tensor_vector<uint16_t> host(per_elems);
+                be.check(be.api.osg_download(be.ctx, host.data(), (char*)ptr(o.f32val) + i * per_elems * 2, per_elems * 2), "osg_download");
+                t.set_vector(std::move(host));
+            } else {
+                tensor_vector<float> host(per_elems);
+                be.check(be.api.osg_download(be.ctx, host.data(), (char*)ptr(o.f32val) + i * per_elems * sizeof(float), per_elems * sizeof(float)), "osg_download");
+                t.set_vector(std::move(host));
+            }
             if (i == 0) first = std::move(t);
             else {
                 if (!first.m_batch) first.m_batch = std::make_shared<std::vector<Tensor>>();
@@ -3081,7 +3204,27 @@ void Plan::restream(const WRecipe& r) {
         using T = typename decltype(tag)::type;
         const size_t bytes = (size_t)r.count * sizeof(T);
         auto send = [&](const T* host, bool stable) {
-            if (r.val < 0) return;
+            if (r.val < 0 || r.resident) return;        // fetched to keep the provider's sequence; already on the device
+            if (r.ring) {
+                if (vals[r.val].last < 0) return;       // nobody reads it in this plan
+                // FIFO slot in the ring; whatever it overlaps must have been read by launches that are at least enqueued (else the ring
+                // is too small for one step's weights) and the COPY stream waits for those launches before it overwrites them
+                const size_t need = (bytes + 255) & ~(size_t)255;
+                if (need > ring_bytes) throw std::runtime_error("Model::run: a weight is larger than the VRAM streaming ring.");
+                if (ring_head + need > ring_bytes) ring_head = 0;
+                for (size_t k = 0; k < ring_occ.size();) {
+                    RingOcc& o = ring_occ[k];
+                    if (o.off < ring_head + need && ring_head < o.off + o.size) {
+                        if (o.last >= cur_step) throw std::runtime_error("Model::run: the VRAM budget leaves no room for the weights one step reads (raise m_vram_to_use).");
+                        if (o.marker >= 0) be.check(be.api.osg_copy_wait_marker(be.ctx, o.marker), "osg_copy_wait_marker");
+                        ring_occ.erase(ring_occ.begin() + k);
+                    } else
+                        k++;
+                }
+                vals[r.val].dptr = (char*)ring + ring_head;
+                ring_occ.push_back(RingOcc{ring_head, need, vals[r.val].last, -1});
+                ring_head += need;
+            }
             void* dst = r.raw ? r.raw : vals[r.val].dptr;
             if (stable) {   // provider-owned memory that outlives the pass: page-lock once, DMA without a staging copy
                 auto it = registered.find(host);
@@ -3165,6 +3308,7 @@ double Plan::sampler_loop(const std::string& sample_name, const std::string& tim
     for (auto& o : outputs)
         if (o.name == out_name) out = &o;
     if (!in_s || !in_t || !out) throw std::invalid_argument("Model::hip_sampler_loop: input/output tensor not found.");
+    if (out->raw16) throw std::invalid_argument("Model::hip_sampler_loop: the output is excluded from the fp32 conversion (m_outputs_convert_set).");
     const long L = vals[in_s->staging].numel(), TL = vals[in_t->staging].numel();
     if (vals[out->f32val].numel() != L || !vals[out->f32val].batched)
         throw std::invalid_argument("Model::hip_sampler_loop: the output must have the shape of the sample input.");

@@ -138,14 +138,24 @@ struct Plan {
         float scale = 1.f;
         int zp = 0;
         void* raw = nullptr;          // device staging for weights that need a dtype conversion after the copy
+        bool resident = false;        // VRAM-budget mode: inside the budget -- uploaded once, later passes only fetch it from the provider
+        bool ring = false;            // VRAM-budget mode: over the budget -- lives in the streaming ring, re-sent every pass
     };
+    // ---- VRAM budget (CudaOptions::m_vram_to_use) ----
+    size_t vram_budget = 0, resident_bytes = 0, ring_weight_bytes = 0;
+    bool budgeted = false;
+    void* ring = nullptr;
+    size_t ring_bytes = 0, ring_head = 0;
+    struct RingOcc { size_t off, size; int last; int marker; };
+    std::vector<RingOcc> ring_occ;
+    int next_marker = 0, cur_step = 0;
     std::vector<WRecipe> recipes;
     std::map<const void*, size_t> registered;   // provider host buffers page-locked for zero-copy DMA
     size_t streamed_bytes = 0;
     void restream(const WRecipe& r);
 
     struct In { std::string name; int val; int staging; TensorDataType host_type; std::vector<size_t> shape; };
-    struct Out { std::string name; int val; int f32val; std::vector<size_t> shape; };
+    struct Out { std::string name; int val; int f32val; std::vector<size_t> shape; bool raw16 = false; };
     struct Calib { int step; std::string op; int val; };   // m_range_data_calibrate: val is measured after `step`, range kept under the op's name
     std::vector<Calib> calib;
     std::vector<In> inputs;

@@ -55,7 +55,26 @@ void store(const Key& k, const Choice& c) {
 }
 }  // namespace osg_tune
 
+#include <dlfcn.h>
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+    }
+};
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+
 extern "C" {
+
+void osg_range_push(const char* name) { if (roctx().push) roctx().push(name); }
+void osg_range_pop(void) { if (roctx().pop) roctx().pop(); }
 
 int osg_device_count(void) {
     int n = 0;
@@ -121,6 +140,8 @@ void osg_destroy(osg_ctx* c) {
     if (c->ev_t1) hipEventDestroy(c->ev_t1);
     if (c->ev_a0) hipEventDestroy(c->ev_a0);
     if (c->ev_a1) hipEventDestroy(c->ev_a1);
+    for (auto& e : c->markers)
+        if (e) hipEventDestroy(e);
     if (c->compute) hipStreamDestroy(c->compute);
     if (c->copy) hipStreamDestroy(c->copy);
     delete c;
@@ -178,6 +199,21 @@ int osg_upload_pinned(osg_ctx* c, void* dst, const void* pinned_src, size_t byte
     OSG_HIP(c, hipMemcpyAsync(dst, pinned_src, bytes, hipMemcpyHostToDevice, c->copy));
     OSG_HIP(c, hipEventRecord(c->ev_copy, c->copy));
     OSG_HIP(c, hipStreamWaitEvent(c->compute, c->ev_copy, 0));
+    return 0;
+}
+
+int osg_marker_record(osg_ctx* c, int slot) {
+    if (slot < 0 || slot >= osg_ctx::kMarkers) OSG_FAIL(c, "osg_marker_record: slot out of range");
+    if (c->capturing) OSG_FAIL(c, "osg_marker_record inside graph capture");
+    if (!c->markers[slot]) OSG_HIP(c, hipEventCreateWithFlags(&c->markers[slot], hipEventDisableTiming));
+    OSG_HIP(c, hipEventRecord(c->markers[slot], c->compute));
+    return 0;
+}
+
+int osg_copy_wait_marker(osg_ctx* c, int slot) {
+    if (slot < 0 || slot >= osg_ctx::kMarkers) OSG_FAIL(c, "osg_copy_wait_marker: slot out of range");
+    if (!c->markers[slot]) return 0;   // never recorded: nothing to wait for
+    OSG_HIP(c, hipStreamWaitEvent(c->copy, c->markers[slot], 0));
     return 0;
 }
 

@@ -7,6 +7,7 @@ GPU box, "gloo" in the CPU tests) only moves the tiny tensors either side of it:
 
     scatter_prompts   rank 0 draws/holds every prompt's inputs and broadcasts them; each rank keeps its own slice
     gather_results    every rank's predicted noise back to rank 0 (what the samplers on rank 0 would consume)
+    share_tune_table  rank 0's measured kernel-configuration table to every rank (identical plans => identical bits on every GPU)
 """
 from __future__ import annotations
 
@@ -72,3 +73,35 @@ def gather_results(dist, rank: int, world: int, n_prompts: int, results: Dict[in
         for j, i in enumerate(prompts_of_rank(n_prompts, r, world)):
             out[i] = gathered[r][j].cpu().numpy()
     return out
+
+
+def broadcast_text(dist, rank: int, world: int, text: Optional[str], device="cpu") -> str:
+    """rank 0's `text` to every rank (the measured tile / split-K table, osg_tune.h: all ranks of a node must make the SAME choices, or the
+    same prompt would give different last bits on different GPUs)."""
+    import torch
+    if dist is None or world == 1:
+        return text or ""
+    data = (text or "").encode() if rank == 0 else b""
+    n = torch.tensor([len(data)], dtype=torch.int64, device=device)
+    dist.broadcast(n, src=0)
+    buf = torch.zeros(int(n.item()), dtype=torch.uint8, device=device)
+    if rank == 0 and len(data):
+        buf = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(device)
+    if buf.numel():
+        dist.broadcast(buf, src=0)
+    return bytes(buf.cpu().numpy().tolist()).decode()
+
+
+def share_tune_table(dist, rank: int, world: int, path: str, build_on_rank0: Callable[[], None], device="cpu") -> None:
+    """Rank 0 runs `build_on_rank0` (plans + tunes with OSG_TUNE_CACHE = path), its table is broadcast, every other rank writes it to ITS
+    `path` before creating any Model -- a process seeded from a table issues no timing launches and reproduces rank 0's choices."""
+    import os
+    os.environ["OSG_TUNE_CACHE"] = path
+    if rank == 0:
+        if os.path.exists(path):
+            os.remove(path)
+        build_on_rank0()
+    text = broadcast_text(dist, rank, world, open(path).read() if rank == 0 and os.path.exists(path) else None, device)
+    if rank != 0:
+        with open(path, "w") as f:
+            f.write(text)

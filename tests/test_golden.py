@@ -249,6 +249,43 @@ def test_streamed_weights_mode(wp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("wp", ["ram+nocache", "prefetch"])
+def test_vram_budget_mode_equals_resident_mode(wp):
+    """m_vram_to_use = a third of the weights: the over-budget weights travel through the recycled device ring every pass (copy stream
+    ordered behind the launches that read a slot's previous occupant); results must equal the all-resident streamed mode bit for bit."""
+    from onnxstream_amd import build as b
+    from onnxstream_amd.bindings import Model
+    ins, oname, r16, r32 = load("unet_tiny")
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        gc.emit("unet_tiny", DirSink(d))
+        wbytes = sum(os.path.getsize(d + f) for f in os.listdir(d) if f.endswith(".bin"))
+        outs = {}
+        for budget in (0, wbytes // 3, 64 * 1024):
+            m = Model(b.LIB_HOST, 0, wp)
+            if budget:
+                m.hip_set_vram_budget(budget)
+            else:
+                m._set_option("hip_stream_weights", 1)
+            m.read_file(d + "model.txt")
+            res = []
+            for r in range(3):
+                for k, v in ins.items():
+                    m.add_tensor(k, v)
+                m.set_use_fp16_arithmetic(True)
+                m.set_fuse_ops_in_attention(True)
+                m.run()
+                res.append(m.get_tensor(oname)[0])
+                m.clear_tensors()
+            if budget:
+                assert m.hip_streamed_bytes() > 0 and m.hip_resident_weight_bytes() < wbytes
+            m.close()
+            assert np.array_equal(res[0], res[1]) and np.array_equal(res[1], res[2])
+            outs[budget] = res[0]
+    assert np.array_equal(outs[0], outs[wbytes // 3]) and np.array_equal(outs[0], outs[64 * 1024])
+
+
+@pytest.mark.gpu
 def test_passes_are_bitwise_reproducible():
     """Pass 1 (eager), pass 2 (hipGraph capture) and the replays must agree bit for bit: no float atomics, fixed reduction orders,
     split-K slabs folded in slab order (also catches races between the loader and math waves of the convolution kernels)."""

@@ -270,6 +270,38 @@ def test_plan_rebuild_never_goes_back_to_the_provider(stub_backend, wp, ops_cach
     assert counts[0] == counts[1] == counts[4] and counts[2] < counts[1] < counts[3]
 
 
+@pytest.mark.parametrize("wp", ["ram+nocache", "nocache", "prefetch"])
+def test_vram_budget_streams_the_weights_beyond_it(stub_backend, wp):
+    """CudaOptions::m_vram_to_use (reference src/onnxstream.cpp:396-398): weights stay resident in model order until the budget is spent,
+    the rest are pulled from the provider and sent through the device ring EVERY pass, the first included; the provider's strict
+    sequence survives (DiskPrefetch throws otherwise) and the device never holds more weight bytes than budget + ring."""
+    from onnxstream_amd import build as b
+    from onnxstream_amd.bindings import Model
+    ins = sd_unet.unet_inputs(sd_unet.TINY, 42)
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        sd_unet.build_unet(DirSink(d), sd_unet.TINY)
+        wbytes = sum(os.path.getsize(d + f) for f in os.listdir(d) if f.endswith(".bin"))
+        budget = wbytes // 3
+        m = Model(b.LIB_HOST, 0, wp)
+        m.hip_set_vram_budget(budget)
+        m.read_file(d + "model.txt")
+        streamed = []
+        for _ in range(3):
+            for k, v in ins.items():
+                m.add_tensor(k, v)
+            m.set_use_fp16_arithmetic(True)
+            m.set_fuse_ops_in_attention(True)
+            m.run()
+            streamed.append(m.hip_streamed_bytes())
+            assert m.get_tensor("out_sample") is not None
+            m.clear_tensors()
+        held = m.hip_resident_weight_bytes()
+        m.close()
+    assert streamed[0] == streamed[1] == streamed[2] > 0.5 * wbytes           # everything beyond the budget, every pass
+    assert streamed[0] < wbytes and held < wbytes                              # ... and the resident part is not re-sent / the footprint shrank
+
+
 def test_device_sampler_loop_plumbing(stub_backend):
     """model_hip_sampler_loop / model_hip_set_input: argument checking and the 2-samples-per-prompt contract (no numbers: the stub computes nothing)."""
     from onnxstream_amd import build as b

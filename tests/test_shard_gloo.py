@@ -65,3 +65,76 @@ def test_partition_properties():
             assert max(map(len, parts)) - min(map(len, parts)) <= 1             # balanced
     assert np.array_equal(shard.gather_results(None, 0, 1, 2, {0: np.ones(3, np.float32), 1: np.zeros(3, np.float32)}),
                           np.stack([np.ones(3, np.float32), np.zeros(3, np.float32)]))
+
+
+# ---- the whole N > 1 flow of bench.py over the no-op stand-in for libosgpu: tune table shared, prompts scattered, a PASS per rank through the
+# ---- model_* C API (plan built, batch-2 run), results gathered -------------------------------------------------------------------------
+def _flow_worker(rank, world, port, stub, model_dir, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OSGPU_LIB"] = stub
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from onnxstream_amd import build as b
+        from onnxstream_amd.bindings import Model
+        from onnxstream_amd.synth import sd_unet
+        table = os.path.join(model_dir, f"tune_rank{rank}.txt")
+        row = "0 0 8192 320 320 1 320 0 0 0 0 0 0 0 2 6 1 0 11.500\n"
+        shard.share_tune_table(dist, rank, world, table, lambda: open(table, "w").write(row))
+        ok = open(table).read() == row and os.environ["OSG_TUNE_CACHE"] == table
+
+        def draw(i):
+            c, u = sd_unet.unet_inputs(sd_unet.TINY, 42 + 2 * i), sd_unet.unet_inputs(sd_unet.TINY, 43 + 2 * i)
+            return {k: np.stack([c[k], u[k]]) for k in c}
+        mine = shard.scatter_prompts(dist, rank, world, world, draw)
+        (pi, pack), = mine.items()
+        m = Model(b.LIB_HOST, 0, "ram+nocache")
+        m._set_option("hip_device", 0)
+        m._set_option("hip_autotune", 1)
+        m.read_file(model_dir + "model.txt")
+        for br in range(2):                       # cond + uncond of this rank's prompt: one batch-2 pass
+            for k, v in pack.items():
+                m.add_tensor(k, v[br])
+        m.set_use_fp16_arithmetic(True)
+        m.set_fuse_ops_in_attention(True)
+        m.run()
+        eps = np.stack([m.get_tensor("out_sample", i)[0] for i in range(2)])
+        m.close()
+        allr = shard.gather_results(dist, rank, world, world, {pi: eps})
+        ok = ok and pi == rank and eps.shape == (2, 1, 4, 16, 16)
+        ok = ok and ((allr is not None and allr.shape == (world, 2, 1, 4, 16, 16)) if rank == 0 else allr is None)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_shard_flow_world2_over_the_stub_backend():
+    import sys
+    import tempfile
+    import torch.multiprocessing as mp
+    from onnxstream_amd import build as b
+    from onnxstream_amd.synth import sd_unet
+    from onnxstream_amd.synth.graph import DirSink
+    if not os.path.exists(b.LIB_HOST):
+        pytest.skip("host library not built")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub"))
+    import make_stub
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        stub = make_stub.build(d + "stub")
+        sd_unet.build_unet(DirSink(d), sd_unet.TINY)
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_flow_worker, args=(r, 2, port, stub, d, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        got = dict(q.get(timeout=180) for _ in procs)
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    assert got == {0: True, 1: True}
