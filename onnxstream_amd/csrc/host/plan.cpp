@@ -2949,18 +2949,40 @@ void Plan::build() {
         for (int v : born[si]) vals[v].offset = take(aligned(val_bytes(v)));
         for (int v : dies[si]) give(vals[v].offset, aligned(val_bytes(v)));
     }
+    if (stream_weights) {
+        // Providers serve strictly in MODEL order, launches run in PLAN order (fusions move an op's weights to where the fused launch sits):
+        // before step si everything up to the last-in-model-order weight it reads has to be pulled (and sent).  flush_upto[si] = that
+        // prefix of `recipes`, made monotonic.
+        std::map<int, size_t> recipe_of;
+        for (size_t ri = 0; ri < recipes.size(); ri++)
+            if (recipes[ri].val >= 0) recipe_of[recipes[ri].val] = ri;
+        flush_upto.assign(steps.size(), 0);
+        size_t upto = 0;
+        for (size_t si = 0; si < steps.size(); si++) {
+            for (int v : steps[si].reads) {
+                auto it = recipe_of.find(root_of(v));
+                if (it != recipe_of.end()) upto = std::max(upto, it->second + 1);
+            }
+            flush_upto[si] = upto;
+        }
+    }
     if (budgeted && ring_weight_bytes) {
         // the streaming ring: FIFO of the over-budget weights in the order the steps read them.  It must hold what ONE step reads plus what
         // the next one is being sent (upload(i+1) overlaps compute(i)): twice the largest per-step demand, or a quarter of the streamed
         // weights up to 32 MiB if that is more
         std::vector<size_t> per_step(steps.size() + 1, 0);
         size_t worst = 0;
-        for (auto& r : recipes)
-            if (r.ring && r.val >= 0 && vals[r.val].last >= 0)
-                for (int si = vals[r.val].first; si <= vals[r.val].last; si++) {
-                    per_step[si] += ((size_t)r.count * esize(r.want) + 255) & ~(size_t)255;
-                    worst = std::max(worst, per_step[si]);
-                }
+        for (size_t ri = 0; ri < recipes.size(); ri++) {
+            const WRecipe& r = recipes[ri];
+            if (!(r.ring && r.val >= 0 && vals[r.val].last >= 0)) continue;
+            int sent = vals[r.val].first;        // it occupies the ring from the step whose flush sends it ...
+            for (int si = 0; si < (int)steps.size(); si++)
+                if (flush_upto[si] > ri) { sent = std::min(sent, si); break; }
+            for (int si = sent; si <= vals[r.val].last; si++) {
+                per_step[si] += ((size_t)r.count * esize(r.want) + 255) & ~(size_t)255;
+                worst = std::max(worst, per_step[si]);
+            }
+        }
         ring_bytes = std::max<size_t>(2 * worst + 4096, std::min<size_t>((size_t)32 << 20, ring_weight_bytes / 4));
         ring = be.malloc(ring_bytes);
     }
@@ -3086,12 +3108,7 @@ void Plan::execute() {
         ring_head = 0;
         for (size_t si = 0; si < steps.size(); si++) {
             cur_step = (int)si;
-            while (ri < recipes.size()) {
-                const WRecipe& r = recipes[ri];
-                if (r.val >= 0 && vals[r.val].first > (int)si && vals[r.val].last >= 0) break;
-                restream(r);
-                ri++;
-            }
+            while (ri < flush_upto[si]) restream(recipes[ri++]);
             steps[si].run();
             // ring occupants whose last reader has just been enqueued: mark the compute stream here, the slot may be overwritten after it
             for (auto& o : ring_occ)

@@ -150,6 +150,7 @@ struct Plan {
     std::vector<RingOcc> ring_occ;
     int next_marker = 0, cur_step = 0;
     std::vector<WRecipe> recipes;
+    std::vector<size_t> flush_upto;             // per step: how many leading recipes must have been pulled / sent before it runs
     std::map<const void*, size_t> registered;   // provider host buffers page-locked for zero-copy DMA
     size_t streamed_bytes = 0;
     void restream(const WRecipe& r);
