@@ -211,7 +211,7 @@ def main():
     ap.add_argument("--profile-reps", type=int, default=3)
     ap.add_argument("--steps-per-image", type=int, default=0, help="denoising steps per image (default 20; BASELINE config 4 = SDXL uses 10)")
     ap.add_argument("--side-stream", action="store_true", help="shortcut convolutions etc. on a second stream beside the main chain (parallel hipGraph branches; measured slower)")
-    ap.add_argument("--ln-fold", action="store_true", help="fold every LayerNorm into the GEMM that consumes it (osg_gemm_ln; 48 launches less, measured time-neutral)")
+    ap.add_argument("--no-ln-fold", action="store_true", help="standalone LayerNorm launches instead of folding every LayerNorm into the GEMM that consumes it (osg_gemm_ln, default)")
     ap.add_argument("--no-autotune", action="store_true", help="tile / split-K configurations from the cost model only (no measured choice in the first pass)")
     ap.add_argument("--host-loop", action="store_true", help="pipeline mode: CFG + Euler-A on the host with one round trip per step (the reference app's shape) instead of the device loop")
     ap.add_argument("--prompts-per-gpu", type=int, default=1, help="prompts denoised together on each GPU (2P samples per UNet pass: the reference's --num batching)")
@@ -305,8 +305,8 @@ def main():
     m = pipe.unet
     if args.w8_resident:
         m._set_option("hip_w8_resident", 1)
-    if args.ln_fold:
-        m._set_option("hip_fuse_ln_gemm", 1)
+    if args.no_ln_fold:
+        m._set_option("hip_fuse_ln_gemm", 0)
     if args.side_stream:
         m._set_option("hip_side_stream", 1)
     L = cfg.latent

@@ -105,6 +105,11 @@ void osg_graph_destroy(osg_graph* g);
 /* ---- timing on the compute stream (HIP events) ------------------------------------------------------------ */
 int osg_timer_start(osg_ctx* ctx);
 int osg_timer_stop(osg_ctx* ctx, float* ms); /* waits for the stop event */
+/* a sequence of timestamps on the compute stream WITHOUT host synchronisation in between: osg_timer_mark(i) records event i (i < 4096) behind
+ * everything enqueued so far; osg_timer_between(a, b) waits for event b and returns the device time from a to b.  Lets a profiler time every
+ * launch of a pass while the queue stays full (per-launch figures comparable with rocprofv3's kernel durations, no idle-launch latency). */
+int osg_timer_mark(osg_ctx* ctx, int index);
+int osg_timer_between(osg_ctx* ctx, int a, int b, float* ms);
 
 /* ---- tracing: rocTX ranges around the launches of one graph op (visible in rocprofv3 --marker-trace timelines); no-ops when libroctx64 is absent.
  * The host Model opens a range per step when m_ops_printf / m_ops_times_printf is set or OSG_ROCTX=1 (the reference's tracing is the two printf

@@ -142,6 +142,8 @@ void osg_destroy(osg_ctx* c) {
     if (c->ev_a1) hipEventDestroy(c->ev_a1);
     for (auto& e : c->markers)
         if (e) hipEventDestroy(e);
+    for (auto& e : c->marks)
+        if (e) hipEventDestroy(e);
     if (c->compute) hipStreamDestroy(c->compute);
     if (c->copy) hipStreamDestroy(c->copy);
     delete c;
@@ -332,6 +334,22 @@ void osg_graph_destroy(osg_graph* g) {
 
 int osg_timer_start(osg_ctx* c) {
     OSG_HIP(c, hipEventRecord(c->ev_t0, c->compute));
+    return 0;
+}
+
+int osg_timer_mark(osg_ctx* c, int index) {
+    if (index < 0 || index >= 4096) OSG_FAIL(c, "osg_timer_mark: index out of range");
+    if (c->capturing) OSG_FAIL(c, "osg_timer_mark inside graph capture");
+    if ((int)c->marks.size() <= index) c->marks.resize(index + 1, nullptr);
+    if (!c->marks[index]) OSG_HIP(c, hipEventCreate(&c->marks[index]));
+    OSG_HIP(c, hipEventRecord(c->marks[index], c->compute));
+    return 0;
+}
+
+int osg_timer_between(osg_ctx* c, int a, int b, float* ms) {
+    if (a < 0 || b < 0 || a >= (int)c->marks.size() || b >= (int)c->marks.size() || !c->marks[a] || !c->marks[b]) OSG_FAIL(c, "osg_timer_between: unknown mark");
+    OSG_HIP(c, hipEventSynchronize(c->marks[b]));
+    OSG_HIP(c, hipEventElapsedTime(ms, c->marks[a], c->marks[b]));
     return 0;
 }
 

@@ -138,7 +138,7 @@ def test_unet_plan_structure(stub_backend):
     with tempfile.TemporaryDirectory() as d:
         d += "/"
         sd_unet.build_unet(DirSink(d), sd_unet.TINY)
-        m, info = _plan(d, ins, pushes=2)                      # cond + uncond pushed under the same names = one batch-2 pass
+        m, info = _plan(d, ins, (("hip_fuse_ln_gemm", 0),), pushes=2)   # cond + uncond pushed under the same names = one batch-2 pass
         steps, vals, arena = _parse(info)
         kinds = [s["what"].split(" ", 1)[0].split("+")[0] for s in steps]
         m.close()
@@ -164,7 +164,7 @@ def test_full_size_sd15_plan(stub_backend):
         sd_unet.build_unet(DirSink(d), sd_unet.SD15)
         open(d + ".complete", "w").write("ok")
     ins = sd_unet.unet_inputs(sd_unet.SD15, 42)
-    m, info = _plan(d, ins, (("hip_side_stream", 1),), pushes=2)
+    m, info = _plan(d, ins, (("hip_side_stream", 1), ("hip_fuse_ln_gemm", 0)), pushes=2)
     steps, vals, arena = _parse(info)
     m.close()
     assert len(steps) == 366
@@ -176,6 +176,9 @@ def test_full_size_sd15_plan(stub_backend):
     assert arena < 400 * 2 ** 20                                # activations of a batch-2 pass pack into well under 400 MiB
     kinds = [s["what"].split(" ", 1)[0].split("+")[0] for s in steps]
     assert kinds.count("Attention") == 32 and kinds.count("GroupNorm") == 61 and kinds.count("LayerNorm") == 48
+    m, info = _plan(d, ins, (), pushes=2)                       # the default plan folds every LayerNorm into its consuming GEMM
+    assert len(_parse(info)[0]) == 318
+    m.close()
 
 
 def test_errors_are_the_reference_style_and_loud(stub_backend):
@@ -253,7 +256,7 @@ def test_plan_rebuild_never_goes_back_to_the_provider(stub_backend, wp, ops_cach
         m.read_file(d + "model.txt")
         m.set_use_ops_cache(bool(ops_cache))
         counts = []
-        for pushes, opts in ((1, ()), (2, ()), (2, (("hip_fuse_ln_gemm", 1),)), (1, (("hip_fusion_level", 0),)), (3, (("hip_fusion_level", 2), ("hip_fuse_ln_gemm", 0)))):
+        for pushes, opts in ((1, (("hip_fuse_ln_gemm", 0),)), (2, ()), (2, (("hip_fuse_ln_gemm", 1),)), (1, (("hip_fusion_level", 0),)), (3, (("hip_fusion_level", 2), ("hip_fuse_ln_gemm", 0)))):
             for k, v in opts:
                 m._set_option(k, v)
             for _ in range(pushes):
