@@ -319,6 +319,8 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
         });
     }
     gemm_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0, lane, 0, zs);
+    // split-K over slabs: the last block to arrive at the tile folds the slabs (only the 4 math waves are still here: tid 0..255)
+    if (p.splits > 1 && p.tickets) splitk_finish<128, BN>(p, m0, n0, m_tile * p.nt + n_tile, 0, reinterpret_cast<int*>(smem3), tid, 256);
 }
 
 template <int W_, int BN, int WGM, int WGN, int MODE, bool PRE>
@@ -470,6 +472,9 @@ int osg_conv3x3_launch(osg_ctx* ctx, GemmParams p, int bn, int s) {
         size_t need = (size_t)p.splits * p.M * p.N * sizeof(float);
         if (osg_ensure_workspace(ctx, need)) return 1;
         p.partial = (float*)ctx->ws;
+        static const bool use_tickets = getenv("OSG_SPLITK_TICKET") && atoi(getenv("OSG_SPLITK_TICKET")) != 0;   // opt-in: measured slower than the reduce launch (6.60 vs 6.34 ms per step, round 2)
+        const long n_tiles = (long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
+        if (use_tickets && p.N % 4 == 0 && ctx->tickets && n_tiles <= osg_ctx::kTickets) p.tickets = ctx->tickets;
     }
     p.n_major = (double)p.N * p.K * 2.0 > (double)p.a_bytes_l;
     int rc;
@@ -478,7 +483,7 @@ int osg_conv3x3_launch(osg_ctx* ctx, GemmParams p, int bn, int s) {
     else if (p.W == 16) rc = launch3_bn<16>(ctx, p, bn);
     else rc = launch3_bn<8>(ctx, p, bn);
     if (rc) return rc;
-    if (p.splits > 1) return launch_splitk_reduce(ctx, p, 1);
+    if (p.splits > 1 && !p.tickets) return launch_splitk_reduce(ctx, p, 1);
     return 0;
 }
 

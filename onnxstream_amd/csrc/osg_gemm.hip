@@ -421,61 +421,9 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm2_kernel(GemmParams p) {
     }
     gemm_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0, lane, zb, zb * p.splits + zs);
 
-    // ---- split-K: the LAST k-slice block to arrive at this tile folds the f32 slabs (fixed order => deterministic) and writes
-    // the f16 tile -- no separate reduce launch.  Hand-off = agent-scope release (writer) / acquire (reducer), relaxed ticket.
-    if (p.splits > 1 && p.tickets) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int* flag = reinterpret_cast<int*>(smem2);
-        const int tile_id = (zb * p.mt + m_tile) * p.nt + n_tile;
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            *flag = __hip_atomic_fetch_add(&p.tickets[tile_id], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        if (*flag != p.splits - 1) return;
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(&p.tickets[tile_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        constexpr int VPR = BN / 4;
-        const long MN = (long)p.M * p.N;
-        const float* __restrict__ P0 = p.partial + (long)zb * p.splits * MN;
-        f16* __restrict__ C = p.C + zb * p.strideC;
-        const f16* __restrict__ R = p.residual ? p.residual + zb * p.strideC : nullptr;
-        for (int v = tid; v < BM * VPR; v += 256) {
-            const int r = v / VPR, m = m0 + r, n = n0 + (v - r * VPR) * 4;
-            if (m >= p.M || n >= p.N) continue;
-            const float* src = P0 + (long)m * p.N + n;
-            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-            for (int s2 = 0; s2 < p.splits; s2++) sum += *reinterpret_cast<const f32x4*>(src + s2 * MN);
-            if (p.bias) {
-                if (p.bias_f32) sum += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
-                else {
-                    f16x4 bv = *reinterpret_cast<const f16x4*>((const f16*)p.bias + n);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) sum[e] += (float)bv[e];
-                }
-            }
-            if (p.rowbias) {
-                f16x4 rb = *reinterpret_cast<const f16x4*>(p.rowbias + (long)(m / p.rb_rows) * p.rb_ld + n);
-#pragma unroll
-                for (int e = 0; e < 4; e++) sum[e] += (float)rb[e];
-            }
-            if (R) {
-                f16x4 rv = *reinterpret_cast<const f16x4*>(R + (long)m * p.N + n);
-#pragma unroll
-                for (int e = 0; e < 4; e++) sum[e] += (float)rv[e];
-            }
-            f16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; e++) o[e] = (f16)osg_apply_act(sum[e], p.act);
-            *reinterpret_cast<f16x4*>(C + (long)m * p.N + n) = o;
-        }
-    }
+    // ---- split-K: the last k-slice block to arrive at this tile folds the slabs (osg_gemm_common.h splitk_finish): no reduce launch
+    if (p.splits > 1 && p.tickets)
+        splitk_finish<BM, BN>(p, m0, n0, (zb * p.mt + m_tile) * p.nt + n_tile, zb, reinterpret_cast<int*>(smem2), tid, 256);
 }
 
 template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0, int LN = 0, int NCH = 5>
@@ -792,9 +740,9 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
         if (osg_ensure_workspace(ctx, need)) return 1;
         p.partial = (float*)ctx->ws;
         const long n_tiles = (long)batch * ((p.M + kV2BM[ch.cfg] - 1) / kV2BM[ch.cfg]) * ((p.N + kV2BN[ch.cfg] - 1) / kV2BN[ch.cfg]);
-        // in-kernel last-arriver reduction: measured SLOWER than the reduce launch (the agent-scope release of freshly written
-        // slabs costs ~6 us per block, MI355X_MICROARCH.md 'publish-large'); kept for experiments only
-        static const bool use_tickets = getenv("OSG_GEMM_TICKET") != nullptr;
+        // in-kernel last-arriver reduction over write-through slabs (round 1's version published the slabs with plain stores + an
+        // agent-scope release, ~6 us per block); correct and bit-identical, but still loses to the separate reduce launch => OSG_SPLITK_TICKET=1 to try it
+        static const bool use_tickets = getenv("OSG_SPLITK_TICKET") && atoi(getenv("OSG_SPLITK_TICKET")) != 0;   // opt-in: measured slower than the reduce launch (6.60 vs 6.34 ms per step, round 2)
         if (use_tickets && p.N % 4 == 0 && ctx->tickets && n_tiles <= osg_ctx::kTickets) p.tickets = ctx->tickets;
     }
     // split the operand with more unique bytes across the XCDs (each private L2 then streams its slice from HBM once)

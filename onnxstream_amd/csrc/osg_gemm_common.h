@@ -181,7 +181,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                 const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
                 if (n >= N) continue;
                 if ((N & 3) == 0) {
-                    *reinterpret_cast<f32x4*>(P + (long)m * N + n) = acc[i][j];
+                    if (p.tickets) {
+                        // write-through (sc1): the slab goes past this XCD's L2 to memory, so the last-arriving block of the tile -- maybe on
+                        // another XCD -- can read it with sc1 loads after the ticket, no release / acquire fence on either side
+                        const float* dst = P + (long)m * N + n;
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(acc[i][j]) : "memory");
+                    } else
+                        *reinterpret_cast<f32x4*>(P + (long)m * N + n) = acc[i][j];
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; r++)
@@ -223,6 +229,68 @@ __device__ __forceinline__ void gemm_epilogue_geglu(const GemmParams& p, f32x4 (
             }
             *reinterpret_cast<f16x4*>(C + (long)m * No + c) = o;
         }
+    }
+}
+
+// ---- split-K without a reduce launch: the LAST k-slice block to arrive at an output tile folds the f32 slabs (in slab order => the same
+// bits whoever arrives last) and writes the f16 tile.  Slabs are published write-through (sc1 stores, see gemm_epilogue), every wave drains
+// its stores (vmcnt(0)) before the block's single relaxed agent-scope ticket; the reducer reads the slabs with sc1 loads (they bypass its
+// L1 and revalidate against memory): the hand-off needs neither the release fence (an L2 write-back of freshly dirtied slabs, ~6 us per
+// block) nor the acquire.  Call with every thread of the block that ran gemm_epilogue (nthr of them, tid = 0 .. nthr-1).
+template <int BM, int BN>
+__device__ __forceinline__ void splitk_finish(const GemmParams& p, int m0, int n0, int tile_id, int zb, int* flag, int tid, int nthr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) *flag = __hip_atomic_fetch_add(&p.tickets[tile_id], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*flag != p.splits - 1) return;
+    if (tid == 0) __hip_atomic_store(&p.tickets[tile_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    constexpr int VPR = BN / 4;
+    const long MN = (long)p.M * p.N;
+    const float* __restrict__ P0 = p.partial + (long)zb * p.splits * MN;
+    f16* __restrict__ C = p.C + zb * p.strideC;
+    const f16* __restrict__ R = p.residual ? p.residual + zb * p.strideC : nullptr;
+    for (int v = tid; v < BM * VPR; v += nthr) {
+        const int r = v / VPR, m = m0 + r, n = n0 + (v - r * VPR) * 4;
+        if (m >= p.M || n >= p.N) continue;
+        const float* src = P0 + (long)m * p.N + n;
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < p.splits; s0 += 4) {
+            f32x4 part[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float* a = src + (long)min(s0 + u, p.splits - 1) * MN;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[u]) : "v"(a) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                asm volatile("" : "+v"(part[u]));
+                if (s0 + u < p.splits) sum += part[u];
+            }
+        }
+        if (p.bias) {
+            if (p.bias_f32) sum += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
+            else {
+                f16x4 bv = *reinterpret_cast<const f16x4*>((const f16*)p.bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; e++) sum[e] += (float)bv[e];
+            }
+        }
+        if (p.rowbias) {
+            f16x4 rb = *reinterpret_cast<const f16x4*>(p.rowbias + (long)(m / p.rb_rows) * p.rb_ld + n);
+#pragma unroll
+            for (int e = 0; e < 4; e++) sum[e] += (float)rb[e];
+        }
+        if (R) {
+            f16x4 rv = *reinterpret_cast<const f16x4*>(R + (long)m * p.N + n);
+#pragma unroll
+            for (int e = 0; e < 4; e++) sum[e] += (float)rv[e];
+        }
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = (f16)osg_apply_act(sum[e], p.act);
+        *reinterpret_cast<f16x4*>(C + (long)m * p.N + n) = o;
     }
 }
 
