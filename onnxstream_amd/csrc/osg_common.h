@@ -39,6 +39,7 @@ struct osg_ctx {
     bool capturing = false;
     bool autotune = false;              // osg_set_autotune: contraction launches pick tile/split configurations by measurement (osg_tune.h)
     hipEvent_t ev_a0 = nullptr, ev_a1 = nullptr;
+    void* evict = nullptr;              // OSG_TUNE_COLD: fill target that evicts L2 / MALL before a timed launch
     std::vector<hipEvent_t> marks;      // osg_timer_mark / osg_timer_between
     static constexpr int kMarkers = 256;
     hipEvent_t markers[kMarkers] = {};   // osg_marker_record / osg_copy_wait_marker (created on first use)

@@ -474,7 +474,7 @@ int osg_conv3x3_launch(osg_ctx* ctx, GemmParams p, int bn, int s) {
         p.partial = (float*)ctx->ws;
         static const bool use_tickets = getenv("OSG_SPLITK_TICKET") && atoi(getenv("OSG_SPLITK_TICKET")) != 0;   // opt-in: measured slower than the reduce launch (6.60 vs 6.34 ms per step, round 2)
         const long n_tiles = (long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
-        if (use_tickets && p.N % 4 == 0 && ctx->tickets && n_tiles <= osg_ctx::kTickets) p.tickets = ctx->tickets;
+        if (use_tickets && p.N % 4 == 0 && ctx->tickets && n_tiles <= osg_ctx::kTickets / 2) p.tickets = ctx->tickets;
     }
     p.n_major = (double)p.N * p.K * 2.0 > (double)p.a_bytes_l;
     int rc;

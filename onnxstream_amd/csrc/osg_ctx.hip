@@ -128,6 +128,7 @@ void osg_destroy(osg_ctx* c) {
         if (c->stage_free[i]) hipEventDestroy(c->stage_free[i]);
     }
     if (c->tickets) hipFree(c->tickets);
+    if (c->evict) hipFree(c->evict);
     if (c->ws) hipFree(c->ws);
     if (c->ws2) hipFree(c->ws2);
     if (c->ws_s) hipFree(c->ws_s);

@@ -16,6 +16,7 @@
 #include "osg_tune.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 using namespace osg_mm;
@@ -687,9 +688,10 @@ static std::vector<std::pair<double, V2Choice>> rank_v2(const osg_ctx* ctx, int 
     const int kt = K / 64;
     std::vector<std::pair<double, V2Choice>> out;
     for (int c = 0; c < (ctx->autotune ? 4 : 3); c++)
-        for (int nst = 6; nst >= 2; nst -= 2) {
-            // 6 stages (every tile of a K <= 384 GEMM in flight at once): only as a measured candidate, only where the ring fits the LDS
+        for (int nst = 8; nst >= 2; nst -= 2) {
+            // 6 / 8 stages (every tile of a short-K GEMM in flight at once): only as a measured candidate, only where the ring fits the LDS
             if (nst == 6 && (!ctx->autotune || c == 0)) continue;
+            if (nst == 8 && (!ctx->autotune || c != 2)) continue;
             const double tiles = (double)((M + kV2BM[c] - 1) / kV2BM[c]) * ((N + kV2BN[c] - 1) / kV2BN[c]) * batch;
             const double mfma = kV2BM[c] * kV2BN[c] * 128.0 / 4069.0;
             const double tload = (kV2BM[c] + kV2BN[c]) * 128.0 / 23.0;
@@ -743,7 +745,7 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
         // in-kernel last-arriver reduction over write-through slabs (round 1's version published the slabs with plain stores + an
         // agent-scope release, ~6 us per block); correct and bit-identical, but still loses to the separate reduce launch => OSG_SPLITK_TICKET=1 to try it
         static const bool use_tickets = getenv("OSG_SPLITK_TICKET") && atoi(getenv("OSG_SPLITK_TICKET")) != 0;   // opt-in: measured slower than the reduce launch (6.60 vs 6.34 ms per step, round 2)
-        if (use_tickets && p.N % 4 == 0 && ctx->tickets && n_tiles <= osg_ctx::kTickets) p.tickets = ctx->tickets;
+        if (use_tickets && p.N % 4 == 0 && ctx->tickets && n_tiles <= osg_ctx::kTickets / 2) p.tickets = ctx->tickets;
     }
     // split the operand with more unique bytes across the XCDs (each private L2 then streams its slice from HBM once)
     const double a_unique = CONV ? (double)p.a_bytes : (double)p.M * p.K * 2.0;
@@ -781,7 +783,7 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
     else if (ch.cfg == 0) rc = ch.nst == 4 ? launch_v2<128, 128, 4, CONV>(ctx, p, batch) : launch_v2<128, 128, 2, CONV>(ctx, p, batch);
     else if (ch.cfg == 1) rc = ch.nst == 6 ? launch_v2<128, 64, 6, CONV>(ctx, p, batch) : ch.nst == 4 ? launch_v2<128, 64, 4, CONV>(ctx, p, batch) : launch_v2<128, 64, 2, CONV>(ctx, p, batch);
     else if (ch.cfg == 3) rc = ch.nst == 6 ? launch_v2<64, 128, 6, CONV>(ctx, p, batch) : ch.nst == 4 ? launch_v2<64, 128, 4, CONV>(ctx, p, batch) : launch_v2<64, 128, 2, CONV>(ctx, p, batch);
-    else rc = ch.nst == 6 ? launch_v2<64, 64, 6, CONV>(ctx, p, batch) : ch.nst == 4 ? launch_v2<64, 64, 4, CONV>(ctx, p, batch) : launch_v2<64, 64, 2, CONV>(ctx, p, batch);
+    else rc = ch.nst == 8 ? launch_v2<64, 64, 8, CONV>(ctx, p, batch) : ch.nst == 6 ? launch_v2<64, 64, 6, CONV>(ctx, p, batch) : ch.nst == 4 ? launch_v2<64, 64, 4, CONV>(ctx, p, batch) : launch_v2<64, 64, 2, CONV>(ctx, p, batch);
     if (rc) return rc;
     if (p.splits > 1 && !p.tickets) return launch_splitk_reduce(ctx, p, batch);
     return 0;
@@ -806,6 +808,9 @@ int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced) {
                 float best = -1.f;
                 for (auto& cand : ranked) {
                     const float us = osg_tune::time_us(ctx, [&] { return launch_v2_choice<CONV>(ctx, p, batch, cand.second); });
+                    static const bool dump = getenv("OSG_TUNE_DUMP") != nullptr;
+                    if (dump) fprintf(stderr, "[tune] %s M=%d N=%d K=%d flags=%d: tile %dx%d nst=%d splits=%d -> %.2f us (model %.0f)\n", CONV ? "conv" : "gemm", p.M, p.N, p.K, key.flags,
+                                      kV2BM[cand.second.cfg], kV2BN[cand.second.cfg], cand.second.nst, cand.second.splits, us, cand.first);
                     if (us >= 0.f && (best < 0.f || us < best)) { best = us; ch = cand.second; }
                 }
                 if (best < 0.f) OSG_FAIL(ctx, "osg_gemm: autotune could not time any configuration");

@@ -239,17 +239,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 // [HW x CW] slab in registers between the statistics and the apply: x is read once, y written once, no workspace, no second launch.
 // The UNet's 8x8 / 16x16 / 32x32 levels (45 of SD1.5's 61 GroupNorms) are launch-latency bound, not bandwidth bound, and run this way;
 // larger slabs use the three-pass path below.  Thread t keeps ONE vector column (8 channels => at most two groups when cpg >= 8).
-template <int NV>
+// CL (cluster): blockIdx.z = s splits the pixel rows of the slab over S co-resident blocks (the 64x64 level: 16 x 2 x 8 blocks instead of a
+// statistics launch and an apply launch that reads x again).  Each block publishes its per-group (sum, sumsq) write-through (sc1), takes a
+// relaxed agent-scope ticket, waits until all S partials of its slab are there, folds them in slab order (=> the same bits in every block) and
+// applies from registers.  The grid never exceeds the CU count, so every block is resident while its peers spin; the last block to LEAVE a
+// cluster zeroes its two counters for the next launch.
+template <int NV, bool CL>
 __global__ __launch_bounds__(1024) void gn_slab_kernel(const f16* __restrict__ x, const f16* __restrict__ gamma, const f16* __restrict__ beta,
-                                                       f16* __restrict__ y, int HW, int C, int cpg, int gb, float eps, int act) {
+                                                       f16* __restrict__ y, int HW, int C, int cpg, int gb, float eps, int act, int S,
+                                                       double* __restrict__ part, int* __restrict__ cnt) {
     __shared__ float red[8][16][2];   // [local group][wave][sum, sumsq]
     __shared__ float stat[8][2];      // [local group][mean, rstd]
+    const int HWs = CL ? HW / S : HW;      // rows of this block
     const int NT = blockDim.x, nw = NT >> 6;
     const int CW = gb * cpg, VR = CW >> 3, RT = NT / VR;
     const int t = threadIdx.x, tr = t / VR, tc = t - tr * VR;
     const bool active = tr < RT;
     const int ch = blockIdx.x * CW + tc * 8;                 // first of this thread's 8 channels
-    const long img = (long)blockIdx.y * HW * C + blockIdx.x * CW;   // uniform base; per-thread offsets stay 32-bit (scalar base + voffset loads)
+    const long img = (long)blockIdx.y * HW * C + blockIdx.x * CW + (CL ? (long)blockIdx.z * HWs * C : 0);   // uniform base; per-thread offsets stay 32-bit (scalar base + voffset loads)
     const f16* xb = x + img;
     f16* yb = y + img;
     const unsigned off0 = (unsigned)tr * C + tc * 8, step = (unsigned)RT * C;
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const f16* __restrict__ x
 #pragma unroll
     for (int j = 0; j < NV; j++) {
         const int row = tr + j * RT;
-        if (active && row < HW) v[j] = *reinterpret_cast<const f16x8*>(xb + (off0 + j * step));
+        if (active && row < HWs) v[j] = *reinterpret_cast<const f16x8*>(xb + (off0 + j * step));
         else v[j] = (f16x8)(f16)0;
     }
     float sm[8], sq[8];
@@ -293,6 +300,54 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const f16* __restrict__ x
         if (lane == 0) { red[gl][wave][0] = s; red[gl][wave][1] = q; }
     }
     __syncthreads();
+    if constexpr (CL) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const long slab = (long)blockIdx.y * gridDim.x + blockIdx.x;
+        double* mine = part + ((slab * gb) * S) * 2;
+        int* c2 = cnt + slab * 2;
+        if (t < gb) {
+            d2 pq = {0.0, 0.0};
+            for (int w = 0; w < nw; w++) { pq[0] += red[t][w][0]; pq[1] += red[t][w][1]; }
+            double* dst = mine + ((long)t * S + blockIdx.z) * 2;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(pq) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (t == 0) {
+            __hip_atomic_fetch_add(c2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < S) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        if (t < gb) {
+            double s = 0, q = 0;
+            for (int s0 = 0; s0 < S; s0 += 4) {
+                d2 pv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const double* a = mine + ((long)t * S + min(s0 + u, S - 1)) * 2;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pv[u]) : "v"(a) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    asm volatile("" : "+v"(pv[u]));
+                    if (s0 + u < S) { s += pv[u][0]; q += pv[u][1]; }
+                }
+            }
+            const double icnt = (double)(1.0f / ((float)HW * (float)cpg));
+            const double mean = s * icnt;
+            const float var = fmaxf((float)(q * icnt - mean * mean), 0.f);
+            stat[t][0] = (float)mean;
+            stat[t][1] = 1.0f / sqrtf(var + eps);
+        }
+        __syncthreads();
+        if (t == 0) {   // (every reader of this cluster's partials is past its loads when the last one leaves)
+            if (__hip_atomic_fetch_add(c2 + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1) {
+                __hip_atomic_store(c2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(c2 + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    } else {
     if (t < gb) {
         double s = 0, q = 0;
         for (int w = 0; w < nw; w++) { s += red[t][w][0]; q += red[t][w][1]; }
@@ -303,6 +358,7 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const f16* __restrict__ x
         stat[t][1] = 1.0f / sqrtf(var + eps);
     }
     __syncthreads();
+    }
     if (!active) return;
     float ca[8], cb[8];
     {
@@ -321,7 +377,7 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const f16* __restrict__ x
 #pragma unroll
     for (int j = 0; j < NV; j++) {
         const int row = tr + j * RT;
-        if (row < HW) {
+        if (row < HWs) {
             f16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; e++) o[e] = (f16)osg_apply_act(fmaf((float)v[j][e], ca[e], cb[e]), act);
@@ -352,6 +408,38 @@ bool gn_slab_plan(long HW, int C, int G, GnSlabPlan* pl) {
             while (nv < need) nv *= 2;
             *pl = {gb, nt, nv};
             return true;
+        }
+    }
+    return false;
+}
+
+// cluster plan (slabs too large for one block's registers): the largest S in {16, 8, 4, 2} whose grid still fits the CUs, then the smallest block
+struct GnClusterPlan { int gb, nt, nv, S; };
+bool gn_cluster_plan(long HW, int C, int G, int N, int num_cu, GnClusterPlan* pl) {
+    const bool off = getenv("OSG_GN_CLUSTER_OFF") != nullptr;   // (tests: pin the three-pass statistics)
+    if (off || G <= 0 || C % G || C % 8) return false;
+    const int cpg = C / G;
+    if (cpg < 8) return false;
+    int gb = 1;
+    while (gb <= 8 && ((gb * cpg) % 8 || G % gb)) gb++;
+    if (gb > 8) return false;
+    const int VR = gb * cpg / 8;
+    if (VR > 128 || HW > (1 << 20)) return false;
+    const long slabs = (long)(G / gb) * N;
+    if (slabs * 2 > osg_ctx::kTickets / 2) return false;
+    for (int S = 16; S >= 2; S >>= 1) {
+        if (slabs * S > num_cu || HW % S) continue;
+        const long HWs = HW / S;
+        for (int nt = 256; nt <= 1024; nt *= 2) {
+            const int RT = nt / VR;
+            if (RT < 1) continue;
+            const long need = (HWs + RT - 1) / RT;
+            if (need <= (nt < 1024 ? 4 : 8)) {
+                int nv = 1;
+                while (nv < need) nv *= 2;
+                *pl = {gb, nt, nv, S};
+                return true;
+            }
         }
     }
     return false;
@@ -512,8 +600,8 @@ int osg_group_norm_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void
     if (dtype == OSG_F16 && gn_slab_plan(HW, C, G, &sp)) {
         const dim3 grid(G / sp.gb, N), block(sp.nt);
 #define OSG_GN_SLAB(NV_)                                                                                                             \
-    hipLaunchKernelGGL(gn_slab_kernel<NV_>, grid, block, 0, ctx->compute, (const f16*)x, (const f16*)gamma, (const f16*)beta, (f16*)y, \
-                       (int)HW, C, C / G, sp.gb, eps, (int)act)
+    hipLaunchKernelGGL((gn_slab_kernel<NV_, false>), grid, block, 0, ctx->compute, (const f16*)x, (const f16*)gamma, (const f16*)beta, (f16*)y, \
+                       (int)HW, C, C / G, sp.gb, eps, (int)act, 1, (double*)nullptr, (int*)nullptr)
         switch (sp.nv) {
             case 1: OSG_GN_SLAB(1); break;
             case 2: OSG_GN_SLAB(2); break;
@@ -521,6 +609,24 @@ int osg_group_norm_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void
             default: OSG_GN_SLAB(8); break;
         }
 #undef OSG_GN_SLAB
+        OSG_LAUNCH_CHECK(ctx);
+        return 0;
+    }
+    GnClusterPlan cp;
+    if (dtype == OSG_F16 && ctx->tickets && gn_cluster_plan(HW, C, G, N, ctx->num_cu, &cp)) {
+        if (osg_ensure_workspace(ctx, (size_t)N * G * cp.S * 2 * sizeof(double))) return 1;
+        const dim3 grid(G / cp.gb, N, cp.S), block(cp.nt);
+        int* cnt = ctx->tickets + osg_ctx::kTickets / 2;   // (the lower half belongs to the split-K tickets)
+#define OSG_GN_CL(NV_)                                                                                                               \
+    hipLaunchKernelGGL((gn_slab_kernel<NV_, true>), grid, block, 0, ctx->compute, (const f16*)x, (const f16*)gamma, (const f16*)beta, (f16*)y, \
+                       (int)HW, C, C / G, cp.gb, eps, (int)act, cp.S, (double*)ctx->ws, cnt)
+        switch (cp.nv) {
+            case 1: OSG_GN_CL(1); break;
+            case 2: OSG_GN_CL(2); break;
+            case 4: OSG_GN_CL(4); break;
+            default: OSG_GN_CL(8); break;
+        }
+#undef OSG_GN_CL
         OSG_LAUNCH_CHECK(ctx);
         return 0;
     }

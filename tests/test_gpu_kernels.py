@@ -218,6 +218,7 @@ def test_group_norm_conv3x3_fused(gpu, N, H, Cin, Cout, bn, splits, monkeypatch)
     if bn:
         monkeypatch.setenv("OSG_CONV3X3_BN", str(bn))
         monkeypatch.setenv("OSG_CONV3X3_SPLITS", str(splits))
+    monkeypatch.setenv("OSG_GN_CLUSTER_OFF", "1")   # the fused path takes its statistics from the three-pass kernels: compare like with like
     rng = np.random.default_rng(N * 17 + H + Cin + Cout)
     x = (rnd(rng, (N, H, H, Cin), 2.0).astype(f32) + 0.7).astype(f16)
     gamma, beta = (1 + rnd(rng, (Cin,), 0.1).astype(f32)).astype(f16), rnd(rng, (Cin,), 0.1)
@@ -307,7 +308,10 @@ def test_instance_norm(gpu, rows, L):
 @pytest.mark.parametrize("N,H,W,C,act", [(2, 64, 64, 320, 1), (1, 8, 8, 2560, 0), (2, 16, 16, 1280, 1), (1, 5, 3, 64, 0),
                                          # single-launch slab kernel: every vectors-per-thread instantiation, ragged HW, groups straddling a vector
                                          (2, 32, 32, 640, 1), (2, 32, 32, 1920, 1), (1, 32, 32, 960, 0), (2, 16, 16, 2560, 1), (2, 8, 8, 1280, 1),
-                                         (1, 7, 9, 320, 1), (1, 3, 3, 256, 0), (1, 16, 16, 1920, 0), (3, 1, 1, 384, 1)])
+                                         (1, 7, 9, 320, 1), (1, 3, 3, 256, 0), (1, 16, 16, 1920, 0), (3, 1, 1, 384, 1),
+                                         # cluster kernel (pixel rows of a slab split over co-resident blocks): the 64x64 level, P = 4, the wide concat inputs
+                                         (2, 64, 64, 640, 1), (2, 64, 64, 960, 1), (8, 64, 64, 320, 1), (1, 64, 64, 320, 0), (2, 32, 32, 1280, 1),
+                                         (1, 128, 128, 256, 1), (1, 64, 64, 512, 1), (40, 64, 64, 320, 1)])
 def test_group_norm_nhwc(gpu, N, H, W, C, act):
     rng = np.random.default_rng(C + H)
     x = rnd(rng, (N, H, W, C), 1.5) + f16(0.3)
@@ -340,6 +344,21 @@ def test_reduce_mean_softmax(gpu):
     assert rel_max(got, want) <= 2e-3
     xl = rnd(rng, (16, 4096), 3.0)
     assert rel_max(gpu.softmax_last(gpu.to_dev(xl)).numpy(), ref.softmax_last(xl)) <= 2e-3
+
+
+def test_group_norm_cluster_relaunch_is_bit_stable(gpu):
+    """The cluster kernel's arrival / departure counters reset themselves: ten launches in a row (two shapes interleaved) give the same bits."""
+    rng = np.random.default_rng(5)
+    xs = [rnd(rng, (2, 64, 64, 320), 1.5), rnd(rng, (2, 32, 32, 1920), 1.5)]
+    gs = [(1 + rnd(rng, (x.shape[-1],), 0.1).astype(f32)).astype(f16) for x in xs]
+    bs = [rnd(rng, (x.shape[-1],), 0.1) for x in xs]
+    dev = [(gpu.to_dev(x), gpu.to_dev(g), gpu.to_dev(b)) for x, g, b in zip(xs, gs, bs)]
+    first = [gpu.group_norm_nhwc(*d, 32, 1e-5, 1).numpy() for d in dev]
+    for _ in range(10):
+        for d, f in zip(dev, first):
+            assert np.array_equal(gpu.group_norm_nhwc(*d, 32, 1e-5, 1).numpy(), f)
+    for x, g, b, f in zip(xs, gs, bs, first):
+        assert rel_max(f, ref.group_norm_nhwc_exact(x, g, b, 32, 1e-5, True)) <= 1e-3
 
 
 # ---------------------------------------------------------------------------------------------------------------------
