@@ -31,12 +31,13 @@ for i in (1, 2, 3, 4):
         out[k]["dispatches"] = max(out[k]["dispatches"], n)
 res = {"note": f"sums over {sys.argv[2]} eager SD1.5 batch-2 UNet passes (tools/pmc_pass.py, hip_use_graph=0, autotune off); FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 "
                "reports them (gfx950: FETCH_SIZE x2 for wide coalesced reads, MI355X_MICROARCH.md); SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs; "
-               "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs)", "passes": int(sys.argv[2]), "kernels": {k: dict(v) for k, v in out.items()}}
+               "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES / 32 shader engines x 256 CUs x 4 SIMDs)", "passes": int(sys.argv[2]), "kernels": {k: dict(v) for k, v in out.items()}}
 json.dump(res, open(f"gpurun_out/pmc_{sys.argv[1]}.json", "w"), indent=1)
 rows = []
 for k, v in out.items():
     g = v.get("GRBM_GUI_ACTIVE", 0.0)
-    util = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (g * 1024.0) if g else 0.0
+    sq = v.get("SQ_BUSY_CYCLES", 0.0) / 32.0   # (summed over the 32 shader engines)
+    util = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (sq * 1024.0) if sq else 0.0
     rows.append((g, k[:70], int(v["dispatches"]), util, 2 * v.get("FETCH_SIZE", 0.0) * 1024 / 1e6, v.get("WRITE_SIZE", 0.0) * 1024 / 1e6))
 for g, k, n, u, f, w in sorted(rows, reverse=True)[:24]:
     print(f"{k:70s} n={n:5d} gui_cycles={g:12.0f} mfma_util={u:6.3f} fetch(MB,x2)={f:9.1f} write(MB)={w:9.1f}")
