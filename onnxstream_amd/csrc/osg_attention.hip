@@ -32,6 +32,32 @@ struct AttnParams {
 
 constexpr int BKV = 64;
 
+// all-reduce over the 4 lanes {l, l^16, l^32, l^48} that share a query row, on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap: the odd
+// 16-lane rows of one operand trade places with the even rows of the other, resp. the upper half with the lower half) -- the ds_bpermute a
+// __shfl_xor compiles to is an LDS round trip of ~100 cycles, and the softmax chains four of them per query tile behind each other
+// (inline asm: the __builtin_amdgcn_permlane*_swap pair comes back from hipcc 7.2 with both results folded into one register; s_nop 1 covers
+// the VALU-write -> permlane-read hazard the compiler cannot see inside the asm)
+__device__ __forceinline__ void lane_swap16(float v, float& a, float& b) {
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lane_swap32(float v, float& a, float& b) {
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float row4_max(float v) {
+    float a, b;
+    lane_swap16(v, a, b);
+    lane_swap32(fmaxf(a, b), a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float row4_sum(float v) {
+    float a, b;
+    lane_swap16(v, a, b);
+    lane_swap32(a + b, a, b);
+    return a + b;
+}
+
 template <int DP, int DT, int QT>
 __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     constexpr int KLD = DP + 8;     // Ks row stride (halves): 16-byte aligned rows, conflict-free b128 reads
@@ -88,11 +114,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     f16x8 kreg[NCH], vreg[NCH];
     // loads are UNCONDITIONAL (row / chunk clamped into range) and the out-of-range zeroing happens at store time: a predicated load
     // makes hipcc wait for it right after the issue (it needs the value for the select), which serialises the prefetch
-    bool tile_ok = false;
+    // Rows past Tkv are NOT zeroed either: they hold copies of the last valid row (finite), their scores are masked to -inf on the partial tile,
+    // so their probabilities are exactly 0 and the copies contribute exactly 0 to P V.
     auto load_tile = [&](int kv0) {
-        const int kv = kv0 + lane;
-        tile_ok = kv < p.Tkv;
-        const long krow = (long)(tile_ok ? kv : p.Tkv - 1) * p.k_tok, vrow = (long)(tile_ok ? kv : p.Tkv - 1) * p.v_tok;
+        const int kv = min(kv0 + lane, p.Tkv - 1);
+        const long krow = (long)kv * p.k_tok, vrow = (long)kv * p.v_tok;
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             const int dc = min(wave + c * 4, dchunks - 1);
@@ -104,12 +130,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     // order a lane's 8 probabilities come out of the S^T tiles, so the PV operand is ONE ds_read_b128 (no register shuffling)
     const int vcol = ((lane >> 5) << 5) + (((lane >> 2) & 3) << 3) + (((lane >> 4) & 1) << 2) + (lane & 3);
     auto store_tile = [&]() {
-        const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             const int dc = wave + c * 4;
             if (dc < dchunks) {
-                const f16x8 kv8 = tile_ok ? kreg[c] : zero, vv8 = tile_ok ? vreg[c] : zero;
+                const f16x8 kv8 = kreg[c], vv8 = vreg[c];
                 *reinterpret_cast<f16x8*>(&Ks[lane * KLD + dc * 8]) = kv8;
 #pragma unroll
                 for (int e = 0; e < 8; e++) Vt[(dc * 8 + e) * VLD + vcol] = vv8[e];
@@ -164,8 +189,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                         mx = fmaxf(mx, x);
                     }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = row4_max(mx);
             const float m_new = fmaxf(m_run[qt], mx);             // raw (unscaled) running max; scale > 0
             const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * c);
             const float mc = -m_new * c;
@@ -178,14 +202,16 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                     s[qt][t][r] = e;
                     sum += e;
                 }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
+            sum = row4_sum(sum);
             l_run[qt] = l_run[qt] * alpha + sum;
+            // the running maximum settles after a few tiles: when no row of this wave moved, alpha is exactly 1 everywhere and the rescale is skipped
+            if (__builtin_amdgcn_ballot_w64(m_new != m_run[qt]) != 0) {
+#pragma unroll
+                for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) oacc[qt][dt][r] *= alpha;
+            }
             m_run[qt] = m_new;
-#pragma unroll
-            for (int dt = 0; dt < DT; dt++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) oacc[qt][dt][r] *= alpha;
 #pragma unroll
             for (int st = 0; st < 2; st++) {
                 f16x8 pv;
