@@ -217,6 +217,8 @@ def main():
     ap.add_argument("--prompts-per-gpu", type=int, default=1, help="prompts denoised together on each GPU (2P samples per UNet pass: the reference's --num batching)")
     ap.add_argument("--w8-resident", action="store_true", help="with --quant-weights: keep the codes resident and dequantise on chip (osg_*_w8 kernels)")
     ap.add_argument("--quant-weights", action="store_true", help="W8A16: uint8 weights + scale/zero-point in model.txt, dequantised at load")
+    ap.add_argument("--clamp", action="store_true", help="clamp the latent to +-4 max(sigma, 1) after every step (NOT in the reference loop; rounds 1 used it to keep "
+                    "random-weight trajectories finite -- they stay finite without it, see config.latent_absmax)")
     ap.add_argument("--breakdown", default="", help="write the per-step HIP-event profile to this file")
     args = ap.parse_args()
     if args.config in ("VAE_QU8", "VAE_QU8_TINY"):
@@ -326,8 +328,9 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
     noise_pool, noise_rng = ThreadPoolExecutor(1), np.random.default_rng(99 + rank)
     scal = pipe.loop_scalars(sig)
-    # random-weight UNets do not denoise (|x| would grow without bound over 20 CFG-7 steps): clamp to the scale a real trajectory has
-    clip = np.asarray([4.0 * max(float(sig[i + 1]), 1.0) for i in range(STEPS_PER_IMAGE)], np.float32)
+    # the timed loop is the reference's arithmetic and nothing else: no clamp unless --clamp (a random-weight UNet does not denoise, its
+    # latents stay at the initial noise scale ~ sigma_0 instead of shrinking to ~1; they stay finite, asserted after the timed region)
+    clip = np.asarray([4.0 * max(float(sig[i + 1]), 1.0) for i in range(STEPS_PER_IMAGE)], np.float32) if args.clamp else None
     n_names = pipe.names
 
     def end_of_image(x):
@@ -356,7 +359,8 @@ def main():
                 den = pipe.denoise(x, float(sig[i]), ctx_cs, ctx_us, extra_cond=ex_c, extra_uncond=ex_u)
                 dev += m.hip_last_pass_ms()
                 x = (x + ((x - den) / scal[3][i]) * scal[4][i] + rng.standard_normal(lat_shape, dtype=np.float32) * scal[5][i]).astype(np.float32)
-                x = np.clip(x, -clip[i], clip[i])
+                if clip is not None:
+                    x = np.clip(x, -clip[i], clip[i])
                 n = 1
             else:
                 n = min(k, STEPS_PER_IMAGE - i)
@@ -368,7 +372,7 @@ def main():
                 nxt = min(k - n, rem_img) if k > n else rem_img
                 state["noise"] = noise_pool.submit(noise_rng.standard_normal, (nxt,) + lat_shape, np.float32)
                 state["noise"].n = nxt
-                dev += m.hip_sampler_loop(n_names["sample"], n_names["timestep"], n_names["out"], x, noise, *[a[i:i + n] for a in scal], 7.0, clip[i:i + n])
+                dev += m.hip_sampler_loop(n_names["sample"], n_names["timestep"], n_names["out"], x, noise, *[a[i:i + n] for a in scal], 7.0, clip[i:i + n] if clip is not None else None)
             if i + n == STEPS_PER_IMAGE:
                 x = end_of_image(x)
             state["x"], state["i"] = x, (i + n) % STEPS_PER_IMAGE
@@ -409,6 +413,9 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = dev_acc / max(args.steps, 1)
     out = state["last"] if state["last"] is not None else state["x"]
+    latent_absmax = float(np.abs(state["x"]).max())
+    if not (np.isfinite(np.asarray(out, np.float32)).all() and np.isfinite(latent_absmax)):
+        raise SystemExit("bench.py: non-finite latents / image after the timed region")
     if dist is not None:
         tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -487,7 +494,7 @@ def main():
                                     f"weights resident; ms_per_step = wall / K with the decode amortised; images/s = gpus x prompts_per_gpu / (steps_per_image x ms_per_step)")
                                    if vae_dir else (f"{cfg.name} UNet denoising step: cond+uncond 2x4x{cfg.latent}x{cfg.latent} latents, W16A16, "
                                                     f"weights resident, mode={args.mode}; NO VAE decode"),
-                       "mode": args.mode, "sampler": "host" if args.host_loop else "device", "autotune": not args.no_autotune, "vae_decode_in_timed_region": bool(vae_dir), "images_completed": state["images"],
+                       "mode": args.mode, "sampler": "host" if args.host_loop else "device", "autotune": not args.no_autotune, "vae_decode_in_timed_region": bool(vae_dir), "images_completed": state["images"], "clamp": bool(args.clamp), "latent_absmax": round(latent_absmax, 3),
                        "prompts_per_gpu": P, "unet_passes_per_step": 2 * P, "steps_per_image": STEPS_PER_IMAGE, "launches_per_step": kernels,
                        "vae_launches": vae_kernels, "fusion_level": args.fusion, "unet_device_ms_per_step": round(dev_ms, 4),
                        "parallelism": f"replica x{world}"},
