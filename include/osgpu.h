@@ -181,6 +181,14 @@ int osg_attention(osg_ctx* ctx, osg_dtype dtype, const void* q, const void* k, c
 int osg_attention_strided(osg_ctx* ctx, osg_dtype dtype, const void* q, long q_tok, long q_head, long q_batch, const void* k,
                           long k_tok, long k_head, long k_batch, const void* v, long v_tok, long v_head, long v_batch, void* o,
                           long o_tok, long o_head, long o_batch, int batch, int heads, int Tq, int Tkv, int D, float scale);
+/* ScaledDotProductAttention == the reference's pseudo-op of that name (formed at run time from Transpose/MatMul/Div/Add/Softmax/MatMul or
+ * Transpose/Mul/Mul/MatMul/Add/Softmax/MatMul when m_use_scaled_dp_attn_op, onnxstream.cpp:3635-3755; executed at :7767-7882 through
+ * XnnPack::scaled_dot_product_attention :2054-2150): out = softmax(scale * q k^T + mask) v per batch and head.  Dense q [B][Hq][Tq][D],
+ * k / v [B][Hkv][Tkv][D] (K in its natural layout: the op takes the Transpose's INPUT), mask [Tq][Tkv] additive, shared by all batches and
+ * heads, or NULL; out [B][Hq][Tq][D].  Hq % Hkv == 0 (query head h reads key/value head h / (Hq/Hkv)).  `scale` is the f16-rounded
+ * 1/s (Div form) or s*s2 (Mul/Mul form) the reference computes at :7840-7862.  Same flash-style kernel as osg_attention (f32 scores). */
+int osg_sdpa(osg_ctx* ctx, osg_dtype dtype, const void* q, const void* k, const void* v, const void* mask, void* o, int batch, int q_heads,
+             int kv_heads, int Tq, int Tkv, int D, float scale);
 
 /* ---- normalisation / reductions ---------------------------------------------------------------------------- */
 /* InstanceNormalization on [rows, L] (reference input [1,G,L], onnxstream.cpp:4788-5055): per row mean/var in f32,

@@ -103,6 +103,8 @@ Plan::Plan(Model& model, HipBackend& backend, ConstPool& cpool, size_t batch) : 
     u8_qdq = m.m_use_uint8_qdq;
     autotune = m.m_hip_autotune;
     calibrate = m.m_range_data_calibrate;
+    fuse_attn = m.m_fuse_ops_in_attention;
+    sdp_attn = m.m_use_scaled_dp_attn_op;
     outputs_convert_set = m.m_outputs_convert_set;
     side_stream = m.m_hip_side_stream && !stream_weights;
     extra_outputs = m.m_extra_outputs;
@@ -115,7 +117,7 @@ bool Plan::compatible(Model& mm, size_t batch) const {
         mm.m_hip_fuse_gn_conv != fuse_gn_conv || mm.m_hip_fuse_ln_gemm != fuse_ln_gemm || (mm.m_hip_side_stream && !want_stream) != side_stream ||
         (mm.m_hip_w8_resident && !want_stream) != w8_resident || mm.m_extra_outputs != extra_outputs ||
         mm.m_use_uint8_arithmetic != u8 || mm.m_use_uint8_qdq != u8_qdq || mm.m_hip_autotune != autotune || mm.m_outputs_convert_set != outputs_convert_set ||
-        mm.m_range_data_calibrate != calibrate)
+        mm.m_range_data_calibrate != calibrate || mm.m_fuse_ops_in_attention != fuse_attn || mm.m_use_scaled_dp_attn_op != sdp_attn)
         return false;
     // a pushed input with another shape / type (dynamic-shape models) re-plans, the way the reference simply re-executes (:3550)
     for (auto& in : inputs)
@@ -557,6 +559,7 @@ struct Lowering {
 
     void run_fusions() {
         dead.assign(ops().size(), 0);
+        if (m.m_use_scaled_dp_attn_op) { index_graph(); fuse_sdpa(); }   // (a Model option of the reference, independent of hip_fusion_level)
         if (P.fusion >= 1) {
             index_graph(); fuse_silu();
             index_graph(); fuse_group_norm();
@@ -812,6 +815,77 @@ struct Lowering {
         *src = s;
         chain->insert(chain->end(), {r1, tp, r0});
         return true;
+    }
+
+    // m_use_scaled_dp_attn_op: the reference's ScaledDotProductAttention rewrite (src/onnxstream.cpp:3635-3755), both forms:
+    //   Transpose(k) -> MatMul(q, .) -> Div(., s) -> Add(., mask) -> Softmax(-1) -> MatMul(., v)              scale = f16(1 / s)
+    //   Transpose(k) -> Mul(., s2); Mul(q, s) -> MatMul -> Add(., mask) -> Softmax(-1) -> MatMul(., v)         scale = f16(s2 * s)
+    // every intermediate with exactly one consumer (the reference's m_intermediate_refs == 1 checks).  The reference matches the ops
+    // as CONSECUTIVE queue entries; here they are matched through the graph (the same chains, whatever else the exporter interleaved).
+    void fuse_sdpa() {
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (!is((int)i, "Softmax")) continue;
+            Operation& sm = ops()[i];
+            auto* ax = attr(sm, "axis");
+            if (!ax || *ax != "-1" || sm.m_attributes.size() != 1 || sm.m_input.size() != 1 || sm.m_output.size() != 1) continue;
+            const int add = prod_of(sm.m_input[0]);
+            if (!is(add, "Add") || use_count(sm.m_input[0].m_name) != 1 || ops()[add].m_input.size() != 2) continue;
+            const Tensor mask = ops()[add].m_input[1];
+            const Tensor scores = ops()[add].m_input[0];
+            const int pre = prod_of(scores);
+            if (pre < 0 || use_count(scores.m_name) != 1) continue;
+            int mm0 = -1, tp = -1;
+            std::vector<int> chain = {(int)i, add};
+            Tensor q, s_t, s2_t;
+            if (is(pre, "Div") && ops()[pre].m_input.size() == 2) {
+                s_t = ops()[pre].m_input[1];
+                mm0 = prod_of(ops()[pre].m_input[0]);
+                if (!is(mm0, "MatMul") || use_count(ops()[pre].m_input[0].m_name) != 1 || ops()[mm0].m_input.size() != 2) continue;
+                q = ops()[mm0].m_input[0];
+                tp = prod_of(ops()[mm0].m_input[1]);
+                if (tp < 0 || use_count(ops()[mm0].m_input[1].m_name) != 1) continue;
+                chain.insert(chain.end(), {pre, mm0});
+            } else if (is(pre, "MatMul") && ops()[pre].m_input.size() == 2) {
+                mm0 = pre;
+                const int mul0 = prod_of(ops()[mm0].m_input[0]), mul1 = prod_of(ops()[mm0].m_input[1]);
+                if (!is(mul0, "Mul") || !is(mul1, "Mul") || ops()[mul0].m_input.size() != 2 || ops()[mul1].m_input.size() != 2) continue;
+                if (use_count(ops()[mm0].m_input[0].m_name) != 1 || use_count(ops()[mm0].m_input[1].m_name) != 1) continue;
+                q = ops()[mul0].m_input[0];
+                s_t = ops()[mul0].m_input[1];
+                s2_t = ops()[mul1].m_input[1];
+                tp = prod_of(ops()[mul1].m_input[0]);
+                if (tp < 0 || use_count(ops()[mul1].m_input[0].m_name) != 1) continue;
+                chain.insert(chain.end(), {mm0, mul0, mul1});
+            } else continue;
+            auto* pm = is(tp, "Transpose") ? attr(ops()[tp], "perm") : nullptr;
+            if (!pm || int_list(*pm) != std::vector<int>{0, 1, 3, 2} || ops()[tp].m_input.size() != 1) continue;
+            const Tensor k = ops()[tp].m_input[0];
+            const int mm1 = sole_consumer(sm.m_output[0]);
+            if (!is(mm1, "MatMul") || ops()[mm1].m_input.size() != 2 || ops()[mm1].m_input[0].m_name != sm.m_output[0].m_name) continue;
+            const Tensor v = ops()[mm1].m_input[1];
+            if (!act(q) || !act(k) || !act(v)) continue;
+            float s = 0.f, s2 = 0.f;
+            auto scalar = [&](const Tensor& t, float* out) {   // "invalid shape of scale" (:7785): a scalar or a 1-element vector
+                const Val* sv = cval(t);
+                return sv && sv->numel() == 1 && sv->shape.size() <= 1 && const_scalar(t, out);
+            };
+            if (!scalar(s_t, &s) || (!s2_t.m_name.empty() && !scalar(s2_t, &s2))) continue;
+            // fp16 arithmetic: the constants are f16 by the time the op sees them, the product / reciprocal is formed in fp32 and rounded to f16 (:7840-7862)
+            const float s16 = half_to_float(float_to_half(s));
+            const float val = s2_t.m_name.empty() ? 1.0f / s16 : half_to_float(float_to_half(s2)) * s16;
+            const float scale = half_to_float(float_to_half(val));
+            Operation f;
+            f.m_name = ops()[tp].m_name + "_ScaledDotProductAttention";
+            f.m_type = "ScaledDotProductAttention";
+            f.m_input = {q, k, mask, v};
+            f.m_output = {ops()[mm1].m_output[0]};
+            char buf[64];
+            snprintf(buf, sizeof buf, "%.9g", scale);
+            f.m_attributes = {{"scale", buf}};
+            chain.push_back(tp);
+            for (int c : chain) dead[c] = 1;
+            ops()[mm1] = std::move(f);
+        }
     }
 
     // MatMul(q,kT) -> [Mul(scale)] -> Softmax(-1) -> MatMul(.,v)
@@ -1641,6 +1715,7 @@ struct Lowering {
         if (t == "osg.GEGLU") return lower_geglu(op);
         if (t == "osg.Attention") return lower_attention(op);
         if (t == "AttentionFusedOps") return lower_attention_fused_ops(op);
+        if (t == "ScaledDotProductAttention") return lower_sdpa(op);
         if (t == "ReduceMean") return lower_reduce_mean(op);
         if (t == "Softmax") return lower_softmax(op);
         if (t == "Reshape") return lower_reshape(op);
@@ -2366,6 +2441,34 @@ struct Lowering {
                      "Attention");
         });
         P.steps.back().flops = 4.0 * nb * h * Tq * Tk * d;
+    }
+
+    // ScaledDotProductAttention (reference :7767-7882): q [B,Hq,T,D], k [B,Hkv,S,D], mask [T,S] | [1,1,T,S], v [B,Hkv,S,Dv] -> [B,Hq,T,Dv]
+    void lower_sdpa(const Operation& op) {
+        need(op, op.m_input.size() == 4, "wrong number of inputs.");
+        need(op, op.m_output.size() == 1, "wrong number of outputs.");
+        const int q = P.ensure_plain(in_val(op.m_input[0])), k = P.ensure_plain(in_val(op.m_input[1])), mk = P.ensure_plain(in_val(op.m_input[2])),
+                  v = P.ensure_plain(in_val(op.m_input[3]));
+        const Shape qs = V(q).shape, ks = V(k).shape, vs = V(v).shape, ms = V(mk).shape;
+        need(op, qs.size() == 4, "invalid shape of query.");
+        need(op, ks.size() == 4, "invalid shape of key.");
+        need(op, vs.size() == 4, "invalid shape of value.");
+        need(op, ms.size() == 2 || (ms.size() == 4 && ms[0] == 1 && ms[1] == 1), "invalid shape of mask.");
+        const long Bq = qs[0], Hq = qs[1], T = qs[2], D = qs[3], Hkv = ks[1], S = ks[2], Dv = vs[3];
+        need(op, ks[0] == Bq && vs[0] == Bq && ks[3] == D && vs[1] == Hkv && vs[2] == S && Hkv > 0 && Hq % Hkv == 0, "invalid shape of query, key or value.");
+        need(op, ms[ms.size() - 2] == T && ms[ms.size() - 1] == S, "invalid shape of mask.");
+        need(op, V(q).dtype == OSG_F16 && V(k).dtype == OSG_F16 && V(v).dtype == OSG_F16 && V(mk).dtype == OSG_F16, "wrong data type of query.");
+        need(op, Dv == D && D % 8 == 0 && D <= 160, "head dims other than a multiple of 8 up to 160 with Dv == D are not implemented on the HIP backend.");
+        need(op, !V(mk).batched && V(q).batched == V(k).batched && V(k).batched == V(v).batched, "q/k/v batching mismatch.");
+        const float scale = std::stof(*attr(op, "scale"));
+        need(op, scale > 0.f, "a scale <= 0 is not implemented on the HIP backend.");
+        const int y = out_val(op, Shape{Bq, Hq, T, Dv}, Lay::plain, V(q).batched);
+        const long nb = Bq * B(q);
+        P.add_step("ScaledDotProductAttention " + op.m_name, {q, k, mk, v}, {y}, [=, this] {
+            be.check(be.api.osg_sdpa(be.ctx, OSG_F16, P.ptr(q), P.ptr(k), P.ptr(v), P.ptr(mk), P.ptr(y), (int)nb, (int)Hq, (int)Hkv, (int)T, (int)S, (int)D, scale),
+                     "ScaledDotProductAttention");
+        });
+        P.steps.back().flops = 4.0 * nb * Hq * T * S * D;
     }
 
     // AttentionFusedOps (reference :6696-6929): q [n,Tq,d], k [n,d,Tk] (already transposed), optional scalar s, v [n,Tk,d]

@@ -172,7 +172,7 @@ struct Plan {
     double m_last_ms = 0;
     // options the plan was built with
     bool fp16 = true;
-    bool u8_qdq = false, autotune = false, calibrate = false;
+    bool u8_qdq = false, autotune = false, calibrate = false, fuse_attn = false, sdp_attn = false;
     std::set<std::string> outputs_convert_set;
     bool u8 = false;               // m_use_uint8_arithmetic: uint8 activations (the reference's W8A8 path, VAE decoder)
     bool stream_weights = false;

@@ -28,6 +28,12 @@ struct AttnParams {
     long o_tok, o_head, o_batch;
     int heads, Tq, Tkv, D;
     float scale_log2e;
+    // ScaledDotProductAttention (osg_sdpa): additive mask [Tq][Tkv] shared by every batch and head (null = none), applied to the raw scores
+    // as s + mask / scale (the kernel tracks raw maxima and scales inside the exponent); grouped-query attention: query head h reads
+    // key/value head h / kv_div
+    const f16* mask;
+    float inv_scale;
+    int kv_div;
 };
 
 constexpr int BKV = 64;
@@ -75,8 +81,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     const int D = p.D;
 
     const f16* __restrict__ Q = p.q + b * p.q_batch + h * p.q_head;
-    const f16* __restrict__ K = p.k + b * p.k_batch + h * p.k_head;
-    const f16* __restrict__ V = p.v + b * p.v_batch + h * p.v_head;
+    const f16* __restrict__ K = p.k + b * p.k_batch + (h / p.kv_div) * p.k_head;
+    const f16* __restrict__ V = p.v + b * p.v_batch + (h / p.kv_div) * p.v_head;
     f16* __restrict__ O = p.o + b * p.o_batch + h * p.o_head;
 
     // zero the LDS padding once (pad columns of Ks, pad rows of Vt) so no NaN bit patterns enter the MFMAs
@@ -167,6 +173,17 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         // ---- online softmax (log2 domain).  The kernel is VALU-bound here (28 MFMAs vs ~300 vector ops per tile and wave), so the
         // per-score work is kept to max / fma / v_exp_f32 / add: the scale rides in the fma (scores stay raw, max is tracked raw),
         // the kv-bound mask only exists on the last, partial tile, and exp2 is the bare hardware op (arguments are <= 0).
+        if (p.mask) {   // (not on the SD hot path: scalar f16 loads, clamped into range -- out-of-range scores are masked below anyway)
+#pragma unroll
+            for (int qt = 0; qt < QT; qt++) {
+                const f16* mrow = p.mask + (long)min(q0 + qt * 16 + lq, p.Tq - 1) * p.Tkv;
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        s[qt][t][r] = fmaf((float)mrow[min(kv0 + t * 16 + g * 4 + r, p.Tkv - 1)], p.inv_scale, s[qt][t][r]);
+            }
+        }
         const bool full = kv0 + BKV <= p.Tkv;
         const float c = p.scale_log2e;
         f16x8 pf[QT][2];
@@ -271,6 +288,18 @@ int launch_attn(osg_ctx* ctx, const AttnParams& p, int batch) {
     return 0;
 }
 
+int dispatch_attn(osg_ctx* ctx, const AttnParams& p, int batch) {
+    const int D = p.D;
+    if (D <= 32) return launch_attn<32, 2>(ctx, p, batch);
+    if (D <= 48) return launch_attn<64, 3>(ctx, p, batch);
+    if (D <= 64) return launch_attn<64, 4>(ctx, p, batch);
+    if (D <= 80) return launch_attn<96, 5>(ctx, p, batch);
+    if (D <= 96) return launch_attn<96, 6>(ctx, p, batch);
+    if (D <= 128) return launch_attn<128, 8>(ctx, p, batch);
+    if (D <= 160) return launch_attn<160, 10>(ctx, p, batch);
+    OSG_FAIL(ctx, "osg_attention: head dim > 160 not implemented");
+}
+
 }  // namespace
 
 extern "C" {
@@ -285,17 +314,23 @@ int osg_attention_strided(osg_ctx* ctx, osg_dtype dtype, const void* q, long q_t
     if ((q_tok | q_head | q_batch | k_tok | k_head | k_batch | v_tok | v_head | v_batch) % 8 || (o_tok | o_head | o_batch) % 4)
         OSG_FAIL(ctx, "osg_attention: strides must keep 16-byte (q,k,v) / 8-byte (o) alignment");
     AttnParams p{(const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, q_tok, q_head, q_batch, k_tok, k_head, k_batch,
-                 v_tok, v_head, v_batch, o_tok, o_head, o_batch, heads, Tq, Tkv, D, scale * 1.4426950408889634f};
-    const int dt = (D + 15) / 16;
-    if (D <= 32) return launch_attn<32, 2>(ctx, p, batch);
-    if (D <= 48) return launch_attn<64, 3>(ctx, p, batch);
-    if (D <= 64) return launch_attn<64, 4>(ctx, p, batch);
-    if (D <= 80) return launch_attn<96, 5>(ctx, p, batch);
-    if (D <= 96) return launch_attn<96, 6>(ctx, p, batch);
-    if (D <= 128) return launch_attn<128, 8>(ctx, p, batch);
-    if (D <= 160) return launch_attn<160, 10>(ctx, p, batch);
-    (void)dt;
-    OSG_FAIL(ctx, "osg_attention: head dim > 160 not implemented");
+                 v_tok, v_head, v_batch, o_tok, o_head, o_batch, heads, Tq, Tkv, D, scale * 1.4426950408889634f, nullptr, 0.f, 1};
+    return dispatch_attn(ctx, p, batch);
+}
+
+// ScaledDotProductAttention (reference op src/onnxstream.cpp:7767-7882 -> XnnPack::scaled_dot_product_attention :2054-2150): dense
+// q [B][Hq][Tq][D], k / v [B][Hkv][Tkv][D], optional additive mask [Tq][Tkv], out [B][Hq][Tq][D]; Hq % Hkv == 0.
+int osg_sdpa(osg_ctx* ctx, osg_dtype dtype, const void* q, const void* k, const void* v, const void* mask, void* o, int batch, int q_heads,
+             int kv_heads, int Tq, int Tkv, int D, float scale) {
+    if (dtype != OSG_F16) OSG_FAIL(ctx, "osg_sdpa: only f16 arithmetic is implemented on the device");
+    if (batch <= 0 || q_heads <= 0 || kv_heads <= 0 || Tq <= 0 || Tkv <= 0 || D <= 0) OSG_FAIL(ctx, "ScaledDotProductAttention: invalid shape of query, key or value.");
+    if (q_heads % kv_heads) OSG_FAIL(ctx, "ScaledDotProductAttention: query heads must be a multiple of key/value heads.");
+    if (!(scale > 0.f)) OSG_FAIL(ctx, "osg_sdpa: the fused kernel tracks the row maximum of the raw scores and needs scale > 0");
+    if (D % 8) OSG_FAIL(ctx, "osg_sdpa: head dim must be a multiple of 8");
+    const long qh = (long)Tq * D, kh = (long)Tkv * D;
+    AttnParams p{(const f16*)q, (const f16*)k, (const f16*)v, (f16*)o, D, qh, qh * q_heads, D, kh, kh * kv_heads, D, kh, kh * kv_heads,
+                 D, qh, qh * q_heads, q_heads, Tq, Tkv, D, scale * 1.4426950408889634f, (const f16*)mask, 1.0f / scale, q_heads / kv_heads};
+    return dispatch_attn(ctx, p, batch);
 }
 
 int osg_attention(osg_ctx* ctx, osg_dtype dtype, const void* q, const void* k, const void* v, void* o, int heads, int Tq, int Tkv, int D,
