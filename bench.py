@@ -450,7 +450,7 @@ def main():
         for cand in sorted((f for f in os.listdir(os.path.join(REPO, "profiles")) if f.startswith("r02_pmc") and f.endswith(".json")), reverse=True):
             pmc_src = cand
             break
-        if pmc_src and cfg.name == "sd15":
+        if pmc_src and cfg.name == "sd15" and P == 1:   # (the counter file describes the batch-2 pass of one prompt)
             tj = json.load(open(os.path.join(REPO, "profiles", pmc_src)))["kernels"]
             sel = [v for k, v in tj.items() if "gemm2_kernel" in k or "conv3x3_kernel" in k or "conv_small" in k or "gemm_kernel" in k or "splitk_reduce" in k]
             nd = sum(v["dispatches"] for k, v in tj.items() if ("gemm2_kernel" in k or "conv3x3_kernel" in k or "conv_small" in k or "gemm_kernel" in k))
