@@ -235,12 +235,20 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # OSA_BENCH_ONE_GPU=1 (dev check of the N > 1 flow on a 1-GPU box, tools/two_rank_check.sh): every rank drives cuda:0 and the process group is
+    # gloo over host tensors (RCCL refuses two ranks on one device).  Never set by the driver; the line it prints says so ("dev_one_gpu").
+    one_gpu = os.environ.get("OSA_BENCH_ONE_GPU") == "1"
+    gpu_index = 0 if one_gpu else local_rank
+    coll_dev = "cpu" if one_gpu else "cuda"
+    torch.cuda.set_device(gpu_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if dist is not None:
@@ -265,7 +273,7 @@ def main():
     def draw(i):
         c, u = sd_unet.unet_inputs(cfg, 42 + 2 * i), sd_unet.unet_inputs(cfg, 43 + 2 * i)
         return {k: np.stack([c[k], u[k]]) for k in c}
-    mine = shard.scatter_prompts(dist, rank, world, world, draw, device="cuda" if dist is not None else "cpu")
+    mine = shard.scatter_prompts(dist, rank, world, world, draw, device=coll_dev if dist is not None else "cpu")
     (my_prompt, pack), = mine.items()
     cond = {k: v[0] for k, v in pack.items()}
     uncond = {k: v[1] for k, v in pack.items()}
@@ -287,7 +295,7 @@ def main():
     t_build = time.time()
 
     def make_pipe():
-        return Txt2Img(b.LIB_HOST, model_dir, vae_dir, batched=True, device=local_rank, fusion=args.fusion, autotune=not args.no_autotune)
+        return Txt2Img(b.LIB_HOST, model_dir, vae_dir, batched=True, device=gpu_index, fusion=args.fusion, autotune=not args.no_autotune)
     pipe = None
     if dist is not None and not args.no_autotune:
         # N > 1: every rank must make the SAME measured tile / split-K choices (else the same prompt gives different last bits on different
@@ -301,7 +309,7 @@ def main():
                          extra_uncond={k: uncond[k] for k in ("text_embeds", "time_ids") if k in uncond} or None)
             if pipe.vae is not None:
                 pipe.decode(x0)
-        shard.share_tune_table(dist, rank, world, f"/tmp/osg_tune_shared_rank{rank}.txt", tune_on_rank0, device="cuda")
+        shard.share_tune_table(dist, rank, world, f"/tmp/osg_tune_shared_rank{rank}.txt", tune_on_rank0, device=coll_dev)
     if pipe is None:
         pipe = make_pipe()
     m = pipe.unet
@@ -417,11 +425,11 @@ def main():
     if not (np.isfinite(np.asarray(out, np.float32)).all() and np.isfinite(latent_absmax)):
         raise SystemExit("bench.py: non-finite latents / image after the timed region")
     if dist is not None:
-        tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        tw = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
         # gather every prompt's result (image, or latents when no image completed) on rank 0
-        allr = shard.gather_results(dist, rank, world, world, {my_prompt: np.asarray(out, np.float32)}, device="cuda")
+        allr = shard.gather_results(dist, rank, world, world, {my_prompt: np.asarray(out, np.float32)}, device=coll_dev)
         assert rank != 0 or (allr.shape[0] == world and np.isfinite(allr).all())
     ms_per_step = wall * 1e3 / args.steps
     images_per_s = world * P / (STEPS_PER_IMAGE * ms_per_step * 1e-3)
@@ -497,7 +505,7 @@ def main():
                        "mode": args.mode, "sampler": "host" if args.host_loop else "device", "autotune": not args.no_autotune, "vae_decode_in_timed_region": bool(vae_dir), "images_completed": state["images"], "clamp": bool(args.clamp), "latent_absmax": round(latent_absmax, 3),
                        "prompts_per_gpu": P, "unet_passes_per_step": 2 * P, "steps_per_image": STEPS_PER_IMAGE, "launches_per_step": kernels,
                        "vae_launches": vae_kernels, "fusion_level": args.fusion, "unet_device_ms_per_step": round(dev_ms, 4),
-                       "parallelism": f"replica x{world}"},
+                       "parallelism": f"replica x{world}" + (" (dev_one_gpu: all ranks on cuda:0, gloo)" if one_gpu else "")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
     if pipe is not None:
