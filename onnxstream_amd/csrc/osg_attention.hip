@@ -36,7 +36,6 @@ struct AttnParams {
     int kv_div;
 };
 
-constexpr int BKV = 64;
 
 // all-reduce over the 4 lanes {l, l^16, l^32, l^48} that share a query row, on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap: the odd
 // 16-lane rows of one operand trade places with the even rows of the other, resp. the upper half with the lower half) -- the ds_bpermute a
@@ -64,8 +63,12 @@ __device__ __forceinline__ float row4_sum(float v) {
     return a + b;
 }
 
-template <int DP, int DT, int QT>
+// BKV: keys per tile (64, or 128 where registers and LDS allow: half the barriers, running-max updates and accumulator rescales per key)
+template <int DP, int DT, int QT, int BKV>
 __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+    constexpr int NT = BKV / 16;    // 16-key score tiles per KV tile
+    constexpr int NS = BKV / 32;    // 32-deep contraction steps of P V
+    constexpr int RPL = BKV / 64;   // KV rows staged per lane
     constexpr int KLD = DP + 8;     // Ks row stride (halves): 16-byte aligned rows, conflict-free b128 reads
     constexpr int VLD = BKV + 8;    // Vt row stride (halves): 8-byte aligned b64 reads
     constexpr int DV = DT * 16;
@@ -117,19 +120,22 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     // K/V staging: lane = kv row of the tile, the 4 waves stride over the 16-byte d-chunks.  The NEXT tile's global loads are issued
     // into registers BEFORE this tile's MFMAs and written to LDS after them, so their latency hides behind the math.
     constexpr int NCH = (DP / 8 + 3) / 4;            // d-chunks per wave (upper bound)
-    f16x8 kreg[NCH], vreg[NCH];
+    f16x8 kreg[RPL][NCH], vreg[RPL][NCH];
     // loads are UNCONDITIONAL (row / chunk clamped into range) and the out-of-range zeroing happens at store time: a predicated load
     // makes hipcc wait for it right after the issue (it needs the value for the select), which serialises the prefetch
     // Rows past Tkv are NOT zeroed either: they hold copies of the last valid row (finite), their scores are masked to -inf on the partial tile,
     // so their probabilities are exactly 0 and the copies contribute exactly 0 to P V.
     auto load_tile = [&](int kv0) {
-        const int kv = min(kv0 + lane, p.Tkv - 1);
-        const long krow = (long)kv * p.k_tok, vrow = (long)kv * p.v_tok;
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const int dc = min(wave + c * 4, dchunks - 1);
-            kreg[c] = *reinterpret_cast<const f16x8*>(K + krow + dc * 8);
-            vreg[c] = *reinterpret_cast<const f16x8*>(V + vrow + dc * 8);
+        for (int j = 0; j < RPL; j++) {
+            const int kv = min(kv0 + j * 64 + lane, p.Tkv - 1);
+            const long krow = (long)kv * p.k_tok, vrow = (long)kv * p.v_tok;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const int dc = min(wave + c * 4, dchunks - 1);
+                kreg[j][c] = *reinterpret_cast<const f16x8*>(K + krow + dc * 8);
+                vreg[j][c] = *reinterpret_cast<const f16x8*>(V + vrow + dc * 8);
+            }
         }
     };
     // V^T columns are stored PERMUTED inside each 32-wide block -- kv = t*16 + g*4 + r  ->  st*32 + g*8 + (t&1)*4 + r -- which is the
@@ -137,15 +143,17 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     const int vcol = ((lane >> 5) << 5) + (((lane >> 2) & 3) << 3) + (((lane >> 4) & 1) << 2) + (lane & 3);
     auto store_tile = [&]() {
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const int dc = wave + c * 4;
-            if (dc < dchunks) {
-                const f16x8 kv8 = kreg[c], vv8 = vreg[c];
-                *reinterpret_cast<f16x8*>(&Ks[lane * KLD + dc * 8]) = kv8;
+        for (int j = 0; j < RPL; j++)
 #pragma unroll
-                for (int e = 0; e < 8; e++) Vt[(dc * 8 + e) * VLD + vcol] = vv8[e];
+            for (int c = 0; c < NCH; c++) {
+                const int dc = wave + c * 4;
+                if (dc < dchunks) {
+                    const f16x8 kv8 = kreg[j][c], vv8 = vreg[j][c];
+                    *reinterpret_cast<f16x8*>(&Ks[(j * 64 + lane) * KLD + dc * 8]) = kv8;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) Vt[(dc * 8 + e) * VLD + j * 64 + vcol] = vv8[e];
+                }
             }
-        }
     };
     load_tile(0);
     for (int kv0 = 0; kv0 < p.Tkv; kv0 += BKV) {
@@ -155,13 +163,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         if (kv0 + BKV < p.Tkv) load_tile(kv0 + BKV);   // in flight during the MFMAs / softmax below
 
         // ---- S^T = K Q^T -------------------------------------------------------------------------------
-        f32x4 s[QT][4];
+        f32x4 s[QT][NT];
 #pragma unroll
         for (int qt = 0; qt < QT; qt++)
 #pragma unroll
-            for (int t = 0; t < 4; t++) s[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT; t++) s[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
+        for (int t = 0; t < NT; t++) {
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) {
                 f16x8 kf = *reinterpret_cast<const f16x8*>(&Ks[(t * 16 + lq) * KLD + ks * 32 + g * 8]);
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
             for (int qt = 0; qt < QT; qt++) {
                 const f16* mrow = p.mask + (long)min(q0 + qt * 16 + lq, p.Tq - 1) * p.Tkv;
 #pragma unroll
-                for (int t = 0; t < 4; t++)
+                for (int t = 0; t < NT; t++)
 #pragma unroll
                     for (int r = 0; r < 4; r++)
                         s[qt][t][r] = fmaf((float)mrow[min(kv0 + t * 16 + g * 4 + r, p.Tkv - 1)], p.inv_scale, s[qt][t][r]);
@@ -186,18 +194,18 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         }
         const bool full = kv0 + BKV <= p.Tkv;
         const float c = p.scale_log2e;
-        f16x8 pf[QT][2];
+        f16x8 pf[QT][NS];
 #pragma unroll
         for (int qt = 0; qt < QT; qt++) {
             float mx = -INFINITY;
             if (full) {
 #pragma unroll
-                for (int t = 0; t < 4; t++)
+                for (int t = 0; t < NT; t++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) mx = fmaxf(mx, s[qt][t][r]);
             } else {
 #pragma unroll
-                for (int t = 0; t < 4; t++)
+                for (int t = 0; t < NT; t++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int kv = kv0 + t * 16 + g * 4 + r;
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
             const float mc = -m_new * c;
             float sum = 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+            for (int t = 0; t < NT; t++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const float e = __builtin_amdgcn_exp2f(fmaf(s[qt][t][r], c, mc));
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
             }
             m_run[qt] = m_new;
 #pragma unroll
-            for (int st = 0; st < 2; st++) {
+            for (int st = 0; st < NS; st++) {
                 f16x8 pv;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 #pragma unroll
         for (int dt = 0; dt < DT; dt++) {
 #pragma unroll
-            for (int st = 0; st < 2; st++) {
+            for (int st = 0; st < NS; st++) {
                 const f16x8 vf = *reinterpret_cast<const f16x8*>(&Vt[(dt * 16 + lq) * VLD + st * 32 + g * 8]);
 #pragma unroll
                 for (int qt = 0; qt < QT; qt++)
@@ -277,12 +285,23 @@ int launch_attn(osg_ctx* ctx, const AttnParams& p, int batch) {
     static const int force_qt = getenv("OSG_ATTN_QT") ? atoi(getenv("OSG_ATTN_QT")) : 0;
     // 128 query rows per workgroup halve the K/V staging per row, but only pay when the grid still has >= 2 workgroups per CU
     const long blocks128 = (long)((p.Tq + 127) / 128) * batch * p.heads;
+    static const int force_bkv = getenv("OSG_ATTN_BKV") ? atoi(getenv("OSG_ATTN_BKV")) : 0;
+    // 128-key tiles (OSG_ATTN_BKV=128, head dims <= 64 only): measured SLOWER -- 171 vs 125 us at 4096x4096x40: the score tile and the staging
+    // registers double (255 VGPRs), and what a tile saves in barriers it loses in exposed latency.  Kept as an experiment switch.
+    constexpr bool kWide = DP <= 64;
+    const bool wide = kWide && force_bkv == 128;
     if (p.Tq >= 1024 && force_qt != 1 && (blocks128 >= 2L * ctx->num_cu || force_qt == 2)) {
         dim3 grid((p.Tq + 127) / 128, batch * p.heads);
-        hipLaunchKernelGGL((attn_kernel<DP, DT, 2>), grid, dim3(256), 0, ctx->compute, p);
+        if constexpr (kWide) {
+            if (wide) hipLaunchKernelGGL((attn_kernel<DP, DT, 2, 128>), grid, dim3(256), 0, ctx->compute, p);
+            else hipLaunchKernelGGL((attn_kernel<DP, DT, 2, 64>), grid, dim3(256), 0, ctx->compute, p);
+        } else hipLaunchKernelGGL((attn_kernel<DP, DT, 2, 64>), grid, dim3(256), 0, ctx->compute, p);
     } else {
         dim3 grid((p.Tq + 63) / 64, batch * p.heads);
-        hipLaunchKernelGGL((attn_kernel<DP, DT, 1>), grid, dim3(256), 0, ctx->compute, p);
+        if constexpr (kWide) {
+            if (wide) hipLaunchKernelGGL((attn_kernel<DP, DT, 1, 128>), grid, dim3(256), 0, ctx->compute, p);
+            else hipLaunchKernelGGL((attn_kernel<DP, DT, 1, 64>), grid, dim3(256), 0, ctx->compute, p);
+        } else hipLaunchKernelGGL((attn_kernel<DP, DT, 1, 64>), grid, dim3(256), 0, ctx->compute, p);
     }
     OSG_LAUNCH_CHECK(ctx);
     return 0;
