@@ -122,7 +122,13 @@ bool Plan::compatible(Model& mm, size_t batch) const {
     // a pushed input with another shape / type (dynamic-shape models) re-plans, the way the reference simply re-executes (:3550)
     for (auto& in : inputs)
         for (auto& t : mm.m_data)
-            if (t.m_name == in.name && (t.m_type != in.host_type || t.m_shape != in.shape)) return false;
+            if (t.m_name == in.name) {
+                if (t.m_type != in.host_type || t.m_shape != in.shape) return false;
+                if (t.m_type == TensorDataType::int64) {
+                    auto& v = t.get_vector<int64_t>();
+                    if (v.size() != in.ivals.size() || !std::equal(v.begin(), v.end(), in.ivals.begin())) return false;
+                }
+            }
     return true;
 }
 
@@ -1164,7 +1170,13 @@ struct Lowering {
             V(r).dptr = be.malloc(bytes);
             P.owned.push_back(V(r).dptr);
             if (V(r).dtype == OSG_I64) be.check(be.api.osg_upload_sync(be.ctx, V(r).dptr, V(r).host_i.data(), V(r).host_i.size() * 8), "osg_upload_sync");
-            else if (V(r).dtype == OSG_F32) be.check(be.api.osg_upload_sync(be.ctx, V(r).dptr, V(r).host_f.data(), V(r).host_f.size() * 4), "osg_upload_sync");
+            else if (V(r).dtype == OSG_F32 && P.fp16) {
+                // the reference's fp32 results are rounded to fp16 when they are pushed with fp16 arithmetic on (push_tensor :3029-3034)
+                std::vector<uint16_t> h(V(r).host_f.size());
+                for (size_t k = 0; k < h.size(); k++) h[k] = float_to_half(V(r).host_f[k]);
+                be.check(be.api.osg_upload_sync(be.ctx, V(r).dptr, h.data(), h.size() * 2), "osg_upload_sync");
+                V(r).dtype = OSG_F16;
+            } else if (V(r).dtype == OSG_F32) be.check(be.api.osg_upload_sync(be.ctx, V(r).dptr, V(r).host_f.data(), V(r).host_f.size() * 4), "osg_upload_sync");
             else throw std::invalid_argument("Model::get_tensor_data: unsupported tensor data format.");
         }
         return it->second;
@@ -1188,10 +1200,74 @@ struct Lowering {
         return v;
     }
 
-    // Ops evaluated on the host while the plan is built: Shape (reference :7003) always, and Gather (:6316) / Cast (:7352) / Concat (:4140) /
-    // Unsqueeze / Squeeze / Reshape / Slice / Add / Sub / Mul / Div whose operands are all int64 values known at plan time.  Tensor shapes
-    // are static per plan (a pushed input with another shape re-plans), so these chains fold to constants.  Returns false when the op
-    // has to run on the device.
+    // Ops evaluated on the host while the plan is built: Shape (reference :7003), Range (:7589) and ConstantOfShape (:7543) always; Gather (:6316),
+    // Cast (:7352), Concat (:4140), Unsqueeze / Squeeze / Reshape, Slice, Add / Sub / Mul / Div, Neg, Less / Greater / Equal / And (:7637), Where (:7034),
+    // Expand (:7154) and Trilu when every operand is known at plan time and at least one of them is a plan-time VALUE (a shape chain, an int64
+    // graph input, something computed from those) rather than a weight.  Tensor shapes and int64 inputs are fixed per plan (another shape or
+    // another token re-plans), so the shape chains exporters leave behind and the mask / position subgraphs of the LLM graphs fold to
+    // constants: int64 or fp32 host tensors that get device storage (fp32 -> f16 under fp16 arithmetic) only if a launch reads them.
+    // Returns false when the op has to run on the device.
+    struct HT {
+        Shape shape;
+        bool is_int = true;
+        std::vector<double> v;
+        long numel() const { return (long)v.size(); }
+    };
+    static HT to_ht(const Val* v) {
+        HT h;
+        h.shape = v->shape;
+        h.is_int = v->dtype == OSG_I64;
+        if (h.is_int) h.v.assign(v->host_i.begin(), v->host_i.end());
+        else h.v.assign(v->host_f.begin(), v->host_f.end());
+        return h;
+    }
+    int host_out(const Operation& op, HT h) {
+        if (h.is_int) {
+            std::vector<int64_t> o(h.v.size());
+            for (size_t k = 0; k < o.size(); k++) o[k] = (int64_t)h.v[k];
+            return host_val(op, h.shape, std::move(o));
+        }
+        std::vector<float> f(h.v.size());
+        for (size_t k = 0; k < f.size(); k++) f[k] = (float)h.v[k];
+        check_out(op, h.shape);
+        int v = P.new_val(op.m_output[0].m_name, h.shape, OSG_F32, Lay::plain, false);
+        V(v).is_const = true;
+        V(v).host_valid = V(v).host_only = true;
+        V(v).host_f = std::move(f);
+        return v;
+    }
+    // numpy broadcasting of two host tensors through `fn`
+    template <class F>
+    HT broadcast2(const Operation& op, const HT& a, const HT& b, bool out_int, F&& fn) {
+        const size_t r = std::max(a.shape.size(), b.shape.size());
+        Shape as(r, 1), bs(r, 1), os(r, 1);
+        std::copy(a.shape.begin(), a.shape.end(), as.begin() + (r - a.shape.size()));
+        std::copy(b.shape.begin(), b.shape.end(), bs.begin() + (r - b.shape.size()));
+        for (size_t k = 0; k < r; k++) {
+            need(op, as[k] == bs[k] || as[k] == 1 || bs[k] == 1, "shapes of A and B not compatible.");
+            os[k] = std::max(as[k], bs[k]);
+        }
+        HT o;
+        o.shape = os;
+        o.is_int = out_int;
+        const long n = prod(os);
+        need(op, n <= (1L << 24), "plan-time tensor too large.");
+        o.v.resize((size_t)n);
+        std::vector<long> idx(r, 0);
+        for (long e = 0; e < n; e++) {
+            long ia = 0, ib = 0;
+            for (size_t k = 0; k < r; k++) {
+                ia = ia * as[k] + (as[k] == 1 ? 0 : idx[k]);
+                ib = ib * bs[k] + (bs[k] == 1 ? 0 : idx[k]);
+            }
+            o.v[(size_t)e] = fn(a.v[(size_t)ia], b.v[(size_t)ib]);
+            for (long k = (long)r - 1; k >= 0; k--) {
+                if (++idx[(size_t)k] < os[(size_t)k]) break;
+                idx[(size_t)k] = 0;
+            }
+        }
+        return o;
+    }
     bool try_host_eval(const Operation& op) {
         const std::string& t = op.m_type;
         if (t == "Shape") {
@@ -1204,22 +1280,28 @@ struct Lowering {
             host_val(op, {(long)xs.size()}, std::vector<int64_t>(xs.begin(), xs.end()));
             return true;
         }
-        if (t != "Gather" && t != "Cast" && t != "Concat" && t != "Unsqueeze" && t != "Squeeze" && t != "Reshape" && t != "Slice" && t != "Add" && t != "Sub" &&
-            t != "Mul" && t != "Div")
-            return false;
-        if (op.m_input.empty() || op.m_output.size() != 1) return false;
+        static const char* kOps[] = {"Gather", "Cast", "Concat", "Unsqueeze", "Squeeze", "Reshape", "Slice", "Add", "Sub", "Mul", "Div", "Neg", "Range",
+                                     "ConstantOfShape", "Less", "Greater", "Equal", "And", "Where", "Expand", "Trilu"};
+        bool known = false;
+        for (auto* k : kOps) known |= t == k;
+        if (!known || op.m_input.empty() || op.m_output.size() != 1) return false;
         std::vector<const Val*> in;
+        bool any_value = false;
         for (auto& ti : op.m_input) {
             if (ti.m_name.empty()) { in.push_back(nullptr); continue; }
             const Val* v = hval(ti);
-            if (!v || !v->host_valid) return false;
+            if (!v || !v->host_valid || (v->dtype != OSG_I64 && v->dtype != OSG_F32 && v->host_f.empty())) return false;
+            if (v->dtype != OSG_I64 && v->host_f.size() != (size_t)v->numel()) return false;   // (a weight without a host copy)
+            any_value |= v->host_only;
             in.push_back(v);
         }
-        // the data operand must be a plan-time VALUE (not merely a small weight): weights stay on the device path
-        if (!in[0] || !in[0]->host_only) {
-            if (!(t == "Add" || t == "Sub" || t == "Mul" || t == "Div") || !in[1] || !in[1]->host_only) return false;
-        }
+        // at least one operand must be a plan-time VALUE (not merely a small weight): all-weight ops stay on the device path
+        if (!any_value || !in[0]) return false;
+        // Gather / Slice / Concat / Expand / Unsqueeze / ... move DATA: the data operand itself has to be a plan-time value
+        if ((t == "Gather" || t == "Slice" || t == "Unsqueeze" || t == "Squeeze" || t == "Reshape" || t == "Expand" || t == "Cast" || t == "Neg" || t == "Trilu") && !in[0]->host_only)
+            return false;
         auto ints = [](const Val* v) { return v->dtype == OSG_I64; };
+        auto attr_none = [&] { need(op, op.m_attributes.empty(), "unrecognized attribute (not implemented)."); };
         if (t == "Cast") {
             int to = -1;
             for (auto& a : op.m_attributes) {
@@ -1227,81 +1309,227 @@ struct Lowering {
                 else throw std::invalid_argument(op.m_type + ": unrecognized attribute (not implemented).");
             }
             need(op, to != -1, "'to' attribute not found.");
+            HT x = to_ht(in[0]);
             if (to == 1) {
-                need(op, ints(in[0]), "wrong data type of input (not implemented).");
-                std::vector<float> f(in[0]->host_i.begin(), in[0]->host_i.end());
-                if (f.empty()) return false;
-                host_val(op, in[0]->shape, {}, std::move(f));
+                need(op, x.is_int, "wrong data type of input (not implemented).");
+                if (x.v.empty()) return false;
+                x.is_int = false;
             } else if (to == 9 || to == 7 || to == 6) {
-                std::vector<int64_t> o;
-                if (ints(in[0])) o = in[0]->host_i;
-                else for (float f : in[0]->host_f) o.push_back((int64_t)f);
-                host_val(op, in[0]->shape, std::move(o));
+                for (auto& e : x.v) e = (double)(int64_t)e;
+                x.is_int = true;
             } else
                 throw std::invalid_argument(op.m_type + ": requested cast not implemented.");
+            host_out(op, std::move(x));
             return true;
         }
-        for (auto* v : in)
-            if (v && !ints(v)) return false;
-        const std::vector<int64_t>& x = in[0]->host_i;
+        if (t == "Range") {
+            need(op, op.m_input.size() == 3, "wrong number of inputs.");
+            attr_none();
+            for (int k = 0; k < 3; k++) need(op, in[k] && ints(in[k]) && in[k]->host_i.size() == 1 && in[k]->shape.empty(), "start, limit and delta must be int64 scalars (not implemented).");
+            const int64_t st = in[0]->host_i[0], lim = in[1]->host_i[0], dl = in[2]->host_i[0];
+            need(op, dl == 1, "delta must be 1 (not implemented).");
+            need(op, st < lim, "start must be less than limit.");
+            std::vector<int64_t> o;
+            for (int64_t k = st; k < lim; k++) o.push_back(k);
+            const long n = (long)o.size();
+            host_val(op, {n}, std::move(o));
+            return true;
+        }
+        if (t == "ConstantOfShape") {
+            need(op, op.m_input.size() == 1, "wrong number of inputs.");
+            std::string value;
+            for (auto& a : op.m_attributes) {
+                if (a.first == "value") value = a.second;
+                else throw std::invalid_argument(op.m_type + ": unrecognized attribute (not implemented).");
+            }
+            need(op, !value.empty(), "'value' attribute not specified (not implemented).");
+            need(op, in[0]->shape.size() == 1, "input must be 1D.");
+            need(op, ints(in[0]), "wrong data type of input.");
+            HT o;
+            o.is_int = false;
+            for (auto d : in[0]->host_i) o.shape.push_back((long)d);
+            need(op, prod(o.shape) <= (1L << 24), "plan-time tensor too large.");
+            o.v.assign((size_t)prod(o.shape), (double)std::stof(value));
+            host_out(op, std::move(o));
+            return true;
+        }
+        if (t == "Neg") {
+            need(op, op.m_input.size() == 1, "wrong number of inputs.");
+            HT x = to_ht(in[0]);
+            for (auto& e : x.v) e = -e;
+            host_out(op, std::move(x));
+            return true;
+        }
+        if (t == "Less" || t == "Greater" || t == "Equal" || t == "And") {
+            need(op, op.m_input.size() == 2 && in[1], "wrong number of inputs.");
+            attr_none();
+            const HT a = to_ht(in[0]), b = to_ht(in[1]);
+            // two fp32 operands are compared as fixed point with 4 decimals (reference :7682-7683)
+            const double fx = !a.is_int && !b.is_int ? 10000.0 : 1.0;
+            const int kind = t == "Less" ? 0 : t == "Greater" ? 1 : t == "Equal" ? 2 : 3;
+            host_out(op, broadcast2(op, a, b, true, [&](double x, double y) {
+                         const int64_t p = a.is_int ? (int64_t)x : (int64_t)((float)x * (float)fx), q = b.is_int ? (int64_t)y : (int64_t)((float)y * (float)fx);
+                         return (double)(kind == 0 ? p < q : kind == 1 ? p > q : kind == 2 ? p == q : (p && q));
+                     }));
+            return true;
+        }
+        if (t == "Where") {
+            need(op, op.m_input.size() == 3 && in[1] && in[2], "wrong number of inputs.");
+            attr_none();
+            const HT c = to_ht(in[0]), a = to_ht(in[1]), b = to_ht(in[2]);
+            need(op, !c.shape.empty(), "condition cannot be a scalar (not implemented).");
+            need(op, c.is_int, "wrong data type of condition (not implemented).");
+            need(op, (a.shape.empty() || a.shape == c.shape) && (b.shape.empty() || b.shape == c.shape), "shapes of condition, A and/or B not equal (broadcasting not implemented).");
+            HT o;
+            o.shape = c.shape;
+            o.is_int = a.is_int || b.is_int;     // (an int64 operand makes the result int64, the other one is truncated: reference :7067-7110)
+            o.v.resize(c.v.size());
+            for (size_t k = 0; k < o.v.size(); k++) {
+                double x = c.v[k] != 0.0 ? a.v[a.v.size() == 1 ? 0 : k] : b.v[b.v.size() == 1 ? 0 : k];
+                o.v[k] = o.is_int ? (double)(int64_t)x : x;
+            }
+            host_out(op, std::move(o));
+            return true;
+        }
+        if (t == "Expand") {
+            need(op, op.m_input.size() == 2 && in[1], "wrong number of inputs.");
+            attr_none();
+            need(op, in[1]->shape.size() == 1 && ints(in[1]), "shape must be 1D.");
+            HT ones;
+            ones.is_int = true;
+            for (auto d : in[1]->host_i) { need(op, d > 0, "dimension <= 0."); ones.shape.push_back((long)d); }
+            need(op, prod(ones.shape) <= (1L << 24), "plan-time tensor too large.");
+            ones.v.assign((size_t)prod(ones.shape), 1.0);
+            const HT x = to_ht(in[0]);
+            host_out(op, broadcast2(op, x, ones, x.is_int, [](double a, double) { return a; }));
+            return true;
+        }
+        if (t == "Trilu") {
+            need(op, op.m_input.size() == 2 && in[1], "wrong number of inputs.");
+            for (auto& a : op.m_attributes) {
+                if (a.first == "upper") need(op, a.second == "1", "'upper' must be 1 (not implemented).");
+                else throw std::invalid_argument(op.m_type + ": unrecognized attribute (not implemented).");
+            }
+            HT x = to_ht(in[0]);
+            need(op, !x.is_int, "wrong data type of input.");
+            need(op, x.shape.size() == 2, "input must be 2D (not implemented).");
+            need(op, ints(in[1]) && in[1]->shape.empty() && in[1]->host_i.size() == 1, "second input (k) must be a scalar (not implemented).");
+            const long w = x.shape[1], h = x.shape[0], k = (long)in[1]->host_i[0];
+            for (long y = 0; y < h; y++)
+                for (long xx = 0; xx < w; xx++)
+                    if (!(xx - k >= y)) x.v[(size_t)(y * w + xx)] = 0.0;
+            host_out(op, std::move(x));
+            return true;
+        }
         if (t == "Gather") {
-            need(op, op.m_input.size() == 2, "wrong number of inputs.");
+            need(op, op.m_input.size() == 2 && in[1], "wrong number of inputs.");
             int axis = 0;
             for (auto& a : op.m_attributes) {
                 if (a.first == "axis") axis = std::stoi(a.second);
                 else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
             }
+            need(op, ints(in[1]), "wrong data type of indices.");
             need(op, in[0]->shape.size() == 1 && (axis == 0 || axis == -1), "axis must be 0 (not implemented).");
-            std::vector<int64_t> o;
+            const HT x = to_ht(in[0]);
+            HT o;
+            o.is_int = x.is_int;
+            o.shape = in[1]->shape;                       // 0-d indices -> 0-d output, 1-d -> 1-d (reference :6391-6394)
             for (int64_t i : in[1]->host_i) {
-                if (i < 0) i += (int64_t)x.size();
-                need(op, i >= 0 && i < (int64_t)x.size(), "invalid index in indices.");
-                o.push_back(x[i]);
+                if (i < 0) i += (int64_t)x.v.size();
+                need(op, i >= 0 && i < (int64_t)x.v.size(), "invalid index in indices.");
+                o.v.push_back(x.v[(size_t)i]);
             }
-            host_val(op, in[1]->shape, std::move(o));   // 0-d indices -> 0-d output, 1-d -> 1-d (reference :6391-6394)
+            host_out(op, std::move(o));
             return true;
         }
         if (t == "Concat") {
-            std::vector<int64_t> o;
+            HT o;
+            o.is_int = true;
             for (auto* v : in) {
                 need(op, v && v->shape.size() <= 1, "invalid shape of inputs.");
-                o.insert(o.end(), v->host_i.begin(), v->host_i.end());
+                const HT x = to_ht(v);
+                o.is_int &= x.is_int;
+                o.v.insert(o.v.end(), x.v.begin(), x.v.end());
             }
-            const long no = (long)o.size();
-            host_val(op, {no}, std::move(o));
+            o.shape = {(long)o.v.size()};
+            host_out(op, std::move(o));
             return true;
         }
-        if (t == "Unsqueeze" || t == "Squeeze" || t == "Reshape") {
+        if (t == "Unsqueeze" || t == "Squeeze") {
+            HT x = to_ht(in[0]);
+            std::vector<long> axes;
+            if (op.m_input.size() > 1 && in[1]) {
+                need(op, ints(in[1]), "wrong data type of axes.");
+                axes.assign(in[1]->host_i.begin(), in[1]->host_i.end());
+            } else if (auto* a = attr(op, "axes"))
+                for (int k : int_list(*a)) axes.push_back(k);
+            need(op, !axes.empty(), "axes cannot be empty (not implemented).");
+            const long rank_out = t == "Unsqueeze" ? (long)x.shape.size() + (long)axes.size() : (long)x.shape.size();
+            for (auto& a : axes) {
+                if (a < 0) a += rank_out;
+                need(op, a >= 0 && a < rank_out, "wrong data in axes.");
+            }
+            std::sort(axes.begin(), axes.end());
+            if (t == "Unsqueeze")
+                for (long a : axes) x.shape.insert(x.shape.begin() + a, 1);
+            else
+                for (auto it = axes.rbegin(); it != axes.rend(); ++it) {
+                    need(op, x.shape[(size_t)*it] == 1, "wrong data in axes.");
+                    x.shape.erase(x.shape.begin() + *it);
+                }
+            host_out(op, std::move(x));
+            return true;
+        }
+        if (t == "Reshape") {
+            need(op, op.m_input.size() == 2 && in[1] && ints(in[1]), "wrong data type of shape.");
+            HT x = to_ht(in[0]);
             Shape os;
-            for (auto& d : op.m_output[0].m_shape) os.push_back((long)d);
-            need(op, prod(os) == (long)x.size(), "invalid shape.");
-            host_val(op, os, x);
+            long unknown = -1, known_n = 1;
+            for (size_t k = 0; k < in[1]->host_i.size(); k++) {
+                long dsz = (long)in[1]->host_i[k];
+                if (dsz == 0) { need(op, k < x.shape.size(), "invalid shape."); dsz = x.shape[k]; }
+                if (dsz == -1) { need(op, unknown < 0, "invalid shape."); unknown = (long)k; os.push_back(1); continue; }
+                os.push_back(dsz);
+                known_n *= dsz;
+            }
+            if (unknown >= 0) { need(op, known_n > 0 && x.numel() % known_n == 0, "invalid shape."); os[(size_t)unknown] = x.numel() / known_n; }
+            need(op, prod(os) == x.numel(), "invalid shape.");
+            x.shape = os;
+            host_out(op, std::move(x));
             return true;
         }
         if (t == "Slice") {
-            need(op, op.m_input.size() >= 3 && in[0]->shape.size() == 1 && in[1]->host_i.size() == 1 && in[2]->host_i.size() == 1, "unsupported slice of a shape vector (not implemented).");
+            need(op, op.m_input.size() >= 3 && in[1] && in[2] && in[0]->shape.size() == 1 && in[1]->host_i.size() == 1 && in[2]->host_i.size() == 1, "unsupported slice of a plan-time vector (not implemented).");
             if (op.m_input.size() > 4 && in[4]) need(op, in[4]->host_i.size() == 1 && in[4]->host_i[0] == 1, "unsupported steps value(s) (not implemented).");
+            HT x = to_ht(in[0]);
             int64_t b = in[1]->host_i[0], e = in[2]->host_i[0];
-            const int64_t n = (int64_t)x.size();
+            const int64_t n = (int64_t)x.v.size();
             if (b < 0) b += n;
             if (e < 0) e += n;
             b = std::min(std::max<int64_t>(b, 0), n);
             e = std::min(std::max<int64_t>(e, 0), n);
             need(op, b < e, "invalid value(s) in starts and/or ends.");
-            host_val(op, {(long)(e - b)}, std::vector<int64_t>(x.begin() + b, x.begin() + e));
+            HT o;
+            o.is_int = x.is_int;
+            o.shape = {(long)(e - b)};
+            o.v.assign(x.v.begin() + b, x.v.begin() + e);
+            host_out(op, std::move(o));
             return true;
         }
-        // Add / Sub / Mul / Div on int64 (scalar broadcast or equal length)
-        const std::vector<int64_t>& y = in[1]->host_i;
-        need(op, x.size() == y.size() || x.size() == 1 || y.size() == 1, "shapes are not broadcastable.");
-        const size_t n = std::max(x.size(), y.size());
-        std::vector<int64_t> o(n);
-        for (size_t i = 0; i < n; i++) {
-            const int64_t a = x[x.size() == 1 ? 0 : i], b = y[y.size() == 1 ? 0 : i];
-            if (t == "Div") need(op, b != 0, "division by zero.");
-            o[i] = t == "Add" ? a + b : t == "Sub" ? a - b : t == "Mul" ? a * b : a / b;
-        }
-        host_val(op, x.size() >= y.size() ? in[0]->shape : in[1]->shape, std::move(o));
+        // Add / Sub / Mul / Div: int64 when both operands are, else fp32 (numpy broadcasting)
+        need(op, op.m_input.size() == 2 && in[1], "wrong number of inputs.");
+        const HT a = to_ht(in[0]), b = to_ht(in[1]);
+        const bool oi = a.is_int && b.is_int;
+        const int kind = t == "Add" ? 0 : t == "Sub" ? 1 : t == "Mul" ? 2 : 3;
+        host_out(op, broadcast2(op, a, b, oi, [&](double x, double y) -> double {
+                     if (oi) {
+                         const int64_t p = (int64_t)x, q = (int64_t)y;
+                         if (kind == 3) need(op, q != 0, "division by zero.");
+                         return (double)(kind == 0 ? p + q : kind == 1 ? p - q : kind == 2 ? p * q : p / q);
+                     }
+                     const float p = (float)x, q = (float)y;
+                     return (double)(kind == 0 ? p + q : kind == 1 ? p - q : kind == 2 ? p * q : p / q);
+                 }));
         return true;
     }
 
@@ -1716,6 +1944,7 @@ struct Lowering {
         if (t == "osg.Attention") return lower_attention(op);
         if (t == "AttentionFusedOps") return lower_attention_fused_ops(op);
         if (t == "ScaledDotProductAttention") return lower_sdpa(op);
+        if (t == "Expand") return lower_expand(op);
         if (t == "ReduceMean") return lower_reduce_mean(op);
         if (t == "Softmax") return lower_softmax(op);
         if (t == "Reshape") return lower_reshape(op);
@@ -2238,6 +2467,46 @@ struct Lowering {
         });
     }
 
+    // Expand (reference :7154-7230): numpy-style broadcast of the input to `shape` (a plan-time int64 vector).  On the device: x * ones, where
+    // `ones` has the target extent in every dimension the input stretches (x * 1 is exact for every f16 value, the sign of zero included)
+    void lower_expand(const Operation& op) {
+        need(op, op.m_input.size() == 2, "wrong number of inputs.");
+        need(op, op.m_output.size() == 1, "wrong number of outputs.");
+        need(op, op.m_attributes.empty(), "unrecognized attribute (not implemented).");
+        const Val* sv = hval(op.m_input[1]);
+        need(op, sv && sv->dtype == OSG_I64 && sv->host_valid, "wrong data type of shape.");
+        need(op, sv->shape.size() == 1, "shape must be 1D.");
+        const int x = P.ensure_plain(in_val(op.m_input[0]));
+        need(op, V(x).dtype == OSG_F16, "wrong data type of input (only the arithmetic type is supported on the device).");
+        Shape xs = V(x).shape;
+        Shape ts(sv->host_i.begin(), sv->host_i.end());
+        need(op, xs.size() <= ts.size(), "invalid shape of input.");
+        while (xs.size() < ts.size()) xs.insert(xs.begin(), 1);
+        Shape os(ts.size()), on(ts.size(), 1);
+        for (size_t k = 0; k < ts.size(); k++) {
+            need(op, ts[k] > 0, "dimension <= 0.");
+            need(op, xs[k] == ts[k] || xs[k] == 1 || ts[k] == 1, "shape of input not matching 'shape'.");
+            os[k] = std::max(xs[k], ts[k]);
+            if (xs[k] == 1 && ts[k] > 1) on[k] = ts[k];
+        }
+        const int y = out_val(op, os, Lay::plain, V(x).batched);
+        const size_t prank = os.size() + 1;
+        need(op, prank <= 6, "rank too large for the device broadcast kernel.");
+        const long n_ones = prod(on);
+        const int ones = P.new_val("", on, OSG_F16, Lay::plain, false);
+        V(ones).is_const = true;
+        bool fresh;
+        V(ones).dptr = P.const_alloc("", std::max<size_t>((size_t)n_ones * 2, 8), &fresh);
+        std::vector<uint16_t> h((size_t)n_ones, float_to_half(1.0f));
+        be.check(be.api.osg_upload_sync(be.ctx, V(ones).dptr, h.data(), h.size() * 2), "osg_upload_sync");
+        std::vector<long> sa(prank, 1), sb(prank, 1);
+        for (size_t k = 0; k < xs.size(); k++) { sa[k + 1] = xs[k]; sb[k + 1] = on[k]; }
+        sa[0] = B(x);
+        P.add_step("Expand " + op.m_name, {x, ones}, {y}, [=, this] {
+            be.check(be.api.osg_binary(be.ctx, OSG_F16, OSG_BIN_MUL, P.ptr(x), sa.data(), P.ptr(ones), sb.data(), P.ptr(y), (int)prank), "Expand");
+        });
+    }
+
     void lower_unary(const Operation& op) {
         need(op, op.m_input.size() == 1, "wrong number of inputs.");
         need(op, op.m_output.size() == 1, "wrong number of outputs.");
@@ -2459,7 +2728,7 @@ struct Lowering {
         need(op, ms[ms.size() - 2] == T && ms[ms.size() - 1] == S, "invalid shape of mask.");
         need(op, V(q).dtype == OSG_F16 && V(k).dtype == OSG_F16 && V(v).dtype == OSG_F16 && V(mk).dtype == OSG_F16, "wrong data type of query.");
         need(op, Dv == D && D % 8 == 0 && D <= 160, "head dims other than a multiple of 8 up to 160 with Dv == D are not implemented on the HIP backend.");
-        need(op, !V(mk).batched && V(q).batched == V(k).batched && V(k).batched == V(v).batched, "q/k/v batching mismatch.");
+        need(op, N == 1 || (!V(mk).batched && V(q).batched == V(k).batched && V(k).batched == V(v).batched), "q/k/v batching mismatch.");
         const float scale = std::stof(*attr(op, "scale"));
         need(op, scale > 0.f, "a scale <= 0 is not implemented on the HIP backend.");
         const int y = out_val(op, Shape{Bq, Hq, T, Dv}, Lay::plain, V(q).batched);
@@ -2699,6 +2968,14 @@ struct Lowering {
         }
         int y = out_val(op, os, all_nhwc ? Lay::nhwc : Lay::plain, batched, V(xs[0]).dtype);
         const int es = (int)esize(V(y).dtype);
+        // empty operands (the zero-length key/value caches of the LLM flow's first call, src/llm.cpp:388-402) contribute nothing
+        {
+            std::vector<int> live;
+            for (int x : xs)
+                if (V(x).numel() > 0) live.push_back(x);
+            xs.swap(live);
+            if (xs.empty()) return;
+        }
         long outer, dst_pitch, off = 0;
         if (all_nhwc) { outer = os[2] * os[3] * (batched ? N : 1); dst_pitch = os[1]; }
         else { outer = prod(os, 0, axis) * (batched ? N : 1); dst_pitch = prod(os, axis); }
@@ -2895,13 +3172,32 @@ void Plan::build() {
                 for (auto& t : m.m_data)
                     if (t.m_name == in.m_name) { src = &t; break; }
                 if (!src) throw std::invalid_argument("Model::get_tensor_data: input tensor not found: " + in.m_name);
-                if (src->m_type != TensorDataType::float32)
-                    throw std::invalid_argument("Model::run: graph inputs must be float32 host tensors on the HIP backend (" + in.m_name + ").");
+                if (src->m_type != TensorDataType::float32 && src->m_type != TensorDataType::int64)
+                    throw std::invalid_argument("Model::run: graph inputs must be float32 or int64 host tensors on the HIP backend (" + in.m_name + ").");
                 Shape shape = to_shape(src->m_shape);
                 In inp;
                 inp.name = in.m_name;
                 inp.host_type = src->m_type;
                 inp.shape = src->m_shape;
+                if (src->m_type == TensorDataType::int64) {
+                    // token ids / positions / masks of the LLM graphs: values known now, consumed by plan-time evaluation (Lowering::try_host_eval)
+                    if (u8 || N != 1) throw std::invalid_argument("Model::run: int64 graph inputs need one sample per pass and floating-point arithmetic (" + in.m_name + ").");
+                    auto& iv = src->get_vector<int64_t>();
+                    inp.ivals.assign(iv.begin(), iv.end());
+                    inp.staging = inp.val = new_val(in.m_name, shape, OSG_I64, Lay::plain, false);
+                    vals[inp.val].is_const = true;
+                    vals[inp.val].host_valid = vals[inp.val].host_only = true;
+                    vals[inp.val].host_i = inp.ivals;
+                    inputs.push_back(std::move(inp));
+                    continue;
+                }
+                if (prod(shape) == 0) {
+                    // an empty tensor (the first call of the LLM flow pushes zero-length key/value caches, src/llm.cpp:388-402): a val without storage
+                    inp.staging = inp.val = new_val(in.m_name, shape, u8 ? OSG_U8 : OSG_F16, Lay::plain, true);
+                    vals[inp.val].pinned = true;
+                    inputs.push_back(std::move(inp));
+                    continue;
+                }
                 if (u8) {
                     // a pushed fp32 input is quantised with the 0.1 % percentiles of ITS OWN data (push_tensor -> Model::quantize, reference
                     // :3024-3028, :3247): done on the host in execute(), the codes are uploaded, scale / zero point live in the val
@@ -3148,6 +3444,7 @@ void Plan::execute() {
         if (!src) throw std::invalid_argument("Model::get_tensor_data: input tensor not found: " + in.name);
         if (src->m_type != in.host_type || src->m_shape != in.shape)
             throw std::invalid_argument("Model::run: input '" + in.name + "' changed type or shape since the plan was built.");
+        if (in.host_type == TensorDataType::int64 || vals[in.staging].numel() == 0) continue;   // plan-time value / empty tensor: nothing to stage
         const size_t per = vals[in.staging].numel() * sizeof(float);
         auto upload = [&](Tensor& t, long idx) {
             auto& vec = t.get_vector<float>();

@@ -155,7 +155,9 @@ struct Plan {
     size_t streamed_bytes = 0;
     void restream(const WRecipe& r);
 
-    struct In { std::string name; int val; int staging; TensorDataType host_type; std::vector<size_t> shape; };
+    // ivals: an int64 graph input (LLM graphs: input_ids, position_ids, attention_mask) is a PLAN-TIME value -- its numbers feed Gather indices and
+    // mask subgraphs that are evaluated while the plan is built, so a plan is only reused for the same numbers (Plan::compatible)
+    struct In { std::string name; int val; int staging; TensorDataType host_type; std::vector<size_t> shape; std::vector<int64_t> ivals; };
     struct Out { std::string name; int val; int f32val; std::vector<size_t> shape; bool raw16 = false; };
     struct Calib { int step; std::string op; int val; };   // m_range_data_calibrate: val is measured after `step`, range kept under the op's name
     std::vector<Calib> calib;

@@ -1,0 +1,124 @@
+"""The LLM flow (second half; reference src/llm.cpp:372-440): ONE dynamic-shape model.txt of a llama-style decoder
+(onnxstream_amd/synth/llama.py) called once with a 5-token prompt and empty key/value caches, then token by token over the growing caches --
+int64 inputs, zero-length tensors, Shape/Range/Less/Where/Cast/Expand subgraphs, the ScaledDotProductAttention chain, opkv* extra outputs fed
+back as pkv*.  Fixture = the reference itself running that flow (tools/make_golden_llama.py).
+
+CPU: the reference reproduces the fixture; the whole flow plans through the no-op stub of libosgpu (every call re-plans: token values and cache
+lengths are plan-time constants here).  GPU: logits of every step and the final caches against the reference, chain op by op and fused SDPA."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from onnxstream_amd.synth import llama
+from onnxstream_amd.synth.graph import DirSink
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+Z = np.load(os.path.join(HERE, "golden", "llama_tiny.npz"))
+CFG = llama.TINY
+PROMPT = [int(t) for t in Z["prompt"]]
+TOKENS = [int(t) for t in Z["tokens"]]
+
+
+def _flow(lib, model_dir, fp16=True, sdpa=False, ops_cache=True, options=()):
+    from onnxstream_amd.bindings import Model
+    m = Model(lib, 1, "ram+nocache")
+    for k, v in options:
+        m._set_option(k, v)
+    llama.configure(m, CFG, model_dir, sdpa=sdpa, ops_cache=ops_cache)
+    outs = []
+    logits, past = llama.forward(m, CFG, PROMPT, None, fp16)
+    outs.append(logits)
+    for t in TOKENS:
+        logits, past = llama.forward(m, CFG, [t], past, fp16)
+        outs.append(logits)
+    return m, outs, past
+
+
+def test_reference_reproduces_llama_golden():
+    from oracle import ref as oref
+    if not oref.available():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        llama.build_llama(DirSink(d), CFG)
+        m, outs, past = _flow(oref.REF_LIB, d)
+        m.close()
+    for s, lg in enumerate(outs):
+        assert np.array_equal(lg, Z[f"logits16_{s}"])
+        # the fixture's tokens ARE the greedy continuation of the reference's own fp16 run
+        if s < len(TOKENS):
+            assert int(np.argmax(lg[0, -1])) == TOKENS[s]
+    for i, p in enumerate(past):
+        assert np.array_equal(p, Z[f"past16_{i}"])
+
+
+sys.path.insert(0, os.path.join(HERE, "stub"))
+
+
+@pytest.fixture(scope="module")
+def stub_backend():
+    import make_stub
+    from onnxstream_amd import build as b
+    if not os.path.exists(b.LIB_HOST):
+        pytest.skip("host library not built")
+    with tempfile.TemporaryDirectory() as d:
+        so = make_stub.build(d)
+        old = os.environ.get("OSGPU_LIB")
+        os.environ["OSGPU_LIB"] = so
+        try:
+            yield so
+        finally:
+            if old is None:
+                os.environ.pop("OSGPU_LIB", None)
+            else:
+                os.environ["OSGPU_LIB"] = old
+
+
+@pytest.mark.parametrize("sdpa", [False, True])
+def test_flow_plans_through_the_stub(stub_backend, sdpa):
+    from onnxstream_amd import build as b
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        llama.build_llama(DirSink(d), CFG)
+        m, outs, past = _flow(b.LIB_HOST, d, sdpa=sdpa)
+        whats = [ln.split(" | ", 1)[1] for ln in m.hip_plan_info().splitlines() if ln.startswith("step ")]
+        m.close()
+    assert [o.shape for o in outs] == [(1, len(PROMPT), CFG.vocab)] + [(1, 1, CFG.vocab)] * len(TOKENS)
+    assert all(p.shape == (1, CFG.kv_heads, len(PROMPT) + len(TOKENS), CFG.head_dim) for p in past)
+    # the mask / position / shape subgraphs were folded while planning: none of their ops is a launch
+    assert not any(w.split(" ")[0] in ("Range", "Less", "Where", "Cast", "Shape", "ConstantOfShape") for w in whats)
+    assert sum(w.startswith("ScaledDotProductAttention") for w in whats) == (CFG.layers if sdpa else 0)
+    assert sum(w.startswith("Softmax") for w in whats) == (0 if sdpa else CFG.layers)
+    assert sum(w.startswith("Expand") for w in whats) == 2 * CFG.layers
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["chain", "sdpa"])
+def test_hip_llm_flow_vs_reference(mode):
+    """Every step's logits against the reference's fp16 logits, relative to the largest fp32 logit: chain op by op within 1e-3 outright (measured
+    4.7e-4 ... 9.4e-4; the reference's own fp16-vs-fp32 drift on this 2-layer decoder is 5e-4 ... 1.2e-3); fused SDPA within 2e-3 or at least as
+    close to the fp32 reference as the reference's own fp16 run (+1e-4) (measured 4.8e-4 ... 1.06e-3, and closer to fp32 than the reference at 4 of 5
+    steps); greedy tokens identical; caches within 1e-3."""
+    from onnxstream_amd import build as b
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        llama.build_llama(DirSink(d), CFG)
+        m, outs, past = _flow(b.LIB_HOST, d, sdpa=mode == "sdpa", options=(("hip_autotune", 0),))
+        m.close()
+    mx = max(float(np.abs(Z[f"logits32_{s}"]).max()) for s in range(len(outs)))
+    for s, lg in enumerate(outs):
+        r16, r32 = Z[f"logits16_{s}"], Z[f"logits32_{s}"]
+        e16, e32, drift = np.abs(lg - r16).max() / mx, np.abs(lg - r32).max() / mx, np.abs(r16 - r32).max() / mx
+        print(f"{mode} step {s}: err16 {e16:.2e} err32 {e32:.2e} (reference drift {drift:.2e})")
+        if mode == "chain":
+            assert e16 <= 1e-3, (s, e16, e32, drift)
+        else:
+            assert e16 <= 2e-3 and (e16 <= 1e-3 or e32 <= drift + 1e-4), (s, e16, e32, drift)
+        if s < len(TOKENS):
+            assert int(np.argmax(lg[0, -1])) == TOKENS[s]
+    pm = max(float(np.abs(Z[f"past32_{i}"]).max()) for i in range(len(past)))
+    for i, p in enumerate(past):
+        assert np.abs(p - Z[f"past16_{i}"]).max() / pm <= 1e-3
