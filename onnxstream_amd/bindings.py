@@ -202,6 +202,46 @@ class Model:
                     clip.ctypes.data_as(fp) if clip is not None else None, ctypes.byref(ms)))
         return ms.value
 
+    def set_upcast_substrings(self, subs):
+        """Model::m_requires_upcast (a std::function in C++, src/llm.cpp:379-383): ops whose name contains one of `subs` run in fp32.  Works on
+        libonnxstream_amd.so (model_hip_set_upcast_substrings) and on the oracle build of the reference (ref_set_upcast_substrings)."""
+        text = "|".join(subs).encode()
+        for sym in ("model_hip_set_upcast_substrings", "ref_set_upcast_substrings"):
+            f = getattr(self._lib, sym, None)
+            if f is not None:
+                f.argtypes = [ctypes.c_void_p, ctypes.c_char_p]; f.restype = None
+                f(self._h, text)
+                return
+        raise OnnxStreamError("this library has no way to set m_requires_upcast through the C API")
+
+    def add_outputs_convert(self, name: str):
+        """Model::m_outputs_convert_set.insert(name): once the set is non-empty only its members are converted back to fp32 at the end of run()."""
+        for sym in ("model_hip_add_outputs_convert", "ref_add_outputs_convert_exclusion"):
+            f = getattr(self._lib, sym, None)
+            if f is not None:
+                f.argtypes = [ctypes.c_void_p, ctypes.c_char_p]; f.restype = None
+                f(self._h, self._name(name))
+                return
+        raise OnnxStreamError("this library has no way to reach m_outputs_convert_set through the C API")
+
+    def drop_tensor(self, name: str) -> bool:
+        """Remove one tensor from Model::m_data (what the LLM app's get_output does after reading a result, src/llm.cpp:342-353)."""
+        for sym in ("model_hip_drop_tensor", "ref_drop_tensor"):
+            f = getattr(self._lib, sym, None)
+            if f is not None:
+                f.argtypes = [ctypes.c_void_p, ctypes.c_char_p]; f.restype = ctypes.c_int
+                return bool(f(self._h, self._name(name)))
+        raise OnnxStreamError("this library cannot drop tensors through the C API")
+
+    def rename_tensor(self, src: str, dst: str) -> bool:
+        """Rename a tensor of Model::m_data in place (the LLM app turns the opkv* outputs of one call into the pkv* inputs of the next this way)."""
+        for sym in ("model_hip_rename_tensor", "ref_rename_tensor"):
+            f = getattr(self._lib, sym, None)
+            if f is not None:
+                f.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]; f.restype = ctypes.c_int
+                return bool(f(self._h, self._name(src), self._name(dst)))
+        raise OnnxStreamError("this library cannot rename tensors through the C API")
+
     def hip_set_vram_budget(self, nbytes: int):
         """CudaOptions.m_vram_to_use: weights (model order) stay resident until `nbytes` are spent, the rest stream every pass."""
         f = self._lib.model_hip_set_vram_budget

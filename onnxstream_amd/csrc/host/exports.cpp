@@ -258,6 +258,41 @@ unsigned long long model_hip_streamed_bytes(Handle* h) { return h->model.hip_str
 unsigned long long model_hip_resident_weight_bytes(Handle* h) { return h->model.hip_resident_weight_bytes(); }
 // CudaOptions::m_vram_to_use through the C API (the reference sets it from C++ only: src/llm.cpp set_cuda_options)
 void model_hip_set_vram_budget(Handle* h, unsigned long long bytes) { h->model.set_cuda_options(CudaOptions(bytes, false)); }
+// Model::m_requires_upcast is a std::function (set from C++ by src/llm.cpp:379-383: ops whose NAME contains "/input_layernorm/" or
+// "/post_attention_layernorm/" run in fp32): through the C API as a '|'-separated list of substrings of the op name; "" clears it
+void model_hip_set_upcast_substrings(Handle* h, const char* list) {
+    std::vector<std::string> subs;
+    std::string cur;
+    for (const char* p = list ? list : ""; ; p++) {
+        if (*p == '|' || *p == 0) {
+            if (!cur.empty()) subs.push_back(cur);
+            cur.clear();
+            if (!*p) break;
+        } else cur.push_back(*p);
+    }
+    if (subs.empty()) h->model.m_requires_upcast = nullptr;
+    else
+        h->model.m_requires_upcast = [subs](const std::string&, const std::string& name) {
+            for (auto& s : subs)
+                if (name.find(s) != std::string::npos) return true;
+            return false;
+        };
+    h->model.hip_invalidate_plan();
+}
+// What src/llm.cpp does to Model::m_data and m_outputs_convert_set from C++ between two calls (:366, :403-407): keep an output out of the
+// fp32 conversion, and hand an output of the last run back as an input of the next one under another name
+void model_hip_add_outputs_convert(Handle* h, char* name) { h->model.m_outputs_convert_set.insert(name); }
+int model_hip_drop_tensor(Handle* h, char* name) {   // (llm.cpp's get_output moves a result out of m_data, :342-353)
+    auto& d = h->model.m_data;
+    for (size_t i = 0; i < d.size(); i++)
+        if (d[i].m_name == name) { d.erase(d.begin() + i); return 1; }
+    return 0;
+}
+int model_hip_rename_tensor(Handle* h, char* from, char* to) {
+    for (auto& t : h->model.m_data)
+        if (t.m_name == from) { t.m_name = to; return 1; }
+    return 0;
+}
 // relaunch the captured pass n times on the resident inputs; ms_each (may be NULL) receives per-launch device times
 char* model_hip_replay(Handle* h, int n, float* ms_each) {
     try {

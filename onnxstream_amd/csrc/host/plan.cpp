@@ -1892,7 +1892,31 @@ struct Lowering {
         throw std::invalid_argument(op.m_type + ": requested cast not implemented (only casts of plan-time integer values are supported on the HIP backend).");
     }
 
-    int in_val(const Tensor& t) { return P.ensure_dense(in_val_raw(t)); }
+    // m_requires_upcast (reference get_tensor_data :2847-2848: the operands of a flagged op are handed over as fp32, the op runs in fp32; its fp32
+    // result stays fp32 only while the NEXT op is its sole consumer, push_tensor :3008-3034): cur_up is set while a flagged op is lowered
+    bool cur_up = false;
+    std::map<int, int> cast_cache32, cast_cache16;
+    int cast_val(int v, osg_dtype to) {
+        auto& cache = to == OSG_F32 ? cast_cache32 : cast_cache16;
+        auto it = cache.find(v);
+        if (it != cache.end()) return it->second;
+        const int src = P.ensure_plain(v);
+        const int y = P.new_val("", V(src).shape, to, Lay::plain, V(src).batched);
+        V(y).up32 = to == OSG_F32;
+        const osg_dtype from = V(src).dtype;
+        const long n = P.total_elems(src);
+        P.add_step(std::string(to == OSG_F32 ? "upcast " : "downcast ") + V(src).name, {src}, {y}, [=, this] {
+            be.check(be.api.osg_convert(be.ctx, from, to, P.ptr(src), P.ptr(y), n, 1.f, 0), "osg_convert");
+        });
+        cache[v] = y;
+        return y;
+    }
+    int in_val(const Tensor& t) {
+        const int v = P.ensure_dense(in_val_raw(t));
+        if (cur_up && V(v).dtype == OSG_F16) return cast_val(v, OSG_F32);
+        if (!cur_up && V(v).up32) return cast_val(v, OSG_F16);
+        return v;
+    }
 
     void check_out(const Operation& op, const Shape& got, size_t idx = 0) {
         // the reference's per-op self check (check_output_shape, :3070)
@@ -1910,11 +1934,38 @@ struct Lowering {
 
     long B(int v) { return V(v).batched ? N : 1; }
 
+    bool upcast_op(const Operation& op) const { return P.fp16 && !P.u8 && m.m_requires_upcast && m.m_requires_upcast(op.m_type, op.m_name); }
     void lower_all() {
         plan_linear_groups();
+        if (m.m_requires_upcast) index_graph();
         for (size_t i = 0; i < ops().size(); i++) {
             if (group_of.count((int)i)) lower_group_member(ops()[i], (int)i);
-            else lower(ops()[i]);
+            else if (upcast_op(ops()[i])) {
+                const Operation& op = ops()[i];
+                const std::string& t = op.m_type;
+                if (!try_host_eval(op)) {
+                    if (!(t == "Pow" || t == "ReduceMean" || t == "Add" || t == "Sub" || t == "Mul" || t == "Div" || t == "Sqrt" || t == "Neg" || t == "Sigmoid" || t == "Erf" ||
+                          t == "Sin" || t == "Cos"))
+                        throw std::invalid_argument("Model::run: m_requires_upcast is not implemented on the HIP backend for operation " + t + " (" + op.m_name + ").");
+                    cur_up = true;
+                    try { lower(op); } catch (...) { cur_up = false; throw; }
+                    cur_up = false;
+                    // push_tensor: the fp32 result is rounded to fp16 unless the next op of the queue is its only consumer
+                    auto it = P.by_name.find(op.m_output[0].m_name);
+                    if (it != P.by_name.end() && V(it->second).up32) {
+                        bool keep = i + 1 < ops().size() && use_count(op.m_output[0].m_name) == 1;
+                        if (keep) {
+                            keep = false;
+                            for (auto& ti : ops()[i + 1].m_input) keep |= ti.m_name == op.m_output[0].m_name;
+                        }
+                        if (!keep) {
+                            const int h = cast_val(it->second, OSG_F16);
+                            V(h).name = op.m_output[0].m_name;
+                            P.by_name[op.m_output[0].m_name] = h;
+                        }
+                    }
+                }
+            } else lower(ops()[i]);
             if (P.calibrate)      // m_range_data_calibrate: every op output is measured right after the launch(es) that produce it
                 for (auto& o : ops()[i].m_output) {
                     auto it = P.by_name.find(o.m_name);
@@ -2412,7 +2463,8 @@ struct Lowering {
         need(op, op.m_input.size() == 2, "wrong number of inputs.");
         need(op, op.m_output.size() == 1, "wrong number of outputs.");
         int a = in_val(op.m_input[0]), b = in_val(op.m_input[1]);
-        need(op, V(a).dtype == OSG_F16 && V(b).dtype == OSG_F16, "wrong data type of inputs (only the arithmetic type is supported on the device).");
+        const osg_dtype adt = cur_up ? OSG_F32 : OSG_F16;   // (a flagged op runs in fp32 on upcast operands, m_requires_upcast)
+        need(op, V(a).dtype == adt && V(b).dtype == adt, "wrong data type of inputs (only the arithmetic type is supported on the device).");
         const osg_binary_kind kind = op.m_type == "Add" ? OSG_BIN_ADD : op.m_type == "Sub" ? OSG_BIN_SUB : op.m_type == "Mul" ? OSG_BIN_MUL : OSG_BIN_DIV;
         // logical output shape (right-aligned broadcast, :855-876)
         const Shape as = V(a).shape, bs = V(b).shape;
@@ -2453,7 +2505,8 @@ struct Lowering {
             }
         }
         if (olay == Lay::plain) { pa = V(a).shape; pb = V(b).shape; }
-        int y = out_val(op, os, olay, batched);
+        int y = out_val(op, os, olay, batched, adt);
+        V(y).up32 = adt == OSG_F32;
         // prepend the sample dim
         const size_t prank = std::max(pa.size(), pb.size()) + 1;
         need(op, prank <= 6, "rank too large for the device broadcast kernel.");
@@ -2463,7 +2516,7 @@ struct Lowering {
         sa[0] = B(a);
         sb[0] = B(b);
         P.add_step(op.m_type + " " + op.m_name, {a, b}, {y}, [=, this] {
-            be.check(be.api.osg_binary(be.ctx, OSG_F16, kind, P.ptr(a), sa.data(), P.ptr(b), sb.data(), P.ptr(y), (int)prank), op.m_type.c_str());
+            be.check(be.api.osg_binary(be.ctx, adt, kind, P.ptr(a), sa.data(), P.ptr(b), sb.data(), P.ptr(y), (int)prank), op.m_type.c_str());
         });
     }
 
@@ -2511,13 +2564,15 @@ struct Lowering {
         need(op, op.m_input.size() == 1, "wrong number of inputs.");
         need(op, op.m_output.size() == 1, "wrong number of outputs.");
         int x = in_val(op.m_input[0]);
-        need(op, V(x).dtype == OSG_F16, "wrong data type of input.");
+        const osg_dtype adt = cur_up ? OSG_F32 : OSG_F16;
+        need(op, V(x).dtype == adt, "wrong data type of input.");
         const std::string& t = op.m_type;
         const osg_unary_kind k = t == "Sigmoid" ? OSG_UN_SIGMOID : t == "Erf" ? OSG_UN_ERF : t == "Sqrt" ? OSG_UN_SQRT : t == "Sin" ? OSG_UN_SIN
                                  : t == "Cos" ? OSG_UN_COS : t == "Neg" ? OSG_UN_NEG : OSG_UN_SILU;
-        int y = out_val(op, V(x).shape, V(x).lay, V(x).batched);
+        int y = out_val(op, V(x).shape, V(x).lay, V(x).batched, adt);
+        V(y).up32 = adt == OSG_F32;
         const long n = P.total_elems(x);
-        P.add_step(t + " " + op.m_name, {x}, {y}, [=, this] { be.check(be.api.osg_unary(be.ctx, OSG_F16, k, P.ptr(x), P.ptr(y), n, 0.f), t.c_str()); });
+        P.add_step(t + " " + op.m_name, {x}, {y}, [=, this] { be.check(be.api.osg_unary(be.ctx, adt, k, P.ptr(x), P.ptr(y), n, 0.f), t.c_str()); });
     }
 
     // Pow (reference :5478-5604): scalar exponent only
@@ -2526,9 +2581,12 @@ struct Lowering {
         int x = in_val(op.m_input[0]);
         float p = 0;
         need(op, const_scalar(op.m_input[1], &p) && cval(op.m_input[1])->shape.empty(), "power must be a scalar (not implemented).");
-        int y = out_val(op, V(x).shape, V(x).lay, V(x).batched);
+        const osg_dtype adt = cur_up ? OSG_F32 : OSG_F16;
+        need(op, V(x).dtype == adt, "wrong data type of input.");
+        int y = out_val(op, V(x).shape, V(x).lay, V(x).batched, adt);
+        V(y).up32 = adt == OSG_F32;
         const long n = P.total_elems(x);
-        P.add_step("Pow " + op.m_name, {x}, {y}, [=, this] { be.check(be.api.osg_unary(be.ctx, OSG_F16, OSG_UN_POW, P.ptr(x), P.ptr(y), n, p), "Pow"); });
+        P.add_step("Pow " + op.m_name, {x}, {y}, [=, this] { be.check(be.api.osg_unary(be.ctx, adt, OSG_UN_POW, P.ptr(x), P.ptr(y), n, p), "Pow"); });
     }
 
     // InstanceNormalization (reference :4788-5055): input [1,G,L]
@@ -2809,9 +2867,12 @@ struct Lowering {
         }
         Shape os = s;
         os.back() = 1;
-        int y = out_val(op, os, Lay::plain, V(x).batched);
+        const osg_dtype adt = cur_up ? OSG_F32 : OSG_F16;
+        need(op, V(x).dtype == adt, "wrong data type of input.");
+        int y = out_val(op, os, Lay::plain, V(x).batched, adt);
+        V(y).up32 = adt == OSG_F32;
         const long C = s.back(), rows = P.total_elems(x) / C;
-        P.add_step("ReduceMean " + op.m_name, {x}, {y}, [=, this] { be.check(be.api.osg_reduce_mean_last(be.ctx, OSG_F16, P.ptr(x), P.ptr(y), rows, C), "ReduceMean"); });
+        P.add_step("ReduceMean " + op.m_name, {x}, {y}, [=, this] { be.check(be.api.osg_reduce_mean_last(be.ctx, adt, P.ptr(x), P.ptr(y), rows, C), "ReduceMean"); });
     }
 
     // Softmax (reference :5862-5998): any axis via transpose-in / softmax / transpose-out (:5883-5923)
@@ -3141,8 +3202,8 @@ void Plan::build() {
                                  "the SD UNet, src/sd.cpp:1633) and uint8 arithmetic (m_use_uint8_arithmetic, src/sd.cpp:1218); fp32 arithmetic is not implemented.");
     if (m.m_use_uint8_qdq)
         throw std::runtime_error("Model::run: m_use_uint8_qdq (uint8 storage between fp32 ops) is not implemented on the HIP backend.");
-    if (m.m_requires_upcast)
-        throw std::runtime_error("Model::run: m_requires_upcast (per-op fp32 upcast, the LLM path of src/llm.cpp:385) is not implemented on the HIP backend.");
+    if (m.m_requires_upcast && u8)
+        throw std::runtime_error("Model::run: m_requires_upcast with uint8 arithmetic is not implemented on the HIP backend.");
     if (calibrate) {
         if (u8) throw std::invalid_argument("Model::run: m_range_data_calibrate runs in floating-point arithmetic (src/sd.cpp:1216-1222), not with m_use_uint8_arithmetic.");
         fusion = 0;      // one output per graph op, at the reference's rounding points
@@ -3172,8 +3233,8 @@ void Plan::build() {
                 for (auto& t : m.m_data)
                     if (t.m_name == in.m_name) { src = &t; break; }
                 if (!src) throw std::invalid_argument("Model::get_tensor_data: input tensor not found: " + in.m_name);
-                if (src->m_type != TensorDataType::float32 && src->m_type != TensorDataType::int64)
-                    throw std::invalid_argument("Model::run: graph inputs must be float32 or int64 host tensors on the HIP backend (" + in.m_name + ").");
+                if (src->m_type != TensorDataType::float32 && src->m_type != TensorDataType::int64 && !(src->m_type == TensorDataType::float16 && fp16 && !u8))
+                    throw std::invalid_argument("Model::run: graph inputs must be float32, float16 (fp16 arithmetic) or int64 host tensors on the HIP backend (" + in.m_name + ").");
                 Shape shape = to_shape(src->m_shape);
                 In inp;
                 inp.name = in.m_name;
@@ -3188,6 +3249,17 @@ void Plan::build() {
                     vals[inp.val].is_const = true;
                     vals[inp.val].host_valid = vals[inp.val].host_only = true;
                     vals[inp.val].host_i = inp.ivals;
+                    inputs.push_back(std::move(inp));
+                    continue;
+                }
+                if (src->m_type == TensorDataType::float16 && prod(shape) != 0) {
+                    // an output the caller kept in fp16 (m_outputs_convert_set excludes it) and feeds back under another name: the LLM app's
+                    // opkv* -> pkv* renaming (src/llm.cpp:403-407).  Uploaded as it is, no rounding step.
+                    if (N != 1) throw std::invalid_argument("Model::run: float16 graph inputs need one sample per pass (" + in.m_name + ").");
+                    inp.staging = inp.val = new_val(in.m_name, shape, OSG_F16, Lay::plain, true);
+                    vals[inp.val].dptr = be.malloc(val_bytes(inp.val));
+                    owned.push_back(vals[inp.val].dptr);
+                    vals[inp.val].pinned = true;
                     inputs.push_back(std::move(inp));
                     continue;
                 }
@@ -3445,6 +3517,12 @@ void Plan::execute() {
         if (src->m_type != in.host_type || src->m_shape != in.shape)
             throw std::invalid_argument("Model::run: input '" + in.name + "' changed type or shape since the plan was built.");
         if (in.host_type == TensorDataType::int64 || vals[in.staging].numel() == 0) continue;   // plan-time value / empty tensor: nothing to stage
+        if (in.host_type == TensorDataType::float16) {
+            auto& vec = src->get_vector<uint16_t>();
+            if (vec.size() != (size_t)vals[in.val].numel()) throw std::invalid_argument("Model::get_tensor_data: mismatch between tensor shape and data size.");
+            be.check(be.api.osg_upload(be.ctx, ptr(in.val), vec.data(), vec.size() * 2), "osg_upload");
+            continue;
+        }
         const size_t per = vals[in.staging].numel() * sizeof(float);
         auto upload = [&](Tensor& t, long idx) {
             auto& vec = t.get_vector<float>();

@@ -38,6 +38,7 @@ struct Val {
     std::vector<float> host_f;    // small constants, available at plan time
     std::vector<int64_t> host_i;
     bool host_valid = false;
+    bool up32 = false;            // fp32 result of an op the Model's m_requires_upcast flags (LLM layer norms): rounded to f16 when an unflagged op reads it
     bool host_only = false;       // value computed at plan time (Shape / Gather / Cast / Concat chains over shapes): no device storage until a launch asks for it
     int as_plain = -1, as_nhwc = -1, as_dense = -1;
     // column-slice view of a wider 2-D buffer (merged projections): rows are `ld` elements apart, starting `view_off` bytes into the root

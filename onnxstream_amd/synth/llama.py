@@ -183,7 +183,31 @@ def forward(m, cfg: LlamaConfig, input_ids, past, fp16: bool = True):
     return logits, new_past
 
 
-def configure(m, cfg: LlamaConfig, model_dir: str, sdpa: bool = False, ops_cache: bool = True):
+UPCAST = ("/input_layernorm/", "/post_attention_layernorm/")   # the ops src/llm.cpp:379-383 runs in fp32 (m_requires_upcast)
+
+
+def forward_resident(m, cfg: LlamaConfig, input_ids, first: bool, P: int, fp16: bool = True):
+    """The same call the way src/llm.cpp:386-428 really makes it: the caches never leave Model::m_data -- m_outputs_convert_set = {"logits"} keeps the
+    opkv* outputs in fp16, and the next call renames them to pkv* (:403-407) instead of pushing new tensors.  Returns logits only."""
+    T_new = len(input_ids)
+    m.set_use_fp16_arithmetic(False)
+    if first:
+        for i in range(2 * cfg.layers):
+            m.add_tensor(f"pkv{i}", np.zeros((1, cfg.kv_heads, 0, cfg.head_dim), np.float32))
+    else:
+        for i in range(2 * cfg.layers):
+            assert m.rename_tensor(f"opkv{i}", f"pkv{i}")
+    m.add_tensor("input_ids", np.asarray([input_ids], np.int64))
+    m.add_tensor("position_ids", np.asarray([list(range(P, P + T_new))], np.int64))
+    m.add_tensor("attention_mask", np.ones((1, P + T_new), np.int64))
+    m.set_use_fp16_arithmetic(fp16)
+    m.run()
+    logits = m.get_tensor("logits")[0]
+    m.drop_tensor("logits")          # (get_output moves the result out of m_data, :342-353)
+    return logits
+
+
+def configure(m, cfg: LlamaConfig, model_dir: str, sdpa: bool = False, ops_cache: bool = True, upcast: bool = False):
     """Model options of src/llm.cpp:361-377 that the C API can express (m_requires_upcast is a std::function: not settable from here).
     ops_cache=False for fp32-arithmetic runs of the reference: its ops cache does not survive a second call over fp16-stored weights."""
     m.set_support_dynamic_shapes(True)
@@ -192,6 +216,8 @@ def configure(m, cfg: LlamaConfig, model_dir: str, sdpa: bool = False, ops_cache
         m.set_use_next_op_cache(True)
     if sdpa:
         m.set_use_scaled_dp_attn_op(True)
+    if upcast:
+        m.set_upcast_substrings(UPCAST)
     for i in range(2 * cfg.layers):
         m.add_extra_output(f"opkv{i}")
     m.read_file(model_dir + "model.txt")

@@ -32,6 +32,37 @@ const char* ref_write_range_data(void* ctx, const char* fn) {
     catch (const std::exception& e) { err = e.what(); return err.c_str(); }
 }
 
+// Model::m_requires_upcast (a std::function the LLM app sets from C++, src/llm.cpp:379-383) as a '|'-separated list of op-name substrings
+void ref_set_upcast_substrings(void* ctx, const char* list) {
+    std::vector<std::string> subs;
+    std::string cur;
+    for (const char* p = list ? list : ""; ; p++) {
+        if (*p == '|' || *p == 0) {
+            if (!cur.empty()) subs.push_back(cur);
+            cur.clear();
+            if (!*p) break;
+        } else cur.push_back(*p);
+    }
+    if (subs.empty()) as_model(ctx)->m_requires_upcast = nullptr;
+    else
+        as_model(ctx)->m_requires_upcast = [subs](const std::string&, const std::string& name) {
+            for (auto& s : subs)
+                if (name.find(s) != std::string::npos) return true;
+            return false;
+        };
+}
+
+int ref_drop_tensor(void* ctx, const char* name) {
+    auto& d = as_model(ctx)->m_data;
+    for (size_t i = 0; i < d.size(); i++)
+        if (d[i].m_name == name) { d.erase(d.begin() + i); return 1; }
+    return 0;
+}
+int ref_rename_tensor(void* ctx, const char* from, const char* to) {
+    for (auto& t : as_model(ctx)->m_data)
+        if (t.m_name == from) { t.m_name = to; return 1; }
+    return 0;
+}
 void ref_add_outputs_convert_exclusion(void* ctx, const char* name) { as_model(ctx)->m_outputs_convert_set.insert(name); }
 
 void ref_add_force_uint8_storage(void* ctx, const char* name) { as_model(ctx)->m_force_uint8_storage_set.insert(name); }

@@ -22,12 +22,12 @@ PROMPT = [int(t) for t in Z["prompt"]]
 TOKENS = [int(t) for t in Z["tokens"]]
 
 
-def _flow(lib, model_dir, fp16=True, sdpa=False, ops_cache=True, options=()):
+def _flow(lib, model_dir, fp16=True, sdpa=False, ops_cache=True, options=(), upcast=False):
     from onnxstream_amd.bindings import Model
     m = Model(lib, 1, "ram+nocache")
     for k, v in options:
         m._set_option(k, v)
-    llama.configure(m, CFG, model_dir, sdpa=sdpa, ops_cache=ops_cache)
+    llama.configure(m, CFG, model_dir, sdpa=sdpa, ops_cache=ops_cache, upcast=upcast)
     outs = []
     logits, past = llama.forward(m, CFG, PROMPT, None, fp16)
     outs.append(logits)
@@ -44,15 +44,43 @@ def test_reference_reproduces_llama_golden():
     with tempfile.TemporaryDirectory() as d:
         d += "/"
         llama.build_llama(DirSink(d), CFG)
-        m, outs, past = _flow(oref.REF_LIB, d)
+        for tag, up in (("16", False), ("16u", True)):
+            m, outs, past = _flow(oref.REF_LIB, d, upcast=up)
+            m.close()
+            for s, lg in enumerate(outs):
+                assert np.array_equal(lg, Z[f"logits{tag}_{s}"])
+                # the fixture's tokens ARE the greedy continuation of the reference's own fp16 run
+                if s < len(TOKENS):
+                    assert int(np.argmax(lg[0, -1])) == TOKENS[s]
+            for i, p in enumerate(past):
+                assert np.array_equal(p, Z[f"past{tag}_{i}"])
+
+
+def _flow_resident(lib, model_dir, sdpa=False, options=(), upcast=False):
+    """src/llm.cpp's own shape of the loop: logits is the only output converted to fp32, the caches stay fp16 inside the Model and are renamed"""
+    from onnxstream_amd.bindings import Model
+    m = Model(lib, 1, "ram+nocache")
+    for k, v in options:
+        m._set_option(k, v)
+    m.add_outputs_convert("logits")
+    llama.configure(m, CFG, model_dir, sdpa=sdpa, upcast=upcast)
+    outs = [llama.forward_resident(m, CFG, PROMPT, True, 0)]
+    for k, t in enumerate(TOKENS):
+        outs.append(llama.forward_resident(m, CFG, [t], False, len(PROMPT) + k))
+    return m, outs
+
+
+def test_reference_resident_caches_reproduce_the_golden():
+    from oracle import ref as oref
+    if not oref.available():
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        llama.build_llama(DirSink(d), CFG)
+        m, outs = _flow_resident(oref.REF_LIB, d, upcast=True)
         m.close()
     for s, lg in enumerate(outs):
-        assert np.array_equal(lg, Z[f"logits16_{s}"])
-        # the fixture's tokens ARE the greedy continuation of the reference's own fp16 run
-        if s < len(TOKENS):
-            assert int(np.argmax(lg[0, -1])) == TOKENS[s]
-    for i, p in enumerate(past):
-        assert np.array_equal(p, Z[f"past16_{i}"])
+        assert np.array_equal(lg, Z[f"logits16u_{s}"])
 
 
 sys.path.insert(0, os.path.join(HERE, "stub"))
@@ -77,13 +105,13 @@ def stub_backend():
                 os.environ["OSGPU_LIB"] = old
 
 
-@pytest.mark.parametrize("sdpa", [False, True])
-def test_flow_plans_through_the_stub(stub_backend, sdpa):
+@pytest.mark.parametrize("sdpa,upcast", [(False, False), (True, False), (True, True)])
+def test_flow_plans_through_the_stub(stub_backend, sdpa, upcast):
     from onnxstream_amd import build as b
     with tempfile.TemporaryDirectory() as d:
         d += "/"
         llama.build_llama(DirSink(d), CFG)
-        m, outs, past = _flow(b.LIB_HOST, d, sdpa=sdpa)
+        m, outs, past = _flow(b.LIB_HOST, d, sdpa=sdpa, upcast=upcast)
         whats = [ln.split(" | ", 1)[1] for ln in m.hip_plan_info().splitlines() if ln.startswith("step ")]
         m.close()
     assert [o.shape for o in outs] == [(1, len(PROMPT), CFG.vocab)] + [(1, 1, CFG.vocab)] * len(TOKENS)
@@ -93,10 +121,41 @@ def test_flow_plans_through_the_stub(stub_backend, sdpa):
     assert sum(w.startswith("ScaledDotProductAttention") for w in whats) == (CFG.layers if sdpa else 0)
     assert sum(w.startswith("Softmax") for w in whats) == (0 if sdpa else CFG.layers)
     assert sum(w.startswith("Expand") for w in whats) == 2 * CFG.layers
+    # m_requires_upcast: each of the 2 layer norms per layer reads its input through ONE upcast and hands ONE fp16 result on (the final norm is not flagged)
+    assert sum(w.startswith("upcast") for w in whats) >= (2 * CFG.layers if upcast else 0)
+    assert (sum(w.startswith("downcast") for w in whats) > 0) == upcast
+
+
+def test_resident_flow_plans_through_the_stub(stub_backend):
+    from onnxstream_amd import build as b
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        llama.build_llama(DirSink(d), CFG)
+        m, outs = _flow_resident(b.LIB_HOST, d, sdpa=True, upcast=True)
+        names = m.get_all_tensor_names()
+        m.close()
+    assert [o.shape for o in outs] == [(1, len(PROMPT), CFG.vocab)] + [(1, 1, CFG.vocab)] * len(TOKENS)
+    assert "logits" not in names and all(f"opkv{i}" in names for i in range(2 * CFG.layers))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["chain", "sdpa"])
+def test_hip_resident_caches_equal_the_round_trip():
+    """fp16 caches kept inside the Model and renamed (the app's way) give the same bits as caches read back as fp32 and pushed again"""
+    from onnxstream_amd import build as b
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        llama.build_llama(DirSink(d), CFG)
+        opts = (("hip_autotune", 0),)
+        m1, outs1, _ = _flow(b.LIB_HOST, d, sdpa=True, options=opts, upcast=True)
+        m1.close()
+        m2, outs2 = _flow_resident(b.LIB_HOST, d, sdpa=True, options=opts, upcast=True)
+        m2.close()
+    for a, c in zip(outs1, outs2):
+        assert np.array_equal(a, c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["chain", "sdpa", "chain-upcast", "sdpa-upcast"])
 def test_hip_llm_flow_vs_reference(mode):
     """Every step's logits against the reference's fp16 logits, relative to the largest fp32 logit: chain op by op within 1e-3 outright (measured
     4.7e-4 ... 9.4e-4; the reference's own fp16-vs-fp32 drift on this 2-layer decoder is 5e-4 ... 1.2e-3); fused SDPA within 2e-3 or at least as
@@ -106,14 +165,16 @@ def test_hip_llm_flow_vs_reference(mode):
     with tempfile.TemporaryDirectory() as d:
         d += "/"
         llama.build_llama(DirSink(d), CFG)
-        m, outs, past = _flow(b.LIB_HOST, d, sdpa=mode == "sdpa", options=(("hip_autotune", 0),))
+        up = mode.endswith("upcast")
+        m, outs, past = _flow(b.LIB_HOST, d, sdpa=mode.startswith("sdpa"), options=(("hip_autotune", 0),), upcast=up)
         m.close()
+    tag = "16u" if up else "16"    # (the reference run with the same m_requires_upcast)
     mx = max(float(np.abs(Z[f"logits32_{s}"]).max()) for s in range(len(outs)))
     for s, lg in enumerate(outs):
-        r16, r32 = Z[f"logits16_{s}"], Z[f"logits32_{s}"]
+        r16, r32 = Z[f"logits{tag}_{s}"], Z[f"logits32_{s}"]
         e16, e32, drift = np.abs(lg - r16).max() / mx, np.abs(lg - r32).max() / mx, np.abs(r16 - r32).max() / mx
         print(f"{mode} step {s}: err16 {e16:.2e} err32 {e32:.2e} (reference drift {drift:.2e})")
-        if mode == "chain":
+        if mode.startswith("chain"):
             assert e16 <= 1e-3, (s, e16, e32, drift)
         else:
             assert e16 <= 2e-3 and (e16 <= 1e-3 or e32 <= drift + 1e-4), (s, e16, e32, drift)
@@ -121,4 +182,4 @@ def test_hip_llm_flow_vs_reference(mode):
             assert int(np.argmax(lg[0, -1])) == TOKENS[s]
     pm = max(float(np.abs(Z[f"past32_{i}"]).max()) for i in range(len(past)))
     for i, p in enumerate(past):
-        assert np.abs(p - Z[f"past16_{i}"]).max() / pm <= 1e-3
+        assert np.abs(p - Z[f"past{tag}_{i}"]).max() / pm <= 1e-3

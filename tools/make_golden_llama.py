@@ -23,9 +23,10 @@ with tempfile.TemporaryDirectory() as d:
     d += "/"
     llama.build_llama(DirSink(d), cfg)
     toks = None
-    for tag, fp16 in (("16", True), ("32", False)):
+    # "16": fp16 arithmetic; "32": fp32 arithmetic; "16u": fp16 arithmetic with the layer-norm ops upcast to fp32 (m_requires_upcast, src/llm.cpp:379-383)
+    for tag, fp16, up in (("16", True, False), ("32", False, False), ("16u", True, True)):
         m = Model(oref.REF_LIB, 1, "ram+nocache")
-        llama.configure(m, cfg, d, ops_cache=fp16)
+        llama.configure(m, cfg, d, ops_cache=fp16, upcast=up)
         logits, past = llama.forward(m, cfg, PROMPT, None, fp16)
         out[f"logits{tag}_0"] = logits
         fed = []
@@ -42,7 +43,10 @@ with tempfile.TemporaryDirectory() as d:
             out[f"past{tag}_{i}"] = p
         m.close()
         print(tag, "tokens", fed, "max|logits|", float(np.abs(logits).max()))
+        assert fed == [int(t) for t in toks]
 mx = max(float(np.abs(out[f"logits32_{s}"]).max()) for s in range(STEPS + 1))
 for s in range(STEPS + 1):
-    print(f"step {s}: |ref16-ref32|/max = {np.abs(out[f'logits16_{s}'] - out[f'logits32_{s}']).max() / mx:.2e}")
+    print(f"step {s}: |ref16-ref32|/max = {np.abs(out[f'logits16_{s}'] - out[f'logits32_{s}']).max() / mx:.2e}   "
+          f"|ref16u-ref32|/max = {np.abs(out[f'logits16u_{s}'] - out[f'logits32_{s}']).max() / mx:.2e}   "
+          f"|ref16u-ref16|/max = {np.abs(out[f'logits16u_{s}'] - out[f'logits16_{s}']).max() / mx:.2e}")
 np.savez_compressed(os.path.join(REPO, "tests", "golden", "llama_tiny.npz"), **out)
