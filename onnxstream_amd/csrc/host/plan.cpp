@@ -5,10 +5,12 @@
 #include "qu8.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <thread>
+#include <unordered_map>
 
 namespace onnxstream {
 
@@ -208,12 +210,28 @@ void* Plan::ptr(int v) const {
     return (char*)arena + r.offset + off;
 }
 
+void* Plan::small_alloc(size_t bytes) {
+    const size_t need = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+    if (need > ((size_t)1 << 20)) {
+        void* p = be.malloc(need);
+        owned.push_back(p);
+        return p;
+    }
+    if (need > slab_left) {
+        slab_left = (size_t)8 << 20;
+        slab = (char*)be.malloc(slab_left);
+        owned.push_back(slab);
+    }
+    void* p = slab;
+    slab += need;
+    slab_left -= need;
+    return p;
+}
+
 void* Plan::const_alloc(const std::string& tag, size_t bytes, bool* fresh) {
     if (stream_weights || tag.empty()) {
-        void* p = be.malloc(bytes);
-        owned.push_back(p);
         *fresh = true;
-        return p;
+        return small_alloc(bytes);
     }
     auto it = pool.derived.find(tag);
     if (it != pool.derived.end() && it->second.second == bytes) {
@@ -304,9 +322,9 @@ struct Lowering {
     Model& m;
     HipBackend& be;
     long N;
-    std::map<std::string, int> uses;                    // activation name -> number of consumer ops
-    std::map<std::string, int> producer;                // activation name -> op index
-    std::map<std::string, std::vector<int>> consumers;  // activation name -> consumer op indices
+    std::unordered_map<std::string, int> uses;                    // activation name -> number of consumer ops
+    std::unordered_map<std::string, int> producer;                // activation name -> op index
+    std::unordered_map<std::string, std::vector<int>> consumers;  // activation name -> consumer op indices
     std::vector<char> dead;
     std::map<std::string, int> const_cache;             // file name + dtype -> val
 
@@ -529,6 +547,7 @@ struct Lowering {
     // ------------------------------------------------------------------------------------------------------------------
     void index_graph() {
         uses.clear(); producer.clear(); consumers.clear();
+        uses.reserve(ops().size() * 2); producer.reserve(ops().size() * 2); consumers.reserve(ops().size() * 2);
         for (size_t i = 0; i < ops().size(); i++) {
             if (dead[i]) continue;
             for (auto& in : ops()[i].m_input)
@@ -563,25 +582,32 @@ struct Lowering {
     // the other operand of a commutative binary op
     int other(const Operation& op, const std::string& name) const { return op.m_input[0].m_name == name ? 1 : 0; }
 
+    // a pass whose anchor op type does not occur in the (live) graph is skipped together with its re-indexing: the LLM flow re-plans on every call
+    // and a 1 200-op llama graph spent 2/3 of its plan time re-indexing for passes that had nothing to match
+    bool has_type(const char* type) const {
+        for (size_t i = 0; i < P.ops.size(); i++)
+            if (!dead[i] && P.ops[i].m_type == type) return true;
+        return false;
+    }
     void run_fusions() {
         dead.assign(ops().size(), 0);
-        if (m.m_use_scaled_dp_attn_op) { index_graph(); fuse_sdpa(); }   // (a Model option of the reference, independent of hip_fusion_level)
+        if (m.m_use_scaled_dp_attn_op && has_type("Softmax")) { index_graph(); fuse_sdpa(); }   // (a Model option of the reference, independent of hip_fusion_level)
         if (P.fusion >= 1) {
-            index_graph(); fuse_silu();
-            index_graph(); fuse_group_norm();
-            index_graph(); fuse_layer_norm();
-            index_graph(); fuse_geglu();
+            if (has_type("Sigmoid")) { index_graph(); fuse_silu(); }
+            if (has_type("InstanceNormalization")) { index_graph(); fuse_group_norm(); }
+            if (has_type("ReduceMean") && has_type("Sub")) { index_graph(); fuse_layer_norm(); }
+            if (has_type("Erf")) { index_graph(); fuse_geglu(); }
         }
         if (P.fusion >= 2) {
-            index_graph(); fuse_attention(true);
-            index_graph(); fuse_linear();
-            index_graph(); fuse_residual();
-            index_graph(); fuse_conv_act();
-            index_graph(); fuse_linear_geglu();
-            index_graph(); cse_silu();
-            index_graph(); fuse_image_bias();
-            index_graph(); fuse_group_norm_conv();   // last: the conv's epilogue inputs (residual, image bias) are final by now
-        } else if (m.m_fuse_ops_in_attention) {
+            if (has_type("Softmax")) { index_graph(); fuse_attention(true); }
+            if (has_type("MatMul")) { index_graph(); fuse_linear(); }
+            if (has_type("Conv") || has_type("osg.Linear")) { index_graph(); fuse_residual(); }
+            if (has_type("Conv")) { index_graph(); fuse_conv_act(); }
+            if (has_type("osg.GEGLU")) { index_graph(); fuse_linear_geglu(); }
+            if (has_type("osg.SiLU")) { index_graph(); cse_silu(); }
+            if (has_type("Conv")) { index_graph(); fuse_image_bias(); }
+            if (has_type("osg.GroupNorm")) { index_graph(); fuse_group_norm_conv(); }   // last: the conv's epilogue inputs (residual, image bias) are final by now
+        } else if (m.m_fuse_ops_in_attention && has_type("Softmax")) {
             index_graph(); fuse_attention(false);
         }
         std::vector<Operation> live;
@@ -1167,8 +1193,7 @@ struct Lowering {
         const int r = P.root_of(it->second);
         if (V(r).host_only && !V(r).dptr) {   // a plan-time value that a launch wants to read after all: give it device storage now
             const size_t bytes = std::max<size_t>(P.val_bytes(r), 8);
-            V(r).dptr = be.malloc(bytes);
-            P.owned.push_back(V(r).dptr);
+            V(r).dptr = P.small_alloc(bytes);
             if (V(r).dtype == OSG_I64) be.check(be.api.osg_upload_sync(be.ctx, V(r).dptr, V(r).host_i.data(), V(r).host_i.size() * 8), "osg_upload_sync");
             else if (V(r).dtype == OSG_F32 && P.fp16) {
                 // the reference's fp32 results are rounded to fp16 when they are pushed with fp16 arithmetic on (push_tensor :3029-3034)
@@ -1555,9 +1580,7 @@ struct Lowering {
     }
     // a 256-byte device table that lives as long as the plan
     void* lut_alloc(size_t bytes) {
-        void* p = be.malloc(bytes);
-        P.owned.push_back(p);
-        return p;
+        return P.small_alloc(bytes);
     }
 
     void lower_u8(const Operation& op) {
@@ -3217,7 +3240,13 @@ void Plan::build() {
     vals.reserve(ops.size() * 12 + 1024);  // belt and braces: lowering code copies shapes, never holds Val& across new_val
     lowering = new Lowering(*this);
     Lowering& L = *lowering;
+    // OSG_PLAN_TIMING=1: host milliseconds of the plan-building phases on stderr (the LLM flow re-plans on every call)
+    static const bool timing = std::getenv("OSG_PLAN_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
+    const auto t_begin = now();
     L.load_weights();
+    const double t_weights = ms_since(t_begin);
 
     // ---- graph inputs: every activation name that is consumed but never produced --------------------------------
     {
@@ -3257,8 +3286,7 @@ void Plan::build() {
                     // opkv* -> pkv* renaming (src/llm.cpp:403-407).  Uploaded as it is, no rounding step.
                     if (N != 1) throw std::invalid_argument("Model::run: float16 graph inputs need one sample per pass (" + in.m_name + ").");
                     inp.staging = inp.val = new_val(in.m_name, shape, OSG_F16, Lay::plain, true);
-                    vals[inp.val].dptr = be.malloc(val_bytes(inp.val));
-                    owned.push_back(vals[inp.val].dptr);
+                    vals[inp.val].dptr = small_alloc(val_bytes(inp.val));
                     vals[inp.val].pinned = true;
                     inputs.push_back(std::move(inp));
                     continue;
@@ -3274,16 +3302,14 @@ void Plan::build() {
                     // a pushed fp32 input is quantised with the 0.1 % percentiles of ITS OWN data (push_tensor -> Model::quantize, reference
                     // :3024-3028, :3247): done on the host in execute(), the codes are uploaded, scale / zero point live in the val
                     inp.staging = inp.val = new_val(in.m_name, shape, OSG_U8, Lay::plain, true);
-                    vals[inp.val].dptr = be.malloc(val_bytes(inp.val));
-                    owned.push_back(vals[inp.val].dptr);
+                    vals[inp.val].dptr = small_alloc(val_bytes(inp.val));
                     vals[inp.val].pinned = true;
                     vals[inp.val].qdyn = true;
                     inputs.push_back(std::move(inp));
                     continue;
                 }
                 inp.staging = new_val("", shape, OSG_F32, Lay::plain, true);
-                vals[inp.staging].dptr = be.malloc(val_bytes(inp.staging));
-                owned.push_back(vals[inp.staging].dptr);
+                vals[inp.staging].dptr = small_alloc(val_bytes(inp.staging));
                 vals[inp.staging].pinned = true;
                 // fp32 inputs are rounded to f16 when pushed with fp16 arithmetic on (reference push_tensor :3029-3034)
                 inp.val = new_val(in.m_name, shape, OSG_F16, Lay::plain, true);
@@ -3296,8 +3322,12 @@ void Plan::build() {
             }
     }
 
+    const auto t_fuse = now();
     L.run_fusions();
+    const double ms_fuse = ms_since(t_fuse);
+    const auto t_lower = now();
     L.lower_all();
+    const double ms_lower = ms_since(t_lower);
 
     // ---- graph outputs: produced but never consumed, plus the caller's extra outputs -> fp32, logical layout --------
     {
@@ -3321,8 +3351,7 @@ void Plan::build() {
                 // m_outputs_convert_set (reference :8234): only the listed outputs are converted back to fp32 at the end of run(); the others
                 // stay in the arithmetic type (f16 bits; here always in the logical layout).  A pinned f16 copy is what the caller reads.
                 o.f32val = new_val("", vals[v].shape, OSG_F16, Lay::plain, vals[v].batched);
-                vals[o.f32val].dptr = be.malloc(val_bytes(o.f32val));
-                owned.push_back(vals[o.f32val].dptr);
+                vals[o.f32val].dptr = small_alloc(val_bytes(o.f32val));
                 vals[o.f32val].pinned = true;
                 o.raw16 = true;
                 const int s0 = v, d0 = o.f32val;
@@ -3332,8 +3361,7 @@ void Plan::build() {
                 continue;
             }
             o.f32val = new_val("", vals[v].shape, OSG_F32, Lay::plain, vals[v].batched);
-            vals[o.f32val].dptr = be.malloc(val_bytes(o.f32val));
-            owned.push_back(vals[o.f32val].dptr);
+            vals[o.f32val].dptr = small_alloc(val_bytes(o.f32val));
             vals[o.f32val].pinned = true;
             const int s = v, d = o.f32val;
             const long n = total_elems(v);
@@ -3367,6 +3395,7 @@ void Plan::build() {
         }
     }
 
+    const auto t_pack = now();
     // ---- liveness + arena packing -----------------------------------------------------------------------------------
     for (size_t si = 0; si < steps.size(); si++)
         for (auto* lst : {&steps[si].reads, &steps[si].writes})
@@ -3460,6 +3489,9 @@ void Plan::build() {
     arena_bytes = top ? top : 256;
     arena = be.malloc(arena_bytes);
     be.check(be.api.osg_sync(be.ctx), "osg_sync");
+    if (timing)
+        fprintf(stderr, "[plan] %zu ops -> %zu steps: weights %.2f ms, fusions %.2f ms, lowering %.2f ms, liveness + packing + arena %.2f ms, whole build %.2f ms (arena %.1f MB)\n", ops.size(),
+                steps.size(), t_weights, ms_fuse, ms_lower, ms_since(t_pack), ms_since(t_begin), arena_bytes / 1e6);
 }
 
 void Plan::run_steps() {

@@ -126,6 +126,11 @@ struct Plan {
     std::map<std::string, int> by_name;
     std::vector<Step> steps;
     std::vector<void*> owned;     // device allocations owned by the plan (weights, staging, outputs)
+    // small per-plan buffers (input staging, pinned outputs, index / ones / mask constants) are carved out of 8 MiB slabs: a plan of the LLM flow
+    // has ~100 of them and is rebuilt on every call -- one hipMalloc each was 2/3 of the rebuild time
+    void* small_alloc(size_t bytes);
+    char* slab = nullptr;
+    size_t slab_left = 0;
     void* arena = nullptr;
     size_t arena_bytes = 0, weight_bytes = 0;
 
