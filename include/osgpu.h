@@ -187,6 +187,11 @@ int osg_attention_strided(osg_ctx* ctx, osg_dtype dtype, const void* q, long q_t
  * k / v [B][Hkv][Tkv][D] (K in its natural layout: the op takes the Transpose's INPUT), mask [Tq][Tkv] additive, shared by all batches and
  * heads, or NULL; out [B][Hq][Tq][D].  Hq % Hkv == 0 (query head h reads key/value head h / (Hq/Hkv)).  `scale` is the f16-rounded
  * 1/s (Div form) or s*s2 (Mul/Mul form) the reference computes at :7840-7862.  Same flash-style kernel as osg_attention (f32 scores). */
+/* The two elementwise chains of the LLM graphs (reference: run op by op through XnnPack::multiply / add / ... and the inline kernels), fused:
+ * RMSNorm = Pow :5478 -> ReduceMean :5237 -> Add -> Sqrt :4001 -> Div -> Mul -> Mul under m_requires_upcast (fp32 from the f16 input to ONE rounding);
+ * rotary embedding = Slice :6499 x2 -> Neg :7475 -> Concat :4140 -> Mul x2 -> Add with the chain's own f16 roundings (bit-identical). */
+int osg_rms_norm(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* w, void* y, long rows, int C, float eps);
+int osg_rope(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* cos_t, const void* sin_t, void* y, long bh, long T, int d);
 int osg_sdpa(osg_ctx* ctx, osg_dtype dtype, const void* q, const void* k, const void* v, const void* mask, void* o, int batch, int q_heads,
              int kv_heads, int Tq, int Tkv, int D, float scale);
 

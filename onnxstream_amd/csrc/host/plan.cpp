@@ -593,6 +593,8 @@ struct Lowering {
         dead.assign(ops().size(), 0);
         if (m.m_use_scaled_dp_attn_op && has_type("Softmax")) { index_graph(); fuse_sdpa(); }   // (a Model option of the reference, independent of hip_fusion_level)
         if (P.fusion >= 1) {
+            if (m.m_requires_upcast && has_type("Pow") && has_type("ReduceMean")) { index_graph(); fuse_rms_norm(); }
+            if (has_type("Neg") && has_type("Slice")) { index_graph(); fuse_rope(); }
             if (has_type("Sigmoid")) { index_graph(); fuse_silu(); }
             if (has_type("InstanceNormalization")) { index_graph(); fuse_group_norm(); }
             if (has_type("ReduceMean") && has_type("Sub")) { index_graph(); fuse_layer_norm(); }
@@ -847,6 +849,116 @@ struct Lowering {
         *src = s;
         chain->insert(chain->end(), {r1, tp, r0});
         return true;
+    }
+
+    // Pow(x, 2) -> ReduceMean(-1, keepdims) -> Add(eps) -> Sqrt -> Div(1, .) -> Mul(x, .) -> Mul(w, .)  ==> osg.RMSNorm, when m_requires_upcast flags
+    // all seven ops (the LLM app's layer norms, src/llm.cpp:379-383): every intermediate then stays fp32 in the reference (each is the sole operand
+    // of the next op), so the chain is fp32 arithmetic from the f16 input to one rounding -- which is what the fused kernel does.  Unflagged
+    // chains keep their op-by-op f16 roundings.
+    bool upcast_flag(const Operation& op) const { return P.fp16 && !P.u8 && m.m_requires_upcast && m.m_requires_upcast(op.m_type, op.m_name); }
+    void fuse_rms_norm() {
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (!is((int)i, "Pow")) continue;
+            Operation& pw = ops()[i];
+            float two = 0.f, eps = 0.f, one = 0.f;
+            if (pw.m_input.size() != 2 || !act(pw.m_input[0]) || !const_scalar(pw.m_input[1], &two) || two != 2.0f) continue;
+            const Tensor x = pw.m_input[0];
+            const int rm = sole_consumer(pw.m_output[0]);
+            if (!is(rm, "ReduceMean")) continue;
+            {
+                auto* ax = attr(ops()[rm], "axes");
+                auto* kd = attr(ops()[rm], "keepdims");
+                if (!ax || int_list(*ax) != std::vector<int>{-1} || !kd || *kd != "1") continue;
+            }
+            const int ad = sole_consumer(ops()[rm].m_output[0]);
+            if (!is(ad, "Add") || ops()[ad].m_input.size() != 2) continue;
+            if (!const_scalar(ops()[ad].m_input[other(ops()[ad], ops()[rm].m_output[0].m_name)], &eps)) continue;
+            const int sq = sole_consumer(ops()[ad].m_output[0]);
+            if (!is(sq, "Sqrt")) continue;
+            const int dv = sole_consumer(ops()[sq].m_output[0]);
+            if (!is(dv, "Div") || ops()[dv].m_input.size() != 2 || ops()[dv].m_input[1].m_name != ops()[sq].m_output[0].m_name ||
+                !const_scalar(ops()[dv].m_input[0], &one) || one != 1.0f)
+                continue;
+            const int m0 = sole_consumer(ops()[dv].m_output[0]);
+            if (!is(m0, "Mul") || ops()[m0].m_input.size() != 2) continue;
+            if (ops()[m0].m_input[other(ops()[m0], ops()[dv].m_output[0].m_name)].m_name != x.m_name) continue;
+            const int m1 = sole_consumer(ops()[m0].m_output[0]);
+            if (!is(m1, "Mul") || ops()[m1].m_input.size() != 2) continue;
+            const Tensor w = ops()[m1].m_input[other(ops()[m1], ops()[m0].m_output[0].m_name)];
+            const Val* wv = cval(w);
+            if (!wv || wv->dtype != OSG_F16 || wv->shape.size() != 1) continue;
+            bool all_up = true;
+            for (int k : {(int)i, rm, ad, sq, dv, m0, m1}) all_up &= upcast_flag(ops()[k]);
+            if (!all_up) continue;
+            Operation f;
+            f.m_name = ops()[m1].m_name + "_RMSNorm";
+            f.m_type = "osg.RMSNorm";
+            f.m_input = {x, w};
+            f.m_output = {ops()[m1].m_output[0]};
+            char buf[64];
+            snprintf(buf, sizeof buf, "%.9g", eps);
+            f.m_attributes = {{"epsilon", buf}};
+            for (int k : {(int)i, rm, ad, sq, dv, m0}) dead[k] = 1;
+            ops()[m1] = std::move(f);
+        }
+    }
+
+    // x * cos + Concat(Neg(Slice(x, d/2:d)), Slice(x, 0:d/2)) * sin  ==> osg.RoPE (HF rotate_half; same f16 roundings as the seven ops: bit-identical)
+    void fuse_rope() {
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (!is((int)i, "Add")) continue;
+            Operation& add = ops()[i];
+            if (add.m_input.size() != 2) continue;
+            const int ma = prod_of(add.m_input[0]), mb = prod_of(add.m_input[1]);
+            if (!is(ma, "Mul") || !is(mb, "Mul") || use_count(add.m_input[0].m_name) != 1 || use_count(add.m_input[1].m_name) != 1) continue;
+            bool done = false;
+            for (int swap = 0; swap < 2 && !done; swap++) {
+                const Operation& mx = ops()[swap ? mb : ma];      // x * cos
+                const Operation& mr = ops()[swap ? ma : mb];      // rotate_half(x) * sin
+                if (mx.m_input.size() != 2 || mr.m_input.size() != 2) continue;
+                for (int rs = 0; rs < 2 && !done; rs++) {
+                    const Tensor rot = mr.m_input[rs], sin_t = mr.m_input[1 - rs];
+                    const int cc = prod_of(rot);
+                    if (!is(cc, "Concat") || use_count(rot.m_name) != 1 || ops()[cc].m_input.size() != 2) continue;
+                    auto* cax = attr(ops()[cc], "axis");
+                    if (!cax) continue;
+                    const int ng = prod_of(ops()[cc].m_input[0]), s1 = prod_of(ops()[cc].m_input[1]);
+                    if (!is(ng, "Neg") || !is(s1, "Slice") || use_count(ops()[cc].m_input[0].m_name) != 1 || use_count(ops()[cc].m_input[1].m_name) != 1) continue;
+                    const int s2 = prod_of(ops()[ng].m_input[0]);
+                    if (!is(s2, "Slice") || use_count(ops()[ng].m_input[0].m_name) != 1) continue;
+                    const Tensor x = ops()[s1].m_input[0];
+                    if (!act(x) || ops()[s2].m_input[0].m_name != x.m_name || x.m_shape.empty()) continue;
+                    const long d = (long)x.m_shape.back(), rank = (long)x.m_shape.size();
+                    if (d <= 0 || d % 2) continue;
+                    const int caxis = std::stoi(*cax);
+                    if (caxis != -1 && caxis != rank - 1) continue;
+                    auto slice_is = [&](int si, long b0, long e0) {
+                        const Operation& so = ops()[si];
+                        if (so.m_input.size() < 4) return false;
+                        const Val *st = cval(so.m_input[1]), *en = cval(so.m_input[2]), *ax = cval(so.m_input[3]);
+                        if (!st || !en || !ax || st->host_i.size() != 1 || en->host_i.size() != 1 || ax->host_i.size() != 1) return false;
+                        if (so.m_input.size() > 4 && !so.m_input[4].m_name.empty()) {
+                            const Val* sp = cval(so.m_input[4]);
+                            if (!sp || sp->host_i.size() != 1 || sp->host_i[0] != 1) return false;
+                        }
+                        const long a = ax->host_i[0];
+                        return (a == -1 || a == rank - 1) && st->host_i[0] == b0 && (en->host_i[0] == e0 || (e0 == d && en->host_i[0] >= d));
+                    };
+                    if (!slice_is(s1, 0, d / 2) || !slice_is(s2, d / 2, d)) continue;
+                    const int xi = mx.m_input[0].m_name == x.m_name ? 0 : mx.m_input[1].m_name == x.m_name ? 1 : -1;
+                    if (xi < 0) continue;
+                    const Tensor cos_t = mx.m_input[1 - xi];
+                    Operation f;
+                    f.m_name = add.m_name + "_RoPE";
+                    f.m_type = "osg.RoPE";
+                    f.m_input = {x, cos_t, sin_t};
+                    f.m_output = {add.m_output[0]};
+                    for (int k : {ma, mb, cc, ng, s1, s2}) dead[k] = 1;
+                    ops()[i] = std::move(f);
+                    done = true;
+                }
+            }
+        }
     }
 
     // m_use_scaled_dp_attn_op: the reference's ScaledDotProductAttention rewrite (src/onnxstream.cpp:3635-3755), both forms:
@@ -1963,6 +2075,7 @@ struct Lowering {
         if (m.m_requires_upcast) index_graph();
         for (size_t i = 0; i < ops().size(); i++) {
             if (group_of.count((int)i)) lower_group_member(ops()[i], (int)i);
+            else if (ops()[i].m_type == "osg.RMSNorm") lower(ops()[i]);   // (fp32 inside by construction: fuse_rms_norm only fuses fully flagged chains)
             else if (upcast_op(ops()[i])) {
                 const Operation& op = ops()[i];
                 const std::string& t = op.m_type;
@@ -2019,6 +2132,8 @@ struct Lowering {
         if (t == "AttentionFusedOps") return lower_attention_fused_ops(op);
         if (t == "ScaledDotProductAttention") return lower_sdpa(op);
         if (t == "Expand") return lower_expand(op);
+        if (t == "osg.RMSNorm") return lower_rms_norm(op);
+        if (t == "osg.RoPE") return lower_rope(op);
         if (t == "ReduceMean") return lower_reduce_mean(op);
         if (t == "Softmax") return lower_softmax(op);
         if (t == "Reshape") return lower_reshape(op);
@@ -2541,6 +2656,33 @@ struct Lowering {
         P.add_step(op.m_type + " " + op.m_name, {a, b}, {y}, [=, this] {
             be.check(be.api.osg_binary(be.ctx, adt, kind, P.ptr(a), sa.data(), P.ptr(b), sb.data(), P.ptr(y), (int)prank), op.m_type.c_str());
         });
+    }
+
+    void lower_rms_norm(const Operation& op) {
+        const int x = P.ensure_plain(in_val(op.m_input[0])), w = in_val(op.m_input[1]);
+        need(op, V(x).dtype == OSG_F16 && V(w).dtype == OSG_F16, "wrong data type of input.");
+        const Shape s = V(x).shape;
+        need(op, !s.empty() && V(w).numel() == s.back(), "invalid shape of the weight.");
+        const float eps = std::stof(*attr(op, "epsilon"));
+        const int y = out_val(op, s, Lay::plain, V(x).batched);
+        const long C = s.back(), rows = P.total_elems(x) / C;
+        P.add_step("RMSNorm " + op.m_name, {x, w}, {y}, [=, this] { be.check(be.api.osg_rms_norm(be.ctx, OSG_F16, P.ptr(x), P.ptr(w), P.ptr(y), rows, (int)C, eps), "RMSNorm"); });
+    }
+
+    void lower_rope(const Operation& op) {
+        const int x = P.ensure_plain(in_val(op.m_input[0])), cs = P.ensure_plain(in_val(op.m_input[1])), sn = P.ensure_plain(in_val(op.m_input[2]));
+        need(op, V(x).dtype == OSG_F16 && V(cs).dtype == OSG_F16 && V(sn).dtype == OSG_F16, "wrong data type of input.");
+        const Shape s = V(x).shape;
+        need(op, s.size() >= 2, "invalid shape of input.");
+        const long d = s.back(), T = s[s.size() - 2];
+        need(op, d % 2 == 0 && V(cs).numel() == T * d && V(sn).numel() == T * d && !V(cs).batched && !V(sn).batched, "cos / sin must be [.., T, d] tables shared by every head.");
+        {   // (leading dims of the tables must be 1: one table row per token)
+            const Shape cshape = V(cs).shape;
+            need(op, cshape.size() >= 2 && cshape.back() == d && cshape[cshape.size() - 2] == T, "invalid shape of the cos / sin tables.");
+        }
+        const int y = out_val(op, s, Lay::plain, V(x).batched);
+        const long bh = P.total_elems(x) / (T * d);
+        P.add_step("RoPE " + op.m_name, {x, cs, sn}, {y}, [=, this] { be.check(be.api.osg_rope(be.ctx, OSG_F16, P.ptr(x), P.ptr(cs), P.ptr(sn), P.ptr(y), bh, T, (int)d), "RoPE"); });
     }
 
     // Expand (reference :7154-7230): numpy-style broadcast of the input to `shape` (a plan-time int64 vector).  On the device: x * ones, where

@@ -232,9 +232,35 @@ int run_binary(osg_ctx* ctx, int kind, const T* a, const long* ash, const T* b, 
     return 0;
 }
 
+__global__ __launch_bounds__(256) void rope_kernel(const f16* __restrict__ x, const f16* __restrict__ cs, const f16* __restrict__ sn, f16* __restrict__ y, long n,
+                                                   long T, int d) {
+#pragma clang fp contract(off)   // (the two products are rounded before the sum, as the separate Mul and Add ops round them: no fma across them)
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int j = (int)(i % d), half = d >> 1;
+    const long t = (i / d) % T;
+    const float xv = (float)x[i];
+    const float rot = j < half ? -(float)x[i + half] : (float)x[i - half];
+    const f16 a = (f16)(xv * (float)cs[t * d + j]);
+    const f16 b = (f16)(rot * (float)sn[t * d + j]);
+    y[i] = (f16)((float)a + (float)b);
+}
+
 }  // namespace
 
 extern "C" {
+
+// Rotary embedding as the LLM graphs spell it: y = x * cos + concat(-x[d/2:], x[:d/2]) * sin on [BH][T][d] with cos / sin [T][d] -- the seven ops
+// Slice, Slice, Neg, Concat, Mul, Mul, Add in one launch with THEIR roundings (both products rounded to f16 before the sum): bit-identical
+int osg_rope(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* cos_t, const void* sin_t, void* y, long bh, long T, int d) {
+    if (bh <= 0 || T <= 0 || d <= 0) return 0;
+    if (dtype != OSG_F16) OSG_FAIL(ctx, "osg_rope: only f16 arithmetic is implemented on the device");
+    if (d % 2) OSG_FAIL(ctx, "osg_rope: the head dim must be even");
+    const long n = bh * T * d;
+    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->compute, (const f16*)x, (const f16*)cos_t, (const f16*)sin_t, (f16*)y, n, T, d);
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
 
 int osg_unary(osg_ctx* ctx, osg_dtype dtype, osg_unary_kind kind, const void* x, void* y, long n, float param) {
     if (n <= 0) return 0;

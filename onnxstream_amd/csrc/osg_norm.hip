@@ -492,6 +492,21 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const T* __restrict__ x
     }
 }
 
+// RMSNorm, one block per row (any C): sum of squares in fp32, y = f16(w * (x * (1 / sqrt(mean + eps))))
+__global__ __launch_bounds__(256) void rms_norm_kernel(const f16* __restrict__ x, const f16* __restrict__ w, f16* __restrict__ y, int C, float eps) {
+    __shared__ float red[8];
+    const f16* xr = x + (long)blockIdx.x * C;
+    f16* yr = y + (long)blockIdx.x * C;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float v = (float)xr[c];
+        ss += v * v;
+    }
+    ss = block_sum(ss, red);
+    const float r = 1.0f / sqrtf(ss / (float)C + eps);
+    for (int c = threadIdx.x; c < C; c += 256) yr[c] = (f16)((float)w[c] * ((float)xr[c] * r));
+}
+
 // generic (any C / dtype): one block per row
 template <typename T>
 __global__ __launch_bounds__(256) void layer_norm_generic_kernel(const T* __restrict__ x, const T* __restrict__ gamma,
@@ -694,6 +709,16 @@ int osg_layer_norm(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* gam
                            (const float*)gamma, (const float*)beta, (float*)y, C, eps);
     } else
         OSG_FAIL(ctx, "osg_layer_norm: unsupported dtype");
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+// RMSNorm as the LLM graphs spell it -- Pow(x, 2) -> ReduceMean(-1) -> Add(eps) -> Sqrt -> Div(1, .) -> Mul(x, .) -> Mul(w, .) -- when the Model's
+// m_requires_upcast runs that chain in fp32 (src/llm.cpp:379-383): fp32 from the f16 input to the single rounding of the result, same op order.
+int osg_rms_norm(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* w, void* y, long rows, int C, float eps) {
+    if (rows <= 0 || C <= 0) return 0;
+    if (dtype != OSG_F16) OSG_FAIL(ctx, "osg_rms_norm: only f16 storage is implemented");
+    hipLaunchKernelGGL(rms_norm_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->compute, (const f16*)x, (const f16*)w, (f16*)y, C, eps);
     OSG_LAUNCH_CHECK(ctx);
     return 0;
 }

@@ -24,7 +24,7 @@ EXPORTS = [
     "osg_device_count", "osg_init", "osg_destroy", "osg_last_error", "osg_device_name", "osg_stream", "osg_set_autotune",
     "osg_malloc", "osg_free", "osg_upload", "osg_upload_sync", "osg_host_register", "osg_host_unregister", "osg_upload_pinned", "osg_download", "osg_copy", "osg_memset", "osg_sync",
     "osg_graph_begin", "osg_graph_end", "osg_graph_launch", "osg_graph_destroy", "osg_side_begin", "osg_side_end", "osg_side_join", "osg_timer_start", "osg_timer_stop",
-    "osg_conv2d_nhwc", "osg_conv2d_nhwc_rb", "osg_gemm", "osg_gemm_ln", "osg_gemm_rowstats", "osg_gemm_w8", "osg_conv2d_nhwc_w8", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided", "osg_sdpa",
+    "osg_conv2d_nhwc", "osg_conv2d_nhwc_rb", "osg_gemm", "osg_gemm_ln", "osg_gemm_rowstats", "osg_gemm_w8", "osg_conv2d_nhwc_w8", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided", "osg_sdpa", "osg_rms_norm", "osg_rope",
     "osg_instance_norm", "osg_group_norm_nhwc", "osg_group_norm_conv3x3_supported", "osg_group_norm_conv3x3", "osg_layer_norm", "osg_reduce_mean_last", "osg_softmax_last",
     "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_concat2", "osg_resize_nearest", "osg_gather_rows",
     "osg_maxpool_nhwc", "osg_convert", "osg_sampler_prepare", "osg_sampler_cfg_euler_a",
@@ -75,6 +75,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_attention_strided.argtypes = [vp, ci, vp, cl, cl, cl, vp, cl, cl, cl, vp, cl, cl, cl, vp, cl, cl, cl, ci, ci, ci, ci,
                                           ci, cf]
     lib.osg_sdpa.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf]
+    lib.osg_rms_norm.argtypes = [vp, ci, vp, vp, vp, cl, ci, cf]
+    lib.osg_rope.argtypes = [vp, ci, vp, vp, vp, vp, cl, cl, ci]
     lib.osg_instance_norm.argtypes = [vp, ci, vp, vp, vp, vp, ci, cl, ci, cf]
     lib.osg_group_norm_nhwc.argtypes = [vp, ci, vp, vp, vp, vp, ci, cl, ci, ci, cf, ci]
     lib.osg_group_norm_conv3x3_supported.argtypes = [ci] * 5
@@ -267,6 +269,19 @@ class Gpu:
         self._ck(self.lib.osg_attention_strided(self.ctx, F16, q.ptr, c, d, tq * c, k.ptr, c, d, tkv * c, v.ptr, c, d, tkv * c, o.ptr, c, d,
                                                 tq * c, bsz, heads, tq, tkv, d, scale))
         return o
+
+    def rms_norm(self, x: DevBuf, w: DevBuf, eps: float):
+        rows, c = int(np.prod(x.shape[:-1])), x.shape[-1]
+        y = self.empty(x.shape, x.dtype)
+        self._ck(self.lib.osg_rms_norm(self.ctx, _NP2DT[x.dtype], x.ptr, w.ptr, y.ptr, rows, c, eps))
+        return y
+
+    def rope(self, x: DevBuf, cos: DevBuf, sin: DevBuf):
+        """x:[..., T, d], cos / sin:[T, d]"""
+        t, d = x.shape[-2], x.shape[-1]
+        y = self.empty(x.shape, x.dtype)
+        self._ck(self.lib.osg_rope(self.ctx, _NP2DT[x.dtype], x.ptr, cos.ptr, sin.ptr, y.ptr, int(np.prod(x.shape[:-2])), t, d))
+        return y
 
     def sdpa(self, q: DevBuf, k: DevBuf, v: DevBuf, mask: Optional[DevBuf], scale: float):
         """q:[B,Hq,Tq,D], k,v:[B,Hkv,Tkv,D], mask:[Tq,Tkv] additive or None -> o:[B,Hq,Tq,D] (the reference's ScaledDotProductAttention op)."""

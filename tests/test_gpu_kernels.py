@@ -335,6 +335,34 @@ def test_layer_norm(gpu, rows, C):
     assert rel_max(got, ref.layer_norm_decomposed(x, g, b, 1e-5)) <= 4e-3
 
 
+@pytest.mark.parametrize("rows,C", [(5, 64), (1, 2048), (33, 320), (7, 100)])
+def test_rms_norm(gpu, rows, C):
+    """fp32 from the f16 input to one rounding, in the op order of the graph chain (Pow, ReduceMean, Add, Sqrt, Div, Mul, Mul)"""
+    rng = np.random.default_rng(rows + C)
+    x = rnd(rng, (rows, C), 3.0)
+    w = (1 + rnd(rng, (C,), 0.1).astype(f32)).astype(f16)
+    xf = x.astype(f32)
+    r = f32(1.0) / np.sqrt((xf * xf).mean(axis=-1, keepdims=True, dtype=f32) + f32(1e-5))
+    want = (w.astype(f32) * (xf * r)).astype(f16)
+    got = gpu.rms_norm(gpu.to_dev(x), gpu.to_dev(w), 1e-5).numpy()
+    assert rel_max(got, want) <= 1e-3
+    assert (got != want).mean() <= 0.02        # (the f32 sum order may move a value across an f16 rounding boundary, nothing more)
+
+
+@pytest.mark.parametrize("BH,T,d", [(4, 5, 16), (32, 1, 64), (6, 37, 128), (1, 300, 8)])
+def test_rope_is_bit_identical_to_the_op_chain(gpu, BH, T, d):
+    rng = np.random.default_rng(BH + T + d)
+    x = rnd(rng, (BH, T, d), 2.0)
+    cs, sn = rnd(rng, (T, d), 1.0), rnd(rng, (T, d), 1.0)
+    half = d // 2
+    rot = np.concatenate([-x[..., half:], x[..., :half]], axis=-1)
+    a = (x.astype(f32) * cs.astype(f32)).astype(f16)
+    b = (rot.astype(f32) * sn.astype(f32)).astype(f16)
+    want = (a.astype(f32) + b.astype(f32)).astype(f16)
+    got = gpu.rope(gpu.to_dev(x), gpu.to_dev(cs), gpu.to_dev(sn)).numpy()
+    assert np.array_equal(got, want)
+
+
 def test_reduce_mean_softmax(gpu):
     rng = np.random.default_rng(9)
     x = rnd(rng, (3, 77, 333), 2.0)

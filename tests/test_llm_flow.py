@@ -121,9 +121,29 @@ def test_flow_plans_through_the_stub(stub_backend, sdpa, upcast):
     assert sum(w.startswith("ScaledDotProductAttention") for w in whats) == (CFG.layers if sdpa else 0)
     assert sum(w.startswith("Softmax") for w in whats) == (0 if sdpa else CFG.layers)
     assert sum(w.startswith("Expand") for w in whats) == 2 * CFG.layers
-    # m_requires_upcast: each of the 2 layer norms per layer reads its input through ONE upcast and hands ONE fp16 result on (the final norm is not flagged)
-    assert sum(w.startswith("upcast") for w in whats) >= (2 * CFG.layers if upcast else 0)
-    assert (sum(w.startswith("downcast") for w in whats) > 0) == upcast
+    # m_requires_upcast: the 2 flagged layer norms of every layer run as ONE fp32-inside launch each (osg.RMSNorm); the final norm is not flagged and
+    # stays op by op; the rotary embeddings of q and k are one launch each in every mode
+    assert sum(w.startswith("RMSNorm") for w in whats) == (2 * CFG.layers if upcast else 0)
+    assert sum(w.startswith("Pow") for w in whats) == (1 if upcast else 2 * CFG.layers + 1)
+    assert sum(w.startswith("RoPE") for w in whats) == 2 * CFG.layers
+    assert not any(w.startswith(("Neg", "Slice")) for w in whats)
+
+
+@pytest.mark.parametrize("fusion", [0, 2])
+def test_upcast_without_fusion_keeps_the_seven_ops(stub_backend, fusion):
+    """hip_fusion_level 0 lowers a flagged chain op by op on the fp32 kernels: one upcast of the block input, fp32 intermediates, one downcast"""
+    from onnxstream_amd import build as b
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        llama.build_llama(DirSink(d), CFG)
+        m, outs, past = _flow(b.LIB_HOST, d, sdpa=False, upcast=True, options=(("hip_fusion_level", fusion),))
+        whats = [ln.split(" | ", 1)[1] for ln in m.hip_plan_info().splitlines() if ln.startswith("step ")]
+        m.close()
+    if fusion == 0:
+        assert sum(w.startswith("upcast") for w in whats) >= 2 * CFG.layers and sum(w.startswith("downcast") for w in whats) == 2 * CFG.layers
+        assert not any(w.startswith(("RMSNorm", "RoPE")) for w in whats)
+    else:
+        assert not any(w.startswith(("upcast", "downcast")) for w in whats)
 
 
 def test_resident_flow_plans_through_the_stub(stub_backend):
@@ -155,7 +175,7 @@ def test_hip_resident_caches_equal_the_round_trip():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["chain", "sdpa", "chain-upcast", "sdpa-upcast"])
+@pytest.mark.parametrize("mode", ["chain", "sdpa", "chain-upcast", "sdpa-upcast", "chain-upcast-f0"])
 def test_hip_llm_flow_vs_reference(mode):
     """Every step's logits against the reference's fp16 logits, relative to the largest fp32 logit: chain op by op within 1e-3 outright (measured
     4.7e-4 ... 9.4e-4; the reference's own fp16-vs-fp32 drift on this 2-layer decoder is 5e-4 ... 1.2e-3); fused SDPA within 2e-3 or at least as
@@ -165,8 +185,9 @@ def test_hip_llm_flow_vs_reference(mode):
     with tempfile.TemporaryDirectory() as d:
         d += "/"
         llama.build_llama(DirSink(d), CFG)
-        up = mode.endswith("upcast")
-        m, outs, past = _flow(b.LIB_HOST, d, sdpa=mode.startswith("sdpa"), options=(("hip_autotune", 0),), upcast=up)
+        up = "upcast" in mode
+        opts = (("hip_autotune", 0),) + ((("hip_fusion_level", 0),) if mode.endswith("f0") else ())   # f0: the flagged chains op by op on the fp32 kernels
+        m, outs, past = _flow(b.LIB_HOST, d, sdpa=mode.startswith("sdpa"), options=opts, upcast=up)
         m.close()
     tag = "16u" if up else "16"    # (the reference run with the same m_requires_upcast)
     mx = max(float(np.abs(Z[f"logits32_{s}"]).max()) for s in range(len(outs)))
