@@ -3677,6 +3677,12 @@ void Plan::run_steps() {
             be.check(be.api.osg_side_end(be.ctx), "osg_side_end");
         } else
             s.run();
+        // OSG_PLAN_TRACE=1 (debugging aid, eager passes only): name every step on stderr and wait for it -- a device fault then points at its launch
+        static const bool trace = std::getenv("OSG_PLAN_TRACE") != nullptr;
+        if (trace && !in_capture) {
+            fprintf(stderr, "[step] %s\n", s.what.c_str());
+            be.check(be.api.osg_sync(be.ctx), "osg_sync");
+        }
     }
     be.check(be.api.osg_side_join(be.ctx), "osg_side_join");
 }
@@ -3777,9 +3783,12 @@ void Plan::execute() {
         be.check(be.api.osg_graph_launch(be.ctx, graph), "osg_graph_launch");
     } else if (runs >= 1 && m.m_hip_use_graph && !print && !graph && !u8 && !calibrate) {   // (uint8 plans read per-run quantisation parameters on the host: no capture)
         be.check(be.api.osg_graph_begin(be.ctx), "osg_graph_begin");
+        in_capture = true;
         try {
             run_steps();
+            in_capture = false;
         } catch (...) {
+            in_capture = false;
             osg_graph* g = nullptr;
             be.api.osg_graph_end(be.ctx, &g);
             if (g) be.api.osg_graph_destroy(g);

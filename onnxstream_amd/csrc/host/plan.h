@@ -177,6 +177,7 @@ struct Plan {
     osg_graph* graph = nullptr;
     Lowering* lowering = nullptr;  // kept alive: the launch closures capture it
     int runs = 0;
+    bool in_capture = false;      // run_steps() is recording the hipGraph (no synchronisation allowed inside)
     double m_last_ms = 0;
     // options the plan was built with
     bool fp16 = true;

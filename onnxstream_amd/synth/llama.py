@@ -37,6 +37,8 @@ class LlamaConfig:
 
 
 TINY = LlamaConfig()
+# Mistral-shaped heads: 128-wide, one key/value head shared by two query heads, a single layer
+TINY_WIDE = LlamaConfig(vocab=64, hidden=256, layers=1, heads=2, kv_heads=1, inter=256, max_pos=48, name="llama_tiny_wide")
 
 
 def build_llama(sink, cfg: LlamaConfig = TINY, seed: int = 777) -> str:

@@ -20,19 +20,22 @@ Z = np.load(os.path.join(HERE, "golden", "llama_tiny.npz"))
 CFG = llama.TINY
 PROMPT = [int(t) for t in Z["prompt"]]
 TOKENS = [int(t) for t in Z["tokens"]]
+# second shape of heads (Mistral's: 128-wide, grouped 2:1, one layer): GPU parity only
+ZW = np.load(os.path.join(HERE, "golden", "llama_tiny_wide.npz"))
 
 
-def _flow(lib, model_dir, fp16=True, sdpa=False, ops_cache=True, options=(), upcast=False):
+def _flow(lib, model_dir, fp16=True, sdpa=False, ops_cache=True, options=(), upcast=False, cfg=None, tokens=None):
     from onnxstream_amd.bindings import Model
+    cfg = cfg or CFG
     m = Model(lib, 1, "ram+nocache")
     for k, v in options:
         m._set_option(k, v)
-    llama.configure(m, CFG, model_dir, sdpa=sdpa, ops_cache=ops_cache, upcast=upcast)
+    llama.configure(m, cfg, model_dir, sdpa=sdpa, ops_cache=ops_cache, upcast=upcast)
     outs = []
-    logits, past = llama.forward(m, CFG, PROMPT, None, fp16)
+    logits, past = llama.forward(m, cfg, PROMPT, None, fp16)
     outs.append(logits)
-    for t in TOKENS:
-        logits, past = llama.forward(m, CFG, [t], past, fp16)
+    for t in (TOKENS if tokens is None else tokens):
+        logits, past = llama.forward(m, cfg, [t], past, fp16)
         outs.append(logits)
     return m, outs, past
 
@@ -156,6 +159,29 @@ def test_resident_flow_plans_through_the_stub(stub_backend):
         m.close()
     assert [o.shape for o in outs] == [(1, len(PROMPT), CFG.vocab)] + [(1, 1, CFG.vocab)] * len(TOKENS)
     assert "logits" not in names and all(f"opkv{i}" in names for i in range(2 * CFG.layers))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["chain", "sdpa-upcast"])
+def test_hip_llm_flow_wide_heads_vs_reference(mode):
+    """128-wide heads, two query heads per key/value head (the Mistral shape of the app's second model): same bounds as the 16-wide fixture"""
+    from onnxstream_amd import build as b
+    cfg, toks = llama.TINY_WIDE, [int(t) for t in ZW["tokens"]]
+    up = "upcast" in mode
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        llama.build_llama(DirSink(d), cfg)
+        m, outs, past = _flow(b.LIB_HOST, d, sdpa=mode.startswith("sdpa"), options=(("hip_autotune", 0),), upcast=up, cfg=cfg, tokens=toks)
+        m.close()
+    tag = "16u" if up else "16"
+    mx = max(float(np.abs(ZW[f"logits32_{s}"]).max()) for s in range(len(outs)))
+    for s, lg in enumerate(outs):
+        r16, r32 = ZW[f"logits{tag}_{s}"], ZW[f"logits32_{s}"]
+        e16, e32, drift = np.abs(lg - r16).max() / mx, np.abs(lg - r32).max() / mx, np.abs(r16 - r32).max() / mx
+        print(f"wide {mode} step {s}: err16 {e16:.2e} err32 {e32:.2e} (reference drift {drift:.2e})")
+        assert e16 <= 2e-3 and (e16 <= 1e-3 or e32 <= drift + 1e-4), (s, e16, e32, drift)
+        if s < len(toks):
+            assert int(np.argmax(lg[0, -1])) == toks[s]
 
 
 @pytest.mark.gpu
