@@ -175,17 +175,25 @@ class Txt2Img:
 
     def sample(self, cond: np.ndarray, uncond: np.ndarray, steps: int = 20, seed: int = 42, latent_shape=(1, 4, 64, 64),
                on_step: Optional[Callable[[int, np.ndarray], None]] = None, init_latent: Optional[np.ndarray] = None,
-               step_noise: Optional[Callable[[int], np.ndarray]] = None) -> np.ndarray:
+               step_noise: Optional[Callable[[int], np.ndarray]] = None, sampler: str = "euler_a") -> np.ndarray:
         """diffusion_solver (src/sd.cpp:1574-1780) with the default sampler, Euler Ancestral as the shipped reference runs it
         (src/samplers.h:1431-1449, ORIGINAL_SAMPLER_ALGORITHMS):  x += ((x - d) / sigma_i) * (sigma_down - sigma_i) + r * sigma_up,
         every operation rounded to float on its own.  init_latent: N(0,1) start (default: numpy stream; the reference draws
-        randn_4_w_h(seed % 1000), :1595) -- it is scaled by sigma[0] here as :1611-1612 does; step_noise(i): the ancestral noise of step i."""
+        randn_4_w_h(seed % 1000), :1595) -- it is scaled by sigma[0] here as :1611-1612 does; step_noise(i): the ancestral noise of step i.
+        sampler="euler": the plain Euler step of the same branch (src/samplers.h:116-126): x += (x - d) / sigma_i * (sigma_{i+1} - sigma_i), no noise."""
+        if sampler not in ("euler_a", "euler"):
+            raise ValueError("sampler must be 'euler_a' (the reference's default) or 'euler'")
         sig = sigma_schedule(steps, self.log_sigmas)
         rng = np.random.default_rng(seed)     # the reference draws mt19937 normals; any N(0,1) stream is equivalent for the harness
         x0 = rng.standard_normal(latent_shape, dtype=f32) if init_latent is None else np.asarray(init_latent, f32).reshape(latent_shape)
         x = (x0 * f32(sig[0])).astype(f32)
         for i in range(steps):
             den = self.denoise(x, float(sig[i]), cond, uncond)
+            if sampler == "euler":
+                x = (x + f32(f32(x - den) / f32(sig[i])) * f32(f32(sig[i + 1]) - f32(sig[i]))).astype(f32)
+                if on_step:
+                    on_step(i, x)
+                continue
             sigma_up, sigma_down = self.ancestral_step_scalars(sig[i], sig[i + 1])
             noise = rng.standard_normal(latent_shape, dtype=f32) if step_noise is None else np.asarray(step_noise(i), f32).reshape(latent_shape)
             x = (x + f32(f32(x - den) / f32(sig[i])) * f32(sigma_down - f32(sig[i])) + noise * sigma_up).astype(f32)
@@ -193,7 +201,7 @@ class Txt2Img:
                 on_step(i, x)
         return x
 
-    def loop_scalars(self, sig: np.ndarray):
+    def loop_scalars(self, sig: np.ndarray, sampler: str = "euler_a"):
         """Per-step fp32 scalars of the loop, computed exactly as denoise()/sample() do: c_in, c_out, t (sigma_to_t), sigma_i, d_sigma =
         sigma_down - sigma_i and sigma_up of the Euler-Ancestral update."""
         steps = len(sig) - 1
@@ -206,13 +214,16 @@ class Txt2Img:
                 self._t_cache[sigma] = sigma_to_t(sigma, self.log_sigmas)
             ts[i] = f32(self._t_cache[sigma])
             sigma_up, sigma_down = self.ancestral_step_scalars(sig[i], sig[i + 1])
+            if sampler == "euler":      # (the Euler step is the ancestral one with sigma_down = sigma_{i+1} and no noise, src/samplers.h:116-126)
+                sigma_up, sigma_down = f32(0.0), f32(sig[i + 1])
             s_arr[i] = f32(sig[i])
             d_sigma[i] = f32(sigma_down - f32(sig[i]))
             s_up[i] = sigma_up
         return c_in, c_out, ts, s_arr, d_sigma, s_up
 
     def sample_device(self, cond, uncond, steps: int = 20, seed: int = 42, latent_shape=(1, 4, 64, 64), guidance: float = 7.0,
-                      init_latent: Optional[np.ndarray] = None, step_noise: Optional[Callable[[int], np.ndarray]] = None) -> np.ndarray:
+                      init_latent: Optional[np.ndarray] = None, step_noise: Optional[Callable[[int], np.ndarray]] = None,
+                      sampler: str = "euler_a") -> np.ndarray:
         """sample() with the whole loop enqueued on the GPU (HIP backend only): per step a scaling kernel fills the UNet's input staging,
         the captured pass is launched, and one kernel does eps -> denoised, the CFG combine and the Euler-Ancestral update -- no host
         round trip until the last step.  Same schedule, same random stream, same fp32 operation order as sample(): the two agree bit
@@ -227,7 +238,7 @@ class Txt2Img:
         x0 = rng.standard_normal(latent_shape, dtype=f32) if init_latent is None else np.asarray(init_latent, f32).reshape(latent_shape)
         x = np.ascontiguousarray(x0 * f32(sig[0]), f32)
         noise = np.empty((steps,) + tuple(latent_shape), f32)
-        c_in, c_out, ts, s_arr, d_sigma, s_up = self.loop_scalars(sig)
+        c_in, c_out, ts, s_arr, d_sigma, s_up = self.loop_scalars(sig, sampler)
         for i in range(steps):
             noise[i] = rng.standard_normal(latent_shape, dtype=f32) if step_noise is None else np.asarray(step_noise(i), f32).reshape(latent_shape)
         key = (id(self.unet), P)

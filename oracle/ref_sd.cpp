@@ -22,7 +22,12 @@ static inline bool cpuinfo_has_arm_neon_fp16_arith() { return false; }
 #include "sd.cpp"
 #undef main
 
+static sampler_type g_ref_sampler = EULER_A;
+
 extern "C" {
+
+// 0 = "euler_a" (the app's default), 1 = "euler": the sampler diffusion_solver dispatches to (src/sd.cpp:1687, --sampler)
+void ref_sd_set_sampler(int euler) { g_ref_sampler = euler ? EULER : EULER_A; }
 
 // Runs `steps` denoising steps of the reference app (default sampler Euler-A, CFG 7) for `num` images batched like `--num` and writes the
 // final latents [num,4,64,64].  cond / uncond: [77,768] fp32.  Returns NULL or the exception text.
@@ -33,7 +38,7 @@ const char* ref_sd_diffusion_solver(const char* models_path_with_slash, int seed
         g_main_args.m_path_with_slash = models_path_with_slash;
         g_main_args.m_latw = g_main_args.m_lath = 64;
         g_main_args.m_num = std::to_string(num);
-        g_main_args.m_sampler = EULER_A;
+        g_main_args.m_sampler = g_ref_sampler;
         n_threads = threads;
         ncnn::Mat c(768, 77, 1, (void*)cond), uc(768, 77, 1, (void*)uncond);
         std::vector<ncnn::Mat> samples;

@@ -185,6 +185,47 @@ def test_harness_20_step_schedule_equals_the_reference_application_bit_for_bit()
     assert np.isfinite(got).all() and np.array_equal(got, z["latents20_micro"]), float(np.abs(got - z["latents20_micro"]).max())
 
 
+@pytest.mark.skipif(not oref.available() or not os.path.exists("/root/reference/src/sd.cpp"), reason="needs oracle/_ref and /root/reference")
+def test_harness_euler_sampler_equals_the_reference_application_bit_for_bit():
+    """--sampler euler (src/samplers.h:116-126, the ORIGINAL_SAMPLER_ALGORITHMS branch): 20 steps on the micro UNet, harness == the reference app"""
+    t = _sd_loop_tools()
+    z = np.load(SD_LOOP)
+    lib = t.ref_lib()
+    cond, uncond = t.contexts()
+    init, _ = t.ref_noise_walk(lib, int(z["seed"]), 20)
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        t.build_micro_unet(DirSink(d + "unet_fp16/"))
+        lib.ref_sd_set_sampler(1)
+        try:
+            live = t.ref_loop(lib, d, 1, threads=1, steps=20)
+        finally:
+            lib.ref_sd_set_sampler(0)
+        assert not np.array_equal(live, z["latents20_micro"])          # (it really is another sampler)
+        p = Txt2Img(oref.REF_LIB, d + "unet_fp16/", None, batched=False, threads=1)
+        p.log_sigmas = _reference_log_sigmas()
+        got = p.sample(cond[None], uncond[None], steps=20, latent_shape=(1, 4, 64, 64), init_latent=init, sampler="euler")
+        p.close()
+    assert np.isfinite(got).all() and np.array_equal(got, live), float(np.abs(got - live).max())
+
+
+@pytest.mark.gpu
+def test_device_euler_loop_matches_host_loop_bitwise():
+    from onnxstream_amd import build as b
+    t = _sd_loop_tools()
+    z = np.load(SD_LOOP)
+    cond, uncond = t.contexts()
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        t.build_micro_unet(DirSink(d + "unet_fp16/"))
+        p = Txt2Img(b.LIB_HOST, d + "unet_fp16/", None, batched=True)
+        kw = dict(steps=20, latent_shape=(1, 4, 64, 64), init_latent=z["init"][0:1], sampler="euler")
+        host = p.sample(cond[None], uncond[None], **kw)
+        dev = p.sample_device(cond[None], uncond[None], **kw)
+        p.close()
+    assert np.isfinite(host).all() and np.array_equal(host, dev)
+
+
 @pytest.mark.gpu
 def test_hip_device_loop_vs_the_reference_application():
     """the product's device loop (2 prompts batched, like the app's --num 2) against the reference application's latents after 3 CFG-7

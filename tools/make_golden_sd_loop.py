@@ -43,6 +43,8 @@ def ref_lib():
     lib = ctypes.CDLL(oref.REF_LIB)
     lib.ref_sd_diffusion_solver.restype = ctypes.c_char_p
     lib.ref_sd_diffusion_solver.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint] + [ctypes.c_void_p] * 3
+    lib.ref_sd_set_sampler.argtypes = [ctypes.c_int]      # 0 = euler_a (the app's default), 1 = euler
+    lib.ref_sd_set_sampler.restype = None
     lib.ref_sd_randn.argtypes = [ctypes.c_int, ctypes.c_void_p]
     lib.ref_sd_step_noise_seed.argtypes = [ctypes.c_int]
     lib.ref_sd_step_noise_seed.restype = ctypes.c_int
