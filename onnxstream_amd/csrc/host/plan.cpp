@@ -3537,6 +3537,13 @@ void Plan::build() {
         }
     }
 
+    if (u8) {
+        // the last step that reads a value whose (scale, zero point) are only known per run; the output dequantisation of a pass-through of
+        // such a value counts too.  Also every step that is not safe inside a capture: none besides these (tables are built at plan time).
+        for (size_t si = 0; si < steps.size(); si++)
+            for (int v : steps[si].reads)
+                if (v >= 0 && qv(v).qdyn) dyn_end = si + 1;
+    }
     const auto t_pack = now();
     // ---- liveness + arena packing -----------------------------------------------------------------------------------
     for (size_t si = 0; si < steps.size(); si++)
@@ -3636,7 +3643,7 @@ void Plan::build() {
                 steps.size(), t_weights, ms_fuse, ms_lower, ms_since(t_pack), ms_since(t_begin), arena_bytes / 1e6);
 }
 
-void Plan::run_steps() {
+void Plan::run_steps(size_t begin, size_t end) {
     // measurement aid (tools/skip_probe.sh): OSG_PLAN_SKIP=<prefix>[,<prefix>...] leaves out every step whose description starts with one of
     // the prefixes -- the pass computes garbage, its captured-graph time shows what that class of launches really costs inside the chain
     static const std::vector<std::string> skip = [] {
@@ -3653,7 +3660,9 @@ void Plan::run_steps() {
         }
         return v;
     }();
-    for (auto& s : steps) {
+    end = std::min(end, steps.size());
+    for (size_t si_ = begin; si_ < end; si_++) {
+        Step& s = steps[si_];
         if (!skip.empty()) {
             bool sk = false;
             for (auto& pre : skip) sk |= s.what.rfind(pre, 0) == 0;
@@ -3780,12 +3789,15 @@ void Plan::execute() {
         while (ri < recipes.size()) restream(recipes[ri++]);   // keep the provider's sequence complete
     } else
     if (graph && !print && !calibrate) {
+        if (dyn_end) run_steps(0, dyn_end);
         be.check(be.api.osg_graph_launch(be.ctx, graph), "osg_graph_launch");
-    } else if (runs >= 1 && m.m_hip_use_graph && !print && !graph && !u8 && !calibrate) {   // (uint8 plans read per-run quantisation parameters on the host: no capture)
+    } else if (runs >= 1 && m.m_hip_use_graph && !print && !graph && !calibrate) {
+        // (uint8 plans: the steps that read per-run quantisation parameters run eagerly first, see dyn_end; the rest is captured)
+        if (dyn_end) run_steps(0, dyn_end);
         be.check(be.api.osg_graph_begin(be.ctx), "osg_graph_begin");
         in_capture = true;
         try {
-            run_steps();
+            run_steps(dyn_end);
             in_capture = false;
         } catch (...) {
             in_capture = false;

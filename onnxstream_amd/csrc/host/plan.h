@@ -188,7 +188,10 @@ struct Plan {
     bool fuse_gn_conv = false;
     bool fuse_ln_gemm = false;
     bool side_stream = false;      // contraction steps whose result is not needed by the next steps run on a second stream (m_hip_side_stream)
-    void run_steps();              // one pass over `steps` honouring the side-stream marks
+    void run_steps(size_t begin = 0, size_t end = (size_t)-1);   // steps [begin, end) honouring the side-stream marks
+    // uint8 plans: steps [0, dyn_end) read values quantised per run (a pushed input and what merely re-arranges its codes): they run eagerly every
+    // pass with the parameters of that pass, the steps after them only see range-data parameters and are captured like any other plan
+    size_t dyn_end = 0;
     bool w8_resident = false;      // uint8 Conv/MatMul/Gemm weights kept as codes, dequantised inside the kernels (osg_*_w8)   // m_hip_stream_weights: weights are re-pulled from the WeightsProvider and re-streamed H2D every pass
     int fusion = 2;
     std::vector<std::string> extra_outputs;

@@ -112,8 +112,11 @@ def _run_vae_qu8(extra=()):
         for e in extra:
             m.add_extra_output(e)
         outs = []
-        for _ in range(2):                                # the second pass re-quantises the input and must reproduce the first
-            m.add_tensor("input_2E_1", z["z"])
+        # pass 2 re-quantises the input and must reproduce pass 1; from pass 2 on everything behind the dynamically quantised input is a captured
+        # hipGraph, so pass 3 (another input => other input scale / zero point) and pass 4 (the first input again) check that the eager
+        # prefix really feeds the replayed graph the parameters of THIS pass
+        for zin in (z["z"], z["z"], (z["z"] * np.float32(0.37) + np.float32(0.2)).astype(np.float32), z["z"]):
+            m.add_tensor("input_2E_1", zin)
             m.run()
             got = {n: m.get_tensor(n) for n in ("out_5F_image",) + tuple(extra)}
             outs.append({n: v[0] for n, v in got.items() if v is not None})
@@ -131,6 +134,8 @@ def test_hip_vae_qu8_reproduces_the_reference_bit_for_bit():
     z, _, outs, launches = _run_vae_qu8()
     assert np.array_equal(outs[0]["out_5F_image"], z["ref_u8"]), int((outs[0]["out_5F_image"] != z["ref_u8"]).sum())
     assert np.array_equal(outs[1]["out_5F_image"], z["ref_u8"])
+    assert not np.array_equal(outs[2]["out_5F_image"], z["ref_u8"])
+    assert np.array_equal(outs[3]["out_5F_image"], z["ref_u8"])
     assert launches > 100
 
 
