@@ -16,6 +16,7 @@
 //     arithmetic on 256 distinct values) -> lookup, Softmax = XNNPACK's exp table + integer normalisation.
 #include "osg_common.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 
@@ -46,98 +47,138 @@ __device__ __forceinline__ uint8_t q8_requant(int acc, float scale, int out_zp) 
 // C[M,N] = requant( sum_k (A[m,k]-za)(Bt[n,k]-zb) + bias ).  64x64 tile, BK = 64 codes = one v_mfma_i32_16x16x64_i8 deep, 256 threads
 // = 2x2 waves of 32x32; global -> registers -> LDS (row stride 80 B: conflict-free ds_read_b128), double-buffered.
 // VEC: 16-byte chunks (K % 16 == 0, rows 16-byte aligned; CONV: Cin % 16 == 0 so a chunk never straddles a filter tap).
-template <bool CONV, bool VEC>
+// BM x BN in {64 x 64, 128 x 128}: the large tile moves half the bytes per MAC (the 512x512 convolutions of the VAE decoder: 8 192 tiles of 64 x 64
+// were fill-bound at 12 % of the int8 MFMA peak); a thread stages BM/64 + BN/64 chunks per k-tile, a wave owns (BM/2) x (BN/2).
+template <bool CONV, bool VEC, int BM, int BN>
 __global__ __launch_bounds__(256) void q8_gemm_kernel(Q8Params p) {
-    constexpr int BM = 64, BN = 64, BK = 64, LDSW = BK + 16;
+    constexpr int BK = 64, LDSW = BK + 16;
+    constexpr int A_IT = BM / 64, B_IT = BN / 64, TM = BM / 32, TN = BN / 32;
     __shared__ __attribute__((aligned(16))) uint8_t smem[2][(BM + BN) * LDSW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, zb = blockIdx.z;
     const uint8_t* __restrict__ A = p.A + (long)zb * p.strideA;
     const uint8_t* __restrict__ Bt = p.Bt + (long)zb * p.strideB;
-    const int row = tid >> 2, kc = (tid & 3) * 16;       // this thread stages one 16-byte chunk of A and one of B per k-tile
+    const int row = tid >> 2, kc = (tid & 3) * 16;       // this thread stages 16-byte chunks of rows row, row + 64, ... of A and of B per k-tile
 
     // A row state
-    const int am = m0 + row;
-    const bool a_ok = am < p.M;
-    long a_off = 0;
-    int hi0 = 0, wi0 = 0;
-    if (CONV) {
-        const int mm = a_ok ? am : 0, hw = p.Ho * p.Wo, n_img = mm / hw, rem = mm - n_img * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
-        a_off = (long)n_img * p.H * p.W * p.Cin;
-        hi0 = ho * p.sh - p.pt;
-        wi0 = wo * p.sw - p.pl;
-    } else
-        a_off = (long)(a_ok ? am : 0) * p.lda;
-    const int bn = n0 + row;
-    const bool b_ok = bn < p.N;
-    const long b_off = (long)(b_ok ? bn : 0) * p.K;
+    bool a_ok[A_IT];
+    long a_off[A_IT];
+    int hi0[A_IT], wi0[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; it++) {
+        const int am = m0 + row + it * 64;
+        a_ok[it] = am < p.M;
+        hi0[it] = wi0[it] = 0;
+        if (CONV) {
+            const int mm = a_ok[it] ? am : 0, hw = p.Ho * p.Wo, n_img = mm / hw, rem = mm - n_img * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            a_off[it] = (long)n_img * p.H * p.W * p.Cin;
+            hi0[it] = ho * p.sh - p.pt;
+            wi0[it] = wo * p.sw - p.pl;
+        } else
+            a_off[it] = (long)(a_ok[it] ? am : 0) * p.lda;
+    }
+    bool b_ok[B_IT];
+    long b_off[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; it++) {
+        const int bn = n0 + row + it * 64;
+        b_ok[it] = bn < p.N;
+        b_off[it] = (long)(b_ok[it] ? bn : 0) * p.K;
+    }
     const unsigned pad4 = ((unsigned)(p.a_zp ^ 0x80) & 0xffu) * 0x01010101u;   // a padding tap holds the input zero point (re-biased)
 
-    v4i areg, breg;
+    v4i areg[A_IT], breg[B_IT];
     auto load_tile = [&](int k0) {
         const int k = k0 + kc;
         if (VEC) {
-            v4i va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
-            if (k < p.K) {
-                if (CONV) {
-                    const int cell = k / p.Cin, c = k - cell * p.Cin, kh = cell / p.KW, kw = cell - kh * p.KW;
-                    const int hi = hi0 + kh, wi = wi0 + kw;
-                    if (a_ok) {
+            int kh = 0, kw = 0, c = k;
+            if (CONV && k < p.K) {
+                const int cell = k / p.Cin;
+                c = k - cell * p.Cin;
+                kh = cell / p.KW;
+                kw = cell - kh * p.KW;
+            }
+#pragma unroll
+            for (int it = 0; it < A_IT; it++) {
+                v4i va = {0, 0, 0, 0};
+                if (k < p.K && a_ok[it]) {
+                    if (CONV) {
+                        const int hi = hi0[it] + kh, wi = wi0[it] + kw;
                         if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
-                            va = *reinterpret_cast<const v4i*>(A + a_off + ((long)hi * p.W + wi) * p.Cin + c);
+                            va = *reinterpret_cast<const v4i*>(A + a_off[it] + ((long)hi * p.W + wi) * p.Cin + c);
                             va ^= (int)0x80808080;
                         } else
                             va = v4i{(int)pad4, (int)pad4, (int)pad4, (int)pad4};
+                    } else {
+                        va = *reinterpret_cast<const v4i*>(A + a_off[it] + k);
+                        va ^= (int)0x80808080;
                     }
-                } else if (a_ok) {
-                    va = *reinterpret_cast<const v4i*>(A + a_off + k);
-                    va ^= (int)0x80808080;
                 }
-                if (b_ok) {
-                    vb = *reinterpret_cast<const v4i*>(Bt + b_off + k);
+                areg[it] = va;
+            }
+#pragma unroll
+            for (int it = 0; it < B_IT; it++) {
+                v4i vb = {0, 0, 0, 0};
+                if (k < p.K && b_ok[it]) {
+                    vb = *reinterpret_cast<const v4i*>(Bt + b_off[it] + k);
                     vb ^= (int)0x80808080;
                 }
+                breg[it] = vb;
             }
-            areg = va;
-            breg = vb;
         } else {
-            unsigned wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int ke = k + e;
-                unsigned xa = 0, xb = 0;     // beyond K: x' = w' = 0 (no contribution to any term)
-                if (ke < p.K) {
-                    if (a_ok) {
+            for (int it = 0; it < A_IT; it++) {
+                unsigned wa[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int ke = k + e;
+                    unsigned xa = 0;     // beyond K: x' = 0 (no contribution to any term)
+                    if (ke < p.K && a_ok[it]) {
                         if (CONV) {
                             const int cell = ke / p.Cin, c = ke - cell * p.Cin, kh = cell / p.KW, kw = cell - kh * p.KW;
-                            const int hi = hi0 + kh, wi = wi0 + kw;
+                            const int hi = hi0[it] + kh, wi = wi0[it] + kw;
                             const unsigned code = ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                                                      ? A[a_off + ((long)hi * p.W + wi) * p.Cin + c] : (unsigned)p.a_zp;
+                                                      ? A[a_off[it] + ((long)hi * p.W + wi) * p.Cin + c] : (unsigned)p.a_zp;
                             xa = (code ^ 0x80u) & 0xffu;
                         } else
-                            xa = ((unsigned)A[a_off + ke] ^ 0x80u) & 0xffu;
+                            xa = ((unsigned)A[a_off[it] + ke] ^ 0x80u) & 0xffu;
                     }
-                    if (b_ok) xb = ((unsigned)Bt[b_off + ke] ^ 0x80u) & 0xffu;
+                    wa[e >> 2] |= xa << ((e & 3) * 8);
                 }
-                wa[e >> 2] |= xa << ((e & 3) * 8);
-                wb[e >> 2] |= xb << ((e & 3) * 8);
+                areg[it] = v4i{(int)wa[0], (int)wa[1], (int)wa[2], (int)wa[3]};
             }
-            areg = v4i{(int)wa[0], (int)wa[1], (int)wa[2], (int)wa[3]};
-            breg = v4i{(int)wb[0], (int)wb[1], (int)wb[2], (int)wb[3]};
+#pragma unroll
+            for (int it = 0; it < B_IT; it++) {
+                unsigned wb[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int ke = k + e;
+                    unsigned xb = 0;
+                    if (ke < p.K && b_ok[it]) xb = ((unsigned)Bt[b_off[it] + ke] ^ 0x80u) & 0xffu;
+                    wb[e >> 2] |= xb << ((e & 3) * 8);
+                }
+                breg[it] = v4i{(int)wb[0], (int)wb[1], (int)wb[2], (int)wb[3]};
+            }
         }
     };
     auto store_tile = [&](int buf) {
-        *reinterpret_cast<v4i*>(&smem[buf][row * LDSW + kc]) = areg;
-        *reinterpret_cast<v4i*>(&smem[buf][(BM + row) * LDSW + kc]) = breg;
+#pragma unroll
+        for (int it = 0; it < A_IT; it++) *reinterpret_cast<v4i*>(&smem[buf][(row + it * 64) * LDSW + kc]) = areg[it];
+#pragma unroll
+        for (int it = 0; it < B_IT; it++) *reinterpret_cast<v4i*>(&smem[buf][(BM + row + it * 64) * LDSW + kc]) = breg[it];
     };
 
-    v4i acc[2][2];
+    v4i acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = v4i{0, 0, 0, 0};
-    int rs[2] = {0, 0}, cs[2] = {0, 0};     // partial sums of x' over this lane's k-chunks of its activation rows / of w' of its weight rows
+        for (int j = 0; j < TN; j++) acc[i][j] = v4i{0, 0, 0, 0};
+    int rs[TM], cs[TN];     // partial sums of x' over this lane's k-chunks of its activation rows / of w' of its weight rows
+#pragma unroll
+    for (int i = 0; i < TM; i++) rs[i] = 0;
+#pragma unroll
+    for (int j = 0; j < TN; j++) cs[j] = 0;
 
     const int nkt = (p.K + BK - 1) / BK;
     load_tile(0);
@@ -147,31 +188,31 @@ __global__ __launch_bounds__(256) void q8_gemm_kernel(Q8Params p) {
     for (int kt = 0; kt < nkt; kt++) {
         const int cur = kt & 1;
         if (kt + 1 < nkt) load_tile((kt + 1) * BK);
-        v4i xa[2], wb[2];
+        v4i xa[TM], wb[TN];
 #pragma unroll
-        for (int i = 0; i < 2; i++) xa[i] = *reinterpret_cast<const v4i*>(&smem[cur][(wm0 + i * 16 + frow) * LDSW + fk]);
+        for (int i = 0; i < TM; i++) xa[i] = *reinterpret_cast<const v4i*>(&smem[cur][(wm0 + i * 16 + frow) * LDSW + fk]);
 #pragma unroll
-        for (int j = 0; j < 2; j++) wb[j] = *reinterpret_cast<const v4i*>(&smem[cur][(BM + wn0 + j * 16 + frow) * LDSW + fk]);
+        for (int j = 0; j < TN; j++) wb[j] = *reinterpret_cast<const v4i*>(&smem[cur][(BM + wn0 + j * 16 + frow) * LDSW + fk]);
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wb[j], xa[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wb[j], xa[i], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                rs[i] = __builtin_amdgcn_sdot4(xa[i][e], 0x01010101, rs[i], false);
-                cs[i] = __builtin_amdgcn_sdot4(wb[i][e], 0x01010101, cs[i], false);
-            }
+            for (int e = 0; e < 4; e++) rs[i] = __builtin_amdgcn_sdot4(xa[i][e], 0x01010101, rs[i], false);
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) cs[j] = __builtin_amdgcn_sdot4(wb[j][e], 0x01010101, cs[j], false);
         if (kt + 1 < nkt) store_tile(cur ^ 1);
         __syncthreads();
     }
     // the four 16-lane groups hold different k-chunks of the same rows
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        rs[i] += __shfl_xor(rs[i], 16, 64); rs[i] += __shfl_xor(rs[i], 32, 64);
-        cs[i] += __shfl_xor(cs[i], 16, 64); cs[i] += __shfl_xor(cs[i], 32, 64);
-    }
+    for (int i = 0; i < TM; i++) { rs[i] += __shfl_xor(rs[i], 16, 64); rs[i] += __shfl_xor(rs[i], 32, 64); }
+#pragma unroll
+    for (int j = 0; j < TN; j++) { cs[j] += __shfl_xor(cs[j], 16, 64); cs[j] += __shfl_xor(cs[j], 32, 64); }
     const int az = 128 - p.a_zp, bz = 128 - p.b_zp;
     const int kab = p.K * az * bz;
     float scale;
@@ -181,10 +222,10 @@ __global__ __launch_bounds__(256) void q8_gemm_kernel(Q8Params p) {
     }
     uint8_t* __restrict__ C = p.C + (long)zb * p.strideC;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < TM; i++) {
         const int m = m0 + wm0 + i * 16 + (lane & 15);
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < TN; j++) {
             const int nb = n0 + wn0 + j * 16 + (lane >> 4) * 4;
             uint8_t o[4];
 #pragma unroll
@@ -215,14 +256,26 @@ __global__ __launch_bounds__(256) void q8_gemm_kernel(Q8Params p) {
 int launch_q8(osg_ctx* ctx, const Q8Params& p, int batch, bool conv) {
     const bool al = ((((uintptr_t)p.A | (uintptr_t)p.Bt) & 15) == 0) && p.strideA % 16 == 0 && p.strideB % 16 == 0;
     const bool vec = al && p.K % 16 == 0 && (conv ? p.Cin % 16 == 0 : p.lda % 16 == 0);
+    // 128 x 128 tiles where they still leave every CU at least two of them (OSG_QU8_TILE=64|128 pins the choice for tests)
+    const int force_tile = getenv("OSG_QU8_TILE") ? atoi(getenv("OSG_QU8_TILE")) : 0;
+    const long tiles128 = (long)((p.N + 127) / 128) * ((p.M + 127) / 128) * batch;
+    const bool big = vec && force_tile != 64 && (force_tile == 128 || (p.N >= 128 && tiles128 >= 2L * ctx->num_cu));
+    if (big) {
+        dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, batch);
+        if (grid.y > 65535u) OSG_FAIL(ctx, "osg_qu8: M too large for one launch");
+        if (conv) hipLaunchKernelGGL((q8_gemm_kernel<true, true, 128, 128>), grid, dim3(256), 0, ctx->compute, p);
+        else hipLaunchKernelGGL((q8_gemm_kernel<false, true, 128, 128>), grid, dim3(256), 0, ctx->compute, p);
+        OSG_LAUNCH_CHECK(ctx);
+        return 0;
+    }
     dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, batch);
     if (grid.y > 65535u) OSG_FAIL(ctx, "osg_qu8: M too large for one launch");
     if (conv) {
-        if (vec) hipLaunchKernelGGL((q8_gemm_kernel<true, true>), grid, dim3(256), 0, ctx->compute, p);
-        else hipLaunchKernelGGL((q8_gemm_kernel<true, false>), grid, dim3(256), 0, ctx->compute, p);
+        if (vec) hipLaunchKernelGGL((q8_gemm_kernel<true, true, 64, 64>), grid, dim3(256), 0, ctx->compute, p);
+        else hipLaunchKernelGGL((q8_gemm_kernel<true, false, 64, 64>), grid, dim3(256), 0, ctx->compute, p);
     } else {
-        if (vec) hipLaunchKernelGGL((q8_gemm_kernel<false, true>), grid, dim3(256), 0, ctx->compute, p);
-        else hipLaunchKernelGGL((q8_gemm_kernel<false, false>), grid, dim3(256), 0, ctx->compute, p);
+        if (vec) hipLaunchKernelGGL((q8_gemm_kernel<false, true, 64, 64>), grid, dim3(256), 0, ctx->compute, p);
+        else hipLaunchKernelGGL((q8_gemm_kernel<false, false, 64, 64>), grid, dim3(256), 0, ctx->compute, p);
     }
     OSG_LAUNCH_CHECK(ctx);
     return 0;

@@ -17,7 +17,9 @@ def _codes(rng, shape):
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,stride,pad", [(1, 12, 10, 32, 48, 3, 1, 1), (2, 9, 7, 16, 20, 3, 2, 1), (1, 16, 16, 4, 32, 3, 1, 1),
                                                          (1, 8, 8, 64, 64, 1, 1, 0), (1, 20, 20, 128, 3, 3, 1, 1), (1, 5, 6, 20, 30, 3, 1, 1),
                                                          (1, 64, 64, 128, 128, 3, 1, 1), (1, 33, 31, 48, 70, 3, 1, 1)])
-def test_qu8_conv(gpu, N, H, W, Cin, Cout, k, stride, pad):
+@pytest.mark.parametrize("tile", [64, 128])
+def test_qu8_conv(gpu, N, H, W, Cin, Cout, k, stride, pad, tile, monkeypatch):
+    monkeypatch.setenv("OSG_QU8_TILE", str(tile))     # both tile instantiations on every shape (128 x 128 only takes the 16-byte-chunk shapes)
     rng = np.random.default_rng(Cin * 100 + Cout + k)
     x, w = _codes(rng, (N, H, W, Cin)), _codes(rng, (Cout, k, k, Cin))
     sx, zx, sw, zw = f32(0.0173), 117, f32(0.0042), 131
@@ -31,7 +33,9 @@ def test_qu8_conv(gpu, N, H, W, Cin, Cout, k, stride, pad):
 
 
 @pytest.mark.parametrize("batch,M,N,K", [(1, 77, 64, 128), (1, 200, 96, 40), (3, 64, 64, 64), (2, 50, 33, 48), (1, 256, 256, 512), (1, 5, 3, 7)])
-def test_qu8_gemm(gpu, batch, M, N, K):
+@pytest.mark.parametrize("tile", [64, 128])
+def test_qu8_gemm(gpu, batch, M, N, K, tile, monkeypatch):
+    monkeypatch.setenv("OSG_QU8_TILE", str(tile))
     rng = np.random.default_rng(M + N + K)
     a = _codes(rng, (batch, M, K) if batch > 1 else (M, K))
     b = _codes(rng, (batch, K, N) if batch > 1 else (K, N))
