@@ -296,6 +296,10 @@ int osg_qu8_binary(osg_ctx* ctx, osg_binary_kind kind, const void* a, const long
  * reference does, requantise -- evaluated per distinct input code from the row's code histogram.  scale/bias: fp32 [n_scale] device vectors. */
 int osg_qu8_instance_norm(osg_ctx* ctx, const void* x, void* y, int rows, long L, int n_scale, const float* scale, const float* bias, float eps,
                           float in_scale, int in_zp, float out_scale, int out_zp);
+/* ... the same op when the [1,G,L] view is a Reshape of an NHWC [HW][C] tensor (row g = channels [g*C/G, (g+1)*C/G) of every pixel): identical codes,
+ * no layout copy around it. */
+int osg_qu8_instance_norm_nhwc(osg_ctx* ctx, const void* x, void* y, long HW, int C, int G, int n_scale, const float* scale, const float* bias, float eps,
+                               float in_scale, int in_zp, float out_scale, int out_zp);
 /* XnnPack::softmax<uint8_t> (onnxstream.cpp:1958-2060 -> XNNPACK qu8 softmax): lut_u32_256 = DEVICE table t[i] = lrint(min(UINT32_MAX / C, 2^23 - 1) *
  * exp((i - 255) * in_scale)) built by the host; y = min(255, ((t[x + 255 - rowmax] << 8) + (sum >> 1)) / sum); output scale 1/256, zero point 0. */
 int osg_qu8_softmax_last(osg_ctx* ctx, const void* x, void* y, long rows, long C, const void* lut_u32_256);

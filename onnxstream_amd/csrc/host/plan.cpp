@@ -589,8 +589,39 @@ struct Lowering {
             if (!dead[i] && P.ops[i].m_type == type) return true;
         return false;
     }
+    // uint8 arithmetic: Reshape[1,G,L] -> InstanceNormalization -> Reshape[x.shape] over a 4-D tensor ==> osg.qu8.InstanceNormNHWC.  Not a fusion of
+    // arithmetic (the two Reshapes carry codes and parameters through unchanged, the normalisation is one table lookup per code either way):
+    // it only keeps the tensor in the convolutions' NHWC layout instead of copying it to NCHW and back (62 of the VAE decoder's launches).
+    void fuse_u8_instance_norm_nhwc() {
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (!is((int)i, "InstanceNormalization")) continue;
+            Operation& in = ops()[i];
+            if (in.m_input.size() != 3 || in.m_output.size() != 1) continue;
+            const int r0 = prod_of(in.m_input[0]);
+            if (!is(r0, "Reshape") || use_count(in.m_input[0].m_name) != 1) continue;
+            const Tensor x = ops()[r0].m_input[0];
+            if (!act(x) || x.m_shape.size() != 4 || x.m_shape[0] != 1) continue;
+            const auto& gs = in.m_input[0].m_shape;
+            if (gs.size() != 3 || gs[0] != 1 || gs[1] == 0) continue;
+            const long G = (long)gs[1], C = (long)x.m_shape[1], HW = (long)x.m_shape[2] * (long)x.m_shape[3];
+            if (C % G || (long)gs[2] != (C / G) * HW || G > 56) continue;
+            const int r1 = sole_consumer(in.m_output[0]);
+            if (!is(r1, "Reshape") || ops()[r1].m_output[0].m_shape != x.m_shape) continue;
+            Operation f;
+            f.m_name = in.m_name;                 // (the op's range data is looked up under the InstanceNormalization's name)
+            f.m_type = "osg.qu8.InstanceNormNHWC";
+            f.m_input = {x, in.m_input[1], in.m_input[2]};
+            f.m_output = {ops()[r1].m_output[0]};
+            f.m_attributes = in.m_attributes;
+            f.m_attributes.emplace_back("groups", std::to_string(G));
+            dead[r0] = dead[i] = 1;
+            ops()[r1] = std::move(f);
+        }
+    }
+
     void run_fusions() {
         dead.assign(ops().size(), 0);
+        if (P.u8 && m.m_hip_fusion_level >= 1 && has_type("InstanceNormalization")) { index_graph(); fuse_u8_instance_norm_nhwc(); }
         if (m.m_use_scaled_dp_attn_op && has_type("Softmax")) { index_graph(); fuse_sdpa(); }   // (a Model option of the reference, independent of hip_fusion_level)
         if (P.fusion >= 1) {
             if (m.m_requires_upcast && has_type("Pow") && has_type("ReduceMean")) { index_graph(); fuse_rms_norm(); }
@@ -1702,6 +1733,7 @@ struct Lowering {
         if (t == "Add" || t == "Mul") return lower_binary_u8(op);
         if (t == "Sigmoid") return lower_sigmoid_u8(op);
         if (t == "InstanceNormalization") return lower_instance_norm_u8(op);
+        if (t == "osg.qu8.InstanceNormNHWC") return lower_instance_norm_u8_nhwc(op);
         if (t == "Softmax") return lower_softmax_u8(op);
         if (t == "Reshape" || t == "Flatten" || t == "Unsqueeze" || t == "Squeeze" || t == "Transpose" || t == "Resize") {
             // the codes are re-arranged, scale and zero point carried over (reference :4783, :5231, :6251)
@@ -1928,6 +1960,46 @@ struct Lowering {
             const Val& qx = P.qv(x);
             be.check(be.api.osg_qu8_instance_norm(be.ctx, P.ptr(x), P.ptr(y), (int)rows, L, (int)rows, (const float*)P.ptr(sc), (const float*)P.ptr(bi), eps, qx.qscale,
                                                   qx.qzp, oq.scale, (int)oq.zero_point),
+                     "InstanceNormalization");
+        });
+    }
+
+    void lower_instance_norm_u8_nhwc(const Operation& op) {
+        const int x0 = in_val(op.m_input[0]);
+        need_u8(op, x0, "input");
+        const int sc = in_val(op.m_input[1]), bi = in_val(op.m_input[2]);
+        const Shape s = V(x0).shape;
+        need(op, s.size() == 4 && s[0] == 1, "input shape must be [1,C,H,W] (not implemented).");
+        float eps = 1e-5f;
+        long G = 0;
+        for (auto& a : op.m_attributes) {
+            if (a.first == "epsilon") eps = std::stof(a.second);
+            else if (a.first == "groups") G = std::stol(a.second);
+            else throw std::invalid_argument("InstanceNormalization: unrecognized attribute: " + a.first + ".");
+        }
+        const long C = s[1], HW = s[2] * s[3];
+        need(op, G > 0 && C % G == 0, "invalid number of groups.");
+        need(op, V(sc).numel() == G && V(bi).numel() == G && V(sc).dtype == OSG_F32 && V(bi).dtype == OSG_F32, "invalid scale/bias.");
+        const qu8::QParams oq = out_q(op);
+        if (V(x0).lay != Lay::nhwc) {
+            // the producer left it in the logical layout: the plain [G][L] kernels apply as they are (rows are contiguous there)
+            const int x = P.ensure_plain(x0);
+            const int y = out_val_u8(op, s, Lay::plain, V(x).batched, oq);
+            const long L = (C / G) * HW;
+            P.add_step("InstanceNorm qu8 " + op.m_name, {x, sc, bi}, {y}, [=, this] {
+                const Val& qx = P.qv(x);
+                be.check(be.api.osg_qu8_instance_norm(be.ctx, P.ptr(x), P.ptr(y), (int)G, L, (int)G, (const float*)P.ptr(sc), (const float*)P.ptr(bi), eps, qx.qscale, qx.qzp,
+                                                      oq.scale, (int)oq.zero_point),
+                         "InstanceNormalization");
+            });
+            return;
+        }
+        const int x = x0;
+        const int y = out_val_u8(op, s, Lay::nhwc, V(x).batched, oq);
+        P.add_step("InstanceNorm qu8 nhwc " + op.m_name, {x, sc, bi}, {y}, [=, this] {
+            const Val& qx = P.qv(x);
+            be.check(be.api.osg_qu8_instance_norm_nhwc(be.ctx, P.ptr(x), P.ptr(y), HW, (int)C, (int)G, (int)G, (const float*)P.ptr(sc), (const float*)P.ptr(bi), eps, qx.qscale,
+                                                       qx.qzp, oq.scale, (int)oq.zero_point),
                      "InstanceNormalization");
         });
     }

@@ -466,6 +466,76 @@ __global__ __launch_bounds__(256) void q8_in_apply_kernel(const uint8_t* __restr
     }
 }
 
+// The same InstanceNormalization on [1,G,L] when the tensor behind the Reshape lives as NHWC [HW][C] (row g = channels [g*cpg, (g+1)*cpg) of every
+// pixel): histogram and table lookup address the codes where they lie -- no NCHW copy before, none after.  Same tables, same codes.
+// sh >= 0: cpg == 1 << sh (a 16-code vector starts at a channel that is a multiple of 16, so its codes' groups are (c0 >> sh) + (j >> sh): no division)
+__global__ __launch_bounds__(256) void q8_in_hist_nhwc_kernel(const uint8_t* __restrict__ x, unsigned* __restrict__ hist, long n, int C, int cpg, int G, int sh) {
+    extern __shared__ unsigned hg[];          // [G][256]
+    const int tid = threadIdx.x;
+    for (int k = tid; k < G * 256; k += 256) hg[k] = 0;
+    __syncthreads();
+    const long beg = (long)blockIdx.x * kInPiece, end = min(n, beg + kInPiece);
+    if ((C & 15) == 0 && ((uintptr_t)(x + beg) & 15) == 0) {
+        const long nv = (end - beg) >> 4;
+        for (long v = tid; v < nv; v += 256) {
+            const long i0 = beg + (v << 4);
+            const int c0 = (int)(i0 % C);
+            const v4i c = *reinterpret_cast<const v4i*>(x + i0);
+            if (sh >= 0) {
+                const int gb = c0 >> sh;
+#pragma unroll
+                for (int w = 0; w < 4; w++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) atomicAdd(&hg[(gb + ((w * 4 + e) >> sh)) * 256 + (((unsigned)c[w] >> (8 * e)) & 0xff)], 1u);
+            } else {
+#pragma unroll
+                for (int w = 0; w < 4; w++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) atomicAdd(&hg[((c0 + w * 4 + e) / cpg) * 256 + (((unsigned)c[w] >> (8 * e)) & 0xff)], 1u);
+            }
+        }
+        for (long i = beg + (nv << 4) + tid; i < end; i += 256) atomicAdd(&hg[((int)(i % C) / cpg) * 256 + x[i]], 1u);
+    } else {
+        for (long i = beg + tid; i < end; i += 256) atomicAdd(&hg[((int)(i % C) / cpg) * 256 + x[i]], 1u);
+    }
+    __syncthreads();
+    for (int k = tid; k < G * 256; k += 256)
+        if (hg[k]) atomicAdd(&hist[k], hg[k]);
+}
+
+__global__ __launch_bounds__(256) void q8_in_apply_nhwc_kernel(const uint8_t* __restrict__ x, uint8_t* __restrict__ y, const uint8_t* __restrict__ lut_g, long n, int C,
+                                                               int cpg, int G, int sh) {
+    extern __shared__ uint8_t lg[];           // [G][256]
+    const int tid = threadIdx.x;
+    for (int k = tid; k < G * 256; k += 256) lg[k] = lut_g[k];
+    __syncthreads();
+    const long beg = (long)blockIdx.x * kInPiece, end = min(n, beg + kInPiece);
+    if ((C & 15) == 0 && ((((uintptr_t)(x + beg)) | ((uintptr_t)(y + beg))) & 15) == 0) {
+        const long nv = (end - beg) >> 4;
+        for (long v = tid; v < nv; v += 256) {
+            const long i0 = beg + (v << 4);
+            const int c0 = (int)(i0 % C);
+            const v4i c = *reinterpret_cast<const v4i*>(x + i0);
+            v4i o;
+            const int gb = sh >= 0 ? c0 >> sh : 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                unsigned r = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int g = sh >= 0 ? gb + ((w * 4 + e) >> sh) : (c0 + w * 4 + e) / cpg;
+                    r |= (unsigned)lg[g * 256 + (((unsigned)c[w] >> (8 * e)) & 0xff)] << (8 * e);
+                }
+                o[w] = (int)r;
+            }
+            *reinterpret_cast<v4i*>(y + i0) = o;
+        }
+        for (long i = beg + (nv << 4) + tid; i < end; i += 256) y[i] = lg[((int)(i % C) / cpg) * 256 + x[i]];
+    } else {
+        for (long i = beg + tid; i < end; i += 256) y[i] = lg[((int)(i % C) / cpg) * 256 + x[i]];
+    }
+}
+
 // XNNPACK qu8 softmax over the last axis, one workgroup per row: t = host-built exp table (uint32[256]);
 // y = min(255, ((t[x + 255 - max] << 8) + (sum >> 1)) / sum)
 __global__ __launch_bounds__(256) void q8_softmax_kernel(const uint8_t* __restrict__ x, uint8_t* __restrict__ y, long C, const unsigned* __restrict__ lut) {
@@ -631,6 +701,28 @@ int osg_qu8_instance_norm(osg_ctx* ctx, const void* x, void* y, int rows, long L
     hipLaunchKernelGGL(q8_in_hist_kernel, dim3(pieces, (unsigned)rows), dim3(256), 0, ctx->compute, (const uint8_t*)x, hist, L);
     hipLaunchKernelGGL(q8_in_lut_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->compute, hist, lut, L, n_scale, scale, bias, eps, in_scale, in_zp, out_scale, out_zp);
     hipLaunchKernelGGL(q8_in_apply_kernel, dim3(pieces, (unsigned)rows), dim3(256), 0, ctx->compute, (const uint8_t*)x, (uint8_t*)y, lut, L);
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+int osg_qu8_instance_norm_nhwc(osg_ctx* ctx, const void* x, void* y, long HW, int C, int G, int n_scale, const float* scale, const float* bias, float eps,
+                               float in_scale, int in_zp, float out_scale, int out_zp) {
+    if (HW <= 0 || C <= 0 || G <= 0 || C % G || n_scale <= 0) OSG_FAIL(ctx, "osg_qu8_instance_norm_nhwc: invalid shape");
+    if (G > 56) OSG_FAIL(ctx, "osg_qu8_instance_norm_nhwc: more than 56 groups do not fit the histogram in LDS");
+    const size_t hist_bytes = (size_t)G * 256 * sizeof(unsigned), lut_bytes = (size_t)G * 256;
+    if (osg_ensure_workspace(ctx, hist_bytes + lut_bytes)) return 1;
+    unsigned* hist = (unsigned*)ctx->ws;
+    uint8_t* lut = (uint8_t*)ctx->ws + hist_bytes;
+    OSG_HIP(ctx, hipMemsetAsync(hist, 0, hist_bytes, ctx->compute));
+    const long n = HW * C, L = HW * (C / G);
+    const unsigned pieces = (unsigned)((n + kInPiece - 1) / kInPiece);
+    const int cpg = C / G;
+    int sh = -1;
+    if ((cpg & (cpg - 1)) == 0)
+        for (sh = 0; (1 << sh) < cpg; sh++) {}
+    hipLaunchKernelGGL(q8_in_hist_nhwc_kernel, dim3(pieces), dim3(256), hist_bytes, ctx->compute, (const uint8_t*)x, hist, n, C, C / G, G, sh);
+    hipLaunchKernelGGL(q8_in_lut_kernel, dim3((unsigned)G), dim3(256), 0, ctx->compute, hist, lut, L, n_scale, scale, bias, eps, in_scale, in_zp, out_scale, out_zp);
+    hipLaunchKernelGGL(q8_in_apply_nhwc_kernel, dim3(pieces), dim3(256), lut_bytes, ctx->compute, (const uint8_t*)x, (uint8_t*)y, lut, n, C, C / G, G, sh);
     OSG_LAUNCH_CHECK(ctx);
     return 0;
 }

@@ -83,6 +83,21 @@ def test_qu8_instance_norm(gpu, rows, L):
     assert np.array_equal(got, want), int((got != want).sum())
 
 
+@pytest.mark.parametrize("H,W,C,G", [(16, 16, 128, 32), (8, 8, 512, 32), (33, 7, 96, 8), (4, 4, 40, 5), (64, 64, 256, 32)])
+def test_qu8_instance_norm_nhwc_equals_the_row_kernels(gpu, H, W, C, G):
+    """the NHWC addressing of the [1,G,L] InstanceNormalization gives the codes of the row-major kernels on the transposed tensor (and those are
+    pinned against the reference restatement above)"""
+    rng = np.random.default_rng(H + W + C)
+    x_nhwc = _codes(rng, (H * W, C))
+    scale, bias = (1 + rng.standard_normal(G) * 0.1).astype(f32), (rng.standard_normal(G) * 0.1).astype(f32)
+    xq, oq = (f32(0.031), 121), (f32(0.024), 118)
+    rows = np.ascontiguousarray(x_nhwc.reshape(H * W, G, C // G).transpose(1, 0, 2)).reshape(G, H * W * (C // G))     # [G][HW*cpg] in (pixel, channel) order
+    want = gpu.qu8_instance_norm(gpu.to_dev(rows), xq, gpu.to_dev(scale), gpu.to_dev(bias), 1e-5, oq).numpy()
+    want_nhwc = want.reshape(G, H * W, C // G).transpose(1, 0, 2).reshape(H * W, C)
+    got = gpu.qu8_instance_norm_nhwc(gpu.to_dev(x_nhwc), G, xq, gpu.to_dev(scale), gpu.to_dev(bias), 1e-5, oq).numpy()
+    assert np.array_equal(got, want_nhwc), int((got != want_nhwc).sum())
+
+
 @pytest.mark.parametrize("rows,C", [(64, 64), (256, 4096), (5, 1000), (3, 7)])
 def test_qu8_softmax(gpu, rows, C):
     rng = np.random.default_rng(rows * C)
