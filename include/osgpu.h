@@ -296,6 +296,13 @@ int osg_qu8_binary(osg_ctx* ctx, osg_binary_kind kind, const void* a, const long
  * reference does, requantise -- evaluated per distinct input code from the row's code histogram.  scale/bias: fp32 [n_scale] device vectors. */
 int osg_qu8_instance_norm(osg_ctx* ctx, const void* x, void* y, int rows, long L, int n_scale, const float* scale, const float* bias, float eps,
                           float in_scale, int in_zp, float out_scale, int out_zp);
+/* Mul(x, g[C]) -> Add(., b[C]) [-> Sigmoid -> Mul(., sigmoid)] of the uint8 graphs (GroupNorm affine + SiLU; reference multiply / add with quint8
+ * parameters :3977-3996, :5105-5124, Sigmoid :4412-4481) as one pass: (scale, zero point) of x, g, the Mul's output (m_*), b, the Add's output (a_*),
+ * the Sigmoid's output (s_*; sig_lut = its 256-entry table, NULL = no activation) and the final Mul's output (o_*).  Channel of element i:
+ * (i / inner) % C.  The codes are those of the separate launches. */
+int osg_qu8_affine_act(osg_ctx* ctx, const void* x, float x_scale, int x_zp, const void* g, float g_scale, int g_zp, float m_scale, int m_zp, const void* b,
+                       float b_scale, int b_zp, float a_scale, int a_zp, const void* sig_lut, float s_scale, int s_zp, float o_scale, int o_zp, void* y, long n, int C,
+                       long inner);
 /* ... the same op when the [1,G,L] view is a Reshape of an NHWC [HW][C] tensor (row g = channels [g*C/G, (g+1)*C/G) of every pixel): identical codes,
  * no layout copy around it. */
 int osg_qu8_instance_norm_nhwc(osg_ctx* ctx, const void* x, void* y, long HW, int C, int G, int n_scale, const float* scale, const float* bias, float eps,

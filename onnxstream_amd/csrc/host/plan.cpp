@@ -619,9 +619,72 @@ struct Lowering {
         }
     }
 
+    // uint8 arithmetic: Mul(x, gamma[C]) -> Add(., beta[C]) [-> Sigmoid -> Mul(., sigmoid)] over a 4-D tensor ==> osg.qu8.AffineAct.  One pass
+    // over the tensor instead of two / four; every stage re-quantises with ITS op's range exactly as the separate launches do (the fused op keeps
+    // the four op names for the range lookups), so the codes are unchanged.
+    void fuse_u8_affine_act() {
+        auto chan_const = [&](const Tensor& t, long C) {
+            const Val* v = cval(t);
+            if (!v || v->dtype != OSG_U8 || v->numel() != C) return false;
+            const Shape& sh = v->shape;
+            return (sh.size() == 3 && sh[0] == C) || (sh.size() == 4 && sh[1] == C);
+        };
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (!is((int)i, "Mul")) continue;
+            Operation& mu = ops()[i];
+            if (mu.m_input.size() != 2 || mu.m_output.size() != 1) continue;
+            int xi = -1;
+            for (int k = 0; k < 2; k++)
+                if (act(mu.m_input[k]) && mu.m_input[k].m_shape.size() == 4 && mu.m_input[k].m_shape[0] == 1 && chan_const(mu.m_input[1 - k], (long)mu.m_input[k].m_shape[1])) xi = k;
+            if (xi < 0) continue;
+            const Tensor x = mu.m_input[xi], gam = mu.m_input[1 - xi];
+            const long C = (long)x.m_shape[1];
+            const int ad = sole_consumer(mu.m_output[0]);
+            if (!is(ad, "Add") || ops()[ad].m_input.size() != 2) continue;
+            const int bidx = other(ops()[ad], mu.m_output[0].m_name);
+            if (!chan_const(ops()[ad].m_input[bidx], C)) continue;
+            const Tensor bet = ops()[ad].m_input[bidx];
+            // optional SiLU: the Add feeds exactly a Sigmoid and the Mul that multiplies it back
+            int sg = -1, m2 = -1;
+            const std::string& an = ops()[ad].m_output[0].m_name;
+            if (use_count(an) == 2) {
+                auto it = consumers.find(an);
+                if (it != consumers.end() && it->second.size() == 2) {
+                    for (int c : it->second)
+                        if (is(c, "Sigmoid")) sg = c;
+                        else if (is(c, "Mul")) m2 = c;
+                    if (sg >= 0 && m2 >= 0 && sole_consumer(ops()[sg].m_output[0]) == m2 && ops()[m2].m_input.size() == 2) {
+                        const std::string &p0 = ops()[m2].m_input[0].m_name, &p1 = ops()[m2].m_input[1].m_name, &sn = ops()[sg].m_output[0].m_name;
+                        if (!((p0 == an && p1 == sn) || (p0 == sn && p1 == an))) sg = m2 = -1;
+                    } else
+                        sg = m2 = -1;
+                }
+            }
+            const bool silu = sg >= 0 && m2 >= 0;
+            if (!silu && use_count(an) != 1) {
+                // (the Add's result is read by several ops and they are not the SiLU pair: still one pass for Mul + Add)
+            }
+            Operation f;
+            const int last = silu ? m2 : ad;
+            f.m_name = ops()[last].m_name;
+            f.m_type = "osg.qu8.AffineAct";
+            f.m_input = {x, gam, bet};
+            f.m_output = {ops()[last].m_output[0]};
+            f.m_attributes = {{"mul", mu.m_name}, {"add", ops()[ad].m_name}};
+            if (silu) {
+                f.m_attributes.emplace_back("sigmoid", ops()[sg].m_name);
+                f.m_attributes.emplace_back("mul2", ops()[m2].m_name);
+            }
+            dead[i] = 1;
+            if (silu) dead[ad] = dead[sg] = 1;
+            ops()[last] = std::move(f);
+        }
+    }
+
     void run_fusions() {
         dead.assign(ops().size(), 0);
         if (P.u8 && m.m_hip_fusion_level >= 1 && has_type("InstanceNormalization")) { index_graph(); fuse_u8_instance_norm_nhwc(); }
+        if (P.u8 && m.m_hip_fusion_level >= 1 && has_type("Mul") && has_type("Add")) { index_graph(); fuse_u8_affine_act(); }
         if (m.m_use_scaled_dp_attn_op && has_type("Softmax")) { index_graph(); fuse_sdpa(); }   // (a Model option of the reference, independent of hip_fusion_level)
         if (P.fusion >= 1) {
             if (m.m_requires_upcast && has_type("Pow") && has_type("ReduceMean")) { index_graph(); fuse_rms_norm(); }
@@ -1734,6 +1797,7 @@ struct Lowering {
         if (t == "Sigmoid") return lower_sigmoid_u8(op);
         if (t == "InstanceNormalization") return lower_instance_norm_u8(op);
         if (t == "osg.qu8.InstanceNormNHWC") return lower_instance_norm_u8_nhwc(op);
+        if (t == "osg.qu8.AffineAct") return lower_affine_act_u8(op);
         if (t == "Softmax") return lower_softmax_u8(op);
         if (t == "Reshape" || t == "Flatten" || t == "Unsqueeze" || t == "Squeeze" || t == "Transpose" || t == "Resize") {
             // the codes are re-arranged, scale and zero point carried over (reference :4783, :5231, :6251)
@@ -1961,6 +2025,42 @@ struct Lowering {
             be.check(be.api.osg_qu8_instance_norm(be.ctx, P.ptr(x), P.ptr(y), (int)rows, L, (int)rows, (const float*)P.ptr(sc), (const float*)P.ptr(bi), eps, qx.qscale,
                                                   qx.qzp, oq.scale, (int)oq.zero_point),
                      "InstanceNormalization");
+        });
+    }
+
+    qu8::QParams range_q(const Operation& op, const std::string& name) {
+        auto it = m.m_range_data.find(name);
+        if (it == m.m_range_data.end()) throw std::invalid_argument(op.m_type + ": range data not found.");
+        return qu8::range_to_scale(it->second.first, it->second.second);
+    }
+    void lower_affine_act_u8(const Operation& op) {
+        const int x = in_val(op.m_input[0]), g = in_val(op.m_input[1]), b = in_val(op.m_input[2]);
+        need_u8(op, x, "inputs");
+        need_u8(op, g, "inputs");
+        need_u8(op, b, "inputs");
+        const Shape s = V(x).shape;
+        need(op, s.size() == 4 && s[0] == 1, "input shape must be [1,C,H,W] (not implemented).");
+        const long C = s[1], HW = s[2] * s[3], n = P.total_elems(x);
+        need(op, V(g).numel() == C && V(b).numel() == C, "invalid shape of the per-channel operands.");
+        const qu8::QParams qm = range_q(op, *attr(op, "mul")), qa = range_q(op, *attr(op, "add"));
+        const bool silu = attr(op, "sigmoid") != nullptr;
+        qu8::QParams qs{}, qo = qa;
+        void* lut = nullptr;
+        if (silu) {
+            qs = range_q(op, *attr(op, "sigmoid"));
+            qo = range_q(op, *attr(op, "mul2"));
+            lut = lut_alloc(256);
+            uint8_t t[256];
+            qu8::sigmoid_lut(qa, qs, t);          // (the Sigmoid's input is the Add's output: parameters from range data, never dynamic)
+            be.check(be.api.osg_upload_sync(be.ctx, lut, t, 256), "osg_upload_sync");
+        }
+        const int y = out_val_u8(op, s, V(x).lay, V(x).batched, qo);
+        const long inner = V(x).lay == Lay::nhwc ? 1 : HW;
+        P.add_step("AffineAct qu8 " + op.m_name, {x, g, b}, {y}, [=, this] {
+            const Val &qx = P.qv(x), &qg = P.qv(g), &qb = P.qv(b);
+            be.check(be.api.osg_qu8_affine_act(be.ctx, P.ptr(x), qx.qscale, qx.qzp, P.ptr(g), qg.qscale, qg.qzp, qm.scale, (int)qm.zero_point, P.ptr(b), qb.qscale, qb.qzp,
+                                               qa.scale, (int)qa.zero_point, lut, qs.scale, (int)qs.zero_point, qo.scale, (int)qo.zero_point, P.ptr(y), n, (int)C, inner),
+                     "AffineAct");
         });
     }
 

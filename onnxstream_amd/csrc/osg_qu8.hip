@@ -368,6 +368,44 @@ __global__ __launch_bounds__(256) void q8_binary_fast_kernel(const uint8_t* __re
         y[i] = q8_bin_op<KIND>(a[i], MODE == 0 ? b[i] : b[(i / inner) % period], q);
 }
 
+template <bool ACT>
+__global__ __launch_bounds__(256) void q8_affine_act_kernel(const uint8_t* __restrict__ x, const uint8_t* __restrict__ g, const uint8_t* __restrict__ b,
+                                                            const uint8_t* __restrict__ lut_g, uint8_t* __restrict__ y, long n, int C, long inner, Q8Bin qm, Q8Bin qa,
+                                                            Q8Bin qs) {
+    __shared__ uint8_t lut[256];
+    if (ACT) {
+        lut[threadIdx.x] = lut_g[threadIdx.x];
+        __syncthreads();
+    }
+    auto one = [&](unsigned code, long i) -> unsigned {
+        const int c = (int)((i / inner) % C);
+        const unsigned v1 = q8_bin_op<1>((int)code, g[c], qm);
+        const unsigned v2 = q8_bin_op<0>((int)v1, b[c], qa);
+        if (!ACT) return v2;
+        return q8_bin_op<1>((int)v2, lut[v2], qs);
+    };
+    const long nv = n >> 4, stride = (long)gridDim.x * 256;
+    const bool al = ((((uintptr_t)x | (uintptr_t)y) & 15) == 0);
+    if (al) {
+        for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nv; v += stride) {
+            const long i0 = v << 4;
+            const v4i xv = *reinterpret_cast<const v4i*>(x + i0);
+            v4i ov;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                unsigned o = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) o |= one(((unsigned)xv[w] >> (8 * e)) & 0xff, i0 + w * 4 + e) << (8 * e);
+                ov[w] = (int)o;
+            }
+            *reinterpret_cast<v4i*>(y + i0) = ov;
+        }
+        for (long i = (nv << 4) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = (uint8_t)one(x[i], i);
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) y[i] = (uint8_t)one(x[i], i);
+    }
+}
+
 __device__ __forceinline__ uint8_t q8_quantize(float x, float inv_scale, int zp) {
 #pragma clang fp contract(off)
     float r = __builtin_rintf(x * inv_scale) + (float)zp;
@@ -611,6 +649,48 @@ int osg_qu8_conv2d_nhwc(osg_ctx* ctx, const void* x, float x_scale, int x_zp, co
 int osg_qu8_lut(osg_ctx* ctx, const void* x, void* y, long n, const void* lut256) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(q8_lut_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->compute, (const uint8_t*)x, (uint8_t*)y, n, (const uint8_t*)lut256);
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+// parameters of one uint8 Add / Mul exactly as osg_qu8_binary derives them (shared with the fused per-channel chain below)
+static int make_q8bin(osg_ctx* ctx, bool mul, float a_scale, int a_zp, float b_scale, int b_zp, float out_scale, int out_zp, Q8Bin* out) {
+    Q8Bin q{};
+    q.a_zp = a_zp; q.b_zp = b_zp; q.out_zp = out_zp;
+    if (mul) {
+        q.scale = (a_scale * b_scale) / out_scale;
+    } else {
+        const float a_os = a_scale / out_scale, b_os = b_scale / out_scale;
+        const float mx = a_os > b_os ? a_os : b_os;
+        unsigned bits;
+        memcpy(&bits, &mx, 4);
+        const int exponent = (int)(bits >> 23) - 127;
+        const int shift = 20 - exponent;
+        if (shift < 1 || shift > 31) OSG_FAIL(ctx, "osg_qu8_binary: scale ratio out of the range of the fixed-point add");
+        q.shift = (unsigned)shift;
+        q.a_mult = (int)lrintf(ldexpf(a_os, shift));
+        q.b_mult = (int)lrintf(ldexpf(b_os, shift));
+        q.bias = (int)((1u << (shift - 1)) - (unsigned)(q.a_mult * a_zp) - (unsigned)(q.b_mult * b_zp));
+    }
+    *out = q;
+    return 0;
+}
+
+// Mul(x, g[C]) -> Add(., b[C]) [-> Sigmoid -> Mul(., sigmoid)] on a tensor whose channel index is (i / inner) % C (NHWC: inner 1, NCHW: inner H*W):
+// the GroupNorm affine (+ SiLU) of the uint8 graphs as ONE pass -- every stage's code is formed by the very functions the separate launches use
+// (q8_bin_op, the host-built sigmoid table), in their order, so the output codes are those of the four launches.
+int osg_qu8_affine_act(osg_ctx* ctx, const void* x, float x_scale, int x_zp, const void* g, float g_scale, int g_zp, float m_scale, int m_zp, const void* b,
+                       float b_scale, int b_zp, float a_scale, int a_zp, const void* sig_lut, float s_scale, int s_zp, float o_scale, int o_zp, void* y, long n, int C,
+                       long inner) {
+    if (n <= 0) return 0;
+    if (C <= 0 || inner <= 0) OSG_FAIL(ctx, "osg_qu8_affine_act: invalid shape");
+    Q8Bin qm, qa, qs{};
+    if (make_q8bin(ctx, true, x_scale, x_zp, g_scale, g_zp, m_scale, m_zp, &qm)) return 1;
+    if (make_q8bin(ctx, false, m_scale, m_zp, b_scale, b_zp, a_scale, a_zp, &qa)) return 1;
+    if (sig_lut && make_q8bin(ctx, true, a_scale, a_zp, s_scale, s_zp, o_scale, o_zp, &qs)) return 1;
+    const dim3 grid(grid_for(n / 16 + 1)), block(256);
+    if (sig_lut) hipLaunchKernelGGL(q8_affine_act_kernel<true>, grid, block, 0, ctx->compute, (const uint8_t*)x, (const uint8_t*)g, (const uint8_t*)b, (const uint8_t*)sig_lut, (uint8_t*)y, n, C, inner, qm, qa, qs);
+    else hipLaunchKernelGGL(q8_affine_act_kernel<false>, grid, block, 0, ctx->compute, (const uint8_t*)x, (const uint8_t*)g, (const uint8_t*)b, (const uint8_t*)nullptr, (uint8_t*)y, n, C, inner, qm, qa, qs);
     OSG_LAUNCH_CHECK(ctx);
     return 0;
 }

@@ -28,7 +28,7 @@ EXPORTS = [
     "osg_instance_norm", "osg_group_norm_nhwc", "osg_group_norm_conv3x3_supported", "osg_group_norm_conv3x3", "osg_layer_norm", "osg_reduce_mean_last", "osg_softmax_last",
     "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_concat2", "osg_resize_nearest", "osg_gather_rows",
     "osg_maxpool_nhwc", "osg_convert", "osg_sampler_prepare", "osg_sampler_cfg_euler_a",
-    "osg_range_push", "osg_range_pop", "osg_marker_record", "osg_copy_wait_marker", "osg_timer_mark", "osg_timer_between", "osg_qu8_conv2d_nhwc", "osg_qu8_gemm", "osg_qu8_lut", "osg_qu8_binary", "osg_qu8_instance_norm", "osg_qu8_instance_norm_nhwc", "osg_qu8_softmax_last",
+    "osg_range_push", "osg_range_pop", "osg_marker_record", "osg_copy_wait_marker", "osg_timer_mark", "osg_timer_between", "osg_qu8_conv2d_nhwc", "osg_qu8_gemm", "osg_qu8_lut", "osg_qu8_binary", "osg_qu8_instance_norm", "osg_qu8_instance_norm_nhwc", "osg_qu8_affine_act", "osg_qu8_softmax_last",
 ]
 
 
@@ -103,6 +103,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_qu8_lut.argtypes = [vp, vp, vp, cl, vp]
     lib.osg_qu8_binary.argtypes = [vp, ci, vp, ctypes.POINTER(cl), cf, ci, vp, ctypes.POINTER(cl), cf, ci, vp, cf, ci, ci]
     lib.osg_qu8_instance_norm.argtypes = [vp, vp, vp, ci, cl, ci, vp, vp, cf, cf, ci, cf, ci]
+    lib.osg_qu8_affine_act.argtypes = [vp, vp, cf, ci, vp, cf, ci, cf, ci, vp, cf, ci, cf, ci, vp, cf, ci, cf, ci, vp, cl, ci, cl]
     lib.osg_qu8_instance_norm_nhwc.argtypes = [vp, vp, vp, cl, ci, ci, ci, vp, vp, cf, cf, ci, cf, ci]
     lib.osg_qu8_softmax_last.argtypes = [vp, vp, vp, cl, cl, vp]
     return lib

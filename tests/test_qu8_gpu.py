@@ -155,7 +155,7 @@ def test_hip_vae_qu8_reproduces_the_reference_bit_for_bit():
     assert np.array_equal(outs[1]["out_5F_image"], z["ref_u8"])
     assert not np.array_equal(outs[2]["out_5F_image"], z["ref_u8"])
     assert np.array_equal(outs[3]["out_5F_image"], z["ref_u8"])
-    assert launches > 100
+    assert 60 < launches < 200          # (174 graph ops: the layout-only and per-channel affine chains run as single launches)
 
 
 def test_hip_vae_qu8_every_op_matches_the_reference_intermediates():
