@@ -440,6 +440,14 @@ class Gpu:
         self._ck(self.lib.osg_qu8_instance_norm(self.ctx, x.ptr, y.ptr, rows, L, scale.size, scale.ptr, bias.ptr, eps, float(xq[0]), int(xq[1]), float(oq[0]), int(oq[1])))
         return y
 
+    def qu8_affine_act(self, x: DevBuf, xq, g: DevBuf, gq, mq, b: DevBuf, bq, aq, sig_lut: Optional[DevBuf], sq, oq, channels: int, inner: int = 1):
+        """Mul(x, g[C]) -> Add(., b[C]) [-> Sigmoid -> Mul] in one pass; *q = (scale, zero point) of x, g, Mul out, b, Add out, Sigmoid out, final Mul out"""
+        y = self.empty(x.shape, np.uint8)
+        self._ck(self.lib.osg_qu8_affine_act(self.ctx, x.ptr, float(xq[0]), int(xq[1]), g.ptr, float(gq[0]), int(gq[1]), float(mq[0]), int(mq[1]), b.ptr, float(bq[0]),
+                                             int(bq[1]), float(aq[0]), int(aq[1]), self._p(sig_lut), float(sq[0]), int(sq[1]), float(oq[0]), int(oq[1]), y.ptr, x.size,
+                                             channels, inner))
+        return y
+
     def qu8_instance_norm_nhwc(self, x: DevBuf, groups: int, xq, scale: DevBuf, bias: DevBuf, eps: float, oq):
         """x: [HW, C] codes (NHWC); rows of the normalisation = `groups` blocks of C/groups channels over every pixel"""
         hw, c = int(np.prod(x.shape[:-1])), x.shape[-1]

@@ -83,6 +83,29 @@ def test_qu8_instance_norm(gpu, rows, L):
     assert np.array_equal(got, want), int((got != want).sum())
 
 
+@pytest.mark.parametrize("HW,C,silu,nchw", [(256, 128, True, False), (77, 48, True, False), (1024, 512, False, False), (64, 40, True, True), (5, 7, False, True)])
+def test_qu8_affine_act_equals_the_separate_launches(gpu, HW, C, silu, nchw):
+    """one pass == Mul, Add, Sigmoid lookup, Mul as separate launches, code for code"""
+    rng = np.random.default_rng(HW + C)
+    shape = (1, C, HW, 1) if nchw else (1, HW, 1, C)          # the per-channel operand broadcasts against dim 1 (NCHW) or the last dim (NHWC)
+    x = _codes(rng, shape)
+    g, b = _codes(rng, (C,)), _codes(rng, (C,))
+    xq, gq, mq, bq, aq, sq, oq = (f32(0.021), 118), (f32(0.011), 90), (f32(0.024), 121), (f32(0.013), 140), (f32(0.027), 117), (f32(1 / 256), 0), (f32(0.019), 15)
+    cshape = (1, C, 1, 1) if nchw else (1, 1, 1, C)
+    dx, dg, db = gpu.to_dev(x), gpu.to_dev(g.reshape(cshape)), gpu.to_dev(b.reshape(cshape))
+    m = gpu.qu8_binary("mul", dx, xq, dg, gq, mq)
+    a = gpu.qu8_binary("add", m, mq, db, bq, aq)
+    want = a
+    lut = None
+    if silu:
+        table = Q.sigmoid_u8(np.arange(256, dtype=np.uint8), aq[0], aq[1], sq[0], sq[1])
+        lut = gpu.to_dev(table)
+        sg = gpu.qu8_lut(a, table)
+        want = gpu.qu8_binary("mul", a, aq, sg, sq, oq)
+    got = gpu.qu8_affine_act(dx, xq, gpu.to_dev(g), gq, mq, gpu.to_dev(b), bq, aq, lut, sq, oq, C, HW if nchw else 1).numpy()
+    assert np.array_equal(got, want.numpy()), int((got != want.numpy()).sum())
+
+
 @pytest.mark.parametrize("H,W,C,G", [(16, 16, 128, 32), (8, 8, 512, 32), (33, 7, 96, 8), (4, 4, 40, 5), (64, 64, 256, 32)])
 def test_qu8_instance_norm_nhwc_equals_the_row_kernels(gpu, H, W, C, G):
     """the NHWC addressing of the [1,G,L] InstanceNormalization gives the codes of the row-major kernels on the transposed tensor (and those are
