@@ -3561,6 +3561,7 @@ void Plan::build() {
     const auto t_begin = now();
     L.load_weights();
     const double t_weights = ms_since(t_begin);
+    const size_t n_const_vals_after_load = vals.size();     // (weights are the first vals of every plan of a Model, in model order)
 
     // ---- graph inputs: every activation name that is consumed but never produced --------------------------------
     {
@@ -3637,7 +3638,30 @@ void Plan::build() {
     }
 
     const auto t_fuse = now();
-    L.run_fusions();
+    {
+        std::string key;
+        const bool cacheable = m.m_support_dynamic_shapes && !stream_weights;
+        if (cacheable) {
+            key = std::to_string(fusion) + "|" + std::to_string(m.m_hip_fusion_level) + (u8 ? "|u8" : "|f") + (fuse_attn ? "a" : "-") + (sdp_attn ? "s" : "-") + (fuse_ln_gemm ? "l" : "-") +
+                  (fuse_gn_conv ? "g" : "-") + "|" + std::to_string(m.m_attention_fused_ops_parts) + "|";
+            for (auto& e : extra_outputs) key += e + ",";
+            key += "|";
+            if (m.m_requires_upcast)
+                for (auto& op : m.m_ops) key += m.m_requires_upcast(op.m_type, op.m_name) ? '1' : '0';
+        }
+        if (cacheable && pool.fused_valid && pool.fused_key == key && pool.fused_const_vals == n_const_vals_after_load) {
+            ops = pool.fused_ops;
+            L.dead.assign(ops.size(), 0);
+        } else {
+            L.run_fusions();
+            if (cacheable) {
+                pool.fused_ops = ops;
+                pool.fused_key = key;
+                pool.fused_const_vals = n_const_vals_after_load;
+                pool.fused_valid = true;
+            }
+        }
+    }
     const double ms_fuse = ms_since(t_fuse);
     const auto t_lower = now();
     L.lower_all();

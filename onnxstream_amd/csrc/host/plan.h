@@ -81,11 +81,19 @@ struct ConstPool {
     std::vector<TensorDataType> occ_types;   // resolved storage type of every weight occurrence, model order
     bool complete = false;                   // every occurrence of the graph went through the provider once
     size_t bytes = 0;
+    // the op list AFTER the fusion passes, for models that re-plan on every call (m_support_dynamic_shapes: the LLM flow): the passes match graph
+    // structure, constants and declared shapes -- none of which change between calls -- so their result is reused while `fused_key` (every option
+    // they read, the extra outputs, the per-op m_requires_upcast answers) and the number of constant vals stay the same
+    std::string fused_key;
+    std::vector<Operation> fused_ops;
+    size_t fused_const_vals = 0;
+    bool fused_valid = false;
     void clear(HipBackend& be) {
         for (auto& kv : base) be.free(kv.second.dptr);
         for (auto& kv : derived) be.free(kv.second.first);
         base.clear(); derived.clear(); occ_types.clear();
         complete = false; bytes = 0;
+        fused_valid = false; fused_ops.clear(); fused_key.clear();
     }
 };
 
