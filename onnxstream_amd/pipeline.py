@@ -75,6 +75,19 @@ def sigma_to_t(sigma: float, log_sigmas: np.ndarray) -> float:
     return float(f32(f32(f32(1) - w) * f32(low)) + f32(w * f32(high)))
 
 
+def save_latents(path: str, latents: np.ndarray) -> None:
+    """`sd --save-latents FILE` (src/sd.cpp:2325-2327): the first sample's latents as raw little-endian float32, [4, h, w]."""
+    np.ascontiguousarray(np.asarray(latents, f32).reshape((-1,) + tuple(np.asarray(latents).shape[-3:]))[0], "<f4").tofile(path)
+
+
+def load_latents(path: str, h: int = 64, w: int = 64) -> np.ndarray:
+    """`sd --decode-latents FILE` (src/sd.cpp:3212-3245): a raw float32 file back as [1, 4, h, w] (the app checks the size against 4*h*w too)."""
+    v = np.fromfile(path, "<f4")
+    if v.size != 4 * h * w:
+        raise ValueError("Invalid size of latents file.")
+    return v.reshape(1, 4, h, w).astype(f32)
+
+
 class Txt2Img:
     def __init__(self, library: str, unet_dir: str, vae_dir: Optional[str], batched: bool = True, device: int = 0,
                  names: Dict[str, str] = None, fusion: Optional[int] = None, threads: int = 0, autotune: Optional[bool] = None):

@@ -18,6 +18,18 @@ from oracle import ref as oref
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pipeline_tiny.npz")
 
 
+def test_latents_file_round_trip(tmp_path):
+    """--save-latents / --decode-latents: raw float32 of the first sample (src/sd.cpp:2325-2327, :3212-3245)"""
+    from onnxstream_amd.pipeline import load_latents, save_latents
+    x = np.random.default_rng(1).standard_normal((2, 4, 64, 64)).astype(np.float32)
+    f = str(tmp_path / "lat.bin")
+    save_latents(f, x)
+    assert os.path.getsize(f) == 4 * 64 * 64 * 4
+    assert np.array_equal(load_latents(f), x[0:1])
+    with pytest.raises(ValueError):
+        load_latents(f, 32, 32)
+
+
 def test_schedule_known_answers():
     ls = log_sigmas_table()
     # first / last three entries of the reference's table (src/sd.cpp:1591)
