@@ -303,6 +303,11 @@ int osg_qu8_instance_norm(osg_ctx* ctx, const void* x, void* y, int rows, long L
 int osg_qu8_affine_act(osg_ctx* ctx, const void* x, float x_scale, int x_zp, const void* g, float g_scale, int g_zp, float m_scale, int m_zp, const void* b,
                        float b_scale, int b_zp, float a_scale, int a_zp, const void* sig_lut, float s_scale, int s_zp, float o_scale, int o_zp, void* y, long n, int C,
                        long inner);
+/* osg_qu8_instance_norm_nhwc followed by osg_qu8_affine_act with the normalisation's table lookup done inside the affine pass (n_out_* = the
+ * normalisation's output parameters): histogram, tables, one pass.  Same codes as the separate ops. */
+int osg_qu8_norm_affine_act_nhwc(osg_ctx* ctx, const void* x, long HW, int C, int G, int n_scale, const float* scale, const float* bias, float eps, float x_scale,
+                                 int x_zp, float n_out_scale, int n_out_zp, const void* g, float g_scale, int g_zp, float m_scale, int m_zp, const void* b, float b_scale,
+                                 int b_zp, float a_scale, int a_zp, const void* sig_lut, float s_scale, int s_zp, float o_scale, int o_zp, void* y);
 /* ... the same op when the [1,G,L] view is a Reshape of an NHWC [HW][C] tensor (row g = channels [g*C/G, (g+1)*C/G) of every pixel): identical codes,
  * no layout copy around it. */
 int osg_qu8_instance_norm_nhwc(osg_ctx* ctx, const void* x, void* y, long HW, int C, int G, int n_scale, const float* scale, const float* bias, float eps,

@@ -26,7 +26,7 @@ namespace onnxstream {
     X(osg_reduce_mean_last) X(osg_softmax_last) X(osg_unary) X(osg_binary) X(osg_geglu) X(osg_transpose) \
     X(osg_copy_2d) X(osg_concat2) X(osg_resize_nearest) X(osg_gather_rows) X(osg_maxpool_nhwc) X(osg_convert) \
     X(osg_sampler_prepare) X(osg_sampler_cfg_euler_a) X(osg_qu8_conv2d_nhwc) X(osg_qu8_gemm) X(osg_qu8_lut) X(osg_qu8_binary) \
-    X(osg_qu8_instance_norm) X(osg_qu8_instance_norm_nhwc) X(osg_qu8_affine_act) X(osg_qu8_softmax_last) X(osg_range_push) X(osg_range_pop) X(osg_marker_record) \
+    X(osg_qu8_instance_norm) X(osg_qu8_instance_norm_nhwc) X(osg_qu8_affine_act) X(osg_qu8_norm_affine_act_nhwc) X(osg_qu8_softmax_last) X(osg_range_push) X(osg_range_pop) X(osg_marker_record) \
     X(osg_copy_wait_marker) X(osg_timer_mark) X(osg_timer_between)
 
 struct OsgApi {

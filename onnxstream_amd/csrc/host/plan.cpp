@@ -675,6 +675,15 @@ struct Lowering {
                 f.m_attributes.emplace_back("sigmoid", ops()[sg].m_name);
                 f.m_attributes.emplace_back("mul2", ops()[m2].m_name);
             }
+            // the normalisation right in front (already in its NHWC form): its table lookup rides in this pass
+            const int nrm = prod_of(x);
+            if (is(nrm, "osg.qu8.InstanceNormNHWC") && use_count(x.m_name) == 1) {
+                f.m_type = "osg.qu8.NormAffineAct";
+                f.m_input = {ops()[nrm].m_input[0], gam, bet, ops()[nrm].m_input[1], ops()[nrm].m_input[2]};
+                f.m_attributes.emplace_back("norm", ops()[nrm].m_name);
+                for (auto& a : ops()[nrm].m_attributes) f.m_attributes.emplace_back("norm_" + a.first, a.second);
+                dead[nrm] = 1;
+            }
             dead[i] = 1;
             if (silu) dead[ad] = dead[sg] = 1;
             ops()[last] = std::move(f);
@@ -1797,7 +1806,7 @@ struct Lowering {
         if (t == "Sigmoid") return lower_sigmoid_u8(op);
         if (t == "InstanceNormalization") return lower_instance_norm_u8(op);
         if (t == "osg.qu8.InstanceNormNHWC") return lower_instance_norm_u8_nhwc(op);
-        if (t == "osg.qu8.AffineAct") return lower_affine_act_u8(op);
+        if (t == "osg.qu8.AffineAct" || t == "osg.qu8.NormAffineAct") return lower_affine_act_u8(op);
         if (t == "Softmax") return lower_softmax_u8(op);
         if (t == "Reshape" || t == "Flatten" || t == "Unsqueeze" || t == "Squeeze" || t == "Transpose" || t == "Resize") {
             // the codes are re-arranged, scale and zero point carried over (reference :4783, :5231, :6251)
@@ -1948,7 +1957,13 @@ struct Lowering {
             int x = V(a).lay == Lay::nhwc ? a : b, o = x == a ? b : a;
             const Shape xs = V(x).shape;
             const long C = xs[1], HW = xs[2] * xs[3];
-            if (V(o).lay == Lay::nhwc && V(o).shape == xs) {
+            if (V(o).shape == xs && xs.size() == 4) {
+                // same-shape operands: stay channels-last (the convolutions either side want it); a plain operand is transposed ONCE here instead of
+                // the NHWC one being transposed now and the result transposed back in front of the next convolution
+                if (V(o).lay != Lay::nhwc) {
+                    const int on = P.ensure_nhwc(o);
+                    (o == a ? a : b) = on;
+                }
                 olay = Lay::nhwc;
                 pa = pb = {HW, C};
             } else if (per_channel(o, C) && os == xs) {
@@ -2034,7 +2049,9 @@ struct Lowering {
         return qu8::range_to_scale(it->second.first, it->second.second);
     }
     void lower_affine_act_u8(const Operation& op) {
-        const int x = in_val(op.m_input[0]), g = in_val(op.m_input[1]), b = in_val(op.m_input[2]);
+        const bool normed = op.m_type == "osg.qu8.NormAffineAct";
+        int x = in_val(op.m_input[0]);
+        const int g = in_val(op.m_input[1]), b = in_val(op.m_input[2]);
         need_u8(op, x, "inputs");
         need_u8(op, g, "inputs");
         need_u8(op, b, "inputs");
@@ -2053,6 +2070,42 @@ struct Lowering {
             uint8_t t[256];
             qu8::sigmoid_lut(qa, qs, t);          // (the Sigmoid's input is the Add's output: parameters from range data, never dynamic)
             be.check(be.api.osg_upload_sync(be.ctx, lut, t, 256), "osg_upload_sync");
+        }
+        int sc = -1, bi = -1;
+        float eps = 1e-5f;
+        long G = 0;
+        qu8::QParams qn{};
+        if (normed) {
+            sc = in_val(op.m_input[3]), bi = in_val(op.m_input[4]);
+            if (auto* e = attr(op, "norm_epsilon")) eps = std::stof(*e);
+            if (auto* gr = attr(op, "norm_groups")) G = std::stol(*gr);
+            need(op, G > 0 && C % G == 0 && V(sc).numel() == G && V(bi).numel() == G && V(sc).dtype == OSG_F32 && V(bi).dtype == OSG_F32, "invalid scale/bias.");
+            qn = range_q(op, *attr(op, "norm"));
+            if (V(x).lay != Lay::nhwc) {
+                // the producer left it in the logical layout: the [G][L] row kernels as they are, then the affine pass below on their output
+                const int xi = P.ensure_plain(x), nv = P.new_val("", s, OSG_U8, Lay::plain, V(x).batched);
+                V(nv).qscale = qn.scale;
+                V(nv).qzp = (int)qn.zero_point;
+                const long L = (C / G) * HW;
+                P.add_step("InstanceNorm qu8 " + *attr(op, "norm"), {xi, sc, bi}, {nv}, [=, this] {
+                    const Val& qx = P.qv(xi);
+                    be.check(be.api.osg_qu8_instance_norm(be.ctx, P.ptr(xi), P.ptr(nv), (int)G, L, (int)G, (const float*)P.ptr(sc), (const float*)P.ptr(bi), eps, qx.qscale, qx.qzp,
+                                                          qn.scale, (int)qn.zero_point),
+                             "InstanceNormalization");
+                });
+                x = nv;
+            }
+        }
+        if (normed && V(x).lay == Lay::nhwc) {
+            const int y = out_val_u8(op, s, Lay::nhwc, V(x).batched, qo);
+            P.add_step("NormAffineAct qu8 " + op.m_name, {x, g, b, sc, bi}, {y}, [=, this] {
+                const Val &qx = P.qv(x), &qg = P.qv(g), &qb = P.qv(b);
+                be.check(be.api.osg_qu8_norm_affine_act_nhwc(be.ctx, P.ptr(x), HW, (int)C, (int)G, (int)G, (const float*)P.ptr(sc), (const float*)P.ptr(bi), eps, qx.qscale, qx.qzp,
+                                                             qn.scale, (int)qn.zero_point, P.ptr(g), qg.qscale, qg.qzp, qm.scale, (int)qm.zero_point, P.ptr(b), qb.qscale, qb.qzp,
+                                                             qa.scale, (int)qa.zero_point, lut, qs.scale, (int)qs.zero_point, qo.scale, (int)qo.zero_point, P.ptr(y)),
+                         "NormAffineAct");
+            });
+            return;
         }
         const int y = out_val_u8(op, s, V(x).lay, V(x).batched, qo);
         const long inner = V(x).lay == Lay::nhwc ? 1 : HW;

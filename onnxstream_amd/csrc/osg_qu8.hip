@@ -368,17 +368,21 @@ __global__ __launch_bounds__(256) void q8_binary_fast_kernel(const uint8_t* __re
         y[i] = q8_bin_op<KIND>(a[i], MODE == 0 ? b[i] : b[(i / inner) % period], q);
 }
 
-template <bool ACT>
+// NORM: the codes first go through the per-group table of a uint8 InstanceNormalization (in_lut [G][256], group = channel / cpg) -- the lookup the
+// separate apply launch would have done -- then through the affine chain
+template <bool ACT, bool NORM>
 __global__ __launch_bounds__(256) void q8_affine_act_kernel(const uint8_t* __restrict__ x, const uint8_t* __restrict__ g, const uint8_t* __restrict__ b,
                                                             const uint8_t* __restrict__ lut_g, uint8_t* __restrict__ y, long n, int C, long inner, Q8Bin qm, Q8Bin qa,
-                                                            Q8Bin qs) {
+                                                            Q8Bin qs, const uint8_t* __restrict__ in_lut, int cpg, int G) {
     __shared__ uint8_t lut[256];
-    if (ACT) {
-        lut[threadIdx.x] = lut_g[threadIdx.x];
-        __syncthreads();
-    }
+    extern __shared__ uint8_t nl[];            // NORM: [G][256]
+    if (ACT) lut[threadIdx.x] = lut_g[threadIdx.x];
+    if (NORM)
+        for (int k = threadIdx.x; k < G * 256; k += 256) nl[k] = in_lut[k];
+    if (ACT || NORM) __syncthreads();
     auto one = [&](unsigned code, long i) -> unsigned {
         const int c = (int)((i / inner) % C);
+        if (NORM) code = nl[(c / cpg) * 256 + code];
         const unsigned v1 = q8_bin_op<1>((int)code, g[c], qm);
         const unsigned v2 = q8_bin_op<0>((int)v1, b[c], qa);
         if (!ACT) return v2;
@@ -689,8 +693,39 @@ int osg_qu8_affine_act(osg_ctx* ctx, const void* x, float x_scale, int x_zp, con
     if (make_q8bin(ctx, false, m_scale, m_zp, b_scale, b_zp, a_scale, a_zp, &qa)) return 1;
     if (sig_lut && make_q8bin(ctx, true, a_scale, a_zp, s_scale, s_zp, o_scale, o_zp, &qs)) return 1;
     const dim3 grid(grid_for(n / 16 + 1)), block(256);
-    if (sig_lut) hipLaunchKernelGGL(q8_affine_act_kernel<true>, grid, block, 0, ctx->compute, (const uint8_t*)x, (const uint8_t*)g, (const uint8_t*)b, (const uint8_t*)sig_lut, (uint8_t*)y, n, C, inner, qm, qa, qs);
-    else hipLaunchKernelGGL(q8_affine_act_kernel<false>, grid, block, 0, ctx->compute, (const uint8_t*)x, (const uint8_t*)g, (const uint8_t*)b, (const uint8_t*)nullptr, (uint8_t*)y, n, C, inner, qm, qa, qs);
+    if (sig_lut) hipLaunchKernelGGL((q8_affine_act_kernel<true, false>), grid, block, 0, ctx->compute, (const uint8_t*)x, (const uint8_t*)g, (const uint8_t*)b, (const uint8_t*)sig_lut, (uint8_t*)y, n, C, inner, qm, qa, qs, (const uint8_t*)nullptr, 1, 0);
+    else hipLaunchKernelGGL((q8_affine_act_kernel<false, false>), grid, block, 0, ctx->compute, (const uint8_t*)x, (const uint8_t*)g, (const uint8_t*)b, (const uint8_t*)nullptr, (uint8_t*)y, n, C, inner, qm, qa, qs, (const uint8_t*)nullptr, 1, 0);
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
+// InstanceNormalization over NHWC (osg_qu8_instance_norm_nhwc) whose table lookup rides in the affine pass that follows it: histogram, tables, then ONE
+// pass x -> table -> Mul -> Add [-> Sigmoid -> Mul].  n_* = the normalisation's own output parameters (the Mul's input).
+int osg_qu8_norm_affine_act_nhwc(osg_ctx* ctx, const void* x, long HW, int C, int G, int n_scale, const float* scale, const float* bias, float eps, float x_scale,
+                                 int x_zp, float n_out_scale, int n_out_zp, const void* g, float g_scale, int g_zp, float m_scale, int m_zp, const void* b, float b_scale,
+                                 int b_zp, float a_scale, int a_zp, const void* sig_lut, float s_scale, int s_zp, float o_scale, int o_zp, void* y) {
+    if (HW <= 0 || C <= 0 || G <= 0 || C % G || n_scale <= 0) OSG_FAIL(ctx, "osg_qu8_norm_affine_act_nhwc: invalid shape");
+    if (G > 56) OSG_FAIL(ctx, "osg_qu8_norm_affine_act_nhwc: more than 56 groups do not fit the histogram in LDS");
+    const size_t hist_bytes = (size_t)G * 256 * sizeof(unsigned), lut_bytes = (size_t)G * 256;
+    if (osg_ensure_workspace(ctx, hist_bytes + lut_bytes)) return 1;
+    unsigned* hist = (unsigned*)ctx->ws;
+    uint8_t* lut = (uint8_t*)ctx->ws + hist_bytes;
+    OSG_HIP(ctx, hipMemsetAsync(hist, 0, hist_bytes, ctx->compute));
+    const long n = HW * C, L = HW * (C / G);
+    const unsigned pieces = (unsigned)((n + kInPiece - 1) / kInPiece);
+    const int cpg = C / G;
+    int sh = -1;
+    if ((cpg & (cpg - 1)) == 0)
+        for (sh = 0; (1 << sh) < cpg; sh++) {}
+    hipLaunchKernelGGL(q8_in_hist_nhwc_kernel, dim3(pieces), dim3(256), hist_bytes, ctx->compute, (const uint8_t*)x, hist, n, C, cpg, G, sh);
+    hipLaunchKernelGGL(q8_in_lut_kernel, dim3((unsigned)G), dim3(256), 0, ctx->compute, hist, lut, L, n_scale, scale, bias, eps, x_scale, x_zp, n_out_scale, n_out_zp);
+    Q8Bin qm, qa, qs{};
+    if (make_q8bin(ctx, true, n_out_scale, n_out_zp, g_scale, g_zp, m_scale, m_zp, &qm)) return 1;
+    if (make_q8bin(ctx, false, m_scale, m_zp, b_scale, b_zp, a_scale, a_zp, &qa)) return 1;
+    if (sig_lut && make_q8bin(ctx, true, a_scale, a_zp, s_scale, s_zp, o_scale, o_zp, &qs)) return 1;
+    const dim3 grid(grid_for(n / 16 + 1)), block(256);
+    if (sig_lut) hipLaunchKernelGGL((q8_affine_act_kernel<true, true>), grid, block, lut_bytes, ctx->compute, (const uint8_t*)x, (const uint8_t*)g, (const uint8_t*)b, (const uint8_t*)sig_lut, (uint8_t*)y, n, C, 1L, qm, qa, qs, (const uint8_t*)lut, cpg, G);
+    else hipLaunchKernelGGL((q8_affine_act_kernel<false, true>), grid, block, lut_bytes, ctx->compute, (const uint8_t*)x, (const uint8_t*)g, (const uint8_t*)b, (const uint8_t*)nullptr, (uint8_t*)y, n, C, 1L, qm, qa, qs, (const uint8_t*)lut, cpg, G);
     OSG_LAUNCH_CHECK(ctx);
     return 0;
 }

@@ -28,7 +28,7 @@ EXPORTS = [
     "osg_instance_norm", "osg_group_norm_nhwc", "osg_group_norm_conv3x3_supported", "osg_group_norm_conv3x3", "osg_layer_norm", "osg_reduce_mean_last", "osg_softmax_last",
     "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_concat2", "osg_resize_nearest", "osg_gather_rows",
     "osg_maxpool_nhwc", "osg_convert", "osg_sampler_prepare", "osg_sampler_cfg_euler_a",
-    "osg_range_push", "osg_range_pop", "osg_marker_record", "osg_copy_wait_marker", "osg_timer_mark", "osg_timer_between", "osg_qu8_conv2d_nhwc", "osg_qu8_gemm", "osg_qu8_lut", "osg_qu8_binary", "osg_qu8_instance_norm", "osg_qu8_instance_norm_nhwc", "osg_qu8_affine_act", "osg_qu8_softmax_last",
+    "osg_range_push", "osg_range_pop", "osg_marker_record", "osg_copy_wait_marker", "osg_timer_mark", "osg_timer_between", "osg_qu8_conv2d_nhwc", "osg_qu8_gemm", "osg_qu8_lut", "osg_qu8_binary", "osg_qu8_instance_norm", "osg_qu8_instance_norm_nhwc", "osg_qu8_affine_act", "osg_qu8_norm_affine_act_nhwc", "osg_qu8_softmax_last",
 ]
 
 
@@ -105,6 +105,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_qu8_instance_norm.argtypes = [vp, vp, vp, ci, cl, ci, vp, vp, cf, cf, ci, cf, ci]
     lib.osg_qu8_affine_act.argtypes = [vp, vp, cf, ci, vp, cf, ci, cf, ci, vp, cf, ci, cf, ci, vp, cf, ci, cf, ci, vp, cl, ci, cl]
     lib.osg_qu8_instance_norm_nhwc.argtypes = [vp, vp, vp, cl, ci, ci, ci, vp, vp, cf, cf, ci, cf, ci]
+    lib.osg_qu8_norm_affine_act_nhwc.argtypes = [vp, vp, cl, ci, ci, ci, vp, vp, cf, cf, ci, cf, ci, vp, cf, ci, cf, ci, vp, cf, ci, cf, ci, vp, cf, ci, cf, ci, vp]
     lib.osg_qu8_softmax_last.argtypes = [vp, vp, vp, cl, cl, vp]
     return lib
 
@@ -453,6 +454,15 @@ class Gpu:
         hw, c = int(np.prod(x.shape[:-1])), x.shape[-1]
         y = self.empty(x.shape, np.uint8)
         self._ck(self.lib.osg_qu8_instance_norm_nhwc(self.ctx, x.ptr, y.ptr, hw, c, groups, scale.size, scale.ptr, bias.ptr, eps, float(xq[0]), int(xq[1]), float(oq[0]), int(oq[1])))
+        return y
+
+    def qu8_norm_affine_act_nhwc(self, x: DevBuf, groups: int, xq, scale: DevBuf, bias: DevBuf, eps: float, nq, g: DevBuf, gq, mq, b: DevBuf, bq, aq, sig_lut: Optional[DevBuf], sq, oq):
+        """qu8_instance_norm_nhwc followed by qu8_affine_act, the normalisation's per-group table applied inside the affine pass"""
+        hw, c = int(np.prod(x.shape[:-1])), x.shape[-1]
+        y = self.empty(x.shape, np.uint8)
+        self._ck(self.lib.osg_qu8_norm_affine_act_nhwc(self.ctx, x.ptr, hw, c, groups, scale.size, scale.ptr, bias.ptr, eps, float(xq[0]), int(xq[1]), float(nq[0]), int(nq[1]),
+                                                       g.ptr, float(gq[0]), int(gq[1]), float(mq[0]), int(mq[1]), b.ptr, float(bq[0]), int(bq[1]), float(aq[0]), int(aq[1]),
+                                                       self._p(sig_lut), float(sq[0]), int(sq[1]), float(oq[0]), int(oq[1]), y.ptr))
         return y
 
     def qu8_softmax_last(self, x: DevBuf, lut_u32: np.ndarray):

@@ -426,3 +426,34 @@ def test_planner_invariants_over_a_sweep_of_unet_shapes(stub_backend, cfg, pushe
             else:
                 assert len(steps) <= base
             m.close()
+
+
+@pytest.mark.parametrize("level", [0, 2])
+def test_full_size_uint8_vae_plan(stub_backend, level):
+    """BASELINE config 3's W8A8 VAE decoder through the uint8 planner with the shipped range data: at fusion level >= 1 every GroupNorm block is
+    ONE launch sequence (histogram, table, per-channel affine + SiLU with the table lookup inside); level 0 keeps one launch per graph op."""
+    from onnxstream_amd import build as b
+    from onnxstream_amd.bindings import Model
+    from onnxstream_amd.synth import sd_vae
+    cfg = sd_vae.SD_VAE
+    d = os.path.join(os.environ.get("OSA_SYNTH_DIR", "/tmp/onnxstream_amd_synth"), cfg.name + "_qu8") + "/"
+    if not os.path.exists(d + ".complete"):
+        os.makedirs(d, exist_ok=True)
+        sd_vae.build_vae_decoder(DirSink(d), cfg, quant_all=True)
+        open(d + ".complete", "w").write("ok")
+    m = Model(b.LIB_HOST, 0, "ram+nocache")
+    m._set_option("hip_fusion_level", level)
+    m.hip_read_range_data(os.path.join(os.path.dirname(b.LIB_HOST), "synth", "data", cfg.name + "_qu8_range_data.txt"))
+    m.set_use_uint8_arithmetic(True)
+    m.read_file(d + "model.txt")
+    m.add_tensor(cfg.in_name, sd_vae.vae_inputs(cfg)[cfg.in_name])
+    m.run()
+    steps, vals, arena = _parse(m.hip_plan_info())
+    m.close()
+    kinds = [s["what"].split(" qu8", 1)[0] for s in steps]
+    if level == 0:
+        assert kinds.count("NormAffineAct") == 0 and kinds.count("AffineAct") == 0 and kinds.count("InstanceNorm") == 30
+    else:
+        assert kinds.count("NormAffineAct") == 30 and kinds.count("AffineAct") == 0 and kinds.count("InstanceNorm") == 0
+        # layouts: latents in, the attention block's [HW,C] detour, image out -- no transposes around the residual adds
+        assert sum(k.startswith(("to_nchw", "to_nhwc")) for k in kinds) <= 4

@@ -121,6 +121,23 @@ def test_qu8_instance_norm_nhwc_equals_the_row_kernels(gpu, H, W, C, G):
     assert np.array_equal(got, want_nhwc), int((got != want_nhwc).sum())
 
 
+@pytest.mark.parametrize("H,W,C,G,silu", [(16, 16, 128, 32, True), (8, 8, 512, 32, True), (33, 7, 96, 8, False), (64, 64, 256, 32, True)])
+def test_qu8_norm_affine_act_equals_the_two_ops(gpu, H, W, C, G, silu):
+    """InstanceNormalization's per-group table applied inside the affine pass == the NHWC normalisation followed by the affine op, code for code"""
+    rng = np.random.default_rng(H * W + C)
+    x = _codes(rng, (H * W, C))
+    scale, bias = (1 + rng.standard_normal(G) * 0.1).astype(f32), (rng.standard_normal(G) * 0.1).astype(f32)
+    g, b = _codes(rng, (C,)), _codes(rng, (C,))
+    xq, nq = (f32(0.031), 121), (f32(0.024), 118)
+    gq, mq, bq, aq, sq, oq = (f32(0.011), 90), (f32(0.024), 121), (f32(0.013), 140), (f32(0.027), 117), (f32(1 / 256), 0), (f32(0.019), 15)
+    lut = gpu.to_dev(Q.sigmoid_u8(np.arange(256, dtype=np.uint8), aq[0], aq[1], sq[0], sq[1])) if silu else None
+    dx, ds, dbi, dg, db = gpu.to_dev(x), gpu.to_dev(scale), gpu.to_dev(bias), gpu.to_dev(g), gpu.to_dev(b)
+    n = gpu.qu8_instance_norm_nhwc(dx, G, xq, ds, dbi, 1e-5, nq)
+    want = gpu.qu8_affine_act(n, nq, dg, gq, mq, db, bq, aq, lut, sq, oq, C, 1).numpy()
+    got = gpu.qu8_norm_affine_act_nhwc(dx, G, xq, ds, dbi, 1e-5, nq, dg, gq, mq, db, bq, aq, lut, sq, oq).numpy()
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
 @pytest.mark.parametrize("rows,C", [(64, 64), (256, 4096), (5, 1000), (3, 7)])
 def test_qu8_softmax(gpu, rows, C):
     rng = np.random.default_rng(rows * C)
