@@ -242,9 +242,12 @@ def main():
     coll_dev = "cpu" if one_gpu else "cuda"
     torch.cuda.set_device(gpu_index)
     dist = None
-    if world > 1:
+    # OSA_BENCH_FORCE_DIST=1 (dev check on a 1-GPU box): a world of ONE rank still goes through the process group, so every RCCL call of the N > 1 flow
+    # (init with device_id, broadcast / all_gather / all_reduce / barrier on device tensors) is exercised on the real backend
+    if world > 1 or os.environ.get("OSA_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if one_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:

@@ -108,7 +108,12 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
         L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
     int m_tile, n_tile, zs;
-    if (p.n_major) {
+    if (p.xcd_local) {
+        int t;
+        if (!xcd_local_map(p, &t, &zs)) return;
+        if (p.n_major) { n_tile = t / p.mt; m_tile = t - n_tile * p.mt; }
+        else { m_tile = t / p.nt; n_tile = t - m_tile * p.nt; }
+    } else if (p.n_major) {
         n_tile = L / (p.splits * p.mt); L -= n_tile * p.splits * p.mt;
         zs = L / p.mt; m_tile = L - zs * p.mt;
     } else {
@@ -320,7 +325,7 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
     }
     gemm_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0, lane, 0, zs);
     // split-K over slabs: the last block to arrive at the tile folds the slabs (only the 4 math waves are still here: tid 0..255)
-    if (p.splits > 1 && p.tickets) splitk_finish<128, BN>(p, m0, n0, m_tile * p.nt + n_tile, 0, reinterpret_cast<int*>(smem3), tid, 256);
+    if (p.splits > 1 && p.tickets) splitk_finish<128, BN>(p, m0, n0, m_tile * p.nt + n_tile, 0, zs, reinterpret_cast<int*>(smem3), tid, 256);
 }
 
 template <int W_, int BN, int WGM, int WGN, int MODE, bool PRE>
@@ -340,7 +345,9 @@ int launch3(osg_ctx* ctx, GemmParams& p) {
     }
     p.mt = (p.M + 127) / 128;
     p.nt = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.mt * p.nt * p.splits)), dim3(512), smem, ctx->compute, p);
+    p.tiles_total = p.mt * p.nt;
+    if (p.xcd_local && !p.tickets) p.xcd_local = 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.xcd_local ? (p.tiles_total + 7) / 8 * 8 * p.splits : p.tiles_total * p.splits)), dim3(512), smem, ctx->compute, p);
     OSG_LAUNCH_CHECK(ctx);
     return 0;
 }
@@ -472,9 +479,8 @@ int osg_conv3x3_launch(osg_ctx* ctx, GemmParams p, int bn, int s) {
         size_t need = (size_t)p.splits * p.M * p.N * sizeof(float);
         if (osg_ensure_workspace(ctx, need)) return 1;
         p.partial = (float*)ctx->ws;
-        static const bool use_tickets = getenv("OSG_SPLITK_TICKET") && atoi(getenv("OSG_SPLITK_TICKET")) != 0;   // opt-in: measured slower than the reduce launch (6.60 vs 6.34 ms per step, round 2)
         const long n_tiles = (long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
-        if (use_tickets && p.N % 4 == 0 && ctx->tickets && n_tiles <= osg_ctx::kTickets / 2) p.tickets = ctx->tickets;
+        osg_mm::splitk_route(ctx, p, n_tiles);
     }
     p.n_major = (double)p.N * p.K * 2.0 > (double)p.a_bytes_l;
     int rc;

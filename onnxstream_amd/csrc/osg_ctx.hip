@@ -71,6 +71,55 @@ struct Roctx {
 Roctx& roctx() { static Roctx r; return r; }
 }  // namespace
 
+// ---- XCD-local split-K support (osg_common.h: xcd_rr / xcc_map / xcd_err) -----------------------------------------------------------------------------
+namespace {
+__global__ void xcc_probe_kernel(int* out) {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)(v & 15u);
+}
+
+// does workgroup i of a launch land on XCD (i mod 8)?  (the dispatcher's documented round robin; true on an MI355X in SPX mode.)  Anything else --
+// another partition mode, fewer XCDs, a failed probe -- leaves xcd_rr false and the XCD-local route unused.
+void calibrate_xcd(osg_ctx* c) {
+    constexpr int kBlocks = 256;
+    int* d = nullptr;
+    int h[kBlocks];
+    if (hipHostMalloc((void**)&c->xcd_err, 64, hipHostMallocMapped) != hipSuccess) { c->xcd_err = nullptr; return; }
+    *c->xcd_err = 0;
+    if (hipHostGetDevicePointer((void**)&c->xcd_err_dev, c->xcd_err, 0) != hipSuccess) return;
+    if (hipMalloc((void**)&d, sizeof(h)) != hipSuccess) return;
+    bool ok = true;
+    for (int rep = 0; rep < 3 && ok; rep++) {
+        hipLaunchKernelGGL(xcc_probe_kernel, dim3(kBlocks), dim3(64), 0, c->compute, d);
+        ok = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, c->compute) == hipSuccess && hipStreamSynchronize(c->compute) == hipSuccess;
+        for (int i = 0; ok && i < kBlocks; i++) ok = h[i] == h[i & 7];
+        for (int i = 0; ok && i < 8; i++)
+            for (int j = 0; j < i; j++) ok = ok && h[i] != h[j];
+    }
+    (void)hipGetLastError();
+    hipFree(d);
+    if (getenv("OSG_XCD_DEBUG")) {
+        fprintf(stderr, "[osg] XCC_ID of workgroups 0..15 of a launch:");
+        for (int i = 0; i < 16; i++) fprintf(stderr, " %d", h[i]);
+        fprintf(stderr, "  -> round robin over 8 XCDs: %s\n", ok ? "yes" : "no");
+    }
+    if (!ok) return;
+    c->xcc_map = 0;
+    for (int i = 0; i < 8; i++) c->xcc_map |= (unsigned)(h[i] & 15) << (4 * i);
+    c->xcd_rr = true;
+}
+
+int xcd_check(osg_ctx* c) {
+    if (c->xcd_err && *(volatile int*)c->xcd_err) {
+        *c->xcd_err = 0;
+        c->xcd_rr = false;   // (later plans fall back to the reduce launch)
+        OSG_FAIL(c, "XCD-local split-K: a workgroup ran on another XCD than workgroup-index mod 8 says (results of this pass are invalid); set OSG_SPLITK_TICKET=0");
+    }
+    return 0;
+}
+}  // namespace
+
 extern "C" {
 
 void osg_range_push(const char* name) { if (roctx().push) roctx().push(name); }
@@ -110,11 +159,13 @@ int osg_init(int device, osg_ctx** out) {
              hipEventCreateWithFlags(&c->stage_free[i], hipEventDisableTiming) == hipSuccess;
     }
     ok = ok && hipMalloc((void**)&c->tickets, osg_ctx::kTickets * sizeof(int)) == hipSuccess &&
-         hipMemset(c->tickets, 0, osg_ctx::kTickets * sizeof(int)) == hipSuccess;
+         hipMemsetAsync(c->tickets, 0, osg_ctx::kTickets * sizeof(int), c->compute) == hipSuccess &&   // on the stream the kernels run on (it does not
+         hipStreamSynchronize(c->compute) == hipSuccess;                                                 // synchronise with the null stream)
     if (!ok) {
         delete c;
         return 5;
     }
+    calibrate_xcd(c);
     *out = c;
     return 0;
 }
@@ -128,6 +179,7 @@ void osg_destroy(osg_ctx* c) {
         if (c->stage_free[i]) hipEventDestroy(c->stage_free[i]);
     }
     if (c->tickets) hipFree(c->tickets);
+    if (c->xcd_err) hipHostFree(c->xcd_err);
     if (c->evict) hipFree(c->evict);
     if (c->ws) hipFree(c->ws);
     if (c->ws2) hipFree(c->ws2);
@@ -241,7 +293,7 @@ int osg_download(osg_ctx* c, void* dst, const void* src, size_t bytes) {
     if (c->capturing) OSG_FAIL(c, "osg_download inside graph capture");
     OSG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->compute));
     OSG_HIP(c, hipStreamSynchronize(c->compute));
-    return 0;
+    return xcd_check(c);
 }
 
 int osg_copy(osg_ctx* c, void* dst, const void* src, size_t bytes) {
@@ -258,7 +310,7 @@ int osg_sync(osg_ctx* c) {
     OSG_HIP(c, hipStreamSynchronize(c->copy));
     OSG_HIP(c, hipStreamSynchronize(c->compute));
     OSG_HIP(c, hipStreamSynchronize(c->side));
-    return 0;
+    return xcd_check(c);
 }
 
 // ---- side branch: independent work (a resnet's 1x1 shortcut convolution, projections of the text context) runs on a second stream

@@ -258,15 +258,24 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm2_kernel(GemmParams p) {
         L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
     const int per_batch = p.mt * p.nt * p.splits;
-    const int zb = L / per_batch;
-    int rem = L - zb * per_batch;
-    int m_tile, n_tile, zs;
-    if (p.n_major) {
-        n_tile = rem / (p.splits * p.mt); rem -= n_tile * p.splits * p.mt;
-        zs = rem / p.mt; m_tile = rem - zs * p.mt;
+    int zb, m_tile, n_tile, zs;
+    if (p.xcd_local) {
+        int t;
+        if (!xcd_local_map(p, &t, &zs)) return;
+        zb = t / (p.mt * p.nt);
+        const int rem = t - zb * p.mt * p.nt;
+        if (p.n_major) { n_tile = rem / p.mt; m_tile = rem - n_tile * p.mt; }
+        else { m_tile = rem / p.nt; n_tile = rem - m_tile * p.nt; }
     } else {
-        m_tile = rem / (p.splits * p.nt); rem -= m_tile * p.splits * p.nt;
-        zs = rem / p.nt; n_tile = rem - zs * p.nt;
+        zb = L / per_batch;
+        int rem = L - zb * per_batch;
+        if (p.n_major) {
+            n_tile = rem / (p.splits * p.mt); rem -= n_tile * p.splits * p.mt;
+            zs = rem / p.mt; m_tile = rem - zs * p.mt;
+        } else {
+            m_tile = rem / (p.splits * p.nt); rem -= m_tile * p.splits * p.nt;
+            zs = rem / p.nt; n_tile = rem - zs * p.nt;
+        }
     }
     const int m0 = m_tile * BM, n0 = n_tile * BN;
     const int kbeg = zs * p.k_per_split;
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void gemm2_kernel(GemmParams p) {
 
     // ---- split-K: the last k-slice block to arrive at this tile folds the slabs (osg_gemm_common.h splitk_finish): no reduce launch
     if (p.splits > 1 && p.tickets)
-        splitk_finish<BM, BN>(p, m0, n0, (zb * p.mt + m_tile) * p.nt + n_tile, zb, reinterpret_cast<int*>(smem2), tid, 256);
+        splitk_finish<BM, BN>(p, m0, n0, (zb * p.mt + m_tile) * p.nt + n_tile, zb, zs, reinterpret_cast<int*>(smem2), tid, 256);
 }
 
 template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0, int LN = 0, int NCH = 5>
@@ -438,7 +447,9 @@ int launch_v2(osg_ctx* ctx, GemmParams& p, int batch) {
     }
     p.mt = (p.M + BM - 1) / BM;
     p.nt = (p.N + BN - 1) / BN;
-    dim3 grid((unsigned)(p.mt * p.nt * p.splits * batch));
+    p.tiles_total = p.mt * p.nt * batch;
+    if (p.xcd_local && (!p.tickets || SPEC)) p.xcd_local = 0;
+    dim3 grid((unsigned)(p.xcd_local ? (p.tiles_total + 7) / 8 * 8 * p.splits : p.tiles_total * p.splits));
     hipLaunchKernelGGL(kern, grid, dim3(SPEC ? 512 : 256), smem, ctx->compute, p);
     OSG_LAUNCH_CHECK(ctx);
     return 0;
@@ -744,8 +755,7 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
         const long n_tiles = (long)batch * ((p.M + kV2BM[ch.cfg] - 1) / kV2BM[ch.cfg]) * ((p.N + kV2BN[ch.cfg] - 1) / kV2BN[ch.cfg]);
         // in-kernel last-arriver reduction over write-through slabs (round 1's version published the slabs with plain stores + an
         // agent-scope release, ~6 us per block); correct and bit-identical, but still loses to the separate reduce launch => OSG_SPLITK_TICKET=1 to try it
-        static const bool use_tickets = getenv("OSG_SPLITK_TICKET") && atoi(getenv("OSG_SPLITK_TICKET")) != 0;   // opt-in: measured slower than the reduce launch (6.60 vs 6.34 ms per step, round 2)
-        if (use_tickets && p.N % 4 == 0 && ctx->tickets && n_tiles <= osg_ctx::kTickets / 2) p.tickets = ctx->tickets;
+        osg_mm::splitk_route(ctx, p, n_tiles);
     }
     // split the operand with more unique bytes across the XCDs (each private L2 then streams its slice from HBM once)
     const double a_unique = CONV ? (double)p.a_bytes : (double)p.M * p.K * 2.0;

@@ -28,6 +28,13 @@ struct GemmParams {
     long a_bytes_l;              // conv: byte size of the whole NHWC input (host side, before the 2 GiB check)
     int mt, nt, n_major;         // tile grid and the order tiles are walked inside an XCD's contiguous chunk
     int* tickets;                // split-K arrival counters (one per output tile), zero between launches
+    int fold_wait;               // splitk_finish: bound of the wait for the sibling slices, in 10 ns ticks of the wall clock
+    // XCD-local split-K: the k-slices of a tile are consecutive workgroups of ONE XCD (xcd_local_map), so the slabs are exchanged through that XCD's
+    // L2 -- plain stores, L1-bypassing loads, no trip to memory.  xcc_map / xcd_err: see osg_ctx; tiles_total = batch * mt * nt.
+    int xcd_local;
+    unsigned xcc_map;
+    int* xcd_err;
+    int tiles_total;
     const float* pre_tab;        // osg_conv3x3.hip PRE variant: per-image affine table [n][2][Cin] (ca, cb) of a fused GroupNorm on the INPUT
     int pre_act, pre_imgs;       //   activation applied after the affine (OSG_ACT_SILU), number of images
     float w_scale;               // W8 kernels (osg_gemm_w8.hip): Bt holds uint8 codes, w = (q - w_zp) * w_scale
@@ -181,12 +188,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                 const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
                 if (n >= N) continue;
                 if ((N & 3) == 0) {
-                    if (p.tickets) {
-                        // write-through (sc1): the slab goes past this XCD's L2 to memory, so the last-arriving block of the tile -- maybe on
+                    if (p.tickets && !p.xcd_local) {
+                        // write-through (sc1): the slab goes past this XCD's L2 to memory, so the folding blocks of the tile -- maybe on
                         // another XCD -- can read it with sc1 loads after the ticket, no release / acquire fence on either side
                         const float* dst = P + (long)m * N + n;
                         asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(acc[i][j]) : "memory");
-                    } else
+                    } else   // (XCD-local: the L1 is write-through, the store is in the shared L2 once vmcnt says so)
                         *reinterpret_cast<f32x4*>(P + (long)m * N + n) = acc[i][j];
                 } else {
 #pragma unroll
@@ -232,69 +239,190 @@ __device__ __forceinline__ void gemm_epilogue_geglu(const GemmParams& p, f32x4 (
     }
 }
 
-// ---- split-K without a reduce launch: the LAST k-slice block to arrive at an output tile folds the f32 slabs (in slab order => the same
-// bits whoever arrives last) and writes the f16 tile.  Slabs are published write-through (sc1 stores, see gemm_epilogue), every wave drains
-// its stores (vmcnt(0)) before the block's single relaxed agent-scope ticket; the reducer reads the slabs with sc1 loads (they bypass its
-// L1 and revalidate against memory): the hand-off needs neither the release fence (an L2 write-back of freshly dirtied slabs, ~6 us per
-// block) nor the acquire.  Call with every thread of the block that ran gemm_epilogue (nthr of them, tid = 0 .. nthr-1).
+// ---- split-K without a reduce launch: the k-slice blocks of an output tile fold the f32 slabs THEMSELVES, each a 1/splits share of the tile, once
+// all of them have published.  Slabs are published write-through (sc1 stores, see gemm_epilogue), every wave drains its stores (vmcnt(0)) before
+// the block's relaxed agent-scope arrival; the folding blocks read the slabs with sc1 loads (they bypass L1 / L2 and revalidate against memory):
+// the hand-off needs neither the release fence (an L2 write-back of freshly dirtied slabs, ~6 us per block) nor the acquire.
+//
+// One 32-bit word per tile: bits 0-4 arrivals, bit 5 CLOSED, bits 8-23 abandoned shares, bits 24-28 departures.
+//   * a block that arrives LAST (arrivals == splits - 1 before it) closes the word and folds its own share plus every abandoned one;
+//   * any other block waits -- BOUNDED, ~5 us of wall clock -- for the arrivals to reach `splits` and then folds its own share.  If the wait runs
+//     out (a sibling is not resident: the grid is larger than the GPU, or another stream holds the CUs) it abandons its share (fetch_or of its
+//     bit) and leaves; when that fetch_or finds the word already CLOSED everyone HAS arrived and it folds its share after all.
+//   No block ever waits without a bound, so there is no residency requirement and no deadlock; the slow case degrades to "the last arriver folds
+//   what is left" (round 2's first version, measured slower than the reduce launch because ONE block walked splits x tile through its 8-deep
+//   load queue).  The per-element order of the additions (slice 0, 1, 2, ...) is the reduce launch's: both routes give the same bits.
+//   The last block to leave (departures == splits - 1 before it) zeroes the word for the next launch.
+// Call with every thread of the block that ran gemm_epilogue (nthr of them, tid = 0 .. nthr-1); zs = this block's k-slice.
+template <int VB, int SB, int VPR, bool LOCAL>
+__device__ __forceinline__ void splitk_fold_share(const GemmParams& p, const float* __restrict__ P0, f16* __restrict__ C, const f16* __restrict__ R, long MN, int m0,
+                                                  int n0, int vbeg, int vend, int tid, int nthr) {
+    for (int vb = vbeg + tid; vb < vend; vb += VB * nthr) {
+        const float* src[VB];
+        f32x4 acc[VB];
+#pragma unroll
+        for (int i = 0; i < VB; i++) {
+            const int v = min(vb + i * nthr, vend - 1), r = v / VPR;   // clamped: loads are unconditional, stores are not
+            src[i] = P0 + (long)min(m0 + r, p.M - 1) * p.N + min(n0 + (v - r * VPR) * 4, p.N - 4);
+            acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int s0 = 0; s0 < p.splits; s0 += SB) {
+            f32x4 part[VB][SB];
+#pragma unroll
+            for (int u = 0; u < SB; u++) {
+                const long so = (long)min(s0 + u, p.splits - 1) * MN;
+#pragma unroll
+                for (int i = 0; i < VB; i++) {
+                    const float* a = src[i] + so;
+                    if (LOCAL) asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(part[i][u]) : "v"(a) : "memory");   // past the L1, hit in the XCD's L2
+                    else asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[i][u]) : "v"(a) : "memory");
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < SB; u++)
+#pragma unroll
+                for (int i = 0; i < VB; i++) {
+                    asm volatile("" : "+v"(part[i][u]));
+                    if (s0 + u < p.splits) acc[i] += part[i][u];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < VB; i++) {
+            const int v = vb + i * nthr;
+            if (v >= vend) continue;
+            const int r = v / VPR, m = m0 + r, n = n0 + (v - r * VPR) * 4;
+            if (m >= p.M || n >= p.N) continue;
+            f32x4 sum = acc[i];
+            if (p.bias) {
+                if (p.bias_f32) sum += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
+                else {
+                    f16x4 bv = *reinterpret_cast<const f16x4*>((const f16*)p.bias + n);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) sum[e] += (float)bv[e];
+                }
+            }
+            if (p.rowbias) {
+                f16x4 rb = *reinterpret_cast<const f16x4*>(p.rowbias + (long)(m / p.rb_rows) * p.rb_ld + n);
+#pragma unroll
+                for (int e = 0; e < 4; e++) sum[e] += (float)rb[e];
+            }
+            if (R) {
+                f16x4 rv = *reinterpret_cast<const f16x4*>(R + (long)m * p.N + n);
+#pragma unroll
+                for (int e = 0; e < 4; e++) sum[e] += (float)rv[e];
+            }
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = (f16)osg_apply_act(sum[e], p.act);
+            *reinterpret_cast<f16x4*>(C + (long)m * p.N + n) = o;
+        }
+    }
+}
+
+// XCD-local launches: flat workgroup index -> (tile, k-slice) with the slices of a tile on consecutive workgroups of ONE XCD.  The grid is
+// 8 * ceil(tiles / 8) * splits workgroups; workgroup b runs on XCD x = b % 8 and is the (b / 8)-th of that XCD, which owns the tiles
+// x * ceil(tiles / 8) ... (slices innermost).  Returns false for the padding workgroups past the last tile.  Every workgroup also checks the dispatcher assumption the scheme
+// rests on (its own XCC_ID against the calibrated map) and raises the host-visible flag if it does not hold.
+__device__ __forceinline__ bool xcd_local_map(const GemmParams& p, int* tile, int* zs) {
+    const int b = blockIdx.x, x = b & 7, i = b >> 3;
+    if (threadIdx.x == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if ((xcc & 15u) != ((p.xcc_map >> (4 * x)) & 15u)) __hip_atomic_store(p.xcd_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const int tg = i / p.splits;
+    *zs = i - tg * p.splits;
+    *tile = x * ((p.tiles_total + 7) >> 3) + tg;   // a CONTIGUOUS run of tiles per XCD: its L2 streams one slice of the operand the tile order walks
+    return *tile < p.tiles_total;
+}
+
 template <int BM, int BN>
-__device__ __forceinline__ void splitk_finish(const GemmParams& p, int m0, int n0, int tile_id, int zb, int* flag, int tid, int nthr) {
+__device__ __forceinline__ void splitk_finish(const GemmParams& p, int m0, int n0, int tile_id, int zb, int zs, int* flag, int tid, int nthr) {
+    constexpr unsigned CNT = 0x1fu, CLOSED = 0x20u;
+    constexpr int MASK_SH = 8, DONE_SH = 24;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) *flag = __hip_atomic_fetch_add(&p.tickets[tile_id], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        unsigned* w = reinterpret_cast<unsigned*>(p.tickets) + tile_id;
+        const unsigned mine = 1u << zs;
+        unsigned shares;
+        unsigned old = __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((old & CNT) == (unsigned)p.splits - 1) {
+            old = __hip_atomic_fetch_or(w, CLOSED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            shares = ((old >> MASK_SH) & 0xffffu) | mine;
+        } else {
+            const unsigned long long t0 = wall_clock64();   // constant 100 MHz
+            bool all;
+            do {
+                all = (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & CNT) == (unsigned)p.splits;
+                if (!all) __builtin_amdgcn_s_sleep(2);
+            } while (!all && wall_clock64() - t0 < (unsigned long long)p.fold_wait);
+            if (all) shares = mine;
+            else {
+                old = __hip_atomic_fetch_or(w, mine << MASK_SH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                shares = (old & CLOSED) ? mine : 0u;
+            }
+        }
+        old = __hip_atomic_fetch_add(w, 1u << DONE_SH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // this block is done with the word
+        if ((old >> DONE_SH) == (unsigned)p.splits - 1) __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        *flag = (int)shares;
+    }
     __syncthreads();
-    if (*flag != p.splits - 1) return;
-    if (tid == 0) __hip_atomic_store(&p.tickets[tile_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-    constexpr int VPR = BN / 4;
+    unsigned shares = (unsigned)*flag;
+    if (!shares) return;
+    constexpr int VPR = BN / 4, NV = BM * VPR;
     const long MN = (long)p.M * p.N;
     const float* __restrict__ P0 = p.partial + (long)zb * p.splits * MN;
     f16* __restrict__ C = p.C + zb * p.strideC;
     const f16* __restrict__ R = p.residual ? p.residual + zb * p.strideC : nullptr;
-    for (int v = tid; v < BM * VPR; v += nthr) {
-        const int r = v / VPR, m = m0 + r, n = n0 + (v - r * VPR) * 4;
-        if (m >= p.M || n >= p.N) continue;
-        const float* src = P0 + (long)m * p.N + n;
-        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-        for (int s0 = 0; s0 < p.splits; s0 += 4) {
-            f32x4 part[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const float* a = src + (long)min(s0 + u, p.splits - 1) * MN;
-                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[u]) : "v"(a) : "memory");
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                asm volatile("" : "+v"(part[u]));
-                if (s0 + u < p.splits) sum += part[u];
-            }
+    const int chunk = (NV + p.splits - 1) / p.splits;
+    while (shares) {
+        const int z = __builtin_ctz(shares);
+        shares &= shares - 1;
+        const int vbeg = z * chunk, vend = min(NV, vbeg + chunk);
+        if (vbeg >= vend) continue;
+        // 8 slab loads in flight per thread (32 VGPRs: the fold must not raise the register count of the kernel it rides in), shaped by the slice
+        // count (any shape is correct for any count); a share is tile / splits, so that is one round trip for the 64-wide tiles, two for 128 x 128
+        if (p.xcd_local) {
+            if (p.splits <= 2) splitk_fold_share<4, 2, VPR, true>(p, P0, C, R, MN, m0, n0, vbeg, vend, tid, nthr);
+            else if (p.splits <= 4) splitk_fold_share<2, 4, VPR, true>(p, P0, C, R, MN, m0, n0, vbeg, vend, tid, nthr);
+            else splitk_fold_share<1, 8, VPR, true>(p, P0, C, R, MN, m0, n0, vbeg, vend, tid, nthr);
+        } else {
+            if (p.splits <= 2) splitk_fold_share<4, 2, VPR, false>(p, P0, C, R, MN, m0, n0, vbeg, vend, tid, nthr);
+            else if (p.splits <= 4) splitk_fold_share<2, 4, VPR, false>(p, P0, C, R, MN, m0, n0, vbeg, vend, tid, nthr);
+            else splitk_fold_share<1, 8, VPR, false>(p, P0, C, R, MN, m0, n0, vbeg, vend, tid, nthr);
         }
-        if (p.bias) {
-            if (p.bias_f32) sum += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
-            else {
-                f16x4 bv = *reinterpret_cast<const f16x4*>((const f16*)p.bias + n);
-#pragma unroll
-                for (int e = 0; e < 4; e++) sum[e] += (float)bv[e];
-            }
-        }
-        if (p.rowbias) {
-            f16x4 rb = *reinterpret_cast<const f16x4*>(p.rowbias + (long)(m / p.rb_rows) * p.rb_ld + n);
-#pragma unroll
-            for (int e = 0; e < 4; e++) sum[e] += (float)rb[e];
-        }
-        if (R) {
-            f16x4 rv = *reinterpret_cast<const f16x4*>(R + (long)m * p.N + n);
-#pragma unroll
-            for (int e = 0; e < 4; e++) sum[e] += (float)rv[e];
-        }
-        f16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; e++) o[e] = (f16)osg_apply_act(sum[e], p.act);
-        *reinterpret_cast<f16x4*>(C + (long)m * p.N + n) = o;
     }
 }
 
 int launch_splitk_reduce(osg_ctx* ctx, const GemmParams& p, int batch);   // osg_gemm.hip
+// OSG_SPLITK_TICKET=1: fold the slabs in the kernel (splitk_finish) instead of with a reduce launch; read per launch (a captured plan keeps what it was
+// captured with)
+inline int splitk_fold_wait() {   // OSG_SPLITK_WAIT: dev knob (0 = nobody waits: the last arriver folds the whole tile)
+    const char* e = getenv("OSG_SPLITK_WAIT");
+    return e ? atoi(e) : 500;
+}
+// = 0: reduce launch; 1: in-kernel fold over write-through slabs (any XCD); 2: in-kernel fold, XCD-local (needs ctx->xcd_rr, else behaves as 0)
+inline int splitk_ticket_mode() {
+    const char* e = getenv("OSG_SPLITK_TICKET");
+    return e ? atoi(e) : 0;
+}
+// sets p.tickets / p.xcd_local / ... for a split launch of n_tiles output tiles
+inline void splitk_route(osg_ctx* ctx, GemmParams& p, long n_tiles) {
+    p.tickets = nullptr;
+    p.xcd_local = 0;
+    const int mode = splitk_ticket_mode();
+    if (mode == 0 || p.splits < 2 || p.N % 4 != 0 || p.splits > 16 || !ctx->tickets || n_tiles + 8 > osg_ctx::kTickets / 2) return;
+    if (mode == 2 && !ctx->xcd_rr) return;
+    p.tickets = ctx->tickets;
+    p.fold_wait = splitk_fold_wait();
+    if (mode == 2) {
+        p.xcd_local = 1;
+        p.xcc_map = ctx->xcc_map;
+        p.xcd_err = ctx->xcd_err_dev;
+    }
+}
 
 }  // namespace osg_mm
 

@@ -424,7 +424,7 @@ def test_uint8_arithmetic_plans_on_cpu_and_qdq_is_rejected_loudly():
             m.add_tensor("input.1", z["z"])
             m.run()
             kinds = [r.split(" | ")[1] for r in m.hip_plan_info().splitlines() if r.startswith("step ")]
-            assert sum(k.startswith("Conv qu8") for k in kinds) == 22 and sum(k.startswith("InstanceNorm qu8") for k in kinds) == 18
+            assert sum(k.startswith("Conv qu8") for k in kinds) == 22 and sum(k.startswith(("InstanceNorm qu8", "NormAffineAct qu8")) for k in kinds) == 18
             assert list(m.get_tensor("out_image")[1]) == [1, 3, 64, 64]
             m.clear_tensors()
             m.add_tensor("input.1", z["z"])

@@ -210,6 +210,46 @@ def test_conv3x3_halo_kernel(gpu, N, H, Cin, Cout, bn, splits, monkeypatch):
     assert rel_max(got, want) <= 1e-3
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("M,N,K,splits,cfg,batch", [(512, 1280, 5120, 8, 2, 1), (128, 1280, 1280, 4, 2, 1), (2048, 320, 1280, 2, 0, 1), (300, 100, 2048, 5, 1, 1),
+                                                    (64, 640, 10240, 16, 2, 1), (77, 320, 2048, 3, 3, 2), (16384, 320, 1280, 2, 2, 1)])
+def test_splitk_fold_in_the_kernel_equals_the_reduce_launch(gpu, M, N, K, splits, cfg, batch, mode, monkeypatch):
+    """OSG_SPLITK_TICKET=1 / 2 (the k-slice blocks of a tile fold the f32 slabs themselves, osg_gemm_common.h splitk_finish; 1: slabs written through to
+    memory, 2: the slices of a tile on one XCD, slabs exchanged through its L2) gives the bits of the separate reduce launch -- every tile, slice count up to 16, ragged M / N, bias + residual, the batched form, and again on the
+    next launches (the tile words are left zeroed); the last case has more blocks than the GPU holds at once (bounded wait -> abandoned shares)."""
+    monkeypatch.setenv("OSG_GEMM_SPLITS", str(splits))
+    monkeypatch.setenv("OSG_GEMM_CFG", str(cfg))
+    rng = np.random.default_rng(M + N + K)
+    a = rnd(rng, (batch, M, K)) if batch > 1 else rnd(rng, (M, K))
+    w, bias, res = rnd(rng, (K, N), K ** -0.5), rnd(rng, (N,), 0.1), rnd(rng, a.shape[:-1] + (N,))
+    da, dw, db, dr = gpu.to_dev(a), gpu.to_dev(w), gpu.to_dev(bias), gpu.to_dev(res)
+    monkeypatch.setenv("OSG_SPLITK_TICKET", "0")
+    want = gpu.gemm(da, dw, db, dr).numpy()
+    assert rel_max(want, ref.matmul(a.reshape(-1, K), w, bias, residual=res.reshape(-1, N)).reshape(want.shape)) <= 1e-3
+    monkeypatch.setenv("OSG_SPLITK_TICKET", mode)
+    for _ in range(4):
+        got = gpu.gemm(da, dw, db, dr).numpy()
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout,bn,splits", [(1, 64, 128, 160, 160, 2), (2, 32, 192, 128, 128, 3), (2, 16, 1280, 320, 80, 10), (1, 8, 2560, 1280, 80, 16),
+                                                    (3, 8, 192, 128, 128, 3)])
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_conv3x3_splitk_fold_in_the_kernel_equals_the_reduce_launch(gpu, N, H, Cin, Cout, bn, splits, mode, monkeypatch):
+    monkeypatch.setenv("OSG_CONV3X3_BN", str(bn))
+    monkeypatch.setenv("OSG_CONV3X3_SPLITS", str(splits))
+    rng = np.random.default_rng(N * 131 + H * 7 + Cin + Cout)
+    x, w = rnd(rng, (N, H, H, Cin)), rnd(rng, (Cout, 3, 3, Cin), (9 * Cin) ** -0.5)
+    bias, res, ib = rnd(rng, (Cout,), 0.1), rnd(rng, (N, H, H, Cout)), rnd(rng, (N, Cout), 0.5)
+    dx, dw, db, dr, di = gpu.to_dev(x), gpu.to_dev(w), gpu.to_dev(bias), gpu.to_dev(res), gpu.to_dev(ib)
+    monkeypatch.setenv("OSG_SPLITK_TICKET", "0")
+    want = gpu.conv2d_nhwc(dx, dw, db, 1, (1, 1, 1, 1), dr, image_bias=di).numpy()
+    monkeypatch.setenv("OSG_SPLITK_TICKET", mode)
+    for _ in range(4):
+        got = gpu.conv2d_nhwc(dx, dw, db, 1, (1, 1, 1, 1), dr, image_bias=di).numpy()
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+
+
 @pytest.mark.parametrize("N,H,Cin,Cout,bn,splits", [(2, 64, 64, 320, 80, 1), (1, 32, 128, 160, 160, 2), (2, 16, 192, 128, 128, 3),
                                                     (2, 8, 128, 80, 80, 1), (3, 8, 64, 160, 160, 1), (2, 64, 320, 320, 0, 0)])
 def test_group_norm_conv3x3_fused(gpu, N, H, Cin, Cout, bn, splits, monkeypatch):
