@@ -46,6 +46,61 @@ __global__ __launch_bounds__(256) void fill_kernel(const char* __restrict__ buf,
     if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) sink[tid] = acc[0] + smem[tid];
 }
 
+// The GEMM's pattern: a wave-instruction fetches 8 ROWS x 128 B (row stride S bytes, the k extent of a row-major operand), a workgroup 256 rows per
+// k-tile, the next k-tile sits 128 B further along every row.  All workgroups read ONE 256-row panel (the shared-operand case; it stays in the L2).
+// DMA = true: buffer_load ... lds, false: into VGPRs.
+template <bool DMA>
+__global__ __launch_bounds__(256) void fill_rows_kernel(const char* __restrict__ buf, float* __restrict__ sink, int S, int panels) {
+    extern __shared__ char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const char* base = buf + (size_t)(blockIdx.x % panels) * 256 * S;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 256 * S, 0x00020000);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int kts = S / 128;
+    int kt = blockIdx.x % kts;   // (workgroups start at different k-tiles, as tiles of different layers' progress would)
+    for (int it = 0; it < kIters; it++) {
+        f32x4 r[16];
+        unsigned soff = 0;
+        asm volatile("" : "+s"(soff));
+#pragma unroll
+        for (int j = 0; j < 16; j++) {   // two k-tiles per sweep: 2 x 8 instructions per wave = 64 KiB per workgroup
+            const int k2 = kt + (j >> 3) < kts ? kt + (j >> 3) : 0;
+            const unsigned off = (unsigned)((wave * 64 + (j & 7) * 8 + (lane >> 3)) * S + k2 * 128 + (lane & 7) * 16);
+            if (DMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(smem + (wave * 8 + (j & 7)) * 1024), 16, off, soff, 0, 0);
+            else r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, soff, 0);
+        }
+        if (!DMA) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc += r[j];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        kt = kt + 2 < kts ? kt + 2 : 0;
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) sink[tid] = acc[0] + smem[tid];
+}
+
+template <bool DMA>
+static void run_rows(const char* d, float* sink, int blocks, int cus, double ghz, int S, int panels, bool lockstep) {
+    auto k = fill_rows_kernel<DMA>;
+    hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 32768, 0, d, sink, S, panels);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 32768, 0, d, sink, S, panels);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = (double)blocks * kIters * (double)kWindow;
+    const double active = blocks < cus ? blocks : cus;
+    printf("%-8s 8 rows x 128 B per instruction, row stride %6d B, %d panel(s) of 256 rows  blocks %4d: %7.3f ms  %7.2f TB/s  %6.1f B/clk per active CU\n", DMA ? "LDS-DMA" : "VGPR", S,
+           panels, blocks, ms, bytes / ms * 1e-9, bytes / (ms * 1e-3) / (ghz * 1e9) / active);
+    (void)lockstep;
+}
+
 template <int MODE>
 static void run(const char* what, const char* d, float* sink, int blocks, int cus, double ghz) {
     auto k = fill_kernel<MODE>;
@@ -87,5 +142,15 @@ int main() {
         run<3>("VGPR, the 4 waves share their addresses", d, sink, blocks, cus, ghz);
         run<4>("LDS-DMA, the 4 waves share their addresses", d, sink, blocks, cus, ghz);
     }
+    printf("\n");
+    char* d2;
+    hipMalloc((void**)&d2, (size_t)8 * 256 * 20480);
+    hipMemset(d2, 1, (size_t)8 * 256 * 20480);
+    for (int blocks : {cus, 2 * cus})
+        for (int S : {640, 2560, 5120, 10240, 10240 + 128, 20480}) {
+            run_rows<true>(d2, sink, blocks, cus, ghz, S, 1, false);
+            run_rows<false>(d2, sink, blocks, cus, ghz, S, 1, false);
+            run_rows<true>(d2, sink, blocks, cus, ghz, S, 8, false);
+        }
     return 0;
 }
