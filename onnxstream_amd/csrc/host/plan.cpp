@@ -2912,6 +2912,38 @@ struct Lowering {
 
     // Expand (reference :7154-7230): numpy-style broadcast of the input to `shape` (a plan-time int64 vector).  On the device: x * ones, where
     // `ones` has the target extent in every dimension the input stretches (x * 1 is exact for every f16 value, the sign of zero included)
+    // Expand [1,Hkv,1,S,d] -> [1,Hkv,rep,S,d] whose result reaches nothing but the key / value input of ScaledDotProductAttention ops, through Reshapes
+    // (to [1,Hkv*rep,S,d]): the transformers `repeat_kv` of a grouped-query model.  Such an Expand is not launched (lower_sdpa reads its source).
+    bool repeat_kv_only(const Operation& op, const Shape& xs, const Shape& os) {
+        if (!P.sdp_attn || os.size() != 5 || xs.size() != 5 || os[0] != 1 || xs[2] != 1 || os[2] < 2) return false;
+        for (int k : {0, 1, 3, 4})
+            if (xs[k] != os[k]) return false;
+        auto consumers_of = [&](const std::string& name) {
+            std::vector<std::pair<int, int>> c;   // (op, input slot)
+            for (size_t i = 0; i < ops().size(); i++) {
+                if (!dead.empty() && dead[i]) continue;
+                for (size_t k = 0; k < ops()[i].m_input.size(); k++)
+                    if (ops()[i].m_input[k].m_name == name) c.push_back({(int)i, (int)k});
+            }
+            return c;
+        };
+        for (auto& e : P.extra_outputs)
+            if (e == op.m_output[0].m_name) return false;
+        const auto c1 = consumers_of(op.m_output[0].m_name);
+        if (c1.empty()) return false;
+        for (auto [ri, rk] : c1) {
+            const Operation& r = ops()[ri];
+            if (r.m_type != "Reshape" || rk != 0 || r.m_output.size() != 1) return false;
+            for (auto& e : P.extra_outputs)
+                if (e == r.m_output[0].m_name) return false;
+            const auto c2 = consumers_of(r.m_output[0].m_name);
+            if (c2.empty()) return false;
+            for (auto [si, sk] : c2)
+                if (ops()[si].m_type != "ScaledDotProductAttention" || (sk != 1 && sk != 3)) return false;
+        }
+        return true;
+    }
+
     void lower_expand(const Operation& op) {
         need(op, op.m_input.size() == 2, "wrong number of inputs.");
         need(op, op.m_output.size() == 1, "wrong number of outputs.");
@@ -2933,6 +2965,11 @@ struct Lowering {
             if (xs[k] == 1 && ts[k] > 1) on[k] = ts[k];
         }
         const int y = out_val(op, os, Lay::plain, V(x).batched);
+        if (repeat_kv_only(op, xs, os)) {   // grouped-query attention's repeat_kv: the attention kernel maps query head h to kv head h / rep itself
+            V(y).rep_src = x;
+            V(y).rep = os[2];
+            return;
+        }
         const size_t prank = os.size() + 1;
         need(op, prank <= 6, "rank too large for the device broadcast kernel.");
         const long n_ones = prod(on);
@@ -3164,8 +3201,16 @@ struct Lowering {
     void lower_sdpa(const Operation& op) {
         need(op, op.m_input.size() == 4, "wrong number of inputs.");
         need(op, op.m_output.size() == 1, "wrong number of outputs.");
-        const int q = P.ensure_plain(in_val(op.m_input[0])), k = P.ensure_plain(in_val(op.m_input[1])), mk = P.ensure_plain(in_val(op.m_input[2])),
-                  v = P.ensure_plain(in_val(op.m_input[3]));
+        // key / value: a virtual repeat_kv Expand (lower_expand) is read at its source, with the un-repeated head count
+        auto kv_operand = [&](const Tensor& t) {
+            const int v0 = in_val(t), r = P.root_of(v0);
+            if (V(r).rep_src < 0) return P.ensure_plain(v0);
+            const int src = P.ensure_plain(V(r).rep_src);
+            const Shape ss = V(src).shape, es = V(v0).shape;   // [1,Hkv,1,S,d] and [1,Hkv*rep,S,d]
+            need(op, es.size() == 4 && ss.size() == 5 && es[0] == 1 && es[1] == ss[1] * V(r).rep && es[2] == ss[3] && es[3] == ss[4], "invalid shape of key or value.");
+            return P.alias(src, Shape{1, ss[1], ss[3], ss[4]}, Lay::plain);
+        };
+        const int q = P.ensure_plain(in_val(op.m_input[0])), k = kv_operand(op.m_input[1]), mk = P.ensure_plain(in_val(op.m_input[2])), v = kv_operand(op.m_input[3]);
         const Shape qs = V(q).shape, ks = V(k).shape, vs = V(v).shape, ms = V(mk).shape;
         need(op, qs.size() == 4, "invalid shape of query.");
         need(op, ks.size() == 4, "invalid shape of key.");
@@ -3382,6 +3427,20 @@ struct Lowering {
             return;
         }
         x = P.ensure_plain(x);
+        {   // a permutation that only moves dimensions of extent 1 leaves the memory image as it is (the head split / merge of a ONE-token decode step:
+            // [1,1,H,d] <-> [1,H,1,d]): zero-copy, like a Reshape
+            int prev = -1;
+            bool same_image = V(x).ld == 0 && V(x).dtype != OSG_U8;
+            for (size_t i = 0; same_image && i < perm.size(); i++) {
+                if (s[perm[i]] == 1) continue;
+                if (perm[i] < prev) same_image = false;
+                prev = perm[i];
+            }
+            if (same_image) {
+                P.alias(x, os, Lay::plain, op.m_output[0].m_name);
+                return;
+            }
+        }
         int y = P.new_val(op.m_output[0].m_name, os, V(x).dtype, Lay::plain, V(x).batched);
         const int rank = (int)s.size() + 1;
         need(op, rank <= 6, "rank too large.");
@@ -3696,7 +3755,7 @@ void Plan::build() {
         const bool cacheable = m.m_support_dynamic_shapes && !stream_weights;
         if (cacheable) {
             key = std::to_string(fusion) + "|" + std::to_string(m.m_hip_fusion_level) + (u8 ? "|u8" : "|f") + (fuse_attn ? "a" : "-") + (sdp_attn ? "s" : "-") + (fuse_ln_gemm ? "l" : "-") +
-                  (fuse_gn_conv ? "g" : "-") + "|" + std::to_string(m.m_attention_fused_ops_parts) + "|";
+                  (fuse_gn_conv ? "g" : "-") + "|" + std::to_string(m.m_attention_fused_ops_parts) + "|" + std::to_string(m.m_ops.size()) + "|";
             for (auto& e : extra_outputs) key += e + ",";
             key += "|";
             if (m.m_requires_upcast)

@@ -49,6 +49,10 @@ struct Val {
     int qsrc = -1;                // >= 0: the val whose (qscale, qzp) this one shares (Reshape / Transpose / Resize carry them over) -- read at RUN time
     bool qdyn = false;            // parameters change from run to run (a pushed input and what merely re-arranges it)
     int as_nk_u8 = -1;            // [N,K] twin of a [K,N] uint8 matrix
+    // a VIRTUAL Expand (grouped-query attention's repeat_kv: [1,Hkv,1,S,d] -> [1,Hkv,rep,S,d], read only by ScaledDotProductAttention through a Reshape):
+    // never materialised -- the attention launch reads `rep_src` with Hkv heads (plan.cpp lower_expand / lower_sdpa)
+    int rep_src = -1;
+    long rep = 1;
     long numel() const { long n = 1; for (auto d : shape) n *= d; return n; }
 };
 
