@@ -12,6 +12,9 @@
 
 #include "backend.h"
 #include "plan.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace onnxstream {
 
@@ -272,7 +275,13 @@ void Model::run() {
             batch = s;
         }
     }
+    static const bool timing = std::getenv("OSG_PLAN_TIMING") != nullptr;   // host milliseconds of a call's parts (the LLM flow re-plans on every call)
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
     if (m_plan && !m_plan->compatible(*this, batch)) hip_invalidate_plan();
+    const auto t1 = now();
+    const bool rebuilt = !m_plan;
     if (!m_plan) {
         if (!m_pool) m_pool = new ConstPool();
         m_plan = new Plan(*this, *m_backend, *m_pool, batch);
@@ -283,7 +292,9 @@ void Model::run() {
             throw;
         }
     }
+    const auto t2 = now();
     m_plan->execute();
+    if (timing && rebuilt) fprintf(stderr, "[run] drop the old plan %.2f ms, new plan %.2f ms, execute %.2f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, now()));
     m_last_kernels = m_plan->kernel_count();
     m_last_ms = m_plan->last_ms();
 }

@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstring>
 #include <thread>
+#include <string_view>
 #include <unordered_map>
+#include <unordered_set>
 
 namespace onnxstream {
 
@@ -110,6 +112,7 @@ Plan::Plan(Model& model, HipBackend& backend, ConstPool& cpool, size_t batch) : 
     outputs_convert_set = m.m_outputs_convert_set;
     side_stream = m.m_hip_side_stream && !stream_weights;
     extra_outputs = m.m_extra_outputs;
+    recycle = m.m_support_dynamic_shapes && !stream_weights;
 }
 
 bool Plan::compatible(Model& mm, size_t batch) const {
@@ -219,12 +222,25 @@ void* Plan::small_alloc(size_t bytes) {
     }
     if (need > slab_left) {
         slab_left = (size_t)8 << 20;
-        slab = (char*)be.malloc(slab_left);
-        owned.push_back(slab);
+        slab = (char*)pooled_malloc(slab_left);
     }
     void* p = slab;
     slab += need;
     slab_left -= need;
+    return p;
+}
+
+// a buffer that returns to the Model's pool when this plan goes (models that re-plan on every call), else an owned allocation
+void* Plan::pooled_malloc(size_t bytes) {
+    if (!recycle) {
+        void* p = be.malloc(bytes);
+        owned.push_back(p);
+        return p;
+    }
+    size_t have = bytes;   // (a spare may be larger than asked for: it goes back with its real size)
+    void* p = pool.take(bytes, &have);
+    if (!p) p = be.malloc(bytes);
+    recyclable.push_back({p, have});
     return p;
 }
 
@@ -394,16 +410,23 @@ struct Lowering {
         // again -- it is exhausted by now and, with m_use_ops_cache, no longer holds the weights.  Only when a different device format
         // is wanted (fp16 arithmetic / hip_w8_resident toggled) the whole sequence is pulled once more, from a restarted provider.
         bool fetch_all = true;
+        std::vector<Occ> resolved;   // of the pool check below, reused by the main loop (a plan of the LLM flow is rebuilt on every call)
         if (use_pool && pool.complete) {
             fetch_all = false;
             size_t occ = 0;
+            resolved.reserve(pool.occ_types.size());
             for (auto& op : ops())
                 for (size_t i = 0; i < op.m_input.size() && !fetch_all; i++) {
                     const Tensor& t = op.m_input[i];
                     if (!is_const_tensor(t)) continue;
-                    if (occ >= pool.occ_types.size() || !pool.base.count(resolve(op, i, t, pool.occ_types[occ]).key)) fetch_all = true;
+                    if (occ >= pool.occ_types.size()) fetch_all = true;
+                    else {
+                        resolved.push_back(resolve(op, i, t, pool.occ_types[occ]));
+                        if (!pool.base.count(resolved.back().key)) fetch_all = true;
+                    }
                     occ++;
                 }
+            if (fetch_all) resolved.clear();
             if (fetch_all) {
                 wp->on_restart();
                 pool.occ_types.clear();
@@ -423,7 +446,8 @@ struct Lowering {
                 } else
                     ty = pool.occ_types[occ];
                 occ++;
-                const Occ o = resolve(op, i, t, ty);
+                const Occ o_fresh = fetch_all ? resolve(op, i, t, ty) : Occ{};
+                const Occ& o = fetch_all ? o_fresh : resolved[occ - 1];
                 const std::string& fn = o.fn;
                 const osg_dtype want = o.want;
                 const long count = o.count;
@@ -3642,7 +3666,8 @@ Plan::~Plan() {
     if (ring) be.free(ring);
     delete lowering;
     for (void* p : owned) be.free(p);
-    if (arena) be.free(arena);
+    for (auto& r : recyclable) pool.give(be, r.first, r.second);   // (the device is idle: osg_sync above)
+    if (arena && !arena_pooled) be.free(arena);
 }
 
 void Plan::build() {
@@ -3662,29 +3687,50 @@ void Plan::build() {
         fusion = 0;      // every op re-quantises to its own (scale, zero point): fusing ops would change codes
     }
     be.check(be.api.osg_set_autotune(be.ctx, m.m_hip_autotune ? 1 : 0), "osg_set_autotune");
-    ops = m.m_ops;
-    vals.reserve(ops.size() * 12 + 1024);  // belt and braces: lowering code copies shapes, never holds Val& across new_val
-    lowering = new Lowering(*this);
-    Lowering& L = *lowering;
     // OSG_PLAN_TIMING=1: host milliseconds of the plan-building phases on stderr (the LLM flow re-plans on every call)
     static const bool timing = std::getenv("OSG_PLAN_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
     const auto t_begin = now();
-    L.load_weights();
+    vals.reserve(m.m_ops.size() * 12 + 1024);  // belt and braces: lowering code copies shapes, never holds Val& across new_val
+    lowering = new Lowering(*this);
+    Lowering& L = *lowering;
+    // models that re-plan on every call (m_support_dynamic_shapes: the LLM flow) reuse two things across plans, both kept in the Model's pool and both
+    // functions of the graph, its constants and the options named in `key` only: the op list AFTER the fusion passes, and the constant vals that
+    // load_weights() makes of the pool's resident weights (`snap_vals`: ~160 vals of a 22-layer Llama, ~1 ms to rebuild, ~0.1 ms to copy)
+    std::string key;
+    const bool cacheable = m.m_support_dynamic_shapes && !stream_weights && !budgeted;
+    if (cacheable) {
+        key = std::to_string(fusion) + "|" + std::to_string(m.m_hip_fusion_level) + (u8 ? "|u8" : "|f") + (fp16 ? "h" : "-") + (w8_resident ? "8" : "-") + (fuse_attn ? "a" : "-") +
+              (sdp_attn ? "s" : "-") + (fuse_ln_gemm ? "l" : "-") + (fuse_gn_conv ? "g" : "-") + "|" + std::to_string(m.m_attention_fused_ops_parts) + "|" + std::to_string(m.m_ops.size()) + "|";
+        for (auto& e : extra_outputs) key += e + ",";
+        key += "|";
+        if (m.m_requires_upcast)
+            for (auto& op : m.m_ops) key += m.m_requires_upcast(op.m_type, op.m_name) ? '1' : '0';
+    }
+    const bool reuse = cacheable && pool.complete && pool.fused_valid && pool.fused_key == key && pool.snap_vals.size() == pool.fused_const_vals && !pool.snap_vals.empty();
+    if (reuse) {
+        vals.assign(pool.snap_vals.begin(), pool.snap_vals.end());
+        weight_bytes = pool.snap_weight_bytes;
+        ops = pool.fused_ops;
+        L.dead.assign(ops.size(), 0);
+    } else {
+        ops = m.m_ops;
+        L.load_weights();
+    }
     const double t_weights = ms_since(t_begin);
     const size_t n_const_vals_after_load = vals.size();     // (weights are the first vals of every plan of a Model, in model order)
 
     // ---- graph inputs: every activation name that is consumed but never produced --------------------------------
     {
-        std::map<std::string, bool> produced;
-        for (auto& op : ops)
-            for (auto& o : op.m_output) produced[o.m_name] = true;
-        std::map<std::string, bool> seen;
-        for (auto& op : ops)
+        std::unordered_set<std::string_view> produced, seen;   // (views into the Model's own op list: the same activation names whatever `ops` holds by now)
+        produced.reserve(m.m_ops.size() * 2);
+        for (auto& op : m.m_ops)
+            for (auto& o : op.m_output) produced.insert(o.m_name);
+        for (auto& op : m.m_ops)
             for (auto& in : op.m_input) {
                 if (in.m_name.empty() || in.m_type != TensorDataType::none || produced.count(in.m_name) || seen.count(in.m_name)) continue;
-                seen[in.m_name] = true;
+                seen.insert(in.m_name);
                 Tensor* src = nullptr;
                 for (auto& t : m.m_data)
                     if (t.m_name == in.m_name) { src = &t; break; }
@@ -3749,29 +3795,17 @@ void Plan::build() {
             }
     }
 
+    const double ms_inputs = ms_since(t_begin) - t_weights;
     const auto t_fuse = now();
-    {
-        std::string key;
-        const bool cacheable = m.m_support_dynamic_shapes && !stream_weights;
+    if (!reuse) {
+        if (cacheable) pool.snap_vals.assign(vals.begin(), vals.begin() + n_const_vals_after_load);   // (before the lowering hangs re-laid-out twins on them)
+        L.run_fusions();
         if (cacheable) {
-            key = std::to_string(fusion) + "|" + std::to_string(m.m_hip_fusion_level) + (u8 ? "|u8" : "|f") + (fuse_attn ? "a" : "-") + (sdp_attn ? "s" : "-") + (fuse_ln_gemm ? "l" : "-") +
-                  (fuse_gn_conv ? "g" : "-") + "|" + std::to_string(m.m_attention_fused_ops_parts) + "|" + std::to_string(m.m_ops.size()) + "|";
-            for (auto& e : extra_outputs) key += e + ",";
-            key += "|";
-            if (m.m_requires_upcast)
-                for (auto& op : m.m_ops) key += m.m_requires_upcast(op.m_type, op.m_name) ? '1' : '0';
-        }
-        if (cacheable && pool.fused_valid && pool.fused_key == key && pool.fused_const_vals == n_const_vals_after_load) {
-            ops = pool.fused_ops;
-            L.dead.assign(ops.size(), 0);
-        } else {
-            L.run_fusions();
-            if (cacheable) {
-                pool.fused_ops = ops;
-                pool.fused_key = key;
-                pool.fused_const_vals = n_const_vals_after_load;
-                pool.fused_valid = true;
-            }
+            pool.fused_ops = ops;
+            pool.fused_key = key;
+            pool.fused_const_vals = n_const_vals_after_load;
+            pool.snap_weight_bytes = weight_bytes;
+            pool.fused_valid = true;
         }
     }
     const double ms_fuse = ms_since(t_fuse);
@@ -3781,10 +3815,11 @@ void Plan::build() {
 
     // ---- graph outputs: produced but never consumed, plus the caller's extra outputs -> fp32, logical layout --------
     {
-        std::map<std::string, int> consumed;
+        std::unordered_set<std::string_view> consumed;
+        consumed.reserve(ops.size() * 3);
         for (auto& op : ops)
             for (auto& in : op.m_input)
-                if (!in.m_name.empty() && in.m_type == TensorDataType::none) consumed[in.m_name]++;
+                if (!in.m_name.empty() && in.m_type == TensorDataType::none) consumed.insert(in.m_name);
         std::vector<std::string> names;
         for (auto& op : ops)
             for (auto& o : op.m_output)
@@ -3852,6 +3887,7 @@ void Plan::build() {
             for (int v : steps[si].reads)
                 if (v >= 0 && qv(v).qdyn) dyn_end = si + 1;
     }
+    const double ms_outputs = ms_since(t_lower) - ms_lower;
     const auto t_pack = now();
     // ---- liveness + arena packing -----------------------------------------------------------------------------------
     for (size_t si = 0; si < steps.size(); si++)
@@ -3944,11 +3980,15 @@ void Plan::build() {
         ring = be.malloc(ring_bytes);
     }
     arena_bytes = top ? top : 256;
-    arena = be.malloc(arena_bytes);
+    if (recycle) {
+        arena = pooled_malloc(arena_bytes);
+        arena_pooled = true;
+    } else
+        arena = be.malloc(arena_bytes);
     be.check(be.api.osg_sync(be.ctx), "osg_sync");
     if (timing)
-        fprintf(stderr, "[plan] %zu ops -> %zu steps: weights %.2f ms, fusions %.2f ms, lowering %.2f ms, liveness + packing + arena %.2f ms, whole build %.2f ms (arena %.1f MB)\n", ops.size(),
-                steps.size(), t_weights, ms_fuse, ms_lower, ms_since(t_pack), ms_since(t_begin), arena_bytes / 1e6);
+        fprintf(stderr, "[plan] %zu ops -> %zu steps: weights %.2f ms, fusions %.2f ms, lowering %.2f ms, liveness + packing + arena %.2f ms, whole build %.2f ms (arena %.1f MB; graph inputs %.2f ms, outputs %.2f ms)\n", ops.size(),
+                steps.size(), t_weights, ms_fuse, ms_lower, ms_since(t_pack), ms_since(t_begin), arena_bytes / 1e6, ms_inputs, ms_outputs);
 }
 
 void Plan::run_steps(size_t begin, size_t end) {

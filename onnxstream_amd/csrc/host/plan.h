@@ -12,6 +12,7 @@
 
 #include <functional>
 #include <map>
+#include <unordered_map>
 #include <set>
 #include <string>
 #include <vector>
@@ -92,12 +93,39 @@ struct ConstPool {
     std::vector<Operation> fused_ops;
     size_t fused_const_vals = 0;
     bool fused_valid = false;
+    std::vector<Val> snap_vals;              // the constant vals load_weights() builds from `base`, as they are right after it (same validity as fused_ops)
+    size_t snap_weight_bytes = 0;
+    // device buffers (arena, small-allocation slabs) of a destroyed plan of such a model, handed to the next one: a hipMalloc + hipFree pair per buffer
+    // and call otherwise
+    std::vector<std::pair<void*, size_t>> spare;
+    void* take(size_t bytes, size_t* got) {
+        int best = -1;
+        for (size_t i = 0; i < spare.size(); i++)
+            if (spare[i].second >= bytes && (best < 0 || spare[i].second < spare[best].second)) best = (int)i;
+        if (best < 0 || spare[best].second > 4 * bytes + ((size_t)8 << 20)) return nullptr;   // (no 1 GiB arena for a 1 MiB request)
+        void* p = spare[best].first;
+        *got = spare[best].second;
+        spare.erase(spare.begin() + best);
+        return p;
+    }
+    void give(HipBackend& be, void* p, size_t bytes) {
+        if (spare.size() >= 8) {   // keep the newest: drop the smallest
+            size_t k = 0;
+            for (size_t i = 1; i < spare.size(); i++)
+                if (spare[i].second < spare[k].second) k = i;
+            be.free(spare[k].first);
+            spare.erase(spare.begin() + k);
+        }
+        spare.push_back({p, bytes});
+    }
     void clear(HipBackend& be) {
         for (auto& kv : base) be.free(kv.second.dptr);
         for (auto& kv : derived) be.free(kv.second.first);
+        for (auto& sp : spare) be.free(sp.first);
+        spare.clear();
         base.clear(); derived.clear(); occ_types.clear();
         complete = false; bytes = 0;
-        fused_valid = false; fused_ops.clear(); fused_key.clear();
+        fused_valid = false; fused_ops.clear(); fused_key.clear(); snap_vals.clear(); snap_weight_bytes = 0;
     }
 };
 
@@ -135,9 +163,12 @@ struct Plan {
 
     std::vector<Operation> ops;  // working copy of the graph (mutated by the fusion passes)
     std::vector<Val> vals;
-    std::map<std::string, int> by_name;
+    std::unordered_map<std::string, int> by_name;
     std::vector<Step> steps;
     std::vector<void*> owned;     // device allocations owned by the plan (weights, staging, outputs)
+    std::vector<std::pair<void*, size_t>> recyclable;   // ... those that go back to the pool's spare list when the model re-plans on every call (slabs, arena)
+    bool recycle = false, arena_pooled = false;
+    void* pooled_malloc(size_t bytes);
     // small per-plan buffers (input staging, pinned outputs, index / ones / mask constants) are carved out of 8 MiB slabs: a plan of the LLM flow
     // has ~100 of them and is rebuilt on every call -- one hipMalloc each was 2/3 of the rebuild time
     void* small_alloc(size_t bytes);

@@ -443,7 +443,7 @@ def test_full_size_uint8_vae_plan(stub_backend, level):
         open(d + ".complete", "w").write("ok")
     m = Model(b.LIB_HOST, 0, "ram+nocache")
     m._set_option("hip_fusion_level", level)
-    m.hip_read_range_data(os.path.join(os.path.dirname(b.LIB_HOST), "synth", "data", cfg.name + "_qu8_range_data.txt"))
+    m.hip_read_range_data(os.path.join(os.path.dirname(os.path.abspath(b.__file__)), "synth", "data", cfg.name + "_qu8_range_data.txt"))
     m.set_use_uint8_arithmetic(True)
     m.read_file(d + "model.txt")
     m.add_tensor(cfg.in_name, sd_vae.vae_inputs(cfg)[cfg.in_name])
