@@ -3723,76 +3723,84 @@ void Plan::build() {
 
     // ---- graph inputs: every activation name that is consumed but never produced --------------------------------
     {
-        std::unordered_set<std::string_view> produced, seen;   // (views into the Model's own op list: the same activation names whatever `ops` holds by now)
-        produced.reserve(m.m_ops.size() * 2);
-        for (auto& op : m.m_ops)
-            for (auto& o : op.m_output) produced.insert(o.m_name);
-        for (auto& op : m.m_ops)
-            for (auto& in : op.m_input) {
-                if (in.m_name.empty() || in.m_type != TensorDataType::none || produced.count(in.m_name) || seen.count(in.m_name)) continue;
-                seen.insert(in.m_name);
-                Tensor* src = nullptr;
-                for (auto& t : m.m_data)
-                    if (t.m_name == in.m_name) { src = &t; break; }
-                if (!src) throw std::invalid_argument("Model::get_tensor_data: input tensor not found: " + in.m_name);
-                if (src->m_type != TensorDataType::float32 && src->m_type != TensorDataType::int64 && !(src->m_type == TensorDataType::float16 && fp16 && !u8))
-                    throw std::invalid_argument("Model::run: graph inputs must be float32, float16 (fp16 arithmetic) or int64 host tensors on the HIP backend (" + in.m_name + ").");
-                Shape shape = to_shape(src->m_shape);
-                In inp;
-                inp.name = in.m_name;
-                inp.host_type = src->m_type;
-                inp.shape = src->m_shape;
-                if (src->m_type == TensorDataType::int64) {
-                    // token ids / positions / masks of the LLM graphs: values known now, consumed by plan-time evaluation (Lowering::try_host_eval)
-                    if (u8 || N != 1) throw std::invalid_argument("Model::run: int64 graph inputs need one sample per pass and floating-point arithmetic (" + in.m_name + ").");
-                    auto& iv = src->get_vector<int64_t>();
-                    inp.ivals.assign(iv.begin(), iv.end());
-                    inp.staging = inp.val = new_val(in.m_name, shape, OSG_I64, Lay::plain, false);
-                    vals[inp.val].is_const = true;
-                    vals[inp.val].host_valid = vals[inp.val].host_only = true;
-                    vals[inp.val].host_i = inp.ivals;
-                    inputs.push_back(std::move(inp));
-                    continue;
+        // the names first -- a function of the graph alone, kept in the pool for the models that re-plan on every call
+        std::vector<std::string> found;
+        if (!(reuse && !pool.in_names.empty())) {
+            std::unordered_set<std::string_view> produced, seen;   // (views into the Model's own op list: the same activation names whatever `ops` holds by now)
+            produced.reserve(m.m_ops.size() * 2);
+            for (auto& op : m.m_ops)
+                for (auto& o : op.m_output) produced.insert(o.m_name);
+            for (auto& op : m.m_ops)
+                for (auto& in : op.m_input) {
+                    if (in.m_name.empty() || in.m_type != TensorDataType::none || produced.count(in.m_name) || seen.count(in.m_name)) continue;
+                    seen.insert(in.m_name);
+                    found.push_back(in.m_name);
                 }
-                if (src->m_type == TensorDataType::float16 && prod(shape) != 0) {
-                    // an output the caller kept in fp16 (m_outputs_convert_set excludes it) and feeds back under another name: the LLM app's
-                    // opkv* -> pkv* renaming (src/llm.cpp:403-407).  Uploaded as it is, no rounding step.
-                    if (N != 1) throw std::invalid_argument("Model::run: float16 graph inputs need one sample per pass (" + in.m_name + ").");
-                    inp.staging = inp.val = new_val(in.m_name, shape, OSG_F16, Lay::plain, true);
-                    vals[inp.val].dptr = small_alloc(val_bytes(inp.val));
-                    vals[inp.val].pinned = true;
-                    inputs.push_back(std::move(inp));
-                    continue;
-                }
-                if (prod(shape) == 0) {
-                    // an empty tensor (the first call of the LLM flow pushes zero-length key/value caches, src/llm.cpp:388-402): a val without storage
-                    inp.staging = inp.val = new_val(in.m_name, shape, u8 ? OSG_U8 : OSG_F16, Lay::plain, true);
-                    vals[inp.val].pinned = true;
-                    inputs.push_back(std::move(inp));
-                    continue;
-                }
-                if (u8) {
-                    // a pushed fp32 input is quantised with the 0.1 % percentiles of ITS OWN data (push_tensor -> Model::quantize, reference
-                    // :3024-3028, :3247): done on the host in execute(), the codes are uploaded, scale / zero point live in the val
-                    inp.staging = inp.val = new_val(in.m_name, shape, OSG_U8, Lay::plain, true);
-                    vals[inp.val].dptr = small_alloc(val_bytes(inp.val));
-                    vals[inp.val].pinned = true;
-                    vals[inp.val].qdyn = true;
-                    inputs.push_back(std::move(inp));
-                    continue;
-                }
-                inp.staging = new_val("", shape, OSG_F32, Lay::plain, true);
-                vals[inp.staging].dptr = small_alloc(val_bytes(inp.staging));
-                vals[inp.staging].pinned = true;
-                // fp32 inputs are rounded to f16 when pushed with fp16 arithmetic on (reference push_tensor :3029-3034)
-                inp.val = new_val(in.m_name, shape, OSG_F16, Lay::plain, true);
-                const int s = inp.staging, d = inp.val;
-                const long n = total_elems(d);
-                add_step("input " + in.m_name, {s}, {d}, [this, s, d, n] {
-                    be.check(be.api.osg_convert(be.ctx, OSG_F32, OSG_F16, ptr(s), ptr(d), n, 1.f, 0), "osg_convert");
-                });
+            if (cacheable) pool.in_names = found;
+        }
+        for (const std::string& iname : (reuse && !pool.in_names.empty()) ? pool.in_names : found) {
+            Tensor* src = nullptr;
+            for (auto& t : m.m_data)
+                if (t.m_name == iname) { src = &t; break; }
+            if (!src) throw std::invalid_argument("Model::get_tensor_data: input tensor not found: " + iname);
+            if (src->m_type != TensorDataType::float32 && src->m_type != TensorDataType::int64 && !(src->m_type == TensorDataType::float16 && fp16 && !u8))
+                throw std::invalid_argument("Model::run: graph inputs must be float32, float16 (fp16 arithmetic) or int64 host tensors on the HIP backend (" + iname + ").");
+            Shape shape = to_shape(src->m_shape);
+            In inp;
+            inp.name = iname;
+            inp.host_type = src->m_type;
+            inp.shape = src->m_shape;
+            if (src->m_type == TensorDataType::int64) {
+                // token ids / positions / masks of the LLM graphs: values known now, consumed by plan-time evaluation (Lowering::try_host_eval)
+                if (u8 || N != 1) throw std::invalid_argument("Model::run: int64 graph inputs need one sample per pass and floating-point arithmetic (" + iname + ").");
+                auto& iv = src->get_vector<int64_t>();
+                inp.ivals.assign(iv.begin(), iv.end());
+                inp.staging = inp.val = new_val(iname, shape, OSG_I64, Lay::plain, false);
+                vals[inp.val].is_const = true;
+                vals[inp.val].host_valid = vals[inp.val].host_only = true;
+                vals[inp.val].host_i = inp.ivals;
                 inputs.push_back(std::move(inp));
+                continue;
             }
+            if (src->m_type == TensorDataType::float16 && prod(shape) != 0) {
+                // an output the caller kept in fp16 (m_outputs_convert_set excludes it) and feeds back under another name: the LLM app's
+                // opkv* -> pkv* renaming (src/llm.cpp:403-407).  Uploaded as it is, no rounding step.
+                if (N != 1) throw std::invalid_argument("Model::run: float16 graph inputs need one sample per pass (" + iname + ").");
+                inp.staging = inp.val = new_val(iname, shape, OSG_F16, Lay::plain, true);
+                vals[inp.val].dptr = small_alloc(val_bytes(inp.val));
+                vals[inp.val].pinned = true;
+                inputs.push_back(std::move(inp));
+                continue;
+            }
+            if (prod(shape) == 0) {
+                // an empty tensor (the first call of the LLM flow pushes zero-length key/value caches, src/llm.cpp:388-402): a val without storage
+                inp.staging = inp.val = new_val(iname, shape, u8 ? OSG_U8 : OSG_F16, Lay::plain, true);
+                vals[inp.val].pinned = true;
+                inputs.push_back(std::move(inp));
+                continue;
+            }
+            if (u8) {
+                // a pushed fp32 input is quantised with the 0.1 % percentiles of ITS OWN data (push_tensor -> Model::quantize, reference
+                // :3024-3028, :3247): done on the host in execute(), the codes are uploaded, scale / zero point live in the val
+                inp.staging = inp.val = new_val(iname, shape, OSG_U8, Lay::plain, true);
+                vals[inp.val].dptr = small_alloc(val_bytes(inp.val));
+                vals[inp.val].pinned = true;
+                vals[inp.val].qdyn = true;
+                inputs.push_back(std::move(inp));
+                continue;
+            }
+            inp.staging = new_val("", shape, OSG_F32, Lay::plain, true);
+            vals[inp.staging].dptr = small_alloc(val_bytes(inp.staging));
+            vals[inp.staging].pinned = true;
+            // fp32 inputs are rounded to f16 when pushed with fp16 arithmetic on (reference push_tensor :3029-3034)
+            inp.val = new_val(iname, shape, OSG_F16, Lay::plain, true);
+            const int s = inp.staging, d = inp.val;
+            const long n = total_elems(d);
+            add_step("input " + iname, {s}, {d}, [this, s, d, n] {
+                be.check(be.api.osg_convert(be.ctx, OSG_F32, OSG_F16, ptr(s), ptr(d), n, 1.f, 0), "osg_convert");
+            });
+            inputs.push_back(std::move(inp));
+        }
     }
 
     const double ms_inputs = ms_since(t_begin) - t_weights;

@@ -95,6 +95,7 @@ struct ConstPool {
     bool fused_valid = false;
     std::vector<Val> snap_vals;              // the constant vals load_weights() builds from `base`, as they are right after it (same validity as fused_ops)
     size_t snap_weight_bytes = 0;
+    std::vector<std::string> in_names;       // the graph's input names (consumed, never produced), in discovery order
     // device buffers (arena, small-allocation slabs) of a destroyed plan of such a model, handed to the next one: a hipMalloc + hipFree pair per buffer
     // and call otherwise
     std::vector<std::pair<void*, size_t>> spare;
@@ -125,7 +126,7 @@ struct ConstPool {
         spare.clear();
         base.clear(); derived.clear(); occ_types.clear();
         complete = false; bytes = 0;
-        fused_valid = false; fused_ops.clear(); fused_key.clear(); snap_vals.clear(); snap_weight_bytes = 0;
+        fused_valid = false; fused_ops.clear(); fused_key.clear(); snap_vals.clear(); snap_weight_bytes = 0; in_names.clear();
     }
 };
 
