@@ -213,6 +213,12 @@ void* Plan::ptr(int v) const {
     return (char*)arena + r.offset + off;
 }
 
+bool Plan::in_one_slab(const char* lo, const char* hi) const {
+    for (auto& sl : slabs)
+        if (lo >= sl.first && hi <= sl.first + sl.second) return true;
+    return false;
+}
+
 void* Plan::small_alloc(size_t bytes) {
     const size_t need = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
     if (need > ((size_t)1 << 20)) {
@@ -223,6 +229,7 @@ void* Plan::small_alloc(size_t bytes) {
     if (need > slab_left) {
         slab_left = (size_t)8 << 20;
         slab = (char*)pooled_malloc(slab_left);
+        slabs.push_back({slab, slab_left});
     }
     void* p = slab;
     slab += need;
@@ -4054,6 +4061,25 @@ void Plan::run_steps(size_t begin, size_t end) {
 
 void Plan::execute() {
     // ---- stage the inputs (host fp32, N samples stacked) -------------------------------------------------------------
+    // Many small fp16 inputs (the LLM flow feeds 2 x layers key/value caches back every call) go up in ONE transfer when their device buffers are
+    // neighbours in a small-allocation slab (they are carved out one after the other): gathered into a host block with the device's own spacing.
+    char* up_lo = nullptr;
+    char* up_hi = nullptr;
+    {
+        size_t sum = 0, cnt = 0;
+        for (auto& in : inputs) {
+            if (in.host_type != TensorDataType::float16 || vals[in.staging].numel() == 0) continue;
+            char* p = (char*)ptr(in.val);
+            const size_t nb = val_bytes(in.val);
+            if (!up_lo || p < up_lo) up_lo = p;
+            if (!up_hi || p + nb > up_hi) up_hi = p + nb;
+            sum += (nb + 255) & ~(size_t)255;   // (what small_alloc hands out)
+            cnt++;
+        }
+        // only a gap-free run inside ONE slab qualifies: nothing else may live in the range that is overwritten
+        if (cnt < 4 || (size_t)(up_hi - up_lo) > sum || !in_one_slab(up_lo, up_hi)) up_lo = up_hi = nullptr;
+        else io_block.assign((size_t)(up_hi - up_lo), 0);
+    }
     for (auto& in : inputs) {
         Tensor* src = nullptr;
         for (auto& t : m.m_data)
@@ -4065,7 +4091,8 @@ void Plan::execute() {
         if (in.host_type == TensorDataType::float16) {
             auto& vec = src->get_vector<uint16_t>();
             if (vec.size() != (size_t)vals[in.val].numel()) throw std::invalid_argument("Model::get_tensor_data: mismatch between tensor shape and data size.");
-            be.check(be.api.osg_upload(be.ctx, ptr(in.val), vec.data(), vec.size() * 2), "osg_upload");
+            if (up_lo) std::memcpy(io_block.data() + ((char*)ptr(in.val) - up_lo), vec.data(), vec.size() * 2);
+            else be.check(be.api.osg_upload(be.ctx, ptr(in.val), vec.data(), vec.size() * 2), "osg_upload");
             continue;
         }
         const size_t per = vals[in.staging].numel() * sizeof(float);
@@ -4089,6 +4116,7 @@ void Plan::execute() {
         if (extra + 1 != N) throw std::invalid_argument("Model::run: inconsistent m_batch.size() across two or more tensors.");
         for (long i = 0; i < extra; i++) upload((*src->m_batch)[i], i + 1);
     }
+    if (up_lo) be.check(be.api.osg_upload(be.ctx, up_lo, io_block.data(), io_block.size()), "osg_upload");
     // ---- run the pass -------------------------------------------------------------------------------------------------
     const bool stream_pass = stream_weights && (runs >= 1 || budgeted);
     const bool times = m.m_ops_times_printf && !calibrate && !stream_pass;
@@ -4215,6 +4243,28 @@ void Plan::execute() {
     for (auto& in : inputs)
         for (size_t i = 0; i < m.m_data.size(); i++)
             if (m.m_data[i].m_name == in.name) { m.m_data.erase(m.m_data.begin() + i); break; }
+    // ... the same for many small outputs (the new caches): one transfer of the slab range that holds their staging buffers, split on the host
+    char* dn_lo = nullptr;
+    char* dn_hi = nullptr;
+    if (outputs.size() >= 4) {
+        size_t sum = 0;
+        for (auto& o : outputs) {
+            char* p = (char*)ptr(o.f32val);
+            const size_t nb = val_bytes(o.f32val);   // (all N samples)
+            if (!dn_lo || p < dn_lo) dn_lo = p;
+            if (!dn_hi || p + nb > dn_hi) dn_hi = p + nb;
+            sum += (nb + 255) & ~(size_t)255;
+        }
+        if ((size_t)(dn_hi - dn_lo) > sum || !in_one_slab(dn_lo, dn_hi)) dn_lo = dn_hi = nullptr;
+        else {
+            io_block.resize((size_t)(dn_hi - dn_lo));
+            be.check(be.api.osg_download(be.ctx, io_block.data(), dn_lo, io_block.size()), "osg_download");
+        }
+    }
+    auto fetch = [&](void* host, const char* dev, size_t bytes) {
+        if (dn_lo) std::memcpy(host, io_block.data() + (dev - dn_lo), bytes);
+        else be.check(be.api.osg_download(be.ctx, host, dev, bytes), "osg_download");
+    };
     for (auto& o : outputs) {
         const size_t per_elems = (size_t)vals[o.f32val].numel();
         const long nb = vals[o.f32val].batched ? N : 1;
@@ -4225,11 +4275,11 @@ void Plan::execute() {
             t.m_shape = o.shape;
             if (o.raw16) {
                 tensor_vector<uint16_t> host(per_elems);
-                be.check(be.api.osg_download(be.ctx, host.data(), (char*)ptr(o.f32val) + i * per_elems * 2, per_elems * 2), "osg_download");
+                fetch(host.data(), (char*)ptr(o.f32val) + i * per_elems * 2, per_elems * 2);
                 t.set_vector(std::move(host));
             } else {
                 tensor_vector<float> host(per_elems);
-                be.check(be.api.osg_download(be.ctx, host.data(), (char*)ptr(o.f32val) + i * per_elems * sizeof(float), per_elems * sizeof(float)), "osg_download");
+                fetch(host.data(), (char*)ptr(o.f32val) + i * per_elems * sizeof(float), per_elems * sizeof(float));
                 t.set_vector(std::move(host));
             }
             if (i == 0) first = std::move(t);

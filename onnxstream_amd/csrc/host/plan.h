@@ -166,6 +166,9 @@ struct Plan {
     std::vector<Val> vals;
     std::unordered_map<std::string, int> by_name;
     std::vector<Step> steps;
+    std::vector<char> io_block;   // host side of the gathered input upload / output download of execute()
+    std::vector<std::pair<char*, size_t>> slabs;   // the small-allocation slabs of this plan
+    bool in_one_slab(const char* lo, const char* hi) const;
     std::vector<void*> owned;     // device allocations owned by the plan (weights, staging, outputs)
     std::vector<std::pair<void*, size_t>> recyclable;   // ... those that go back to the pool's spare list when the model re-plans on every call (slabs, arena)
     bool recycle = false, arena_pooled = false;
