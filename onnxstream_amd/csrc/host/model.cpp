@@ -294,7 +294,9 @@ void Model::run() {
     }
     const auto t2 = now();
     m_plan->execute();
-    if (timing && rebuilt) fprintf(stderr, "[run] drop the old plan %.2f ms, new plan %.2f ms, execute %.2f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, now()));
+    if (timing && rebuilt)
+        fprintf(stderr, "[run] drop the old plan %.2f ms, new plan %.2f ms, execute %.2f ms (gathered transfers: %zu B up, %zu B down)\n", ms(t0, t1), ms(t1, t2), ms(t2, now()),
+                m_plan->gathered_up, m_plan->gathered_down);
     m_last_kernels = m_plan->kernel_count();
     m_last_ms = m_plan->last_ms();
 }

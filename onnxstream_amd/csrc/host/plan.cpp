@@ -4116,6 +4116,7 @@ void Plan::execute() {
         if (extra + 1 != N) throw std::invalid_argument("Model::run: inconsistent m_batch.size() across two or more tensors.");
         for (long i = 0; i < extra; i++) upload((*src->m_batch)[i], i + 1);
     }
+    gathered_up = up_lo ? io_block.size() : 0;
     if (up_lo) be.check(be.api.osg_upload(be.ctx, up_lo, io_block.data(), io_block.size()), "osg_upload");
     // ---- run the pass -------------------------------------------------------------------------------------------------
     const bool stream_pass = stream_weights && (runs >= 1 || budgeted);
@@ -4261,6 +4262,7 @@ void Plan::execute() {
             be.check(be.api.osg_download(be.ctx, io_block.data(), dn_lo, io_block.size()), "osg_download");
         }
     }
+    gathered_down = dn_lo ? io_block.size() : 0;
     auto fetch = [&](void* host, const char* dev, size_t bytes) {
         if (dn_lo) std::memcpy(host, io_block.data() + (dev - dn_lo), bytes);
         else be.check(be.api.osg_download(be.ctx, host, dev, bytes), "osg_download");

@@ -167,6 +167,7 @@ struct Plan {
     std::unordered_map<std::string, int> by_name;
     std::vector<Step> steps;
     std::vector<char> io_block;   // host side of the gathered input upload / output download of execute()
+    size_t gathered_up = 0, gathered_down = 0;   // bytes the last execute() moved that way (0: buffer by buffer)
     std::vector<std::pair<char*, size_t>> slabs;   // the small-allocation slabs of this plan
     bool in_one_slab(const char* lo, const char* hi) const;
     std::vector<void*> owned;     // device allocations owned by the plan (weights, staging, outputs)

@@ -1,0 +1,68 @@
+// CPU test program (tests/test_host_io_cpu.py): the host library's data path WITHOUT a GPU.  The no-op stub of libosgpu does real memcpy for uploads,
+// downloads and device copies, so a graph of zero-copy ops carries real bits end to end: N fp16 graph inputs of different sizes -> Transpose that only
+// moves unit dimensions (an alias) -> outputs kept in fp16 (m_outputs_convert_set names none of them).  With >= 4 inputs / outputs the gathered upload and
+// download of Plan::execute run; the second call renames the outputs back to inputs (the LLM app's cache hand-over, src/llm.cpp:403-407) with NEW sizes,
+// which re-plans on recycled device buffers.  Prints "OK" or the first mismatch.   usage: host_io <model.txt as a string file> <n>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+#include <string>
+
+#include "onnxstream.h"
+
+using namespace onnxstream;
+
+static tensor_vector<uint16_t> pattern(int i, size_t n, int salt) {
+    tensor_vector<uint16_t> v(n);
+    for (size_t k = 0; k < n; k++) v[k] = (uint16_t)((i * 4099 + (int)k * 7 + salt) & 0xffff);
+    return v;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) return 2;
+    std::ifstream f(argv[1]);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    const int n = std::atoi(argv[2]);
+    try {
+        Model m(0);
+        m.m_support_dynamic_shapes = true;
+        m.m_use_fp16_arithmetic = true;
+        m.m_outputs_convert_set = {"no_such_output"};
+        m.read_string(ss.str().c_str());
+        for (int call = 0; call < 3; call++) {
+            std::vector<size_t> T(n);
+            for (int i = 0; i < n; i++) {
+                T[i] = (size_t)(3 + i + 2 * call + (i % 3 == 0 ? 37 * call : 0));      // every input its own size, other sizes on every call
+                Tensor t;
+                t.m_name = "in" + std::to_string(i);
+                t.m_shape = {1, 1, T[i], 8};
+                t.set_vector(pattern(i, T[i] * 8, call));
+                m.m_data.push_back(std::move(t));
+            }
+            m.run();
+            for (int i = 0; i < n; i++) {
+                const Tensor* o = nullptr;
+                for (auto& t : m.m_data)
+                    if (t.m_name == "out" + std::to_string(i)) o = &t;
+                if (!o) { printf("call %d: output out%d not found\n", call, i); return 1; }
+                if (o->m_type != TensorDataType::float16) { printf("call %d: out%d is not float16\n", call, i); return 1; }
+                if (o->m_shape != std::vector<size_t>{1, T[i], 1, 8}) { printf("call %d: out%d has the wrong shape\n", call, i); return 1; }
+                const auto want = pattern(i, T[i] * 8, call);
+                const auto& got = const_cast<Tensor*>(o)->get_vector<uint16_t>();
+                if (got.size() != want.size()) { printf("call %d: out%d has %zu elements, not %zu\n", call, i, got.size(), want.size()); return 1; }
+                for (size_t k = 0; k < want.size(); k++)
+                    if (got[k] != want[k]) { printf("call %d: out%d[%zu] = %u, not %u\n", call, i, k, got[k], want[k]); return 1; }
+            }
+            for (int i = 0; i < n; i++)       // consume the outputs (the next call pushes fresh inputs)
+                for (size_t k = 0; k < m.m_data.size(); k++)
+                    if (m.m_data[k].m_name == "out" + std::to_string(i)) { m.m_data.erase(m.m_data.begin() + k); break; }
+        }
+    } catch (const std::exception& e) {
+        printf("exception: %s\n", e.what());
+        return 1;
+    }
+    printf("OK\n");
+    return 0;
+}

@@ -1,0 +1,38 @@
+"""CPU: real bits through the host library's input staging / zero-copy ops / output publication, on the no-op stub backend (its transfers are memcpy).
+Covers what only the GPU suite reached before: fp16 graph inputs, the gathered upload and download of Plan::execute (>= 4 small buffers that are a
+gap-free run of one slab), the unit-dimension Transpose alias, raw fp16 outputs, re-plans with other sizes on recycled device buffers."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests", "stub"))
+
+
+@pytest.mark.parametrize("n", [1, 3, 6, 44])
+def test_fp16_inputs_reach_the_outputs_bit_for_bit(n):
+    import make_stub
+    from onnxstream_amd import build as b
+    if not os.path.exists(b.LIB_HOST):
+        pytest.skip("host library not built")
+    host = os.path.join(REPO, "onnxstream_amd", "csrc", "host")
+    with tempfile.TemporaryDirectory() as d:
+        stub = make_stub.build(d)
+        lines = [f"/t{i}:Transpose*input:in{i}(1,1,0,8)*output:out{i}(1,0,1,8)*perm:0,2,1,3" for i in range(n)]
+        open(os.path.join(d, "model.txt"), "w").write("\n".join(lines) + "\n")
+        exe = os.path.join(d, "host_io")
+        subprocess.run(["g++", "-std=c++20", "-O1", "-I", host, "-I", os.path.join(REPO, "include"), os.path.join(REPO, "tests", "cpp", "host_io.cpp"), "-o", exe,
+                        b.LIB_HOST, "-Wl,-rpath," + os.path.dirname(b.LIB_HOST), "-ldl", "-lpthread"], check=True)
+        r = subprocess.run([exe, os.path.join(d, "model.txt"), str(n)], env=dict(os.environ, OSGPU_LIB=stub, OSG_PLAN_TIMING="1"), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:]
+    # the call timing line says which way the buffers travelled: one gathered transfer each way from 4 buffers on, buffer by buffer below
+    moved = [tuple(int(x) for x in re.findall(r"(\d+) B", l)) for l in r.stdout.splitlines() if l.startswith("[run]")]
+    assert len(moved) == 3
+    for up, down in moved:
+        assert (up > 0 and down > 0) if n >= 4 else (up == 0 and down == 0)
