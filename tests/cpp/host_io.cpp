@@ -5,6 +5,9 @@
 // which re-plans on recycled device buffers.  Prints "OK" or the first mismatch.   usage: host_io <model.txt as a string file> <n>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <iterator>
+#include <vector>
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -19,7 +22,47 @@ static tensor_vector<uint16_t> pattern(int i, size_t n, int salt) {
     return v;
 }
 
+// mode 2 -- "weights": every output is a zero-copy view of a WEIGHT, so what comes back is what the WeightsProvider handed over and the plan placed:
+// resident, re-streamed every pass (m_hip_stream_weights), or through the VRAM-budget ring (CudaOptions::m_vram_to_use).
+//   usage: host_io weights <model dir with slash> <n> <resident|stream|budget> [budget bytes]
+static int weights_mode(int argc, char** argv) {
+    if (argc < 5) return 2;
+    const std::string dir = argv[2], mode = argv[4];
+    const int n = std::atoi(argv[3]);
+    try {
+        Model m(0);
+        m.m_use_fp16_arithmetic = true;
+        m.m_outputs_convert_set = {"no_such_output"};
+        if (mode == "stream") m.m_hip_stream_weights = true;
+        if (mode == "budget") m.set_cuda_options(CudaOptions((uint64_t)std::atoll(argv[5]), false));
+        m.read_file((dir + "model.txt").c_str());
+        for (int pass = 0; pass < 3; pass++) {
+            m.run();
+            for (int i = 0; i < n; i++) {
+                const std::string nm = "out" + std::to_string(i);
+                Tensor* o = nullptr;
+                for (auto& t : m.m_data)
+                    if (t.m_name == nm) o = &t;
+                if (!o || o->m_type != TensorDataType::float16) { printf("pass %d: %s missing or not float16\n", pass, nm.c_str()); return 1; }
+                std::ifstream wf(dir + "w" + std::to_string(i) + ".bin", std::ios::binary);
+                std::vector<char> raw((std::istreambuf_iterator<char>(wf)), std::istreambuf_iterator<char>());
+                const auto& got = o->get_vector<uint16_t>();
+                if (got.size() * 2 != raw.size()) { printf("pass %d: %s has %zu bytes, the file %zu\n", pass, nm.c_str(), got.size() * 2, raw.size()); return 1; }
+                if (std::memcmp(got.data(), raw.data(), raw.size()) != 0) { printf("pass %d: %s differs from its weight file\n", pass, nm.c_str()); return 1; }
+            }
+            m.m_data.clear();
+        }
+        printf("streamed bytes of the last pass: %zu\n", m.hip_streamed_bytes());
+    } catch (const std::exception& e) {
+        printf("exception: %s\n", e.what());
+        return 1;
+    }
+    printf("OK\n");
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 2 && std::string(argv[1]) == "weights") return weights_mode(argc, argv);
     if (argc < 3) return 2;
     std::ifstream f(argv[1]);
     std::stringstream ss;
