@@ -2328,7 +2328,7 @@ struct Lowering {
     bool upcast_op(const Operation& op) const { return P.fp16 && !P.u8 && m.m_requires_upcast && m.m_requires_upcast(op.m_type, op.m_name); }
     void lower_all() {
         plan_linear_groups();
-        if (m.m_requires_upcast) index_graph();
+        if ((m.m_requires_upcast || P.sdp_attn) && !indexed) { index_graph(); indexed = true; }   // (the op list no longer changes: one index serves the whole lowering)
         for (size_t i = 0; i < ops().size(); i++) {
             if (group_of.count((int)i)) lower_group_member(ops()[i], (int)i);
             else if (ops()[i].m_type == "osg.RMSNorm") lower(ops()[i]);   // (fp32 inside by construction: fuse_rms_norm only fuses fully flagged chains)
@@ -2620,6 +2620,7 @@ struct Lowering {
         long ntot = 0;
         int y = -1;                 // merged output val [rows, ntot]
     };
+    bool indexed = false;   // index_graph() describes the op list being lowered
     std::vector<LinGroup> groups;
     std::map<int, std::pair<int, int>> group_of;   // op index -> (group, slot)
 
@@ -2627,6 +2628,7 @@ struct Lowering {
         if (P.fusion < 2 || P.stream_weights) return;   // streamed weights are consumed as the provider hands them over: no merged copies
         dead.assign(ops().size(), 0);
         index_graph();
+        indexed = true;
         std::map<std::string, std::vector<int>> by_key;
         for (size_t i = 0; i < ops().size(); i++) {
             const Operation& op = ops()[i];
@@ -2951,11 +2953,17 @@ struct Lowering {
             if (xs[k] != os[k]) return false;
         auto consumers_of = [&](const std::string& name) {
             std::vector<std::pair<int, int>> c;   // (op, input slot)
-            for (size_t i = 0; i < ops().size(); i++) {
-                if (!dead.empty() && dead[i]) continue;
+            auto slots = [&](int i) {
                 for (size_t k = 0; k < ops()[i].m_input.size(); k++)
-                    if (ops()[i].m_input[k].m_name == name) c.push_back({(int)i, (int)k});
-            }
+                    if (ops()[i].m_input[k].m_name == name) c.push_back({i, (int)k});
+            };
+            if (indexed) {
+                auto it = consumers.find(name);
+                if (it != consumers.end())
+                    for (int i : it->second) slots(i);
+            } else
+                for (size_t i = 0; i < ops().size(); i++)
+                    if (dead.empty() || !dead[i]) slots((int)i);
             return c;
         };
         for (auto& e : P.extra_outputs)
