@@ -2328,7 +2328,11 @@ struct Lowering {
     bool upcast_op(const Operation& op) const { return P.fp16 && !P.u8 && m.m_requires_upcast && m.m_requires_upcast(op.m_type, op.m_name); }
     void lower_all() {
         plan_linear_groups();
-        if ((m.m_requires_upcast || P.sdp_attn) && !indexed) { index_graph(); indexed = true; }   // (the op list no longer changes: one index serves the whole lowering)
+        if ((m.m_requires_upcast || P.sdp_attn) && !indexed) {   // (the op list no longer changes: one index serves the whole lowering)
+            dead.assign(ops().size(), 0);                         // (run_fusions compacted the list: the flags of the old positions mean nothing now)
+            index_graph();
+            indexed = true;
+        }
         for (size_t i = 0; i < ops().size(); i++) {
             if (group_of.count((int)i)) lower_group_member(ops()[i], (int)i);
             else if (ops()[i].m_type == "osg.RMSNorm") lower(ops()[i]);   // (fp32 inside by construction: fuse_rms_norm only fuses fully flagged chains)
