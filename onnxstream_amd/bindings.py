@@ -233,6 +233,12 @@ class Model:
                 return bool(f(self._h, self._name(name)))
         raise OnnxStreamError("this library cannot drop tensors through the C API")
 
+    def fetch_tensor(self, name: str) -> None:
+        """Bring a device-resident tensor of Model::m_data (option hip_resident_outputs) to the host (backend addition)."""
+        f = self._lib.model_hip_fetch_tensor
+        f.argtypes = [ctypes.c_void_p, ctypes.c_char_p]; f.restype = ctypes.c_void_p
+        self._err(f(self._h, self._name(name)))
+
     def rename_tensor(self, src: str, dst: str) -> bool:
         """Rename a tensor of Model::m_data in place (the LLM app turns the opkv* outputs of one call into the pkv* inputs of the next this way)."""
         for sym in ("model_hip_rename_tensor", "ref_rename_tensor"):

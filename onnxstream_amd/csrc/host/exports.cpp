@@ -237,6 +237,7 @@ void model_set_option(Handle* h, char* name, unsigned int value) {
     else if (n == "hip_fuse_ln_gemm") m.m_hip_fuse_ln_gemm = b;
     else if (n == "hip_stream_weights") m.m_hip_stream_weights = b;
     else if (n == "hip_w8_resident") m.m_hip_w8_resident = b;
+    else if (n == "hip_resident_outputs") m.m_hip_resident_outputs = b;
     else if (n == "hip_fuse_gn_conv") m.m_hip_fuse_gn_conv = b;
     else {
         const char* err = "model_set_option: 'name' not found.";
@@ -287,6 +288,15 @@ int model_hip_drop_tensor(Handle* h, char* name) {   // (llm.cpp's get_output mo
     for (size_t i = 0; i < d.size(); i++)
         if (d[i].m_name == name) { d.erase(d.begin() + i); return 1; }
     return 0;
+}
+// bring a device-resident tensor (hip_resident_outputs) to the host; returns an error string or NULL
+char* model_hip_fetch_tensor(Handle* h, char* name) {
+    try {
+        h->model.hip_fetch_tensor(name);
+        return nullptr;
+    } catch (const std::exception& e) {
+        return dup_cstr(e.what());
+    }
 }
 int model_hip_rename_tensor(Handle* h, char* from, char* to) {
     for (auto& t : h->model.m_data)

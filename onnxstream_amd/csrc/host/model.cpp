@@ -51,10 +51,27 @@ Model::Model(int threads_count) {
 }
 
 Model::~Model() {
+    m_data.clear();        // (device-resident tensors release their buffers while the backend is still there)
     delete m_plan;
+    m_alive.reset();       // ... and copies of such tensors that outlive the Model must not touch it any more
     if (m_pool && m_backend) m_pool->clear(*m_backend);
     delete m_pool;
     delete m_backend;
+}
+
+void Model::hip_fetch_tensor(const std::string& name) {
+    for (auto& t : m_data)
+        if (t.m_name == name) {
+            if (!t.m_hip_resident) return;   // already on the host
+            if (!m_backend) throw std::runtime_error("Model::hip_fetch_tensor: no backend.");
+            tensor_vector<uint16_t> host(t.m_hip_resident_bytes / 2);
+            m_backend->check(m_backend->api.osg_download(m_backend->ctx, host.data(), t.m_hip_resident.get(), t.m_hip_resident_bytes), "osg_download");
+            t.set_vector(std::move(host));
+            t.m_hip_resident.reset();
+            t.m_hip_resident_bytes = 0;
+            return;
+        }
+    throw std::invalid_argument("Model::hip_fetch_tensor: tensor not found: " + name);
 }
 
 void Model::set_cuda_options(const CudaOptions& options) { m_cuda_options = options; }   // m_vram_to_use -> Plan's resident-weight budget; m_compute_fp32: accumulation is always fp32 here

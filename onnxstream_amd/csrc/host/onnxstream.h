@@ -134,6 +134,10 @@ public:
     uint8_t m_zero_point = 0;
     bool m_is_static_weights = false;
     std::shared_ptr<std::vector<Tensor>> m_batch;  // further samples pushed under the same name (reference :3040-3050)
+    // backend addition (Model::m_hip_resident_outputs): this fp16 tensor's data is a DEVICE buffer (the host vector is empty) -- an output that never left
+    // the GPU.  Pushed back under an input name (llm.cpp's opkv* -> pkv* renaming) it is read where it lies; Model::hip_fetch_tensor brings it to the host.
+    std::shared_ptr<void> m_hip_resident;
+    size_t m_hip_resident_bytes = 0;
 
     template <typename T>
     tensor_vector<T>& get_vector() {
@@ -561,6 +565,10 @@ public:
     bool m_hip_autotune = false;   // true: the first (eager) pass TIMES the legal tile / split-K configurations of every GEMM / convolution shape
                                    // (osg_set_autotune) -- faster, but the choice (hence the fp32 summation order, hence the last bits) depends on a
                                    // timer unless OSG_TUNE_CACHE seeds it; default: the deterministic cost-model choice
+    // true (with m_support_dynamic_shapes and a non-empty m_outputs_convert_set): the outputs that are NOT converted to fp32 stay on the device (see
+    // Tensor::m_hip_resident) instead of being downloaded into m_data -- the key/value caches of the LLM flow then never cross PCIe
+    bool m_hip_resident_outputs = false;
+    void hip_fetch_tensor(const std::string& name);   // downloads a device-resident tensor of m_data into its host vector
     bool m_hip_w8_resident = false;     // true: uint8 weights of Conv/MatMul/Gemm stay uint8 in HBM (half the footprint and weight traffic) and are
                                         // dequantised on chip by the osg_*_w8 kernels -- same VALUES as the reference's load-time dequantisation
                                         // (:2887-2891); false (default, currently the faster path: halo conv + merged projections): dequantise once at load
@@ -613,6 +621,7 @@ private:
     size_t m_threads = 1;                  // the reference's pthreadpool size: only the chunking of get_percentiles depends on it (qu8.h)
     Plan* m_plan = nullptr;
     ConstPool* m_pool = nullptr;           // device-resident weights, kept across plan rebuilds (plan.h)
+    std::shared_ptr<bool> m_alive = std::make_shared<bool>(true);   // what the deleters of device-resident tensors check before they touch m_backend
     size_t m_last_kernels = 0;
     double m_last_ms = 0;
 };

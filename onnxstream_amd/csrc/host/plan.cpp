@@ -113,6 +113,7 @@ Plan::Plan(Model& model, HipBackend& backend, ConstPool& cpool, size_t batch) : 
     side_stream = m.m_hip_side_stream && !stream_weights;
     extra_outputs = m.m_extra_outputs;
     recycle = m.m_support_dynamic_shapes && !stream_weights;
+    resident_outputs = m.m_hip_resident_outputs && m.m_support_dynamic_shapes && !stream_weights && !m.m_outputs_convert_set.empty();
 }
 
 bool Plan::compatible(Model& mm, size_t batch) const {
@@ -122,6 +123,7 @@ bool Plan::compatible(Model& mm, size_t batch) const {
         mm.m_hip_fuse_gn_conv != fuse_gn_conv || mm.m_hip_fuse_ln_gemm != fuse_ln_gemm || (mm.m_hip_side_stream && !want_stream) != side_stream ||
         (mm.m_hip_w8_resident && !want_stream) != w8_resident || mm.m_extra_outputs != extra_outputs ||
         mm.m_use_uint8_arithmetic != u8 || mm.m_use_uint8_qdq != u8_qdq || mm.m_hip_autotune != autotune || mm.m_outputs_convert_set != outputs_convert_set ||
+        (mm.m_hip_resident_outputs && mm.m_support_dynamic_shapes && !want_stream && !mm.m_outputs_convert_set.empty()) != resident_outputs ||
         mm.m_range_data_calibrate != calibrate || mm.m_fuse_ops_in_attention != fuse_attn || mm.m_use_scaled_dp_attn_op != sdp_attn)
         return false;
     // a pushed input with another shape / type (dynamic-shape models) re-plans, the way the reference simply re-executes (:3550)
@@ -129,6 +131,7 @@ bool Plan::compatible(Model& mm, size_t batch) const {
         for (auto& t : mm.m_data)
             if (t.m_name == in.name) {
                 if (t.m_type != in.host_type || t.m_shape != in.shape) return false;
+                if (t.m_hip_resident != in.resident) return false;   // a device-resident input is read at ITS address: another buffer (or a host tensor) re-plans
                 if (t.m_type == TensorDataType::int64) {
                     auto& v = t.get_vector<int64_t>();
                     if (v.size() != in.ivals.size() || !std::equal(v.begin(), v.end(), in.ivals.begin())) return false;
@@ -3685,6 +3688,8 @@ Plan::~Plan() {
     if (ring) be.free(ring);
     delete lowering;
     for (void* p : owned) be.free(p);
+    for (auto& o : outputs)
+        if (o.dev) pool.give_class(be, o.dev, ConstPool::size_class(o.dev_bytes));      // (a pass that never ran, or threw: the buffer was not handed to a Tensor)
     for (auto& r : recyclable) pool.give(be, r.first, r.second);   // (the device is idle: osg_sync above)
     if (arena && !arena_pooled) be.free(arena);
 }
@@ -3781,6 +3786,17 @@ void Plan::build() {
                 inputs.push_back(std::move(inp));
                 continue;
             }
+            if (src->m_type == TensorDataType::float16 && prod(shape) != 0 && src->m_hip_resident) {
+                // an output of an earlier call that never left the device (m_hip_resident_outputs): read where it lies, no staging, no upload
+                if (N != 1) throw std::invalid_argument("Model::run: float16 graph inputs need one sample per pass (" + iname + ").");
+                if (src->m_hip_resident_bytes != (size_t)prod(shape) * 2) throw std::invalid_argument("Model::get_tensor_data: mismatch between tensor shape and data size.");
+                inp.staging = inp.val = new_val(iname, shape, OSG_F16, Lay::plain, true);
+                vals[inp.val].dptr = src->m_hip_resident.get();
+                vals[inp.val].pinned = true;
+                inp.resident = src->m_hip_resident;
+                inputs.push_back(std::move(inp));
+                continue;
+            }
             if (src->m_type == TensorDataType::float16 && prod(shape) != 0) {
                 // an output the caller kept in fp16 (m_outputs_convert_set excludes it) and feeds back under another name: the LLM app's
                 // opkv* -> pkv* renaming (src/llm.cpp:403-407).  Uploaded as it is, no rounding step.
@@ -3863,7 +3879,12 @@ void Plan::build() {
                 // m_outputs_convert_set (reference :8234): only the listed outputs are converted back to fp32 at the end of run(); the others
                 // stay in the arithmetic type (f16 bits; here always in the logical layout).  A pinned f16 copy is what the caller reads.
                 o.f32val = new_val("", vals[v].shape, OSG_F16, Lay::plain, vals[v].batched);
-                vals[o.f32val].dptr = small_alloc(val_bytes(o.f32val));
+                if (resident_outputs && N == 1 && val_bytes(v) > 0) {   // stays on the device: its own buffer, handed to the Tensor after the pass
+                    o.dev_bytes = val_bytes(v);
+                    o.dev = pool.take_class(be, ConstPool::size_class(o.dev_bytes));
+                    vals[o.f32val].dptr = o.dev;
+                } else
+                    vals[o.f32val].dptr = small_alloc(val_bytes(o.f32val));
                 vals[o.f32val].pinned = true;
                 o.raw16 = true;
                 const int s0 = v, d0 = o.f32val;
@@ -4080,7 +4101,7 @@ void Plan::execute() {
     {
         size_t sum = 0, cnt = 0;
         for (auto& in : inputs) {
-            if (in.host_type != TensorDataType::float16 || vals[in.staging].numel() == 0) continue;
+            if (in.host_type != TensorDataType::float16 || vals[in.staging].numel() == 0 || in.resident) continue;
             char* p = (char*)ptr(in.val);
             const size_t nb = val_bytes(in.val);
             if (!up_lo || p < up_lo) up_lo = p;
@@ -4100,7 +4121,12 @@ void Plan::execute() {
         if (src->m_type != in.host_type || src->m_shape != in.shape)
             throw std::invalid_argument("Model::run: input '" + in.name + "' changed type or shape since the plan was built.");
         if (in.host_type == TensorDataType::int64 || vals[in.staging].numel() == 0) continue;   // plan-time value / empty tensor: nothing to stage
+        if (in.resident) {   // on the device already; the tensor must still be the one the plan was built on
+            if (src->m_hip_resident != in.resident) throw std::invalid_argument("Model::run: input '" + in.name + "' changed since the plan was built.");
+            continue;
+        }
         if (in.host_type == TensorDataType::float16) {
+            if (src->m_hip_resident) throw std::invalid_argument("Model::run: input '" + in.name + "' changed since the plan was built.");
             auto& vec = src->get_vector<uint16_t>();
             if (vec.size() != (size_t)vals[in.val].numel()) throw std::invalid_argument("Model::get_tensor_data: mismatch between tensor shape and data size.");
             if (up_lo) std::memcpy(io_block.data() + ((char*)ptr(in.val) - up_lo), vec.data(), vec.size() * 2);
@@ -4262,6 +4288,7 @@ void Plan::execute() {
     if (outputs.size() >= 4) {
         size_t sum = 0;
         for (auto& o : outputs) {
+            if (o.dev) continue;
             char* p = (char*)ptr(o.f32val);
             const size_t nb = val_bytes(o.f32val);   // (all N samples)
             if (!dn_lo || p < dn_lo) dn_lo = p;
@@ -4280,6 +4307,26 @@ void Plan::execute() {
         else be.check(be.api.osg_download(be.ctx, host, dev, bytes), "osg_download");
     };
     for (auto& o : outputs) {
+        if (o.dev) {
+            // m_hip_resident_outputs: the Tensor in m_data owns the device buffer from here on (freed with the last copy of the Tensor, as long as the
+            // Model lives); its host vector stays empty
+            Tensor t;
+            t.m_name = o.name;
+            t.m_shape = o.shape;
+            t.set_vector(tensor_vector<uint16_t>());
+            HipBackend* bp = &be;
+            ConstPool* pp = &pool;
+            const size_t cls = ConstPool::size_class(o.dev_bytes);
+            t.m_hip_resident = std::shared_ptr<void>(o.dev, [alive = std::weak_ptr<bool>(m.m_alive), bp, pp, cls](void* p) {
+                if (alive.lock()) pp->give_class(*bp, p, cls);     // (back to the Model's pool: the call after next takes it again)
+            });
+            t.m_hip_resident_bytes = o.dev_bytes;
+            o.dev = nullptr;
+            for (size_t i = 0; i < m.m_data.size(); i++)
+                if (m.m_data[i].m_name == o.name) { m.m_data.erase(m.m_data.begin() + i); break; }
+            m.m_data.push_back(std::move(t));
+            continue;
+        }
         const size_t per_elems = (size_t)vals[o.f32val].numel();
         const long nb = vals[o.f32val].batched ? N : 1;
         Tensor first;

@@ -109,6 +109,28 @@ struct ConstPool {
         spare.erase(spare.begin() + best);
         return p;
     }
+    // ... and the buffers of device-resident outputs (Model::m_hip_resident_outputs), by size class: a cache grows by one row per call, so its buffer is
+    // sized to the next power of two and the buffers of the call before last (released when their plan goes) serve the call that comes
+    std::map<size_t, std::vector<void*>> spare_class;
+    static size_t size_class(size_t bytes) {
+        size_t c = 4096;
+        while (c < bytes) c <<= 1;
+        return c;
+    }
+    void* take_class(HipBackend& be, size_t cls) {
+        auto it = spare_class.find(cls);
+        if (it != spare_class.end() && !it->second.empty()) {
+            void* p = it->second.back();
+            it->second.pop_back();
+            return p;
+        }
+        return be.malloc(cls);
+    }
+    void give_class(HipBackend& be, void* p, size_t cls) {
+        auto& v = spare_class[cls];
+        if (v.size() >= 512) be.free(p);
+        else v.push_back(p);
+    }
     void give(HipBackend& be, void* p, size_t bytes) {
         if (spare.size() >= 8) {   // keep the newest: drop the smallest
             size_t k = 0;
@@ -124,6 +146,9 @@ struct ConstPool {
         for (auto& kv : derived) be.free(kv.second.first);
         for (auto& sp : spare) be.free(sp.first);
         spare.clear();
+        for (auto& kv : spare_class)
+            for (void* p : kv.second) be.free(p);
+        spare_class.clear();
         base.clear(); derived.clear(); occ_types.clear();
         complete = false; bytes = 0;
         fused_valid = false; fused_ops.clear(); fused_key.clear(); snap_vals.clear(); snap_weight_bytes = 0; in_names.clear();
@@ -211,8 +236,16 @@ struct Plan {
 
     // ivals: an int64 graph input (LLM graphs: input_ids, position_ids, attention_mask) is a PLAN-TIME value -- its numbers feed Gather indices and
     // mask subgraphs that are evaluated while the plan is built, so a plan is only reused for the same numbers (Plan::compatible)
-    struct In { std::string name; int val; int staging; TensorDataType host_type; std::vector<size_t> shape; std::vector<int64_t> ivals; };
-    struct Out { std::string name; int val; int f32val; std::vector<size_t> shape; bool raw16 = false; };
+    struct In {
+        std::string name; int val; int staging; TensorDataType host_type; std::vector<size_t> shape; std::vector<int64_t> ivals;
+        std::shared_ptr<void> resident;   // a device-resident tensor (Tensor::m_hip_resident) read where it lies; kept alive by the plan that reads it
+    };
+    struct Out {
+        std::string name; int val; int f32val; std::vector<size_t> shape; bool raw16 = false;
+        void* dev = nullptr;              // m_hip_resident_outputs: the buffer this output is left in (handed to the Tensor in m_data after the pass)
+        size_t dev_bytes = 0;
+    };
+    bool resident_outputs = false;
     struct Calib { int step; std::string op; int val; };   // m_range_data_calibrate: val is measured after `step`, range kept under the op's name
     std::vector<Calib> calib;
     std::vector<In> inputs;

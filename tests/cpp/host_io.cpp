@@ -61,8 +61,88 @@ static int weights_mode(int argc, char** argv) {
     return 0;
 }
 
+// mode 3 -- "resident": Model::m_hip_resident_outputs.  The outputs of a call stay in device buffers (Tensor::m_hip_resident, empty host vector), are renamed
+// to input names and read where they lie by the next call -- three hops without a host copy -- and come back bit for bit through Model::hip_fetch_tensor.
+//   usage: host_io resident <model.txt> <n>
+static int resident_mode(int argc, char** argv) {
+    if (argc < 4) return 2;
+    std::ifstream f(argv[2]);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    const int n = std::atoi(argv[3]);
+    try {
+        Model m(0);
+        m.m_support_dynamic_shapes = true;
+        m.m_use_fp16_arithmetic = true;
+        m.m_outputs_convert_set = {"no_such_output"};
+        m.m_hip_resident_outputs = true;
+        m.read_string(ss.str().c_str());
+        std::vector<size_t> T(n);
+        for (int i = 0; i < n; i++) {
+            T[i] = (size_t)(3 + 5 * i + (i % 4 == 1 ? 900 : 0));
+            Tensor t;
+            t.m_name = "in" + std::to_string(i);
+            t.m_shape = {1, 1, T[i], 8};
+            t.set_vector(pattern(i, T[i] * 8, 11));
+            m.m_data.push_back(std::move(t));
+        }
+        for (int hop = 0; hop < 3; hop++) {
+            m.run();
+            for (int i = 0; i < n; i++) {
+                Tensor* o = nullptr;
+                for (auto& t : m.m_data)
+                    if (t.m_name == "out" + std::to_string(i)) o = &t;
+                if (!o) { printf("hop %d: out%d not found\n", hop, i); return 1; }
+                if (!o->m_hip_resident || o->m_hip_resident_bytes != T[i] * 16 || !o->get_vector<uint16_t>().empty()) { printf("hop %d: out%d is not device-resident\n", hop, i); return 1; }
+                if (hop < 2) {            // hand it back as the next call's input (llm.cpp:403-407 renames; the view here also swaps two dimensions)
+                    o->m_name = "in" + std::to_string(i);
+                    o->m_shape = {1, 1, T[i], 8};
+                }
+            }
+            if (m.m_data.size() != (size_t)n) { printf("hop %d: %zu tensors left in m_data, not %d\n", hop, m.m_data.size(), n); return 1; }
+        }
+        for (int i = 0; i < n; i++) {
+            const std::string nm = "out" + std::to_string(i);
+            m.hip_fetch_tensor(nm);
+            for (auto& t : m.m_data)
+                if (t.m_name == nm) {
+                    const auto want = pattern(i, T[i] * 8, 11);
+                    const auto& got = t.get_vector<uint16_t>();
+                    if (t.m_hip_resident || got.size() != want.size() || std::memcmp(got.data(), want.data(), want.size() * 2) != 0) { printf("%s differs after three hops\n", nm.c_str()); return 1; }
+                }
+        }
+        {   // a copy of a resident tensor that outlives the Model must not touch it
+            Tensor keep;
+            {
+                Model m2(0);
+                m2.m_support_dynamic_shapes = true;
+                m2.m_use_fp16_arithmetic = true;
+                m2.m_outputs_convert_set = {"no_such_output"};
+                m2.m_hip_resident_outputs = true;
+                m2.read_string(ss.str().c_str());
+                for (int i = 0; i < n; i++) {
+                    Tensor t;
+                    t.m_name = "in" + std::to_string(i);
+                    t.m_shape = {1, 1, 4, 8};
+                    t.set_vector(pattern(i, 32, 3));
+                    m2.m_data.push_back(std::move(t));
+                }
+                m2.run();
+                keep = m2.m_data.front();
+            }
+            if (!keep.m_hip_resident) { printf("the copy lost its handle\n"); return 1; }
+        }
+    } catch (const std::exception& e) {
+        printf("exception: %s\n", e.what());
+        return 1;
+    }
+    printf("OK\n");
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc >= 2 && std::string(argv[1]) == "weights") return weights_mode(argc, argv);
+    if (argc >= 2 && std::string(argv[1]) == "resident") return resident_mode(argc, argv);
     if (argc < 3) return 2;
     std::ifstream f(argv[1]);
     std::stringstream ss;

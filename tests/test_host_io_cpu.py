@@ -80,3 +80,24 @@ def test_weights_reach_the_device_bit_for_bit_in_every_residency_mode(mode, budg
         assert streamed == total - sum(t * 16 for t in [5, 33, 9, 64, 17, 128, 1])
     else:
         assert 0 < streamed < total
+
+
+@pytest.mark.parametrize("n", [1, 5, 44])
+def test_device_resident_outputs_are_read_where_they_lie(n):
+    """m_hip_resident_outputs: fp16 outputs stay in device buffers, are handed back as inputs three times without a host copy (no gathered transfer, no
+    upload: the timing line says 0 B both ways from the second call on), come back bit for bit through hip_fetch_tensor, and a Tensor copy that outlives
+    its Model does not touch it."""
+    import make_stub
+    from onnxstream_amd import build as b
+    if not os.path.exists(b.LIB_HOST):
+        pytest.skip("host library not built")
+    with tempfile.TemporaryDirectory() as d:
+        stub = make_stub.build(d)
+        lines = [f"/t{i}:Transpose*input:in{i}(1,1,0,8)*output:out{i}(1,0,1,8)*perm:0,2,1,3" for i in range(n)]
+        open(os.path.join(d, "model.txt"), "w").write("\n".join(lines) + "\n")
+        exe = _build_harness(d)
+        r = subprocess.run([exe, "resident", os.path.join(d, "model.txt"), str(n)], env=dict(os.environ, OSGPU_LIB=stub, OSG_PLAN_TIMING="1"), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:]
+    moved = [tuple(int(x) for x in re.findall(r"(\d+) B", l)) for l in r.stdout.splitlines() if l.startswith("[run]")]
+    assert len(moved) == 4 and all(down == 0 for up, down in moved) and all(up == 0 for up, down in moved[1:3])

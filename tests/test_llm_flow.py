@@ -150,13 +150,20 @@ def test_upcast_without_fusion_keeps_the_seven_ops(stub_backend, fusion):
         assert not any(w.startswith(("upcast", "downcast")) for w in whats)
 
 
-def test_resident_flow_plans_through_the_stub(stub_backend):
+@pytest.mark.parametrize("on_device", [0, 1])
+def test_resident_flow_plans_through_the_stub(stub_backend, on_device):
+    """src/llm.cpp's shape of the loop through the planner; with hip_resident_outputs the caches additionally stay in device buffers between the calls
+    (tests/test_host_io_cpu.py checks such buffers' bits) and come to the host only on request"""
     from onnxstream_amd import build as b
     with tempfile.TemporaryDirectory() as d:
         d += "/"
         llama.build_llama(DirSink(d), CFG)
-        m, outs = _flow_resident(b.LIB_HOST, d, sdpa=True, upcast=True)
+        m, outs = _flow_resident(b.LIB_HOST, d, sdpa=True, upcast=True, options=(("hip_resident_outputs", on_device),))
         names = m.get_all_tensor_names()
+        for i in range(2 * CFG.layers):
+            m.fetch_tensor(f"opkv{i}")       # (a no-op for a tensor that is on the host already)
+        with pytest.raises(Exception, match="tensor not found"):
+            m.fetch_tensor("no_such_tensor")
         m.close()
     assert [o.shape for o in outs] == [(1, len(PROMPT), CFG.vocab)] + [(1, 1, CFG.vocab)] * len(TOKENS)
     assert "logits" not in names and all(f"opkv{i}" in names for i in range(2 * CFG.layers))
