@@ -20,6 +20,8 @@ for sdpa in (True, False):
     m = Model(b.LIB_HOST, 0, "ram+nocache")
     m._set_option("hip_autotune", 0)
     m.add_outputs_convert("logits")
+    if os.environ.get("LLM_RESIDENT_OUTPUTS") == "1":      # the caches never leave the device (Model::m_hip_resident_outputs)
+        m._set_option("hip_resident_outputs", 1)
     llama.configure(m, cfg, d, sdpa=sdpa, upcast=True)
     rng = np.random.default_rng(0)
     prompt = [int(t) for t in rng.integers(0, cfg.vocab, 32)]
