@@ -24,7 +24,7 @@ static tensor_vector<uint16_t> pattern(int i, size_t n, int salt) {
 
 // mode 2 -- "weights": every output is a zero-copy view of a WEIGHT, so what comes back is what the WeightsProvider handed over and the plan placed:
 // resident, re-streamed every pass (m_hip_stream_weights), or through the VRAM-budget ring (CudaOptions::m_vram_to_use).
-//   usage: host_io weights <model dir with slash> <n> <resident|stream|budget> [budget bytes]
+//   usage: host_io weights <model dir with slash> <n> <resident|stream|budget> <budget bytes> [prefetch|nocache|ram|ram+nocache]
 static int weights_mode(int argc, char** argv) {
     if (argc < 5) return 2;
     const std::string dir = argv[2], mode = argv[4];
@@ -35,6 +35,11 @@ static int weights_mode(int argc, char** argv) {
         m.m_outputs_convert_set = {"no_such_output"};
         if (mode == "stream") m.m_hip_stream_weights = true;
         if (mode == "budget") m.set_cuda_options(CudaOptions((uint64_t)std::atoll(argv[5]), false));
+        const std::string wp = argc > 6 ? argv[6] : "prefetch";     // the WeightsProvider behind it (the default of read_file is the prefetching one)
+        if (wp == "nocache") m.set_weights_provider(DiskNoCacheWeightsProvider());
+        else if (wp == "ram") m.set_weights_provider(RamWeightsProvider<DiskPrefetchWeightsProvider>(DiskPrefetchWeightsProvider()));
+        else if (wp == "ram+nocache") m.set_weights_provider(RamWeightsProvider<DiskNoCacheWeightsProvider>(DiskNoCacheWeightsProvider()));
+        else if (wp != "prefetch") return 2;
         m.read_file((dir + "model.txt").c_str());
         for (int pass = 0; pass < 3; pass++) {
             m.run();

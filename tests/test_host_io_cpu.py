@@ -14,28 +14,15 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests", "stub"))
 
 
-@pytest.mark.parametrize("n", [1, 3, 6, 44])
-def test_fp16_inputs_reach_the_outputs_bit_for_bit(n):
+@pytest.fixture(scope="module")
+def harness():
+    """(harness executable, stub library): built once for the module"""
     import make_stub
     from onnxstream_amd import build as b
     if not os.path.exists(b.LIB_HOST):
         pytest.skip("host library not built")
-    host = os.path.join(REPO, "onnxstream_amd", "csrc", "host")
     with tempfile.TemporaryDirectory() as d:
-        stub = make_stub.build(d)
-        lines = [f"/t{i}:Transpose*input:in{i}(1,1,0,8)*output:out{i}(1,0,1,8)*perm:0,2,1,3" for i in range(n)]
-        open(os.path.join(d, "model.txt"), "w").write("\n".join(lines) + "\n")
-        exe = os.path.join(d, "host_io")
-        subprocess.run(["g++", "-std=c++20", "-O1", "-I", host, "-I", os.path.join(REPO, "include"), os.path.join(REPO, "tests", "cpp", "host_io.cpp"), "-o", exe,
-                        b.LIB_HOST, "-Wl,-rpath," + os.path.dirname(b.LIB_HOST), "-ldl", "-lpthread"], check=True)
-        r = subprocess.run([exe, os.path.join(d, "model.txt"), str(n)], env=dict(os.environ, OSGPU_LIB=stub, OSG_PLAN_TIMING="1"), stdout=subprocess.PIPE,
-                           stderr=subprocess.STDOUT, text=True)
-    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:]
-    # the call timing line says which way the buffers travelled: one gathered transfer each way from 4 buffers on, buffer by buffer below
-    moved = [tuple(int(x) for x in re.findall(r"(\d+) B", l)) for l in r.stdout.splitlines() if l.startswith("[run]")]
-    assert len(moved) == 3
-    for up, down in moved:
-        assert (up > 0 and down > 0) if n >= 4 else (up == 0 and down == 0)
+        yield _build_harness(d), make_stub.build(d)
 
 
 def _build_harness(d):
@@ -47,28 +34,42 @@ def _build_harness(d):
     return exe
 
 
+@pytest.mark.parametrize("n", [1, 3, 6, 44])
+def test_fp16_inputs_reach_the_outputs_bit_for_bit(harness, n):
+    exe, stub = harness
+    with tempfile.TemporaryDirectory() as d:
+        lines = [f"/t{i}:Transpose*input:in{i}(1,1,0,8)*output:out{i}(1,0,1,8)*perm:0,2,1,3" for i in range(n)]
+        open(os.path.join(d, "model.txt"), "w").write("\n".join(lines) + "\n")
+        r = subprocess.run([exe, os.path.join(d, "model.txt"), str(n)], env=dict(os.environ, OSGPU_LIB=stub, OSG_PLAN_TIMING="1"), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:]
+    # the call timing line says which way the buffers travelled: one gathered transfer each way from 4 buffers on, buffer by buffer below
+    moved = [tuple(int(x) for x in re.findall(r"(\d+) B", l)) for l in r.stdout.splitlines() if l.startswith("[run]")]
+    assert len(moved) == 3
+    for up, down in moved:
+        assert (up > 0 and down > 0) if n >= 4 else (up == 0 and down == 0)
+
+
+@pytest.mark.parametrize("wp", ["prefetch", "nocache", "ram", "ram+nocache"])
 @pytest.mark.parametrize("mode,budget", [("resident", 0), ("stream", 0), ("budget", 1), ("budget", 60000), ("budget", 10 ** 9)])
-def test_weights_reach_the_device_bit_for_bit_in_every_residency_mode(mode, budget):
+def test_weights_reach_the_device_bit_for_bit_in_every_residency_mode(harness, mode, budget, wp):
     """12 fp16 weights of different sizes (some below, some above the 4096-element "readable on the host" bound) come back through zero-copy views
     exactly as their files hold them, three passes in a row -- resident after the first pass, re-streamed every pass, and with a VRAM budget that keeps
-    none / some / all of them resident while the rest go through the streaming ring."""
+    none / some / all of them resident while the rest go through the streaming ring; behind every WeightsProvider of the reference (the strictly sequential
+    disk providers, the prefetching one with its worker thread, the RAM cache over either)."""
     import numpy as np
-    import make_stub
-    from onnxstream_amd import build as b
-    if not os.path.exists(b.LIB_HOST):
-        pytest.skip("host library not built")
+    exe, stub = harness
     n = 12
     rng = np.random.default_rng(7)
     with tempfile.TemporaryDirectory() as d:
-        stub = make_stub.build(d)
         lines = []
         for i in range(n):
             t = [5, 700, 33, 1200, 9, 64, 2000, 17, 513, 128, 3000, 1][i]
             rng.integers(0, 65536, t * 8, dtype=np.uint16).tofile(os.path.join(d, f"w{i}.bin"))
             lines.append(f"/t{i}:Transpose*input:w{i}.bin(float16:1,1,{t},8)*output:out{i}(1,{t},1,8)*perm:0,2,1,3")
         open(os.path.join(d, "model.txt"), "w").write("\n".join(lines) + "\n")
-        exe = _build_harness(d)
-        r = subprocess.run([exe, "weights", d + "/", str(n), mode, str(budget)], env=dict(os.environ, OSGPU_LIB=stub), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        r = subprocess.run([exe, "weights", d + "/", str(n), mode, str(budget), wp], env=dict(os.environ, OSGPU_LIB=stub), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:]
     streamed = int(re.search(r"streamed bytes of the last pass: (\d+)", r.stdout).group(1))
     total = sum(t * 16 for t in [5, 700, 33, 1200, 9, 64, 2000, 17, 513, 128, 3000, 1])
@@ -83,19 +84,14 @@ def test_weights_reach_the_device_bit_for_bit_in_every_residency_mode(mode, budg
 
 
 @pytest.mark.parametrize("n", [1, 5, 44])
-def test_device_resident_outputs_are_read_where_they_lie(n):
+def test_device_resident_outputs_are_read_where_they_lie(harness, n):
     """m_hip_resident_outputs: fp16 outputs stay in device buffers, are handed back as inputs three times without a host copy (no gathered transfer, no
     upload: the timing line says 0 B both ways from the second call on), come back bit for bit through hip_fetch_tensor, and a Tensor copy that outlives
     its Model does not touch it."""
-    import make_stub
-    from onnxstream_amd import build as b
-    if not os.path.exists(b.LIB_HOST):
-        pytest.skip("host library not built")
+    exe, stub = harness
     with tempfile.TemporaryDirectory() as d:
-        stub = make_stub.build(d)
         lines = [f"/t{i}:Transpose*input:in{i}(1,1,0,8)*output:out{i}(1,0,1,8)*perm:0,2,1,3" for i in range(n)]
         open(os.path.join(d, "model.txt"), "w").write("\n".join(lines) + "\n")
-        exe = _build_harness(d)
         r = subprocess.run([exe, "resident", os.path.join(d, "model.txt"), str(n)], env=dict(os.environ, OSGPU_LIB=stub, OSG_PLAN_TIMING="1"), stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:]
