@@ -11,5 +11,5 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import onnxstream_amd.build as b
 b.LIB_HOST = '/tmp/asan/libonnxstream_amd.so'
 import pytest
-sys.exit(pytest.main(['-x', '-q', '-m', 'not gpu', 'tests/test_planner_cpu.py', 'tests/test_sdpa.py', 'tests/test_llm_flow.py', 'tests/test_maskops.py', 'tests/test_shard_gloo.py', 'tests/test_golden.py', '-p', 'no:cacheprovider']))
+sys.exit(pytest.main(['-x', '-q', '-m', 'not gpu', 'tests/test_planner_cpu.py', 'tests/test_sdpa.py', 'tests/test_llm_flow.py', 'tests/test_maskops.py', 'tests/test_shard_gloo.py', 'tests/test_golden.py', 'tests/test_movement_cpu.py', '-p', 'no:cacheprovider']))
 "
