@@ -196,6 +196,43 @@ int osg_attention(osg_ctx* ctx, osg_dtype dtype, const void* q, const void* k, c
 int osg_attention_strided(osg_ctx* ctx, osg_dtype dtype, const void* q, long q_tok, long q_head, long q_batch, const void* k,
                           long k_tok, long k_head, long k_batch, const void* v, long v_tok, long v_head, long v_batch, void* o,
                           long o_tok, long o_head, long o_batch, int batch, int heads, int Tq, int Tkv, int D, float scale);
+/* The ROW-LOCAL tail of a BasicTransformerBlock as ONE launch (osg_tchain.hip): everything behind the self-attention depends on its own token
+ * row only (cross-attention's K / V are the shared text context), so one workgroup carries 64 rows through
+ *   x1 = a1 . Wo1^T + bo1 + x0                  MatMul + Add + Add                      (onnxstream.cpp:5669-5861, :3906-4000)
+ *   q  = LayerNorm(x1; g2, be2) . Wq2^T         ReduceMean .. Add chain + MatMul        (:5237-5604)
+ *   a2 = softmax(scale q k^T) v   per head      AttentionFusedOps                       (:6696-6929)
+ *   x2 = a2 . Wo2^T + bo2 + x1
+ *   x3 = GEGLU(LayerNorm(x2; g3, be3) . W1^T + b1) . W2^T + b2 + x2     (Slice, Slice, Div, Erf :4001-4139, Add, Mul, Mul, Mul)
+ *   y  = x3 . Wpo^T + bpo + xin                 the 1x1 proj_out Conv (:4494-4707) + the spatial residual; only when wpo != NULL, else y = x3
+ * with the row block resident in LDS and the GEGLU activation never formed.  All tensors f16, weights [N][K] (k contiguous: w1 [8C][C] value rows
+ * then gate rows, w2 [C][4C]); a1 / x0 / xin dense [M][C]; out rows ldo apart (0 = C), out2 (may be NULL) a second copy rows ldo2 apart (the Concat
+ * slot of a skip connection); kp / vtp from osg_tblock_kv_pack.  M rows = images x rows_per_img, a 64-row block lies inside one image.
+ * dbg[0..6] (may be NULL): dense [M][C] dumps of x1, LN(x1), q, a2, x2, LN(x2), x3 (x3 only with wpo) -- the kernel tests read them. */
+typedef struct {
+  const void *a1, *x0;
+  const void *wo1, *bo1;
+  const void *g2, *be2;
+  float eps2;
+  const void *wq2, *bq2;
+  const void *kp, *vtp;
+  float scale;
+  int Tk;
+  const void *wo2, *bo2;
+  const void *g3, *be3;
+  float eps3;
+  const void *w1, *b1, *w2, *b2;
+  const void *wpo, *bpo, *xin;
+  void *out, *out2;
+  long ldo, ldo2;
+  int M, rows_per_img, C, heads;
+  void* dbg[8];
+} osg_tblock_tail_args;
+int osg_tblock_tail_supported(int M, int rows_per_img, int C, int heads, int Tk); /* 1 = osg_tblock_tail takes the shape */
+int osg_tblock_tail(osg_ctx* ctx, const osg_tblock_tail_args* a);
+/* K / V of a cross-attention ([imgs][Tk] rows ldk / ldv apart, head h at column h D) re-packed for osg_tblock_tail: kp [img][head][80][DP] and
+ * vtp [img][head][DP][80] (V transposed), DP = D rounded up to 16, zero padding; osg_tblock_kv_pack_elems = f16 elements of EACH pack. */
+size_t osg_tblock_kv_pack_elems(int imgs, int heads, int D);
+int osg_tblock_kv_pack(osg_ctx* ctx, const void* k, long ldk, const void* v, long ldv, int imgs, int Tk, int heads, int D, void* kp, void* vtp);
 /* ScaledDotProductAttention == the reference's pseudo-op of that name (formed at run time from Transpose/MatMul/Div/Add/Softmax/MatMul or
  * Transpose/Mul/Mul/MatMul/Add/Softmax/MatMul when m_use_scaled_dp_attn_op, onnxstream.cpp:3635-3755; executed at :7767-7882 through
  * XnnPack::scaled_dot_product_attention :2054-2150): out = softmax(scale * q k^T + mask) v per batch and head.  Dense q [B][Hq][Tq][D],

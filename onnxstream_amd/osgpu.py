@@ -29,11 +29,21 @@ EXPORTS = [
     "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_concat2", "osg_resize_nearest", "osg_gather_rows",
     "osg_maxpool_nhwc", "osg_convert", "osg_sampler_prepare", "osg_sampler_cfg_euler_a",
     "osg_range_push", "osg_range_pop", "osg_marker_record", "osg_copy_wait_marker", "osg_timer_mark", "osg_timer_between", "osg_set_stat_sinks", "osg_set_weight_prefetch", "osg_set_blocked_weight_hint", "osg_group_norm_stats_nhwc", "osg_qu8_conv2d_nhwc", "osg_qu8_conv2d_nhwc_t", "osg_qu8_conv_tap_sums", "osg_qu8_gemm", "osg_qu8_lut", "osg_qu8_binary", "osg_qu8_instance_norm", "osg_qu8_instance_norm_nhwc", "osg_qu8_affine_act", "osg_qu8_norm_affine_act_nhwc", "osg_qu8_softmax_last", "osg_kdbg_read",
+    "osg_tblock_tail_supported", "osg_tblock_tail", "osg_tblock_kv_pack_elems", "osg_tblock_kv_pack",
 ]
 
 
 class OsgError(RuntimeError):
     pass
+
+
+class TBlockTailArgs(ctypes.Structure):
+    """osg_tblock_tail_args of include/osgpu.h"""
+    _vp, _cf, _ci, _cl = ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_long
+    _fields_ = [("a1", _vp), ("x0", _vp), ("wo1", _vp), ("bo1", _vp), ("g2", _vp), ("be2", _vp), ("eps2", _cf), ("wq2", _vp), ("bq2", _vp),
+                ("kp", _vp), ("vtp", _vp), ("scale", _cf), ("Tk", _ci), ("wo2", _vp), ("bo2", _vp), ("g3", _vp), ("be3", _vp), ("eps3", _cf),
+                ("w1", _vp), ("b1", _vp), ("w2", _vp), ("b2", _vp), ("wpo", _vp), ("bpo", _vp), ("xin", _vp), ("out", _vp), ("out2", _vp),
+                ("ldo", _cl), ("ldo2", _cl), ("M", _ci), ("rows_per_img", _ci), ("C", _ci), ("heads", _ci), ("dbg", _vp * 8)]
 
 
 def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
@@ -115,6 +125,11 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_qu8_instance_norm_nhwc.argtypes = [vp, vp, vp, cl, ci, ci, ci, vp, vp, cf, cf, ci, cf, ci]
     lib.osg_qu8_norm_affine_act_nhwc.argtypes = [vp, vp, cl, ci, ci, ci, vp, vp, cf, cf, ci, cf, ci, vp, cf, ci, cf, ci, vp, cf, ci, cf, ci, vp, cf, ci, cf, ci, vp]
     lib.osg_qu8_softmax_last.argtypes = [vp, vp, vp, cl, cl, vp]
+    lib.osg_tblock_tail_supported.argtypes = [ci] * 5
+    lib.osg_tblock_tail.argtypes = [vp, ctypes.POINTER(TBlockTailArgs)]
+    lib.osg_tblock_kv_pack_elems.argtypes = [ci, ci, ci]
+    lib.osg_tblock_kv_pack_elems.restype = ctypes.c_size_t
+    lib.osg_tblock_kv_pack.argtypes = [vp, vp, cl, vp, cl, ci, ci, ci, ci, vp, vp]
     return lib
 
 
@@ -300,6 +315,41 @@ class Gpu:
         self._ck(self.lib.osg_attention_strided(self.ctx, F16, q.ptr, c, d, tq * c, k.ptr, c, d, tkv * c, v.ptr, c, d, tkv * c, o.ptr, c, d,
                                                 tq * c, bsz, heads, tq, tkv, d, scale))
         return o
+
+    def tblock_kv_pack(self, k: DevBuf, v: DevBuf, heads: int):
+        """k, v: [imgs, Tk, heads*D] -> (kp [imgs, heads, 80, DP], vtp [imgs, heads, DP, 80]) for tblock_tail"""
+        imgs, tk, c = k.shape
+        d = c // heads
+        dp = (d + 15) // 16 * 16
+        assert self.lib.osg_tblock_kv_pack_elems(imgs, heads, d) == imgs * heads * 80 * dp
+        kp, vtp = self.empty((imgs, heads, 80, dp), k.dtype), self.empty((imgs, heads, dp, 80), k.dtype)
+        self._ck(self.lib.osg_tblock_kv_pack(self.ctx, k.ptr, c, v.ptr, c, imgs, tk, heads, d, kp.ptr, vtp.ptr))
+        return kp, vtp
+
+    def tblock_tail(self, a1: DevBuf, x0: DevBuf, w: dict, kp: DevBuf, vtp: DevBuf, tk: int, heads: int, scale: float, rows_per_img: int, eps: float = 1e-5,
+                    xin: Optional[DevBuf] = None, out2: Optional[DevBuf] = None, out2_col: int = 0, debug: bool = False):
+        """osg_tblock_tail.  w: dict of DevBuf -- wo1 bo1 g2 be2 wq2 wo2 bo2 g3 be3 w1 b1 w2 b2 [wpo bpo]; weights [N,K].  Returns (out, [dumps])."""
+        m, c = a1.shape
+        a = TBlockTailArgs()
+        a.a1, a.x0 = a1.ptr, x0.ptr
+        for k_ in ("wo1", "bo1", "g2", "be2", "wq2", "wo2", "bo2", "g3", "be3", "w1", "b1", "w2", "b2", "wpo", "bpo"):
+            setattr(a, k_, w[k_].ptr if w.get(k_) is not None else None)
+        a.bq2 = None
+        a.kp, a.vtp, a.scale, a.Tk = kp.ptr, vtp.ptr, scale, tk
+        a.eps2 = a.eps3 = eps
+        a.xin = xin.ptr if xin is not None else None
+        out = self.empty((m, c), a1.dtype)
+        a.out, a.ldo = out.ptr, c
+        if out2 is not None:
+            a.out2, a.ldo2 = out2.ptr + out2_col * 2, out2.shape[-1]
+        a.M, a.rows_per_img, a.C, a.heads = m, rows_per_img, c, heads
+        dumps = []
+        if debug:
+            dumps = [self.empty((m, c), a1.dtype) for _ in range(7)]
+            for i, dbuf in enumerate(dumps):
+                a.dbg[i] = dbuf.ptr
+        self._ck(self.lib.osg_tblock_tail(self.ctx, ctypes.byref(a)))
+        return out, dumps
 
     def rms_norm(self, x: DevBuf, w: DevBuf, eps: float):
         rows, c = int(np.prod(x.shape[:-1])), x.shape[-1]

@@ -1,0 +1,155 @@
+"""-m gpu: the row-local transformer-block tail (osg_tblock_tail, onnxstream_amd/csrc/osg_tchain.hip) against
+  (1) the SAME chain run launch by launch through the entry points the round-3 plan used (osg_gemm + residual, osg_layer_norm, osg_attention_strided,
+      osg_gemm + GEGLU ...): every stage dump of the fused kernel is compared with the stage it replaces -- a stage that consumes the very bits the
+      separate launch consumed must land within a couple of f16 ulps of it (same MFMA shape and k order; LayerNorm / softmax differ in summation order);
+  (2) the numpy restatement of the reference arithmetic (oracle/np_ops.py), end to end, tolerance 2e-3 of max|want| (eight roundings deep).
+Reference ops restated: src/onnxstream.cpp:5669-5861 (MatMul), :5237-5604 (the LayerNorm chain), :6696-6929 (AttentionFusedOps), :4001-4139 (Erf)."""
+import numpy as np
+import pytest
+
+from oracle import np_ops as ref
+
+pytestmark = pytest.mark.gpu
+f16, f32 = np.float16, np.float32
+
+
+def rel_max(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def rnd(rng, shape, std=1.0):
+    return (rng.standard_normal(shape, dtype=f32) * std).astype(f16)
+
+
+def make_block(rng, C, ctx_c=768):
+    F = 4 * C
+    w = dict(wo1=rnd(rng, (C, C), C ** -0.5), bo1=rnd(rng, (C,), 0.1), g2=(1 + 0.2 * rng.standard_normal(C)).astype(f16), be2=rnd(rng, (C,), 0.1),
+             wq2=rnd(rng, (C, C), C ** -0.5), wo2=rnd(rng, (C, C), C ** -0.5), bo2=rnd(rng, (C,), 0.1),
+             g3=(1 + 0.2 * rng.standard_normal(C)).astype(f16), be3=rnd(rng, (C,), 0.1),
+             w1=rnd(rng, (2 * F, C), C ** -0.5), b1=rnd(rng, (2 * F,), 0.1), w2=rnd(rng, (C, F), F ** -0.5), b2=rnd(rng, (C,), 0.1),
+             wpo=rnd(rng, (C, C), C ** -0.5), bpo=rnd(rng, (C,), 0.1))
+    return w
+
+
+def chain_separate(gpu, a1, x0, w, k, v, heads, scale, imgs, eps, xin):
+    """the tail as the round-3 plan ran it: one launch per op (weights [N,K])"""
+    d = {n: gpu.to_dev(t) for n, t in w.items()}
+    M, C = a1.shape
+    st = {}
+    x1 = gpu.gemm(gpu.to_dev(a1), d["wo1"], d["bo1"], gpu.to_dev(x0), b_is_nk=True)
+    st["x1"] = x1.numpy()
+    n2 = gpu.layer_norm(x1, d["g2"], d["be2"], eps)
+    st["ln2"] = n2.numpy()
+    q = gpu.gemm(n2, d["wq2"], None, None, b_is_nk=True)
+    st["q"] = q.numpy()
+    q3 = gpu.to_dev(st["q"].reshape(imgs, M // imgs, C))
+    a2 = gpu.attention_tokens(q3, gpu.to_dev(k), gpu.to_dev(v), heads, scale)
+    st["a2"] = a2.numpy().reshape(M, C)
+    x2 = gpu.gemm(gpu.to_dev(st["a2"]), d["wo2"], d["bo2"], x1, b_is_nk=True)
+    st["x2"] = x2.numpy()
+    n3 = gpu.layer_norm(x2, d["g3"], d["be3"], eps)
+    st["ln3"] = n3.numpy()
+    h = gpu.gemm(n3, d["w1"], d["b1"], None, b_is_nk=True)
+    hg = gpu.geglu(h)
+    x3 = gpu.gemm(hg, d["w2"], d["b2"], x2, b_is_nk=True)
+    st["x3"] = x3.numpy()
+    if xin is not None:
+        st["y"] = gpu.gemm(x3, d["wpo"], d["bpo"], gpu.to_dev(xin), b_is_nk=True).numpy()
+    return st
+
+
+def chain_numpy(a1, x0, w, k, v, heads, scale, imgs, eps, xin):
+    """oracle/np_ops.py: f64 arithmetic, one f16 rounding at every op boundary that survives fusion level 2"""
+    from scipy.special import erf
+    M, C = a1.shape
+    D = C // heads
+    x1 = ref.matmul(a1, w["wo1"].T, w["bo1"], x0)
+    n2 = ref.layer_norm_exact(x1, w["g2"], w["be2"], eps)
+    q = ref.matmul(n2, w["wq2"].T)
+    sp = lambda t, T: t.reshape(imgs, T, heads, D).transpose(0, 2, 1, 3).reshape(imgs * heads, T, D)
+    Tq, Tk = M // imgs, k.shape[1]
+    a2 = ref.attention_exact(sp(q, Tq), sp(k, Tk), sp(v, Tk), scale).reshape(imgs, heads, Tq, D).transpose(0, 2, 1, 3).reshape(M, C)
+    x2 = ref.matmul(a2, w["wo2"].T, w["bo2"], x1)
+    n3 = ref.layer_norm_exact(x2, w["g3"], w["be3"], eps)
+    F = w["w2"].shape[1]
+    hh = n3.astype(np.float64) @ w["w1"].T.astype(np.float64) + w["b1"].astype(np.float64)
+    vv, gg = hh[:, :F], hh[:, F:]
+    h = ref.r16(vv * 0.5 * gg * (1.0 + erf(gg / np.sqrt(2.0))))
+    x3 = ref.matmul(h, w["w2"].T, w["b2"], x2)
+    out = dict(x1=x1, ln2=n2, q=q, a2=a2, x2=x2, ln3=n3, x3=x3)
+    if xin is not None:
+        out["y"] = ref.matmul(x3, w["wpo"].T, w["bpo"], xin)
+    return out
+
+
+STAGES = ["x1", "ln2", "q", "a2", "x2", "ln3", "x3"]
+
+
+@pytest.mark.parametrize("M,imgs,Tk,proj", [(128, 2, 77, True), (256, 2, 77, False), (512, 1, 80, True), (192, 3, 50, True), (8192, 2, 77, True)])
+def test_tblock_tail_stage_by_stage(gpu, M, imgs, Tk, proj):
+    C, heads = 320, 8
+    assert gpu.lib.osg_tblock_tail_supported(M, M // imgs, C, heads, Tk) == 1
+    rng = np.random.default_rng(M + Tk)
+    w = make_block(rng, C)
+    a1, x0, xin = rnd(rng, (M, C)), rnd(rng, (M, C)), rnd(rng, (M, C))
+    k, v = rnd(rng, (imgs, Tk, C)), rnd(rng, (imgs, Tk, C))
+    scale, eps = (C // heads) ** -0.5, 1e-5
+    dw = {n: gpu.to_dev(t) for n, t in w.items()}
+    if not proj:
+        dw["wpo"] = dw["bpo"] = None
+    kp, vtp = gpu.tblock_kv_pack(gpu.to_dev(k), gpu.to_dev(v), heads)
+    # the packs are pure data movement: bit-exact
+    D = C // heads
+    kpn, vtn = kp.numpy(), vtp.numpy()
+    want_kp = np.zeros((imgs, heads, 80, 48), f16)
+    want_kp[:, :, :Tk, :D] = k.reshape(imgs, Tk, heads, D).transpose(0, 2, 1, 3)
+    want_vt = np.zeros((imgs, heads, 48, 80), f16)
+    want_vt[:, :, :D, :Tk] = v.reshape(imgs, Tk, heads, D).transpose(0, 2, 3, 1)
+    assert np.array_equal(kpn, want_kp) and np.array_equal(vtn, want_vt)
+
+    out, dumps = gpu.tblock_tail(gpu.to_dev(a1), gpu.to_dev(x0), dw, kp, vtp, Tk, heads, scale, M // imgs, eps, xin=gpu.to_dev(xin) if proj else None, debug=True)
+    got = {n: dumps[i].numpy() for i, n in enumerate(STAGES)}
+    if proj:
+        got["y"] = out.numpy()
+    else:
+        got["x3"] = out.numpy()
+    sep = chain_separate(gpu, a1, x0, w, k, v, heads, scale, imgs, eps, xin if proj else None)
+    npy = chain_numpy(a1, x0, w, k, v, heads, scale, imgs, eps, xin if proj else None)
+    names = STAGES + (["y"] if proj else [])
+    report = {n: (rel_max(got[n], sep[n]), rel_max(got[n], npy[n]), rel_max(sep[n], npy[n])) for n in names}
+    msg = "\n".join(f"{n:4s} fused-vs-separate {a:.2e}  fused-vs-numpy {b:.2e}  separate-vs-numpy {c:.2e}" for n, (a, b, c) in report.items())
+    print("\n" + msg)
+    for n in names:
+        assert np.isfinite(got[n].astype(f32)).all(), n + " not finite\n" + msg
+    last = names[-1]
+    # end to end against the oracle: the fused chain may not be further from it than the separate launches are, beyond rounding noise
+    assert report[last][1] <= max(2e-3, 1.5 * report[last][2]), msg
+    for n in names:
+        assert report[n][1] <= max(2.5e-3, 1.5 * report[n][2]), msg
+    # x1 consumes identical inputs with the same MFMA shape as the separate GEMM (its k split may differ): within an f16 ulp of the largest value
+    assert rel_max(got["x1"], sep["x1"]) <= 5e-4, msg
+
+
+def test_tblock_tail_second_destination_and_row_pitch(gpu):
+    """out2 / ldo2 (a skip connection's Concat slot) receives the same bits as out"""
+    C, heads, M, imgs, Tk = 320, 8, 128, 1, 77
+    rng = np.random.default_rng(5)
+    w = make_block(rng, C)
+    a1, x0, xin = rnd(rng, (M, C)), rnd(rng, (M, C)), rnd(rng, (M, C))
+    k, v = rnd(rng, (imgs, Tk, C)), rnd(rng, (imgs, Tk, C))
+    dw = {n: gpu.to_dev(t) for n, t in w.items()}
+    kp, vtp = gpu.tblock_kv_pack(gpu.to_dev(k), gpu.to_dev(v), heads)
+    wide = gpu.to_dev(np.full((M, 2 * C + 64), 7.0, f16))
+    out, _ = gpu.tblock_tail(gpu.to_dev(a1), gpu.to_dev(x0), dw, kp, vtp, Tk, heads, 40 ** -0.5, M, xin=gpu.to_dev(xin), out2=wide, out2_col=C)
+    o, wd = out.numpy(), wide.numpy()
+    assert np.array_equal(wd[:, C:2 * C], o)
+    assert (wd[:, :C] == 7).all() and (wd[:, 2 * C:] == 7).all()
+    out_b, _ = gpu.tblock_tail(gpu.to_dev(a1), gpu.to_dev(x0), dw, kp, vtp, Tk, heads, 40 ** -0.5, M, xin=gpu.to_dev(xin))
+    assert np.array_equal(out_b.numpy(), o)           # relaunch: same bits
+
+
+def test_tblock_tail_rejects_what_it_does_not_take(gpu):
+    assert gpu.lib.osg_tblock_tail_supported(8192, 4096, 640, 8, 77) == 0
+    assert gpu.lib.osg_tblock_tail_supported(100, 100, 320, 8, 77) == 0
+    assert gpu.lib.osg_tblock_tail_supported(128, 64, 320, 8, 81) == 0

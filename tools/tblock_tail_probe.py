@@ -1,0 +1,72 @@
+"""Dev probe (GPU box): the fused transformer-block tail (osg_tblock_tail) against the same chain as separate launches, at the SD 1.5 64x64 level
+(M = 8192, C = 320), cycling through enough weight sets that every launch finds its weights cold (as inside a pass)."""
+import sys
+import os
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from onnxstream_amd import osgpu
+import test_tblock_tail as t
+
+f16 = np.float16
+
+
+def main():
+    gpu = osgpu.Gpu(0)
+    C, heads, M, imgs, Tk = 320, 8, 8192, 2, 77
+    nsets = int(os.environ.get("NSETS", "96"))
+    reps = int(os.environ.get("REPS", "3"))
+    rng = np.random.default_rng(0)
+    sets = []
+    w0 = t.make_block(rng, C)
+    for i in range(nsets):
+        sets.append({n: gpu.to_dev(np.roll(v, i, axis=0)) for n, v in w0.items()})
+    a1, x0, xin = gpu.to_dev(t.rnd(rng, (M, C))), gpu.to_dev(t.rnd(rng, (M, C))), gpu.to_dev(t.rnd(rng, (M, C)))
+    k, v = gpu.to_dev(t.rnd(rng, (imgs, Tk, C))), gpu.to_dev(t.rnd(rng, (imgs, Tk, C)))
+    kp, vtp = gpu.tblock_kv_pack(k, v, heads)
+    scale = 40 ** -0.5
+    for proj in (True, False):
+        for name, ns in (("cold", nsets), ("hot", 1)):
+            for _ in range(2):
+                gpu.tblock_tail(a1, x0, sets[0], kp, vtp, Tk, heads, scale, M // imgs, xin=xin if proj else None)
+            gpu.sync()
+            gpu.timer_start()
+            n = 0
+            for r in range(reps):
+                for i in range(ns if ns > 1 else 32):
+                    w = dict(sets[i % ns])
+                    if not proj:
+                        w["wpo"] = w["bpo"] = None
+                    gpu.tblock_tail(a1, x0, w, kp, vtp, Tk, heads, scale, M // imgs, xin=xin if proj else None)
+                    n += 1
+            ms = gpu.timer_stop()
+            print(f"fused tail proj_out={int(proj)} {name}: {1000 * ms / n:.1f} us per launch ({n} launches; includes the host-side allocation of the output)")
+    # the separate chain, same weights (hot and cold)
+    q3shape = (imgs, M // imgs, C)
+    for name, ns in (("cold", nsets), ("hot", 1)):
+        gpu.sync()
+        gpu.timer_start()
+        n = 0
+        for r in range(reps):
+            for i in range(ns if ns > 1 else 32):
+                d = sets[i % ns]
+                x1 = gpu.gemm(a1, d["wo1"], d["bo1"], x0, b_is_nk=True)
+                n2 = gpu.layer_norm(x1, d["g2"], d["be2"], 1e-5)
+                q = gpu.gemm(n2, d["wq2"], None, None, b_is_nk=True)
+                q.shape = q3shape
+                a2 = gpu.attention_tokens(q, k, v, heads, scale)
+                a2.shape = (M, C)
+                x2 = gpu.gemm(a2, d["wo2"], d["bo2"], x1, b_is_nk=True)
+                n3 = gpu.layer_norm(x2, d["g3"], d["be3"], 1e-5)
+                h = gpu.gemm(n3, d["w1"], d["b1"], None, b_is_nk=True)
+                hg = gpu.geglu(h)
+                x3 = gpu.gemm(hg, d["w2"], d["b2"], x2, b_is_nk=True)
+                y = gpu.gemm(x3, d["wpo"], d["bpo"], xin, b_is_nk=True)
+                n += 1
+        ms = gpu.timer_stop()
+        print(f"separate launches (10, unfused LayerNorm / GEGLU) {name}: {1000 * ms / n:.1f} us per chain")
+
+
+if __name__ == "__main__":
+    main()
