@@ -229,10 +229,12 @@ typedef struct {
 } osg_tblock_tail_args;
 int osg_tblock_tail_supported(int M, int rows_per_img, int C, int heads, int Tk); /* 1 = osg_tblock_tail takes the shape */
 int osg_tblock_tail(osg_ctx* ctx, const osg_tblock_tail_args* a);
-/* K / V of a cross-attention ([imgs][Tk] rows ldk / ldv apart, head h at column h D) re-packed for osg_tblock_tail: kp [img][head][80][DP] and
- * vtp [img][head][DP][80] (V transposed), DP = D rounded up to 16, zero padding; osg_tblock_kv_pack_elems = f16 elements of EACH pack. */
+/* K / V of cross-attentions re-packed for osg_tblock_tail, several blocks per launch.  All of them are column ranges of ONE matrix `base` ([imgs * Tk] rows
+ * ld apart -- the merged K|V projection of the text context): job j = jobs_dev[4 j .. 4 j + 3] = {column of K, column of V, head dim D, element offset of
+ * its packs inside dst}; head h sits h D columns further in.  At dst + offset: kp [img][head][80][DP], then vtp [img][head][DP][80] (V transposed),
+ * DP = D rounded up to 16, zero padding.  osg_tblock_kv_pack_elems = f16 elements of EACH of the two packs of a job. */
 size_t osg_tblock_kv_pack_elems(int imgs, int heads, int D);
-int osg_tblock_kv_pack(osg_ctx* ctx, const void* k, long ldk, const void* v, long ldv, int imgs, int Tk, int heads, int D, void* kp, void* vtp);
+int osg_tblock_kv_pack_jobs(osg_ctx* ctx, const void* base, long ld, int imgs, int Tk, int heads, int njobs, const int* jobs_dev, void* dst);
 /* ScaledDotProductAttention == the reference's pseudo-op of that name (formed at run time from Transpose/MatMul/Div/Add/Softmax/MatMul or
  * Transpose/Mul/Mul/MatMul/Add/Softmax/MatMul when m_use_scaled_dp_attn_op, onnxstream.cpp:3635-3755; executed at :7767-7882 through
  * XnnPack::scaled_dot_product_attention :2054-2150): out = softmax(scale * q k^T + mask) v per batch and head.  Dense q [B][Hq][Tq][D],

@@ -300,9 +300,13 @@ void Model::run() {
     const auto t0 = now();
     // a plan that no longer fits is replaced -- and torn down only while the device works on the new plan's pass (Plan::execute's hook): its buffers are idle
     // (the pass it ran has been waited for), its pooled arena goes back to the pool for the call after this one
+    // ... for models that re-plan on EVERY call (m_support_dynamic_shapes: the LLM flow -- small arenas that come from and go back to the Model's pool, 0.8 ms of
+    // teardown per token).  Any other model (the SD UNet / VAE: a re-plan is a batch, option or budget change) gives its arena, streaming ring and owned
+    // buffers back BEFORE the replacement is built: old and new arena never coexist, m_vram_to_use is not exceeded (advisor, round 3)
     Plan* old_plan = nullptr;
     if (m_plan && !m_plan->compatible(*this, batch)) {
-        old_plan = m_plan;
+        if (m_plan->recycle) old_plan = m_plan;
+        else delete m_plan;
         m_plan = nullptr;
     }
     struct OldPlan {

@@ -104,6 +104,7 @@ Plan::Plan(Model& model, HipBackend& backend, ConstPool& cpool, size_t batch) : 
     fuse_gn_conv = m.m_hip_fuse_gn_conv;
     fuse_ln_gemm = m.m_hip_fuse_ln_gemm;
     concat_views = m.m_hip_concat_views;
+    fuse_tblock = m.m_hip_fuse_tblock;
     weight_prefetch = m.m_hip_weight_prefetch;
     blocked_weights = m.m_hip_blocked_weights;
     gn_stats_req = m.m_hip_gn_stats;
@@ -131,7 +132,7 @@ bool Plan::compatible(Model& mm, size_t batch) const {
     const bool want_stream = mm.m_hip_stream_weights || mm.m_cuda_options.m_vram_to_use > 0;
     if ((long)batch != N) return no("batch size");
     if (mm.m_use_fp16_arithmetic != fp16 || mm.m_use_uint8_arithmetic != u8 || mm.m_use_uint8_qdq != u8_qdq) return no("arithmetic type");
-    if (mm.m_hip_fusion_level != fusion_req || mm.m_hip_fuse_gn_conv != fuse_gn_conv || mm.m_hip_fuse_ln_gemm != fuse_ln_gemm || mm.m_hip_concat_views != concat_views || mm.m_hip_weight_prefetch != weight_prefetch || mm.m_hip_blocked_weights != blocked_weights || mm.m_hip_gn_stats != gn_stats_req ||
+    if (mm.m_hip_fusion_level != fusion_req || mm.m_hip_fuse_gn_conv != fuse_gn_conv || mm.m_hip_fuse_ln_gemm != fuse_ln_gemm || mm.m_hip_concat_views != concat_views || mm.m_hip_fuse_tblock != fuse_tblock || mm.m_hip_weight_prefetch != weight_prefetch || mm.m_hip_blocked_weights != blocked_weights || mm.m_hip_gn_stats != gn_stats_req ||
         mm.m_fuse_ops_in_attention != fuse_attn || mm.m_use_scaled_dp_attn_op != sdp_attn || mm.m_hip_autotune != autotune)
         return no("fusion / tuning options");
     if (want_stream != stream_weights || (size_t)mm.m_cuda_options.m_vram_to_use != vram_budget || (mm.m_hip_side_stream && !want_stream) != side_stream ||
@@ -761,6 +762,7 @@ struct Lowering {
             if (has_type("Conv") || has_type("osg.Linear")) { index_graph(); fuse_residual(); }
             if (has_type("Conv")) { index_graph(); fuse_conv_act(); }
             if (has_type("osg.GEGLU")) { index_graph(); fuse_linear_geglu(); }
+            if (has_type("osg.Attention") && has_type("osg.LayerNorm")) { index_graph(); fuse_tblock_tail(); }   // (after the residual / GEGLU fusions: it matches their results)
             if (has_type("osg.SiLU")) { index_graph(); cse_silu(); }
             if (has_type("osg.SiLU") && has_type("Gemm")) { index_graph(); fuse_gemm_act(); }   // (after the CSE: the 22 SiLUs behind the time embedding are one by now)
             if (has_type("Conv")) { index_graph(); fuse_image_bias(); }
@@ -1331,6 +1333,106 @@ struct Lowering {
             f.m_output = {ops()[ge].m_output[0]};
             dead[i] = 1;
             ops()[ge] = std::move(f);
+        }
+    }
+
+    // The row-local tail of a BasicTransformerBlock ==> osg.TBlockTail (one launch, osg_tblock_tail / osg_tchain.hip):
+    //   osg.Linear(a1, Wo1, bo1, +x0) = x1 -> osg.LayerNorm -> osg.Linear(Wq2) = q -> osg.Attention(q, k, v) -> osg.Linear(Wo2, bo2, +x1) = x2
+    //   -> osg.LayerNorm -> osg.Linear(W1, b1, geglu) -> osg.Linear(W2, b2, +x2) = x3 [-> Reshape -> Transpose(0,3,1,2) -> Conv 1x1 (+ residual) = y]
+    // anchored at the cross-attention (k / v do not depend on the rows: they are projections of the text context).  Everything between a1 and x3 / y
+    // must have exactly the readers the chain itself accounts for.
+    void fuse_tblock_tail() {
+        if (P.stream_weights || !m.m_hip_fuse_tblock || P.w8_resident) return;
+        for (size_t i = 0; i < ops().size(); i++) {
+            if (!is((int)i, "osg.Attention")) continue;
+            const Operation& at = ops()[i];
+            if (at.m_input.size() != 3 || at.m_output.size() != 1) continue;
+            const Tensor q = at.m_input[0], kt = at.m_input[1], vt = at.m_input[2];
+            if (q.m_name == kt.m_name || q.m_name == vt.m_name) continue;                    // self-attention: q, k, v are views of one projection
+            // q = Linear(LayerNorm(x1)), no residual
+            const int lq = prod_of(q);
+            if (!is(lq, "osg.Linear") || use_count(q.m_name) != 1 || attr(ops()[lq], "osg_residual") || attr(ops()[lq], "osg_geglu")) continue;
+            const int ln2 = prod_of(ops()[lq].m_input[0]);
+            if (!is(ln2, "osg.LayerNorm") || use_count(ops()[lq].m_input[0].m_name) != 1) continue;
+            const Tensor x1 = ops()[ln2].m_input[0];
+            const int lo1 = prod_of(x1);
+            if (!is(lo1, "osg.Linear") || !attr(ops()[lo1], "osg_residual") || attr(ops()[lo1], "osg_geglu") || ops()[lo1].m_input.size() != 4 || use_count(x1.m_name) != 2) continue;
+            // a2 -> Linear(+x1) = x2
+            const int lo2 = sole_consumer(at.m_output[0]);
+            if (!is(lo2, "osg.Linear") || !attr(ops()[lo2], "osg_residual") || attr(ops()[lo2], "osg_geglu") || ops()[lo2].m_input.size() != 4) continue;
+            if (ops()[lo2].m_input[0].m_name != at.m_output[0].m_name || ops()[lo2].m_input[3].m_name != x1.m_name) continue;
+            const Tensor x2 = ops()[lo2].m_output[0];
+            if (use_count(x2.m_name) != 2) continue;
+            int ln3 = -1, l2 = -1;
+            for (int c : consumers[x2.m_name]) { if (is(c, "osg.LayerNorm")) ln3 = c; else if (is(c, "osg.Linear")) l2 = c; }
+            if (ln3 < 0 || l2 < 0 || ops()[ln3].m_input[0].m_name != x2.m_name) continue;
+            const int l1 = sole_consumer(ops()[ln3].m_output[0]);
+            if (!is(l1, "osg.Linear") || !attr(ops()[l1], "osg_geglu") || ops()[l1].m_input[0].m_name != ops()[ln3].m_output[0].m_name) continue;
+            if (sole_consumer(ops()[l1].m_output[0]) != l2 || !attr(ops()[l2], "osg_residual") || ops()[l2].m_input.size() != 4) continue;
+            if (ops()[l2].m_input[0].m_name != ops()[l1].m_output[0].m_name || ops()[l2].m_input[3].m_name != x2.m_name) continue;
+            // operands: f16 resident 2-D weights, f16 vectors
+            auto wok = [&](const Operation& lin, long K, long Nn) {
+                const Val* w = cval(lin.m_input[1]);
+                return w && w->dtype == OSG_F16 && w->shape.size() == 2 && w->shape[0] == K && w->shape[1] == Nn;
+            };
+            auto vok = [&](const Tensor& t, long n, bool may_be_empty) {
+                if (t.m_name.empty()) return may_be_empty;
+                const Val* b = cval(t);
+                return b && b->dtype == OSG_F16 && b->numel() == n;
+            };
+            const auto& xs = x1.m_shape;
+            if (xs.size() != 3 || xs[0] != 1) continue;
+            const long T = (long)xs[1], C = (long)xs[2], F = 4 * C;
+            const Operation &O1 = ops()[lo1], &LQ = ops()[lq], &O2 = ops()[lo2], &L1 = ops()[l1], &L2 = ops()[l2];
+            if (!wok(O1, C, C) || !wok(LQ, C, C) || !wok(O2, C, C) || !wok(L1, C, 2 * F) || !wok(L2, F, C)) continue;
+            if (!vok(O1.m_input[2], C, true) || !vok(O2.m_input[2], C, true) || !vok(L1.m_input.size() > 2 ? L1.m_input[2] : Tensor(), 2 * F, true) || !vok(L2.m_input[2], C, true)) continue;
+            if (LQ.m_input.size() > 2 && !vok(LQ.m_input[2], C, true)) continue;
+            if (!vok(ops()[ln2].m_input[1], C, false) || !vok(ops()[ln2].m_input[2], C, false) || !vok(ops()[ln3].m_input[1], C, false) || !vok(ops()[ln3].m_input[2], C, false)) continue;
+            if (!act(O1.m_input[0]) || !act(O1.m_input[3]) || O1.m_input[0].m_shape != xs || O1.m_input[3].m_shape != xs) continue;
+            if (kt.m_shape.size() != 3 || kt.m_shape[0] != 1 || (long)kt.m_shape[2] != C || vt.m_shape != kt.m_shape) continue;
+            const long heads = std::stol(*attr(at, "heads")), Tk = (long)kt.m_shape[1];
+            if (!be.api.osg_tblock_tail_supported((int)(T * N), (int)T, (int)C, (int)heads, (int)Tk)) continue;
+            // optional: x3 -> Reshape -> Transpose(0,3,1,2) -> Conv 1x1 (bias, + residual)
+            int cv = -1, rsh = -1, trp = -1;
+            {
+                const int r0 = sole_consumer(L2.m_output[0]);
+                const int t0 = is(r0, "Reshape") ? sole_consumer(ops()[r0].m_output[0]) : -1;
+                auto* pm = t0 >= 0 ? attr(ops()[t0], "perm") : nullptr;
+                const int c0 = is(t0, "Transpose") && pm && int_list(*pm) == std::vector<int>{0, 3, 1, 2} ? sole_consumer(ops()[t0].m_output[0]) : -1;
+                if (is(c0, "Conv")) {
+                    const Operation& co = ops()[c0];
+                    const Val* w = cval(co.m_input[1]);
+                    const auto& rs = ops()[r0].m_output[0].m_shape;
+                    bool ok = co.m_input.size() == 4 && attr(co, "osg_residual") && !attr(co, "osg_image_bias") && !attr(co, "osg_prenorm") && !attr(co, "osg_act") &&
+                              co.m_input[0].m_name == ops()[t0].m_output[0].m_name && w && w->dtype == OSG_F16 && w->shape == Shape{C, C, 1, 1} && vok(co.m_input[2], C, true) &&
+                              rs.size() == 4 && rs[0] == 1 && (long)(rs[1] * rs[2]) == T && (long)rs[3] == C && act(co.m_input[3]) && co.m_input[3].m_name != co.m_input[0].m_name;
+                    for (auto& a : co.m_attributes) {
+                        if (a.first == "pads") { for (int v2 : int_list(a.second)) ok = ok && v2 == 0; }
+                        else if (a.first == "strides" || a.first == "dilations" || a.first == "kernel_shape") { for (int v2 : int_list(a.second)) ok = ok && v2 == 1; }
+                        else if (a.first == "group") ok = ok && std::stoi(a.second) == 1;
+                    }
+                    if (ok) { cv = c0; rsh = r0; trp = t0; }
+                }
+            }
+            Operation f;
+            f.m_name = at.m_name + "_TBlockTail";
+            f.m_type = "osg.TBlockTail";
+            const Tensor none;
+            f.m_input = {O1.m_input[0], O1.m_input[3], O1.m_input[1], O1.m_input[2], ops()[ln2].m_input[1], ops()[ln2].m_input[2], LQ.m_input[1],
+                         LQ.m_input.size() > 2 ? LQ.m_input[2] : none, kt, vt, O2.m_input[1], O2.m_input[2], ops()[ln3].m_input[1], ops()[ln3].m_input[2],
+                         L1.m_input[1], L1.m_input.size() > 2 ? L1.m_input[2] : none, L2.m_input[1], L2.m_input[2]};
+            f.m_attributes = {{"heads", *attr(at, "heads")}, {"scale", *attr(at, "scale")}, {"eps2", *attr(ops()[ln2], "epsilon")}, {"eps3", *attr(ops()[ln3], "epsilon")},
+                              {"proj", cv >= 0 ? "1" : "0"}};
+            const int last = cv >= 0 ? cv : l2;
+            if (cv >= 0) {
+                f.m_input.push_back(ops()[cv].m_input[1]);
+                f.m_input.push_back(ops()[cv].m_input[2]);
+                f.m_input.push_back(ops()[cv].m_input[3]);
+            }
+            f.m_output = {ops()[last].m_output[0]};
+            for (int k2 : {lo1, ln2, lq, (int)i, lo2, ln3, l1, l2, rsh, trp})
+                if (k2 >= 0 && k2 != last) dead[k2] = 1;
+            ops()[last] = std::move(f);
         }
     }
 
@@ -2451,6 +2553,7 @@ struct Lowering {
         if (t == "osg.LayerNorm") return lower_layer_norm(op);
         if (t == "osg.GEGLU") return lower_geglu(op);
         if (t == "osg.Attention") return lower_attention(op);
+        if (t == "osg.TBlockTail") return lower_tblock_tail(op);
         if (t == "AttentionFusedOps") return lower_attention_fused_ops(op);
         if (t == "ScaledDotProductAttention") return lower_sdpa(op);
         if (t == "Expand") return lower_expand(op);
@@ -2519,7 +2622,7 @@ struct Lowering {
     // sink[k]: GroupNorm statistics of what the launch stores to dst (k = 0) / dst2 (k = 1), added up by its epilogue into the plan's statistics block at
     // `off` (osg_set_stat_sinks; lower_group_norm arms the producers of the tensor it normalises)
     struct StatSinkRef { long off = -1; int groups = 0, cpg = 0, ch_off = 0; };
-    struct ConvOut { int dst; long dst_ld = 0; size_t dst_off = 0; int dst2 = -1; long dst2_ld = 0; size_t dst2_off = 0; StatSinkRef sink[2]; int sink_hw = 0; };
+    struct ConvOut { int dst; long dst_ld = 0; size_t dst_off = 0; int dst2 = -1; long dst2_ld = 0; size_t dst2_off = 0; StatSinkRef sink[2]; int sink_hw = 0; bool no_sinks = false; };   // (no_sinks: a producer whose epilogue cannot add statistics up, osg.TBlockTail)
     struct ConcatPart { std::shared_ptr<ConvOut> out; int slot; long ch_off; size_t step; };
     std::map<int, std::vector<ConcatPart>> concat_parts;   // root val of a Concat output whose operands ALL go there by output views -> the convolutions that fill it
     struct ConvProducer { size_t step; std::shared_ptr<ConvOut> out; int y; };
@@ -2742,7 +2845,7 @@ struct Lowering {
             else
                 for (int c : cit->second) {
                     const Operation& co = ops()[c];
-                    if (co.m_type == "osg.Attention") continue;
+                    if (co.m_type == "osg.Attention" || co.m_type == "osg.TBlockTail") continue;   // (both read k / v through (pointer, row pitch))
                     if (co.m_type == "Conv" && attr(co, "osg_image_bias") && co.m_input.size() >= 5 && co.m_input[4].m_name == op.m_output[0].m_name) continue;
                     ok = false;
                 }
@@ -3197,7 +3300,7 @@ struct Lowering {
                 if (it != conv_producers.end() && it->second.y == x && it->second.out->dst == x && it->second.out->dst_ld == 0) parts.push_back(ConcatPart{it->second.out, 0, 0, it->second.step});
             }
             bool ok = !parts.empty();
-            for (auto& pt : parts) ok = ok && pt.out->sink[pt.slot].off < 0 && (pt.out->sink_hw == 0 || pt.out->sink_hw == (int)HW);
+            for (auto& pt : parts) ok = ok && !pt.out->no_sinks && pt.out->sink[pt.slot].off < 0 && (pt.out->sink_hw == 0 || pt.out->sink_hw == (int)HW);
             if (ok) {
                 const long off = P.gn_stats_bytes;
                 P.gn_stats_bytes += (size_t)8 * nb * G * 2 * sizeof(long long);     // (eight copies, one per XCD: include/osgpu.h osg_set_stat_sinks)
@@ -3366,6 +3469,127 @@ struct Lowering {
                      "Attention");
         });
         P.steps.back().flops = 4.0 * nb * h * Tq * Tk * d;
+    }
+
+    // ---- osg.TBlockTail (fuse_tblock_tail): one launch of osg_tblock_tail per transformer block, K / V packs of ALL such blocks from one launch --------
+    std::map<std::string, std::pair<int, size_t>> kv_packs;   // fused op name -> (pack buffer val, element offset of its kp; vtp right behind)
+
+    // K / V of cross-attentions that are column views of ONE merged projection of the text context (plan_linear_groups: 32 -> 1) are re-packed by ONE
+    // launch for every osg.TBlockTail of the graph that shares the merged output and the head count with `op`
+    void prepack_kv(const Operation& op, int k, int v, long heads, long Tk) {
+        struct Job { std::string name; long kcol, vcol, D; };
+        std::vector<Job> jobs;
+        const int base = P.root_of(k);
+        const long ld = V(k).ld;
+        const bool shared = ld > 0 && P.root_of(v) == base && V(v).ld == ld && V(k).view_off % 2 == 0 && V(v).view_off % 2 == 0;
+        const long imgs = B(k);
+        int src = base;
+        long src_ld = ld;
+        if (shared) {
+            jobs.push_back(Job{op.m_name, (long)V(k).view_off / 2, (long)V(v).view_off / 2, V(k).shape.back() / heads});
+            const int gk = indexed && producer.count(op.m_input[8].m_name) && group_of.count(producer[op.m_input[8].m_name]) ? group_of[producer[op.m_input[8].m_name]].first : -1;
+            if (gk >= 0)
+                for (size_t i = 0; i < ops().size(); i++) {
+                    const Operation& o = ops()[i];
+                    if (o.m_type != "osg.TBlockTail" || o.m_name == op.m_name || kv_packs.count(o.m_name) || std::stol(*attr(o, "heads")) != heads) continue;
+                    auto pk = producer.find(o.m_input[8].m_name), pv = producer.find(o.m_input[9].m_name);
+                    if (pk == producer.end() || pv == producer.end()) continue;
+                    auto gik = group_of.find(pk->second), giv = group_of.find(pv->second);
+                    if (gik == group_of.end() || giv == group_of.end() || gik->second.first != gk || giv->second.first != gk) continue;
+                    if ((long)o.m_input[8].m_shape[1] != Tk) continue;
+                    const LinGroup& g = groups[gk];
+                    jobs.push_back(Job{o.m_name, g.off[gik->second.second], g.off[giv->second.second], (long)o.m_input[8].m_shape[2] / heads});
+                }
+        } else {
+            // dense K and V of one block: side by side in a scratch matrix first (never the case in the SD graphs: their K / V projections are merged)
+            const long C = V(k).shape.back();
+            const int kd = P.ensure_plain(k), vd = P.ensure_plain(v);
+            src = P.new_val("", {imgs * Tk, 2 * C}, OSG_F16, Lay::plain, false);
+            src_ld = 2 * C;
+            const long rows = imgs * Tk;
+            P.add_step("KVPack gather " + op.m_name, {kd, vd}, {src}, [=, this] { be.check(be.api.osg_concat2(be.ctx, 2, P.ptr(kd), C, P.ptr(vd), C, P.ptr(src), rows), "KVPack"); });
+            jobs.push_back(Job{op.m_name, 0, C, C / heads});
+        }
+        std::vector<int> table;
+        size_t total = 0;
+        for (auto& j : jobs) {
+            const size_t each = be.api.osg_tblock_kv_pack_elems((int)imgs, (int)heads, (int)j.D);
+            table.insert(table.end(), {(int)j.kcol, (int)j.vcol, (int)j.D, (int)total});
+            total += 2 * each;
+        }
+        const int pack = P.new_val("", {(long)total}, OSG_F16, Lay::plain, false);
+        void* tdev = P.small_alloc(table.size() * sizeof(int));
+        be.check(be.api.osg_upload_sync(be.ctx, tdev, table.data(), table.size() * sizeof(int)), "osg_upload_sync");
+        for (size_t j = 0; j < jobs.size(); j++) kv_packs[jobs[j].name] = {pack, (size_t)table[4 * j + 3]};
+        const int nj = (int)jobs.size();
+        P.add_step("KVPack x" + std::to_string(nj) + " " + op.m_name, {src}, {pack}, [=, this] {
+            be.check(be.api.osg_tblock_kv_pack_jobs(be.ctx, P.ptr(src), src_ld, (int)imgs, (int)Tk, (int)heads, nj, (const int*)tdev, P.ptr(pack)), "KVPack");
+        });
+    }
+
+    void lower_tblock_tail(const Operation& op) {
+        const bool proj = *attr(op, "proj") == "1";
+        need(op, op.m_input.size() == (proj ? 21u : 18u) && op.m_output.size() == 1, "wrong number of inputs.");
+        const long heads = std::stol(*attr(op, "heads"));
+        const float scale = std::stof(*attr(op, "scale")), eps2 = std::stof(*attr(op, "eps2")), eps3 = std::stof(*attr(op, "eps3"));
+        const int a1 = P.ensure_plain(in_val(op.m_input[0])), x0 = P.ensure_plain(in_val(op.m_input[1]));
+        auto opt = [&](const Tensor& t) { return t.m_name.empty() ? -1 : in_val(t); };
+        const int wo1 = weight_nk(in_val(op.m_input[2])), bo1 = opt(op.m_input[3]), g2 = in_val(op.m_input[4]), be2 = in_val(op.m_input[5]);
+        const int wq2 = weight_nk(in_val(op.m_input[6])), bq2 = opt(op.m_input[7]);
+        const int k = in_val_raw(op.m_input[8]), v = in_val_raw(op.m_input[9]);
+        const int wo2 = weight_nk(in_val(op.m_input[10])), bo2 = opt(op.m_input[11]), g3 = in_val(op.m_input[12]), be3 = in_val(op.m_input[13]);
+        const int w1 = weight_nk(in_val(op.m_input[14])), b1 = opt(op.m_input[15]), w2 = weight_nk(in_val(op.m_input[16])), b2 = opt(op.m_input[17]);
+        const Shape as = V(a1).shape;
+        need(op, as.size() == 3 && as[0] == 1 && V(x0).shape == as && V(a1).ld == 0 && V(x0).ld == 0, "invalid shape of inputs.");
+        const long T = as[1], C = as[2], F = 4 * C, Tk = V(k).shape[1], nb = B(a1), M = T * nb;
+        need(op, V(a1).batched == V(x0).batched && V(k).batched == V(a1).batched && V(v).batched == V(a1).batched, "q/k/v batching mismatch.");
+        need(op, be.api.osg_tblock_tail_supported((int)M, (int)T, (int)C, (int)heads, (int)Tk) == 1, "shape not taken by osg_tblock_tail.");
+        for (int g : {g2, be2, g3, be3}) need(op, V(g).dtype == OSG_F16 && V(g).numel() == C, "invalid LayerNorm operands.");
+        int wpo = -1, bpo = -1, xin = -1;
+        if (proj) {
+            wpo = in_val(op.m_input[18]);
+            bpo = opt(op.m_input[19]);
+            xin = P.ensure_nhwc(in_val(op.m_input[20]));
+            need(op, V(wpo).is_const && V(wpo).lay == Lay::nhwc && V(wpo).dtype == OSG_F16 && V(xin).ld == 0 && P.total_elems(xin) == M * C, "invalid proj_out operands.");
+        }
+        if (!kv_packs.count(op.m_name)) prepack_kv(op, k, v, heads, Tk);
+        const auto [pack, koff] = kv_packs.at(op.m_name);
+        const size_t each = be.api.osg_tblock_kv_pack_elems((int)nb, (int)heads, (int)(C / heads));
+        int y;
+        if (proj) {
+            const Shape xs = V(xin).shape;   // [1, C, H, W]
+            y = out_val(op, xs, Lay::nhwc, V(a1).batched);
+        } else
+            y = out_val(op, as, Lay::plain, V(a1).batched);
+        auto co = std::make_shared<ConvOut>();
+        co->dst = y;
+        co->no_sinks = true;
+        std::vector<int> reads = {a1, x0, wo1, g2, be2, wq2, pack, wo2, g3, be3, w1, w2};
+        for (int r : {bo1, bq2, bo2, b1, b2, wpo, bpo, xin})
+            if (r >= 0) reads.push_back(r);
+        const std::string what = std::string("TBlockTail") + (proj ? "+proj_out " : " ") + op.m_name;
+        P.add_step(what, reads, {y}, [=, this] {
+            const ConvOut& o = *co;
+            auto p = [&](int val) -> const void* { return val >= 0 ? P.ptr(val) : nullptr; };
+            osg_tblock_tail_args a{};
+            a.a1 = p(a1); a.x0 = p(x0);
+            a.wo1 = p(wo1); a.bo1 = p(bo1);
+            a.g2 = p(g2); a.be2 = p(be2); a.eps2 = eps2;
+            a.wq2 = p(wq2); a.bq2 = p(bq2);
+            a.kp = (const char*)P.ptr(pack) + koff * 2;
+            a.vtp = (const char*)a.kp + each * 2;
+            a.scale = scale; a.Tk = (int)Tk;
+            a.wo2 = p(wo2); a.bo2 = p(bo2);
+            a.g3 = p(g3); a.be3 = p(be3); a.eps3 = eps3;
+            a.w1 = p(w1); a.b1 = p(b1); a.w2 = p(w2); a.b2 = p(b2);
+            a.wpo = p(wpo); a.bpo = p(bpo); a.xin = p(xin);
+            a.out = (char*)P.ptr(o.dst) + o.dst_off; a.ldo = o.dst_ld;
+            a.out2 = o.dst2 >= 0 ? (char*)P.ptr(o.dst2) + o.dst2_off : nullptr; a.ldo2 = o.dst2_ld;
+            a.M = (int)M; a.rows_per_img = (int)T; a.C = (int)C; a.heads = (int)heads;
+            be.check(be.api.osg_tblock_tail(be.ctx, &a), what.c_str());
+        });
+        P.steps.back().flops = 2.0 * M * C * C * (proj ? 4 : 3) + 2.0 * M * C * 2 * F + 2.0 * M * F * C + 4.0 * nb * heads * T * Tk * (C / heads);
+        if (proj) conv_producers[P.root_of(y)] = ConvProducer{P.steps.size() - 1, co, y};
     }
 
     // ScaledDotProductAttention (reference :7767-7882): q [B,Hq,T,D], k [B,Hkv,S,D], mask [T,S] | [1,1,T,S], v [B,Hkv,S,Dv] -> [B,Hq,T,Dv]
@@ -3659,7 +3883,7 @@ struct Lowering {
                 const int x = xs[k];
                 const long Cx = V(x).shape[1];
                 auto it = conv_producers.find(P.root_of(x));
-                const bool whole = it != conv_producers.end() && V(x).ld == 0 && V(x).view_off == 0 && V(x).numel() > 0 && V(x).batched == batched &&
+                const bool whole = it != conv_producers.end() && it->second.y == x /* the convolution's OWN output, not a same-shape alias of it (advisor, round 3) */ && V(x).ld == 0 && V(x).view_off == 0 && V(x).numel() > 0 && V(x).batched == batched &&
                                    V(it->second.y).shape == V(x).shape && V(x).lay == Lay::nhwc && Cx % 4 == 0 && (coff * es) % 8 == 0;
                 if (whole && it->second.out->dst2 < 0 && it->second.out->dst == it->second.y && it->second.out->dst_ld == 0) {
                     ConvOut& o = *it->second.out;

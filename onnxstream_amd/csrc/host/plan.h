@@ -274,6 +274,7 @@ struct Plan {
     bool fuse_gn_conv = false;
     bool fuse_ln_gemm = false;
     bool concat_views = true;     // m_hip_concat_views
+    bool fuse_tblock = true;      // m_hip_fuse_tblock
     bool in_flight = false;       // a pass of this plan may still be running on the device (set while execute() / replay() are between enqueue and wait)
     bool weight_prefetch = false; // m_hip_weight_prefetch
     bool blocked_weights = false; // m_hip_blocked_weights

@@ -24,7 +24,8 @@ struct StatSink {
 };
 constexpr int kStatCopies = 8;
 constexpr float kStatSX = 1048576.f;   // 2^20: |sum x| of a group up to 2^43
-constexpr float kStatSQ = 256.f;       // 2^8:  sum x^2 of a group up to 2^55 (655 360 elements of 65504^2 still fit)
+constexpr float kStatSQ = 1048576.f;   // 2^20 (round 4; 2^8 before: a wave's partial sum of squares of a SMALL-magnitude tensor -- 64 rows x 4 channels of |x| ~ 1e-3 -- rounded to 0,
+                                       // advisor): sum x^2 of a group up to 2^43 = an rms of 2 900 over the 2^20 elements of the VAE decoder's largest group
 
 struct GemmParams {
     const f16* A;

@@ -504,18 +504,25 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     }
 }
 
-// K [imgs][Tk][ldk] (head h at column h D) -> [img][head][TKP][DP]; V likewise -> V^T [img][head][DP][TKP]; zero padding
-__global__ __launch_bounds__(256) void kv_pack_kernel(const f16* __restrict__ k, long ldk, const f16* __restrict__ v, long ldv, int Tk, int heads, int D, int DP, int TKP,
-                                                      f16* __restrict__ kp, f16* __restrict__ vtp) {
-    const int ih = blockIdx.x, img = ih / heads, h = ih - img * heads;
-    const long base = (long)ih * TKP * DP;
+// K / V of a cross-attention re-packed for cross_attention(): rows [imgs][Tk] of ONE matrix `base` (row pitch ld), job j's K at column k_col, its V at
+// column v_col (head h a further h D columns in) -> kp [img][head][TKP][DP] at dst + job.dst, vtp [img][head][DP][TKP] right behind it; zero padding
+struct PackJob { int k_col, v_col, D, dst; };
+__global__ __launch_bounds__(256) void kv_pack_kernel(const f16* __restrict__ base, long ld, int Tk, int heads, int imgs, const PackJob* __restrict__ jobs, f16* __restrict__ dst) {
+    const int per_job = imgs * heads;
+    const int j = blockIdx.x / per_job, ih = blockIdx.x - j * per_job, img = ih / heads, h = ih - img * heads;
+    const PackJob job = jobs[j];
+    const int D = job.D, DP = (D + 15) / 16 * 16, TKP = 80;
+    f16* kp = dst + job.dst + (long)ih * TKP * DP;
+    f16* vtp = dst + job.dst + (long)per_job * TKP * DP + (long)ih * TKP * DP;
+    const f16* k = base + job.k_col + h * D;
+    const f16* v = base + job.v_col + h * D;
     for (int idx = threadIdx.x; idx < TKP * DP; idx += 256) {
         const int t = idx / DP, d = idx - t * DP;
-        kp[base + idx] = (t < Tk && d < D) ? k[((long)img * Tk + t) * ldk + h * D + d] : (f16)0.f;
+        kp[idx] = (t < Tk && d < D) ? k[((long)img * Tk + t) * ld + d] : (f16)0.f;
     }
     for (int idx = threadIdx.x; idx < TKP * DP; idx += 256) {
         const int d = idx / TKP, t = idx - d * TKP;
-        vtp[base + idx] = (t < Tk && d < D) ? v[((long)img * Tk + t) * ldv + h * D + d] : (f16)0.f;
+        vtp[idx] = (t < Tk && d < D) ? v[((long)img * Tk + t) * ld + d] : (f16)0.f;
     }
 }
 
@@ -529,10 +536,10 @@ int osg_tblock_tail_supported(int M, int rows_per_img, int C, int heads, int Tk)
 
 size_t osg_tblock_kv_pack_elems(int imgs, int heads, int D) { return (size_t)imgs * heads * 80 * (size_t)((D + 15) / 16 * 16); }
 
-int osg_tblock_kv_pack(osg_ctx* ctx, const void* k, long ldk, const void* v, long ldv, int imgs, int Tk, int heads, int D, void* kp, void* vtp) {
-    if (Tk < 1 || Tk > 80 || D % 4 || D < 4 || D > 160) OSG_FAIL(ctx, "osg_tblock_kv_pack: unsupported shape");
-    hipLaunchKernelGGL(osg_tb::kv_pack_kernel, dim3((unsigned)(imgs * heads)), dim3(256), 0, ctx->compute, (const f16*)k, ldk, (const f16*)v, ldv, Tk, heads, D,
-                       (D + 15) / 16 * 16, 80, (f16*)kp, (f16*)vtp);
+int osg_tblock_kv_pack_jobs(osg_ctx* ctx, const void* base, long ld, int imgs, int Tk, int heads, int njobs, const int* jobs_dev, void* dst) {
+    if (Tk < 1 || Tk > 80 || njobs < 1 || imgs < 1 || heads < 1) OSG_FAIL(ctx, "osg_tblock_kv_pack_jobs: unsupported shape");
+    hipLaunchKernelGGL(osg_tb::kv_pack_kernel, dim3((unsigned)(njobs * imgs * heads)), dim3(256), 0, ctx->compute, (const f16*)base, ld, Tk, heads, imgs,
+                       (const osg_tb::PackJob*)jobs_dev, (f16*)dst);
     OSG_LAUNCH_CHECK(ctx);
     return 0;
 }

@@ -29,7 +29,7 @@ EXPORTS = [
     "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_concat2", "osg_resize_nearest", "osg_gather_rows",
     "osg_maxpool_nhwc", "osg_convert", "osg_sampler_prepare", "osg_sampler_cfg_euler_a",
     "osg_range_push", "osg_range_pop", "osg_marker_record", "osg_copy_wait_marker", "osg_timer_mark", "osg_timer_between", "osg_set_stat_sinks", "osg_set_weight_prefetch", "osg_set_blocked_weight_hint", "osg_group_norm_stats_nhwc", "osg_qu8_conv2d_nhwc", "osg_qu8_conv2d_nhwc_t", "osg_qu8_conv_tap_sums", "osg_qu8_gemm", "osg_qu8_lut", "osg_qu8_binary", "osg_qu8_instance_norm", "osg_qu8_instance_norm_nhwc", "osg_qu8_affine_act", "osg_qu8_norm_affine_act_nhwc", "osg_qu8_softmax_last", "osg_kdbg_read",
-    "osg_tblock_tail_supported", "osg_tblock_tail", "osg_tblock_kv_pack_elems", "osg_tblock_kv_pack",
+    "osg_tblock_tail_supported", "osg_tblock_tail", "osg_tblock_kv_pack_elems", "osg_tblock_kv_pack_jobs",
 ]
 
 
@@ -129,7 +129,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_tblock_tail.argtypes = [vp, ctypes.POINTER(TBlockTailArgs)]
     lib.osg_tblock_kv_pack_elems.argtypes = [ci, ci, ci]
     lib.osg_tblock_kv_pack_elems.restype = ctypes.c_size_t
-    lib.osg_tblock_kv_pack.argtypes = [vp, vp, cl, vp, cl, ci, ci, ci, ci, vp, vp]
+    lib.osg_tblock_kv_pack_jobs.argtypes = [vp, vp, cl, ci, ci, ci, ci, vp, vp]
     return lib
 
 
@@ -317,17 +317,24 @@ class Gpu:
         return o
 
     def tblock_kv_pack(self, k: DevBuf, v: DevBuf, heads: int):
-        """k, v: [imgs, Tk, heads*D] -> (kp [imgs, heads, 80, DP], vtp [imgs, heads, DP, 80]) for tblock_tail"""
+        """k, v: [imgs, Tk, heads*D] -> (kp [imgs, heads, 80, DP], vtp [imgs, heads, DP, 80]) for tblock_tail.  Goes through the multi-job entry point the
+        planner uses: K and V become two column ranges of one [imgs*Tk, 2C] matrix."""
         imgs, tk, c = k.shape
         d = c // heads
         dp = (d + 15) // 16 * 16
-        assert self.lib.osg_tblock_kv_pack_elems(imgs, heads, d) == imgs * heads * 80 * dp
+        n = self.lib.osg_tblock_kv_pack_elems(imgs, heads, d)
+        assert n == imgs * heads * 80 * dp
+        kv = self.to_dev(np.concatenate([k.numpy().reshape(imgs * tk, c), v.numpy().reshape(imgs * tk, c)], axis=1))
+        jobs = self.to_dev(np.array([0, c, d, 0], np.int32))
+        dst = self.empty((2 * n,), k.dtype)
+        self._ck(self.lib.osg_tblock_kv_pack_jobs(self.ctx, kv.ptr, 2 * c, imgs, tk, heads, 1, jobs.ptr, dst.ptr))
         kp, vtp = self.empty((imgs, heads, 80, dp), k.dtype), self.empty((imgs, heads, dp, 80), k.dtype)
-        self._ck(self.lib.osg_tblock_kv_pack(self.ctx, k.ptr, c, v.ptr, c, imgs, tk, heads, d, kp.ptr, vtp.ptr))
+        self._ck(self.lib.osg_copy(self.ctx, kp.ptr, dst.ptr, n * 2))
+        self._ck(self.lib.osg_copy(self.ctx, vtp.ptr, dst.ptr + n * 2, n * 2))
         return kp, vtp
 
     def tblock_tail(self, a1: DevBuf, x0: DevBuf, w: dict, kp: DevBuf, vtp: DevBuf, tk: int, heads: int, scale: float, rows_per_img: int, eps: float = 1e-5,
-                    xin: Optional[DevBuf] = None, out2: Optional[DevBuf] = None, out2_col: int = 0, debug: bool = False):
+                    xin: Optional[DevBuf] = None, out2: Optional[DevBuf] = None, out2_col: int = 0, debug: bool = False, out: Optional[DevBuf] = None):
         """osg_tblock_tail.  w: dict of DevBuf -- wo1 bo1 g2 be2 wq2 wo2 bo2 g3 be3 w1 b1 w2 b2 [wpo bpo]; weights [N,K].  Returns (out, [dumps])."""
         m, c = a1.shape
         a = TBlockTailArgs()
@@ -338,7 +345,8 @@ class Gpu:
         a.kp, a.vtp, a.scale, a.Tk = kp.ptr, vtp.ptr, scale, tk
         a.eps2 = a.eps3 = eps
         a.xin = xin.ptr if xin is not None else None
-        out = self.empty((m, c), a1.dtype)
+        if out is None:
+            out = self.empty((m, c), a1.dtype)
         a.out, a.ldo = out.ptr, c
         if out2 is not None:
             a.out2, a.ldo2 = out2.ptr + out2_col * 2, out2.shape[-1]

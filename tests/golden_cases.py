@@ -115,6 +115,17 @@ def transformer_block(g):
     return {"x": _rn(16, (1, 64, 8, 8)), "ctx": _rn(17, (1, 11, 48))}
 
 
+def transformer_block_320(g):
+    """the SD 1.5 64x64-level spatial transformer at its real widths (320 channels, 8 heads of 40, text context 77 x 768, 32 groups) on an 8 x 8 image:
+    GroupNorm -> proj_in -> BasicTransformerBlock -> proj_out + residual.  The shape osg_tblock_tail takes: at fusion level 2 everything behind the
+    self-attention of this graph is ONE launch (round 4)."""
+    cfg = sd_unet.UNetConfig(block_out=(320, 640), heads=8, ctx_dim=768, ctx_len=77, latent=8, groups=32, name="case320")
+    x = g.input("x", (1, 320, 8, 8))
+    c = g.input("ctx", (1, 77, 768))
+    sd_unet._UNet(g, cfg).transformer2d("/tr", x, c, 1)
+    return {"x": _rn(21, (1, 320, 8, 8)), "ctx": _rn(22, (1, 77, 768))}
+
+
 def upsample_concat(g):
     x = g.input("x", (1, 32, 6, 6))
     s = g.input("skip", (1, 32, 12, 12))
@@ -152,6 +163,8 @@ def shape_gather_chain(g):
 
 CASES = [conv3x3, conv3x3_stride2, conv1x1_nobias, conv_in_4ch, conv_ragged, linear_bias, gemm_temb, group_norm_silu, layer_norm,
          self_attention, cross_attention, geglu_ff, resnet_block, transformer_block, upsample_concat, time_embedding, shape_gather_chain]
+# longer chains at real widths (15 rounding points deep): held to the whole-net bound of tests/test_golden.py, not the single-pattern one
+CHAINS = [transformer_block_320]
 # whole (miniature) networks: SD1.5-shaped and SDXL-shaped UNets, the VAE decoder (single 32-wide attention head + 3 resolutions)
 UNETS = {"unet_tiny": sd_unet.TINY, "unet_tinyxl": sd_unet.TINY_XL, "vae_tiny": sd_vae.TINY_VAE,
          # W8A16 (BASELINE config 3, UNet half): uint8 weights + per-tensor scale/zero-point in model.txt, dequantised at load
@@ -183,11 +196,11 @@ def emit(case, sink, seed=1234):
 
 
 def all_case_names():
-    return [c.__name__ for c in CASES] + list(UNETS)
+    return [c.__name__ for c in CASES] + [c.__name__ for c in CHAINS] + list(UNETS)
 
 
 def by_name(name):
-    for c in CASES:
+    for c in CASES + CHAINS:
         if c.__name__ == name:
             return c
     if name in UNETS:

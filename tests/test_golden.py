@@ -185,6 +185,26 @@ def test_hip_backend_vs_golden_whole_nets(name, fusion):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fusion", [0, 1, 2, "2-separate"])
+@pytest.mark.parametrize("name", [c.__name__ for c in gc.CHAINS])
+def test_hip_backend_vs_golden_chains(name, fusion):
+    """Chains at the SD 1.5 UNet's real widths (transformer_block_320: 320 channels, 8 heads of 40, context 77 x 768).  At fusion 2 everything behind the
+    self-attention is ONE launch (osg_tblock_tail: to_out + residual, LayerNorm, to_q, cross-attention, to_out + residual, LayerNorm, GEGLU, ff.net.2 +
+    residual, proj_out + residual); "2-separate" = the same plan with that fusion off (hip_fuse_tblock 0: the seven launches of round 3).  Bound: on the
+    reference's fp16 output (<= 1e-3) or as close to its fp32 output as its own fp16 path gets (the whole-net rule: the chain is 15 roundings deep)."""
+    sep = fusion == "2-separate"
+    ins, oname, r16, r32 = load(name)
+    got = _run_hip(name, ins, oname, 2 if sep else fusion, True, options=(("hip_fuse_tblock", 0 if sep else 1),))
+    assert list(got.shape) == list(r16.shape)
+    mx = float(np.abs(r32).max())
+    err16 = float(np.abs(got - r16).max()) / mx
+    err32 = float(np.abs(got - r32).max()) / mx
+    noise = float(np.abs(r16 - r32).max()) / mx
+    print(f"{name} fusion {fusion}: |gpu-ref16|/max={err16:.2e} |gpu-ref32|/max={err32:.2e} reference fp16 drift={noise:.2e}")
+    assert err16 <= 1e-3 or err32 <= 1.5 * noise + 1e-3, (name, fusion, err16, err32, noise)
+
+
+@pytest.mark.gpu
 def test_measured_plan_choice_is_reproducible_from_a_tune_table(tmp_path, monkeypatch):
     """hip_autotune picks tile / split-K by timing, so two tuning runs may differ in the last bits; a tune table (OSG_TUNE_CACHE) pins the
     choice: a process seeded from the table issues no timing launches and reproduces the tuning run's output bit for bit -- and that

@@ -164,7 +164,7 @@ def test_full_size_sd15_plan(stub_backend):
         sd_unet.build_unet(DirSink(d), sd_unet.SD15)
         open(d + ".complete", "w").write("ok")
     ins = sd_unet.unet_inputs(sd_unet.SD15, 42)
-    m, info = _plan(d, ins, (("hip_side_stream", 1), ("hip_fuse_ln_gemm", 0)), pushes=2)
+    m, info = _plan(d, ins, (("hip_side_stream", 1), ("hip_fuse_ln_gemm", 0), ("hip_fuse_tblock", 0)), pushes=2)
     steps, vals, arena = _parse(info)
     m.close()
     assert len(steps) == 352                                    # (366 before round 3; the two time-embedding Gemm + SiLU pairs are one launch each; the 12 skip-connection Concats are no launches any more, see below)
@@ -176,10 +176,23 @@ def test_full_size_sd15_plan(stub_backend):
     assert arena < 400 * 2 ** 20                                # activations of a batch-2 pass pack into well under 400 MiB
     kinds = [s["what"].split(" ", 1)[0].split("+")[0] for s in steps]
     assert kinds.count("Attention") == 32 and kinds.count("GroupNorm") == 61 and kinds.count("LayerNorm") == 48
-    m, info = _plan(d, ins, (), pushes=2)                       # the default plan folds every LayerNorm into its consuming GEMM
-    steps_d, vals_d, arena_d = _parse(info)
-    assert len(steps_d) == 304
+    m, info = _plan(d, ins, (("hip_fuse_tblock", 0),), pushes=2)   # round 3's default plan: every LayerNorm folded into its consuming GEMM
+    steps_3 = _parse(info)[0]
     m.close()
+    assert len(steps_3) == 304
+    # round 4's default: at the 64 x 64 level (320 channels: the shape osg_tblock_tail takes) everything behind a block's self-attention -- to_out + residual,
+    # LayerNorm, to_q, cross-attention, to_out + residual, LayerNorm, GEGLU projection, ff.net.2 + residual, proj_out + residual: 7 launches -- is ONE launch;
+    # the K / V of all five blocks are re-packed by one launch right behind the merged K|V projection of the text context
+    m, info = _plan(d, ins, (), pushes=2)
+    steps_d, vals_d, arena_d = _parse(info)
+    m.close()
+    assert len(steps_d) == 304 - 5 * 6 + 1
+    tails = [s for s in steps_d if s["what"].startswith("TBlockTail+proj_out ")]
+    packs = [s for s in steps_d if s["what"].startswith("KVPack x5 ")]
+    assert len(tails) == 5 and len(packs) == 1 and all(s["i"] > packs[0]["i"] for s in tails)
+    assert all(packs[0]["writes"][0] in s["reads"] for s in tails)             # every tail reads the one pack buffer, which therefore lives until the last of them
+    assert vals_d[packs[0]["writes"][0]]["last"] == max(s["i"] for s in tails)
+    assert [s["what"].split(" ", 1)[0] for s in steps_d].count("Attention") == 32 - 5
     _check_arena(steps_d, vals_d, arena_d)
     # round 3: every skip-connection Concat of the up path is gone -- both of its operands come straight out of convolutions, which store into their
     # column slice of the concatenated buffer themselves (osg_conv2d_nhwc_v): 24 convolutions carry the mark, the only Concat launch left is the
@@ -197,7 +210,7 @@ def test_full_size_sd15_plan(stub_backend):
     assert len(cat_vals) == 12 and all(len(v) == 2 for v in cat_vals.values())
     for v, writers in cat_vals.items():
         assert vals_d[v]["first"] == min(writers) and vals_d[v]["last"] > max(writers)
-    m, info = _plan(d, ins, (("hip_concat_views", 0),), pushes=2)
+    m, info = _plan(d, ins, (("hip_concat_views", 0), ("hip_fuse_tblock", 0)), pushes=2)
     steps_o = _parse(info)[0]
     m.close()
     assert len(steps_o) == 316 and [s["what"].split(" ", 1)[0] for s in steps_o].count("Concat") == 13
@@ -531,6 +544,7 @@ def test_group_norm_statistics_from_producers_plan(stub_backend):
         m = Model(b.LIB_HOST, 0, "ram+nocache")
         if on is not None:
             m._set_option("hip_gn_stats", on)
+        m._set_option("hip_fuse_tblock", 0)       # (a block tail fused into one launch cannot add statistics up: tested below)
         m.read_file(d + "model.txt")
         for i in (sd_unet.unet_inputs(cfg, 42), sd_unet.unet_inputs(cfg, 43)):
             for k, v in i.items():
@@ -549,6 +563,21 @@ def test_group_norm_statistics_from_producers_plan(stub_backend):
             first_gn = min(i for i, w in enumerate(what) if w.startswith("GroupNorm stats<"))
             assert any("+gnstats" in w for w in what[:first_gn])
             assert all(w.startswith("Conv ") for w in what if "+gnstats" in w)
+    # with the block tails fused (the default), a GroupNorm whose input -- or one operand of the Concat it reads -- comes out of an osg_tblock_tail launch keeps
+    # its own statistics pass (that launch's epilogue does not add statistics up): fewer armed producers, still convolutions only, same launch count
+    m = Model(b.LIB_HOST, 0, "ram+nocache")
+    m._set_option("hip_gn_stats", 1)
+    m.read_file(d + "model.txt")
+    for i in (sd_unet.unet_inputs(cfg, 42), sd_unet.unet_inputs(cfg, 43)):
+        for k, v in i.items():
+            m.add_tensor(k, v)
+    m.set_use_fp16_arithmetic(True)
+    m.set_fuse_ops_in_attention(True)
+    m.run()
+    what = [s["what"] for s in _parse(m.hip_plan_info())[0]]
+    m.close()
+    assert len(what) == 275 and 10 <= sum(w.startswith("GroupNorm stats<") for w in what) < 31
+    assert all(w.startswith("Conv ") for w in what if "+gnstats" in w) and not any("+gnstats" in w for w in what if w.startswith("TBlockTail"))
 
 
 def test_vae_decoder_plan_reads_group_norm_statistics_from_its_convolutions(stub_backend):

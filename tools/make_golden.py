@@ -20,7 +20,8 @@ from oracle import ref as oref  # noqa: E402
 out_dir = os.path.join(REPO, "tests", "golden")
 os.makedirs(out_dir, exist_ok=True)
 assert oref.available(), "build the oracle first: make -C oracle ref"
-for name in gc.all_case_names():
+only = sys.argv[1:]          # optional: the cases to (re)generate; default all + the pipeline fixture
+for name in (only or gc.all_case_names()):
     with tempfile.TemporaryDirectory() as d:
         d += "/"
         ins = gc.emit(gc.by_name(name), DirSink(d))
@@ -34,6 +35,8 @@ for name in gc.all_case_names():
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), out_name=np.asarray(oname), ref16=v16, ref32=v32,
                             **{"in_" + k: v for k, v in ins.items()})
 
+if only:
+    sys.exit(0)
 # ---- end-to-end: 3 Euler-A steps with CFG + VAE decode, driven through the reference library by the same harness the product uses
 from onnxstream_amd.pipeline import Txt2Img  # noqa: E402
 from onnxstream_amd.synth import sd_unet, sd_vae  # noqa: E402
