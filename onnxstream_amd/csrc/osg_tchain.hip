@@ -52,12 +52,24 @@ struct TailParams {
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): loop indices that ARE constants (not merely become constants once an unrolling pass
+// has run): the register slots bq[s % NS] below must be addressed with literal indices, or the array is left in scratch memory
+template <int I, int N, typename Fn>
+__device__ __forceinline__ void static_for_impl(Fn&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_impl<I + 1, N>(f);
+    }
+}
+template <int N, typename Fn>
+__device__ __forceinline__ void static_for(Fn&& f) { static_for_impl<0, N>(f); }
+
 constexpr int kTileBytes = 8192;   // one k-tile of a row block: 64 rows x 128 B (64 halves), chunk c of row r at slot c ^ (r & 7)
 
 // byte offset of element (m, n), n % 4 == 0, inside a swizzled [64 x C] LDS image
 __device__ __forceinline__ int img_off(int m, int n) { return (n >> 6) * kTileBytes + m * 128 + ((((n & 63) >> 3) ^ (m & 7)) << 4) + (n & 7) * 2; }
 
-// the B fragments of one 64-deep k-tile of a [N][ld] weight (k contiguous), NT tiles of 16 rows `rstep` BYTES apart: b[ks * NT + j].  Buffer loads:
+// the B fragments of one 64-deep k-tile of a [N][ld] weight (k contiguous), NT tiles of 16 rows `rstep` BYTES apart: b[5 ks + j].  Buffer loads:
 // the descriptor and the tile / chunk offset `so` are wave-uniform (scalar registers), the ONE per-lane 32-bit offset `lo` (row nb + l16, k 8 g) never
 // changes -- no 64-bit pointer arithmetic in vector registers (hipcc turns plain pointer loads into a VGPR pointer pair per tile row)
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -69,14 +81,19 @@ __device__ __forceinline__ void load_b(f16x8 (&b)[10], __amdgpu_buffer_rsrc_t rs
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-        for (int j = 0; j < NT; j++) b[ks * NT + j] = ldb(rs, lo, so + j * rstep + ks * 64);
+        for (int j = 0; j < NT; j++) b[ks * 5 + j] = ldb(rs, lo, so + j * rstep + ks * 64);
 }
-// GEGLU projection: tiles 0, 1 = value rows, tiles 2, 3 = the matching gate rows (gate_off bytes further down)
+// GEGLU projection: tiles 0, 1 = value rows, tiles 2, 3 = the matching gate rows (gate_off bytes further down).  Same slot layout as five tiles (b[5 ks + j]),
+// and the fifth entry is WRITTEN too (a copy of the fourth): where a uniform run-time branch requests either kind of tile into one slot, both sides then
+// store the same ten entries in the same order -- otherwise hipcc's store sinking merges the tails of the two sides into a store through a pointer phi
+// and the whole slot array stays in scratch memory (480 bytes of private memory per lane, every fragment a scratch round trip)
 __device__ __forceinline__ void load_b_geglu(f16x8 (&b)[10], __amdgpu_buffer_rsrc_t rs, unsigned lo, int so, int rstep, int gate_off) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++)
+    for (int ks = 0; ks < 2; ks++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) b[ks * 4 + j] = ldb(rs, lo, so + (j & 1) * rstep + (j >> 1) * gate_off + ks * 64);
+        for (int j = 0; j < 4; j++) b[ks * 5 + j] = ldb(rs, lo, so + (j & 1) * rstep + (j >> 1) * gate_off + ks * 64);
+        b[ks * 5 + 4] = b[ks * 5 + 3];
+    }
 }
 
 // one k-tile of a [64 x 16 NT] wave tile: A fragments from the swizzled LDS image, B fragments from a register slot
@@ -90,23 +107,23 @@ __device__ __forceinline__ void mma_ktile(const char* At, int a_rd, const f16x8 
 #pragma unroll
         for (int j = 0; j < NT; j++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[ks * NT + j], a[i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[ks * 5 + j], a[i], acc[i][j], 0, 0, 0);
     }
 }
 
-// a whole contraction over KT k-tiles.  SS = index of its first k-tile in the kernel-wide sequence of k-tiles: tile s is consumed from register slot
-// s & 1 while the loads of tile s + 1 fly into the other one; `load(b, t)` requests this contraction's tile t, `next(b)` the FIRST tile of whatever
-// contraction follows.
-template <int KT, int NT, int SS, typename Load, typename Next>
-__device__ __forceinline__ void gemm_stage(const char* A, int a_rd, f16x8 (&bq)[2][10], f32x4 (&acc)[4][NT], Load&& load, Next&& next) {
-#pragma unroll
-    for (int t = 0; t < KT; t++) {
-        if (t + 1 < KT) load(bq[(SS + t + 1) & 1], t + 1);
-        else next(bq[(SS + t + 1) & 1]);
+// A whole contraction over KT k-tiles.  Every k-tile of the kernel has an index s in ONE kernel-wide sequence (SS = the index of this contraction's
+// first tile): tile s is consumed from register slot s % NS while the requests of the next NS - 1 tiles are in flight -- at tile s the request of tile
+// s + NS - 1 goes out, into the slot tile s - 1 has just left.  `load(b, t)` requests this contraction's tile t, `next(b, j)` tile j of whatever follows.
+template <int KT, int NT, int SS, int NS, typename Load, typename Next>
+__device__ __forceinline__ void gemm_stage(const char* A, int a_rd, f16x8 (&bq)[NS][10], f32x4 (&acc)[4][NT], Load&& load, Next&& next) {
+    static_for<KT>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (t + NS - 1 < KT) load(bq[(SS + t + NS - 1) % NS], t + NS - 1);
+        else next(bq[(SS + t + NS - 1) % NS], t + NS - 1 - KT);
         __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks every request down to its first use: one exposed L2 round trip per fragment)
-        mma_ktile<NT>(A + t * kTileBytes, a_rd, bq[(SS + t) & 1], acc);
+        mma_ktile<NT>(A + t * kTileBytes, a_rd, bq[(SS + t) % NS], acc);
         __builtin_amdgcn_sched_barrier(0);
-    }
+    });
 }
 
 template <int NT>
@@ -118,20 +135,15 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[4][NT]) {
 }
 
 // acc + bias (+ residual from the LDS image `res`) -> f16 -> the LDS image `dst`.  res may be dst: a lane reads exactly the bytes it overwrites.
-// (uniform decisions -- is there a bias, a residual -- are taken OUTSIDE the tile loops: inside, hipcc clones the tile code per combination)
+// bias: this op's [C] vector in the LDS copy of the block's small operands (zeros when the op has none) -- a load from global memory here would be a cold
+// round trip on the critical path of every stage, and (vector-memory results return in order) a wait for every weight tile requested before it
 template <int NT, bool RES>
-__device__ __forceinline__ void epi_to_lds(const f32x4 (&acc)[4][NT], const f16* __restrict__ bias, int nb, const char* res, char* dst, int lane) {
+__device__ __forceinline__ void epi_to_lds(const f32x4 (&acc)[4][NT], const char* bias, int nb, const char* res, char* dst, int lane) {
     const int l16 = lane & 15, g4 = (lane >> 4) * 4;
-    f16x4 bv[NT];
-#pragma unroll
-    for (int j = 0; j < NT; j++) bv[j] = f16x4{0, 0, 0, 0};
-    if (bias) {
-#pragma unroll
-        for (int j = 0; j < NT; j++) bv[j] = *reinterpret_cast<const f16x4*>(bias + nb + j * 16 + g4);
-    }
 #pragma unroll
     for (int j = 0; j < NT; j++) {
         const int n = nb + j * 16 + g4;
+        const f16x4 bv = *reinterpret_cast<const f16x4*>(bias + n * 2);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int off = img_off(i * 16 + l16, n);
@@ -139,50 +151,38 @@ __device__ __forceinline__ void epi_to_lds(const f32x4 (&acc)[4][NT], const f16*
             if constexpr (RES) rv = *reinterpret_cast<const f16x4*>(res + off);
             f16x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; r++) o[r] = (f16)((acc[i][j][r] + (float)bv[j][r]) + (float)rv[r]);
+            for (int r = 0; r < 4; r++) o[r] = (f16)((acc[i][j][r] + (float)bv[r]) + (float)rv[r]);
             *reinterpret_cast<f16x4*>(dst + off) = o;
         }
     }
 }
 
-// acc + bias + residual (RES 1: LDS image, 2: global rows ldr apart) -> f16 -> global rows (and, OUT2, a second destination)
-template <int NT, int RES, bool OUT2>
-__device__ __forceinline__ void epi_to_global(const f32x4 (&acc)[4][NT], const f16* __restrict__ bias, int nb, const char* res_lds, const f16* __restrict__ res_g, long ldr,
+// acc + bias + residual (an LDS image, or fragments `rg` fetched from global rows by the caller) -> f16 -> global rows (and, OUT2, a second destination)
+template <int NT, bool RES_LDS, bool OUT2>
+__device__ __forceinline__ void epi_to_global(const f32x4 (&acc)[4][NT], const char* bias, int nb, const char* res_lds, const f16x4 (&rg)[4][NT],
                                               f16* __restrict__ out, long ldo, f16* __restrict__ out2, long ldo2, long row0, int lane) {
     const int l16 = lane & 15, g4 = (lane >> 4) * 4;
-    f16x4 bv[NT];
 #pragma unroll
-    for (int j = 0; j < NT; j++) bv[j] = f16x4{0, 0, 0, 0};
-    if (bias) {
+    for (int j = 0; j < NT; j++) {
+        const int n = nb + j * 16 + g4;
+        const f16x4 bv = *reinterpret_cast<const f16x4*>(bias + n * 2);
 #pragma unroll
-        for (int j = 0; j < NT; j++) bv[j] = *reinterpret_cast<const f16x4*>(bias + nb + j * 16 + g4);
-    }
-    f16x4 rv[4][NT];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < NT; j++) {
-            const int m = i * 16 + l16, n = nb + j * 16 + g4;
-            if constexpr (RES == 1) rv[i][j] = *reinterpret_cast<const f16x4*>(res_lds + img_off(m, n));
-            else if constexpr (RES == 2) rv[i][j] = *reinterpret_cast<const f16x4*>(res_g + (row0 + m) * ldr + n);
-            else rv[i][j] = f16x4{0, 0, 0, 0};
-        }
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < NT; j++) {
-            const int m = i * 16 + l16, n = nb + j * 16 + g4;
+        for (int i = 0; i < 4; i++) {
+            const int m = i * 16 + l16;
+            f16x4 rv = rg[i][j];
+            if constexpr (RES_LDS) rv = *reinterpret_cast<const f16x4*>(res_lds + img_off(m, n));
             f16x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; r++) o[r] = (f16)((acc[i][j][r] + (float)bv[j][r]) + (float)rv[i][j][r]);
+            for (int r = 0; r < 4; r++) o[r] = (f16)((acc[i][j][r] + (float)bv[r]) + (float)rv[r]);
             *reinterpret_cast<f16x4*>(out + (row0 + m) * ldo + n) = o;
             if constexpr (OUT2) *reinterpret_cast<f16x4*>(out2 + (row0 + m) * ldo2 + n) = o;
         }
+    }
 }
 
 // LayerNorm of the 64 rows of image X into image P: layer_norm_kernel's arithmetic (osg_norm.hip), four adjacent lanes per row
 template <int C>
-__device__ __forceinline__ void ln_rows(const char* X, char* P, const f16* __restrict__ gamma, const f16* __restrict__ beta, float eps, int tid) {
+__device__ __forceinline__ void ln_rows(const char* X, char* P, const char* gamma, const char* beta, float eps, int tid) {   // (gamma, beta: LDS copies)
     constexpr int NCH = C / 8, PER = NCH / 4;
     static_assert(NCH % 4 == 0, "row chunks split over four lanes");
     const int row = tid >> 2, part = tid & 3;
@@ -209,8 +209,8 @@ __device__ __forceinline__ void ln_rows(const char* X, char* P, const f16* __res
 #pragma unroll
     for (int i = 0; i < PER; i++) {
         const int c = part + 4 * i;
-        const f16x8 gm = *reinterpret_cast<const f16x8*>(gamma + c * 8);
-        const f16x8 bt = *reinterpret_cast<const f16x8*>(beta + c * 8);
+        const f16x8 gm = *reinterpret_cast<const f16x8*>(gamma + c * 16);
+        const f16x8 bt = *reinterpret_cast<const f16x8*>(beta + c * 16);
         f16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; e++) o[e] = (f16)((v[i][e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
@@ -307,19 +307,78 @@ __device__ __forceinline__ void cross_attention(const char* Qi, char* Oi, const 
     }
 }
 
-template <int C, int D, int TKT>
+// one dword of every 128-byte line of [rows x row_bytes] (rows `pitch` bytes apart): pulls the lines into this XCD's L2.  Requests only, nothing waits
+// for the data: LDS-DMA loads into a scratch corner of the LDS (no register is written, so no register has to stay reserved until the data arrives)
+__device__ __forceinline__ void touch_lines(const void* base, int rows, int row_bytes, long pitch, int tid, char* lds_dummy) {
+    const int lpr = (row_bytes + 127) >> 7, n = rows * lpr;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((rows - 1) * pitch + row_bytes), 0x00020000);
+    for (int i = tid; i < n; i += 256) {
+        const int r = i / lpr, l = i - r * lpr;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)lds_dummy, 4, (unsigned)(r * pitch + l * 128), 0, 0, 0);
+    }
+}
+
+// NS = register slots for weight tiles (2: one tile ahead, 3: two tiles ahead)
+template <int C, int D, int TKT, int NS>
 __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     constexpr int KT = C / 64;                 // k-tiles of a C-deep contraction
     constexpr int NTW = C / 64;                // 16-column tiles per wave when four waves split C output columns
     constexpr int F = 4 * C;                   // GEGLU hidden width
     constexpr int HC = 128, NCHUNK = F / HC;   // hidden columns per chunk
+    constexpr int G2T = HC / 64;               // k-tiles of ff.net.2 per chunk
+    constexpr int PER = KT + G2T;              // k-tiles per chunk iteration
     constexpr int IMG = KT * kTileBytes;
-    static_assert(C % 64 == 0 && NTW <= 5 && NCHUNK % 2 == 0 && 2 * (HC / 64) * kTileBytes <= IMG, "shape");
+    constexpr int AH = NS - 1;                 // tiles requested ahead
+    static_assert(C % 64 == 0 && NTW <= 5 && 2 * G2T * kTileBytes <= IMG && (NS == 2 || NS == 3) && PER % NS == 1 && AH <= G2T && AH <= KT, "shape");
+    constexpr int RS_C = 16 * C * 2, RS_F = 16 * F * 2, GATE = F * C * 2, CH1 = HC * C * 2, CH2 = HC * 2;
+    const int tid = threadIdx.x;
+    const int nblk = p.M >> 6;
+
+    // ---- the workgroups behind the row blocks do no arithmetic: each pulls the block's weights into the L2 of ITS XCD (workgroup i runs on XCD i mod 8),
+    // in the order the row blocks will want them.  A launch's weights are cold (the L2s are invalidated between launches, a pass streams 1.7 GB through
+    // them): without this every k-tile of every row block waits a memory round trip of ~2 000 cycles behind a request that is ~600 cycles old, and the
+    // whole tail lasts as long as its seven launches did (profiles/r04_tblock_tail_v1_ab.txt)
+    if ((int)blockIdx.x >= nblk) {
+        extern __shared__ __attribute__((aligned(16))) char lds_pf[];
+        char* dummy = lds_pf + __builtin_amdgcn_readfirstlane(tid >> 6) * 256;       // (256 bytes per wave)
+        touch_lines(p.wo1, C, C * 2, C * 2, tid, dummy);
+        touch_lines(p.wq2, C, C * 2, C * 2, tid, dummy);
+        {
+            constexpr int DP = (D + 15) / 16 * 16;
+            const int imgs = p.M / p.rows_per_img;
+            touch_lines(p.kp, 1, imgs * p.heads * TKT * 16 * DP * 2 * 2, 0, tid, dummy);     // kp and, right behind it, vtp
+        }
+        touch_lines(p.wo2, C, C * 2, C * 2, tid, dummy);
+        for (int c = 0; c < NCHUNK; c++) {
+            touch_lines(p.w1 + (long)c * HC * C, HC, C * 2, C * 2, tid, dummy);
+            touch_lines(p.w1 + (long)(F + c * HC) * C, HC, C * 2, C * 2, tid, dummy);
+            touch_lines(p.w2 + c * HC, C, HC * 2, F * 2, tid, dummy);
+        }
+        if (p.wpo) touch_lines(p.wpo, C, C * 2, C * 2, tid, dummy);
+        return;
+    }
+
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* const X = lds;                       // the residual stream of the row block (x0 -> x1 -> x2)
     char* const P = lds + IMG;                 // the current A operand (a1 -> LN(x1) -> a2 -> LN(x2) -> x3)
     char* const R = lds + 2 * IMG;             // q; then the two GEGLU chunk buffers
-    const int tid = threadIdx.x, lane = tid & 63;
+    // the block's small operands: nine [C] vectors and the [2F] bias of ff.net.0.proj, copied once (zeros where an op has no bias)
+    char* const VEC = lds + 3 * IMG;
+    enum { V_BO1, V_G2, V_BE2, V_BQ2, V_BO2, V_G3, V_BE3, V_B2, V_BPO, V_B1 };
+    auto vec = [&](int k) __attribute__((always_inline)) { return VEC + k * (C * 2); };
+    {
+        const f16* src[10] = {p.bo1, p.g2, p.be2, p.bq2, p.bo2, p.g3, p.be3, p.b2, p.bpo, p.b1};
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            const int n16 = (k == V_B1 ? 2 * F : C) / 8;
+            for (int i = tid; i < n16; i += 256) {
+                f16x8 v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (src[k]) v = *reinterpret_cast<const f16x8*>(src[k] + i * 8);
+                *reinterpret_cast<f16x8*>(vec(k) + i * 16) = v;
+            }
+        }
+    }
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, g = lane >> 4;
     const long row0 = (long)blockIdx.x * 64;
@@ -327,12 +386,11 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     const int a_rd = l16 * 128 + ((g ^ (l16 & 7)) << 4);
     const int nb = wave * (C / 4);             // this wave's output columns of a C-wide contraction
 
-    f16x8 bq[2][10];
+    f16x8 bq[NS][10];
     // per-lane weight offsets (bytes; the bases stay in scalar registers): row nb + l16 (+ 16 j), k offset 8 g
     const unsigned lo_c = (unsigned)(((nb + l16) * C + g * 8) * 2);          // [C][C] weights
     const unsigned lo_1 = (unsigned)(((wave * 32 + l16) * C + g * 8) * 2);   // w1 [2F][C]: + chunk * HC rows; gate rows F rows further
     const unsigned lo_2 = (unsigned)(((nb + l16) * F + g * 8) * 2);          // w2 [C][F]: + chunk * HC columns
-    constexpr int RS_C = 16 * C * 2, RS_F = 16 * F * 2, GATE = F * C * 2, CH1 = HC * C * 2, CH2 = HC * 2;
     const __amdgpu_buffer_rsrc_t u_o1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.wo1, 0, C * C * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t u_q2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq2, 0, C * C * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t u_o2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.wo2, 0, C * C * 2, 0x00020000);
@@ -340,8 +398,15 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     const __amdgpu_buffer_rsrc_t u_2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, C * F * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t u_po = __builtin_amdgcn_make_buffer_rsrc((void*)p.wpo, 0, p.wpo ? C * C * 2 : 0, 0x00020000);
     const bool has_po = p.wpo != nullptr;
+    // requests by position: a [C x C] contraction's tile t; the feed-forward's tile `pos` of chunk iteration cc -- positions 0 .. KT-1 = ff.net.0.proj of
+    // chunk cc (value + gate rows), KT .. PER-1 = ff.net.2 over chunk cc - 1
+    auto ld_cc = [&](f16x8 (&b)[10], __amdgpu_buffer_rsrc_t rs, int t) __attribute__((always_inline)) { load_b<NTW>(b, rs, lo_c, t * 128, RS_C); };
+    auto ld_ff = [&](f16x8 (&b)[10], int cc, int pos) __attribute__((always_inline)) {
+        if (pos < KT) load_b_geglu(b, u_1, lo_1, cc * CH1 + pos * 128, RS_C, GATE);
+        else load_b<NTW>(b, u_2, lo_2, (cc - 1) * CH2 + (pos - KT) * 128, RS_F);
+    };
 
-    load_b<NTW>(bq[0], u_o1, lo_c, 0, RS_C);      // k-tile 0 of the first contraction: in flight while the row block arrives
+    static_for<AH>([&](auto tc) __attribute__((always_inline)) { ld_cc(bq[decltype(tc)::value % NS], u_o1, decltype(tc)::value); });      // the first tiles of the first contraction: in flight while the row block arrives
 
     // ---- the row block: a1 -> P, x0 -> X (LDS-DMA, the swizzle on the source side as in gemm2_kernel) ----------------------------------
     {
@@ -365,12 +430,13 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     {
         f32x4 acc[4][NTW];
         zero_acc(acc);
-        gemm_stage<KT, NTW, 0>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { load_b<NTW>(b, u_o1, lo_c, t * 128, RS_C); }, [&](f16x8 (&b)[10]) __attribute__((always_inline)) { load_b<NTW>(b, u_q2, lo_c, 0, RS_C); });
-        epi_to_lds<NTW, true>(acc, p.bo1, nb, X, X, lane);
+        gemm_stage<KT, NTW, 0, NS>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_cc(b, u_o1, t); },
+                                   [&](f16x8 (&b)[10], int j) __attribute__((always_inline)) { ld_cc(b, u_q2, j); });
+        epi_to_lds<NTW, true>(acc, vec(V_BO1), nb, X, X, lane);
     }
     __builtin_amdgcn_s_barrier();
     dump_img<C>(X, p.dbg[0], row0, tid);
-    ln_rows<C>(X, P, p.g2, p.be2, p.eps2, tid);
+    ln_rows<C>(X, P, vec(V_G2), vec(V_BE2), p.eps2, tid);
     __builtin_amdgcn_s_barrier();
     dump_img<C>(P, p.dbg[1], row0, tid);
 
@@ -378,8 +444,9 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     {
         f32x4 acc[4][NTW];
         zero_acc(acc);
-        gemm_stage<KT, NTW, KT>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { load_b<NTW>(b, u_q2, lo_c, t * 128, RS_C); }, [&](f16x8 (&b)[10]) __attribute__((always_inline)) { load_b<NTW>(b, u_o2, lo_c, 0, RS_C); });
-        epi_to_lds<NTW, false>(acc, p.bq2, nb, nullptr, R, lane);
+        gemm_stage<KT, NTW, KT, NS>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_cc(b, u_q2, t); },
+                                    [&](f16x8 (&b)[10], int j) __attribute__((always_inline)) { ld_cc(b, u_o2, j); });
+        epi_to_lds<NTW, false>(acc, vec(V_BQ2), nb, nullptr, R, lane);
     }
     __builtin_amdgcn_s_barrier();
     dump_img<C>(R, p.dbg[2], row0, tid);
@@ -398,22 +465,22 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     {
         f32x4 acc[4][NTW];
         zero_acc(acc);
-        gemm_stage<KT, NTW, 2 * KT>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { load_b<NTW>(b, u_o2, lo_c, t * 128, RS_C); }, [&](f16x8 (&b)[10]) __attribute__((always_inline)) { load_b_geglu(b, u_1, lo_1, 0, RS_C, GATE); });
-        epi_to_lds<NTW, true>(acc, p.bo2, nb, X, X, lane);
+        gemm_stage<KT, NTW, 2 * KT, NS>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_cc(b, u_o2, t); },
+                                        [&](f16x8 (&b)[10], int j) __attribute__((always_inline)) { ld_ff(b, 0, j); });
+        epi_to_lds<NTW, true>(acc, vec(V_BO2), nb, X, X, lane);
     }
     __builtin_amdgcn_s_barrier();
     dump_img<C>(X, p.dbg[4], row0, tid);
-    ln_rows<C>(X, P, p.g3, p.be3, p.eps3, tid);
+    ln_rows<C>(X, P, vec(V_G3), vec(V_BE3), p.eps3, tid);
     __builtin_amdgcn_s_barrier();
     dump_img<C>(P, p.dbg[5], row0, tid);
 
     // ---- x3 = ff.net.2(GEGLU(ff.net.0.proj(LN(x2)))) + x2, the hidden activation 128 columns at a time ----------------------------------
-    // k-tile sequence: G1(0) | G1(1) G2(0) | G1(2) G2(1) | ... | G1(9) G2(8) | G2(9); G1 = 5 tiles (NT 4), G2 = 2 tiles (NT 5)
+    // k-tile sequence: G1(0) | G1(1) G2(0) | G1(2) G2(1) | ... | G1(NCHUNK-1) G2(NCHUNK-2) | G2(NCHUNK-1); G1 = KT tiles (4 fragments each), G2 = G2T tiles (NTW)
     f32x4 accY[4][NTW];
     zero_acc(accY);
     {
         constexpr int S0 = 3 * KT;                 // sequence index of G1(0)'s first k-tile
-        constexpr int G2T = HC / 64;
         f32x4 accG[4][4];
         // GEGLU epilogue of chunk c into hidden buffer c & 1 (value tiles 0, 1; gate tiles 2, 3)
         auto geglu_store = [&](int c) __attribute__((always_inline)) {
@@ -421,11 +488,8 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
 #pragma unroll
             for (int jt = 0; jt < 2; jt++) {
                 const int hc = wave * 32 + jt * 16 + g * 4;          // column inside the chunk
-                f16x4 bv = f16x4{0, 0, 0, 0}, bg = f16x4{0, 0, 0, 0};
-                if (p.b1) {
-                    bv = *reinterpret_cast<const f16x4*>(p.b1 + c * HC + hc);
-                    bg = *reinterpret_cast<const f16x4*>(p.b1 + F + c * HC + hc);
-                }
+                const f16x4 bv = *reinterpret_cast<const f16x4*>(vec(V_B1) + (c * HC + hc) * 2);
+                const f16x4 bg = *reinterpret_cast<const f16x4*>(vec(V_B1) + (F + c * HC + hc) * 2);
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     f16x4 o;
@@ -435,72 +499,91 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
                 }
             }
         };
-        // chunk 0: projection only
+        // chunk 0: projection only (its last AH requests are the first tiles of iteration 1)
         zero_acc(accG);
-        gemm_stage<KT, 4, S0>(P, a_rd, bq, accG, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { load_b_geglu(b, u_1, lo_1, t * 128, RS_C, GATE); }, [&](f16x8 (&b)[10]) __attribute__((always_inline)) { load_b_geglu(b, u_1, lo_1, CH1, RS_C, GATE); });
+        gemm_stage<KT, 4, S0, NS>(P, a_rd, bq, accG, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_ff(b, 0, t); },
+                                  [&](f16x8 (&b)[10], int j) __attribute__((always_inline)) { ld_ff(b, 1, j); });
         geglu_store(0);
         __builtin_amdgcn_s_barrier();
-        // chunk c >= 1: projection of chunk c, then ff.net.2 over chunk c - 1 beside the GEGLU arithmetic of chunk c
-        auto ff_iter = [&](auto par, int c, bool last) __attribute__((always_inline)) {
-            constexpr int SS = S0 + KT + decltype(par)::value;   // parity of the first k-tile of G1(c): (S0 + KT + 7 (c - 1)) & 1
-            const int w1c = c * CH1, w2p = (c - 1) * CH2;   // byte offsets: rows of ff.net.0.proj of chunk c, columns of ff.net.2 of chunk c - 1
+        // iteration c >= 1: projection of chunk c, then ff.net.2 over chunk c - 1 beside the GEGLU arithmetic of chunk c.  Its tile `pos` sits in slot
+        // (ST + pos) % NS; the request that goes out with it is position pos + AH of this iteration, or of the next one (the last iteration is followed by
+        // positions KT .. PER-1 of a pseudo-iteration NCHUNK -- ff.net.2 over the last chunk -- and then by proj_out)
+        auto ff_iter = [&](auto st, int c) __attribute__((always_inline)) {
+            constexpr int ST = decltype(st)::value;
+            const bool last = c == NCHUNK - 1;
+            auto request = [&](f16x8 (&b)[10], int pos) __attribute__((always_inline)) {     // pos: compile-time after unrolling
+                if (pos < PER) ld_ff(b, c, pos);
+                else if (!last) ld_ff(b, c + 1, pos - PER);
+                else ld_ff(b, NCHUNK, KT + pos - PER);
+            };
             zero_acc(accG);
-#pragma unroll
-            for (int t = 0; t < KT; t++) {
-                if (t + 1 < KT) load_b_geglu(bq[(SS + t + 1) & 1], u_1, lo_1, w1c + (t + 1) * 128, RS_C, GATE);
-                else load_b<NTW>(bq[(SS + t + 1) & 1], u_2, lo_2, w2p, RS_F);
+            static_for<KT>([&](auto tc) __attribute__((always_inline)) {
+                constexpr int t = decltype(tc)::value;
+                request(bq[(ST + t + AH) % NS], t + AH);
                 __builtin_amdgcn_sched_barrier(0);
-                mma_ktile<4>(P + t * kTileBytes, a_rd, bq[(SS + t) & 1], accG);
+                mma_ktile<4>(P + t * kTileBytes, a_rd, bq[(ST + t) % NS], accG);
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            });
             const char* Hp = R + ((c - 1) & 1) * (G2T * kTileBytes);
-#pragma unroll
-            for (int u = 0; u < G2T; u++) {
-                if (u + 1 < G2T) load_b<NTW>(bq[(SS + KT + u + 1) & 1], u_2, lo_2, w2p + (u + 1) * 128, RS_F);
-                else if (!last) load_b_geglu(bq[(SS + KT + u + 1) & 1], u_1, lo_1, w1c + CH1, RS_C, GATE);
-                else load_b<NTW>(bq[(SS + KT + u + 1) & 1], u_2, lo_2, w2p + CH2, RS_F);
+            static_for<G2T>([&](auto uc) __attribute__((always_inline)) {
+                constexpr int u = decltype(uc)::value;
+                request(bq[(ST + KT + u + AH) % NS], KT + u + AH);
                 __builtin_amdgcn_sched_barrier(0);
-                mma_ktile<NTW>(Hp + u * kTileBytes, a_rd, bq[(SS + KT + u) & 1], accY);
-            }
+                mma_ktile<NTW>(Hp + u * kTileBytes, a_rd, bq[(ST + KT + u) % NS], accY);
+            });
             geglu_store(c);
             __builtin_amdgcn_s_barrier();
         };
-        static_assert((KT + G2T) % 2 == 1, "chunk parity alternates");
-        for (int c = 1; c + 1 < NCHUNK; c += 2) {
-            ff_iter(std::integral_constant<int, 0>{}, c, false);
-            ff_iter(std::integral_constant<int, 1>{}, c + 1, false);
+        constexpr int B0 = (S0 + KT) % NS;          // slot of the first tile of iteration 1; iteration c starts at (B0 + (c - 1) PER) % NS = (B0 + c - 1) % NS
+        int c = 1;
+        for (; c + NS <= NCHUNK; c += NS) {
+            ff_iter(std::integral_constant<int, B0 % NS>{}, c);
+            ff_iter(std::integral_constant<int, (B0 + 1) % NS>{}, c + 1);
+            if constexpr (NS == 3) ff_iter(std::integral_constant<int, (B0 + 2) % NS>{}, c + 2);
         }
-        ff_iter(std::integral_constant<int, 0>{}, NCHUNK - 1, true);
-        // ff.net.2 over the last chunk; its first k-tile was requested by the last ff_iter
+        constexpr int REM = (NCHUNK - 1) % NS;      // iterations left over (their slots continue the rotation from B0)
+        if constexpr (REM >= 1) ff_iter(std::integral_constant<int, B0 % NS>{}, c);
+        if constexpr (REM >= 2) ff_iter(std::integral_constant<int, (B0 + 1) % NS>{}, c + 1);
+        // ff.net.2 over the last chunk (positions KT .. PER-1 of pseudo-iteration NCHUNK); the requests that go out with it are proj_out's first tiles
         {
-            constexpr int SS = S0 + KT + (NCHUNK - 1) * (KT + G2T);          // sequence index of G2(NCHUNK - 1)'s first k-tile
+            constexpr int ST = (S0 + KT + (NCHUNK - 1) * PER) % NS;        // slot of its first tile
             const char* Hp = R + ((NCHUNK - 1) & 1) * (G2T * kTileBytes);
-#pragma unroll
-            for (int u = 0; u < G2T; u++) {
-                if (u + 1 < G2T) load_b<NTW>(bq[(SS + u + 1) & 1], u_2, lo_2, (NCHUNK - 1) * CH2 + (u + 1) * 128, RS_F);
-                else if (has_po) load_b<NTW>(bq[(SS + u + 1) & 1], u_po, lo_c, 0, RS_C);
+            static_for<G2T>([&](auto uc) __attribute__((always_inline)) {
+                constexpr int u = decltype(uc)::value;
+                if constexpr (u + AH < G2T) ld_ff(bq[(ST + u + AH) % NS], NCHUNK, KT + u + AH);
+                else if (has_po) ld_cc(bq[(ST + u + AH) % NS], u_po, u + AH - G2T);
                 __builtin_amdgcn_sched_barrier(0);
-                mma_ktile<NTW>(Hp + u * kTileBytes, a_rd, bq[(SS + u) & 1], accY);
+                mma_ktile<NTW>(Hp + u * kTileBytes, a_rd, bq[(ST + u) % NS], accY);
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            });
         }
     }
+    f16x4 rg[4][NTW];                          // proj_out's residual x_in: requested now, behind the last weight tiles, consumed after the contraction
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < NTW; j++) rg[i][j] = f16x4{0, 0, 0, 0};
     if (!has_po) {
-        if (p.out2) epi_to_global<NTW, 1, true>(accY, p.b2, nb, X, nullptr, 0, p.out, p.ldo, p.out2, p.ldo2, row0, lane);
-        else epi_to_global<NTW, 1, false>(accY, p.b2, nb, X, nullptr, 0, p.out, p.ldo, nullptr, 0, row0, lane);
+        if (p.out2) epi_to_global<NTW, true, true>(accY, vec(V_B2), nb, X, rg, p.out, p.ldo, p.out2, p.ldo2, row0, lane);
+        else epi_to_global<NTW, true, false>(accY, vec(V_B2), nb, X, rg, p.out, p.ldo, nullptr, 0, row0, lane);
         return;
     }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < NTW; j++) rg[i][j] = *reinterpret_cast<const f16x4*>(p.xin + (row0 + i * 16 + l16) * C + nb + j * 16 + g * 4);
     // x3 into P (every wave is past its last read of LN(x2): the barrier of the last chunk), then y = proj_out(x3) + x_in
-    epi_to_lds<NTW, true>(accY, p.b2, nb, X, P, lane);
+    epi_to_lds<NTW, true>(accY, vec(V_B2), nb, X, P, lane);
     __builtin_amdgcn_s_barrier();
     dump_img<C>(P, p.dbg[6], row0, tid);
     {
-        constexpr int SS = 3 * KT + KT + (NCHUNK - 1) * (KT + HC / 64) + HC / 64;
+        constexpr int SS = 3 * KT + KT + (NCHUNK - 1) * PER + G2T;
         f32x4 acc[4][NTW];
         zero_acc(acc);
-        gemm_stage<KT, NTW, SS>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { load_b<NTW>(b, u_po, lo_c, t * 128, RS_C); }, [&](f16x8 (&)[10]) __attribute__((always_inline)) {});
-        if (p.out2) epi_to_global<NTW, 2, true>(acc, p.bpo, nb, nullptr, p.xin, C, p.out, p.ldo, p.out2, p.ldo2, row0, lane);
-        else epi_to_global<NTW, 2, false>(acc, p.bpo, nb, nullptr, p.xin, C, p.out, p.ldo, nullptr, 0, row0, lane);
+        gemm_stage<KT, NTW, SS, NS>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_cc(b, u_po, t); },
+                                    [&](f16x8 (&)[10], int) __attribute__((always_inline)) {});
+        if (p.out2) epi_to_global<NTW, false, true>(acc, vec(V_BPO), nb, nullptr, rg, p.out, p.ldo, p.out2, p.ldo2, row0, lane);
+        else epi_to_global<NTW, false, false>(acc, vec(V_BPO), nb, nullptr, rg, p.out, p.ldo, nullptr, 0, row0, lane);
     }
 }
 
@@ -566,14 +649,18 @@ int osg_tblock_tail(osg_ctx* ctx, const osg_tblock_tail_args* a) {
     p.ldo = a->ldo ? a->ldo : a->C; p.ldo2 = a->ldo2;
     p.M = a->M; p.rows_per_img = a->rows_per_img; p.heads = a->heads;
     for (int i = 0; i < 8; i++) p.dbg[i] = (f16*)a->dbg[i];
-    auto kern = osg_tb::tblock_tail_kernel<320, 40, 5>;
-    constexpr int smem = 3 * 5 * osg_tb::kTileBytes;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static const int ns = getenv("OSG_TBLOCK_SLOTS") ? atoi(getenv("OSG_TBLOCK_SLOTS")) : 3;            // dev knobs: register slots (2 | 3) and the
+    static const int pfw = getenv("OSG_TBLOCK_PREFETCH") ? atoi(getenv("OSG_TBLOCK_PREFETCH")) : 8;      // number of weight-prefetching workgroups (0 = none)
+    auto kern = ns == 2 ? osg_tb::tblock_tail_kernel<320, 40, 5, 2> : osg_tb::tblock_tail_kernel<320, 40, 5, 3>;
+    constexpr int smem = 3 * 5 * osg_tb::kTileBytes + (9 * 320 + 8 * 320) * 2;   // three row-block images + the small operands
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[ns == 2]) {
         OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
+        attr_set[ns == 2] = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a->M / 64)), dim3(256), smem, ctx->compute, p);
+    const int nblk = a->M / 64;
+    const int npf = nblk >= 64 ? pfw : 0;     // (a launch that leaves CUs idle anyway spends eight of them on pulling the weights into the eight L2s)
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nblk + npf)), dim3(256), smem, ctx->compute, p);
     OSG_LAUNCH_CHECK(ctx);
     return 0;
 }
