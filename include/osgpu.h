@@ -204,8 +204,8 @@ int osg_attention_strided(osg_ctx* ctx, osg_dtype dtype, const void* q, long q_t
  *   x2 = a2 . Wo2^T + bo2 + x1
  *   x3 = GEGLU(LayerNorm(x2; g3, be3) . W1^T + b1) . W2^T + b2 + x2     (Slice, Slice, Div, Erf :4001-4139, Add, Mul, Mul, Mul)
  *   y  = x3 . Wpo^T + bpo + xin                 the 1x1 proj_out Conv (:4494-4707) + the spatial residual; only when wpo != NULL, else y = x3
- * with the row block resident in LDS and the GEGLU activation never formed.  All tensors f16, weights [N][K] (k contiguous: w1 [8C][C] value rows
- * then gate rows, w2 [C][4C]); a1 / x0 / xin dense [M][C]; out rows ldo apart (0 = C), out2 (may be NULL) a second copy rows ldo2 apart (the Concat
+ * with the row block resident in LDS and the GEGLU activation never formed.  All tensors f16; the seven weights in the kn8 layout of osg_tblock_pack_weight
+ * ([K/8][N][8]; w1 from [8C][C] = value rows then gate rows, w2 from [C][4C]); a1 / x0 / xin dense [M][C]; out rows ldo apart (0 = C), out2 (may be NULL) a second copy rows ldo2 apart (the Concat
  * slot of a skip connection); kp / vtp from osg_tblock_kv_pack.  M rows = images x rows_per_img, a 64-row block lies inside one image.
  * dbg[0..6] (may be NULL): dense [M][C] dumps of x1, LN(x1), q, a2, x2, LN(x2), x3 (x3 only with wpo) -- the kernel tests read them. */
 typedef struct {
@@ -229,6 +229,10 @@ typedef struct {
 } osg_tblock_tail_args;
 int osg_tblock_tail_supported(int M, int rows_per_img, int C, int heads, int Tk); /* 1 = osg_tblock_tail takes the shape */
 int osg_tblock_tail(osg_ctx* ctx, const osg_tblock_tail_args* a);
+/* A resident [N][K] weight (k contiguous: a MatMul's [K,N] after osg_transpose_kn_to_nk, a 1x1 convolution's OHWI) -> the layout osg_tblock_tail streams:
+ * [K/8][N][8], i.e. for every 8-deep k chunk the N rows side by side -- an MFMA fragment request (lane = row, lane group = k chunk) is then four runs of
+ * 256 contiguous bytes.  Done once per weight, when it becomes resident.  K % 8 == 0. */
+int osg_tblock_pack_weight(osg_ctx* ctx, const void* w_nk, int N, int K, void* w_kn8);
 /* K / V of cross-attentions re-packed for osg_tblock_tail, several blocks per launch.  All of them are column ranges of ONE matrix `base` ([imgs * Tk] rows
  * ld apart -- the merged K|V projection of the text context): job j = jobs_dev[4 j .. 4 j + 3] = {column of K, column of V, head dim D, element offset of
  * its packs inside dst}; head h sits h D columns further in.  At dst + offset: kp [img][head][80][DP], then vtp [img][head][DP][80] (V transposed),

@@ -3527,6 +3527,21 @@ struct Lowering {
         });
     }
 
+    // a resident [N,K] weight in the layout osg_tblock_tail streams ([K/8][N][8], osg_tblock_pack_weight): a derived constant of the Model's pool, made once
+    int weight_kn8(int wnk) {
+        const long Nn = V(wnk).shape[0], K = V(wnk).shape.size() == 2 ? V(wnk).shape[1] : prod(V(wnk).shape) / Nn;
+        int t = P.new_val("", {K / 8, Nn, 8}, OSG_F16, Lay::plain, false);
+        V(t).is_const = true;
+        V(t).name = V(wnk).name + "|kn8";
+        bool fresh;
+        V(t).dptr = P.const_alloc(V(t).name, (size_t)Nn * K * 2, &fresh);
+        if (fresh) {
+            be.check(be.api.osg_tblock_pack_weight(be.ctx, P.ptr(wnk), (int)Nn, (int)K, V(t).dptr), "osg_tblock_pack_weight");
+            be.check(be.api.osg_sync(be.ctx), "osg_sync");
+        }
+        return t;
+    }
+
     void lower_tblock_tail(const Operation& op) {
         const bool proj = *attr(op, "proj") == "1";
         need(op, op.m_input.size() == (proj ? 21u : 18u) && op.m_output.size() == 1, "wrong number of inputs.");
@@ -3534,11 +3549,11 @@ struct Lowering {
         const float scale = std::stof(*attr(op, "scale")), eps2 = std::stof(*attr(op, "eps2")), eps3 = std::stof(*attr(op, "eps3"));
         const int a1 = P.ensure_plain(in_val(op.m_input[0])), x0 = P.ensure_plain(in_val(op.m_input[1]));
         auto opt = [&](const Tensor& t) { return t.m_name.empty() ? -1 : in_val(t); };
-        const int wo1 = weight_nk(in_val(op.m_input[2])), bo1 = opt(op.m_input[3]), g2 = in_val(op.m_input[4]), be2 = in_val(op.m_input[5]);
-        const int wq2 = weight_nk(in_val(op.m_input[6])), bq2 = opt(op.m_input[7]);
+        const int wo1 = weight_kn8(weight_nk(in_val(op.m_input[2]))), bo1 = opt(op.m_input[3]), g2 = in_val(op.m_input[4]), be2 = in_val(op.m_input[5]);
+        const int wq2 = weight_kn8(weight_nk(in_val(op.m_input[6]))), bq2 = opt(op.m_input[7]);
         const int k = in_val_raw(op.m_input[8]), v = in_val_raw(op.m_input[9]);
-        const int wo2 = weight_nk(in_val(op.m_input[10])), bo2 = opt(op.m_input[11]), g3 = in_val(op.m_input[12]), be3 = in_val(op.m_input[13]);
-        const int w1 = weight_nk(in_val(op.m_input[14])), b1 = opt(op.m_input[15]), w2 = weight_nk(in_val(op.m_input[16])), b2 = opt(op.m_input[17]);
+        const int wo2 = weight_kn8(weight_nk(in_val(op.m_input[10]))), bo2 = opt(op.m_input[11]), g3 = in_val(op.m_input[12]), be3 = in_val(op.m_input[13]);
+        const int w1 = weight_kn8(weight_nk(in_val(op.m_input[14]))), b1 = opt(op.m_input[15]), w2 = weight_kn8(weight_nk(in_val(op.m_input[16]))), b2 = opt(op.m_input[17]);
         const Shape as = V(a1).shape;
         need(op, as.size() == 3 && as[0] == 1 && V(x0).shape == as && V(a1).ld == 0 && V(x0).ld == 0, "invalid shape of inputs.");
         const long T = as[1], C = as[2], F = 4 * C, Tk = V(k).shape[1], nb = B(a1), M = T * nb;
@@ -3551,6 +3566,7 @@ struct Lowering {
             bpo = opt(op.m_input[19]);
             xin = P.ensure_nhwc(in_val(op.m_input[20]));
             need(op, V(wpo).is_const && V(wpo).lay == Lay::nhwc && V(wpo).dtype == OSG_F16 && V(xin).ld == 0 && P.total_elems(xin) == M * C, "invalid proj_out operands.");
+            wpo = weight_kn8(wpo);      // (OHWI of a 1x1 convolution IS [N][K])
         }
         if (!kv_packs.count(op.m_name)) prepack_kv(op, k, v, heads, Tk);
         const auto [pack, koff] = kv_packs.at(op.m_name);

@@ -21,6 +21,11 @@
 //   * LayerNorm is the standalone kernel's arithmetic on the rows in LDS; cross-attention runs per (head, 16-row group) on v_mfma_f32_16x16x16_f16
 //     (head dim 40 = 2.5 k-steps, probabilities go from accumulator layout straight into the B operand) against K / V^T re-packed once per pass
 //     (osg_tblock_kv_pack: zero padding to 80 tokens x 48 channels is in the pack, not in the kernel).
+// Weight layout (round 4, second version): [K/8][N][8] ("kn8", osg_tblock_pack_weight) -- for every 8-deep k chunk the N rows sit side by side, 16 bytes each.
+// A fragment request (lane l: row l & 15, k chunk l >> 4) is then four runs of 256 contiguous bytes.  Read out of the resident [N][K] layout the same
+// request touches 64 different 64-byte pieces in an order in which no four consecutive lanes are contiguous: the CU's address path took ~64 cycles per
+// request instead of 16, four waves x 10 requests per k-tile = 2 500 cycles against 640 cycles of MFMA work -- the first version ran as long as the seven
+// launches it replaced (profiles/r04_tblock_tail_v1_ab.txt), whatever the prefetch depth.
 // Numerics: f32 accumulation in the order of gemm2_kernel's one-slice form, one RNE rounding per reference op boundary that survives fusion level 2
 // (x1, LN, q, a2, x2, LN, h, x3, y), scores / probabilities in f32 as attn_kernel keeps them.
 #include "osg_common.h"
@@ -69,29 +74,29 @@ constexpr int kTileBytes = 8192;   // one k-tile of a row block: 64 rows x 128 B
 // byte offset of element (m, n), n % 4 == 0, inside a swizzled [64 x C] LDS image
 __device__ __forceinline__ int img_off(int m, int n) { return (n >> 6) * kTileBytes + m * 128 + ((((n & 63) >> 3) ^ (m & 7)) << 4) + (n & 7) * 2; }
 
-// the B fragments of one 64-deep k-tile of a [N][ld] weight (k contiguous), NT tiles of 16 rows `rstep` BYTES apart: b[5 ks + j].  Buffer loads:
-// the descriptor and the tile / chunk offset `so` are wave-uniform (scalar registers), the ONE per-lane 32-bit offset `lo` (row nb + l16, k 8 g) never
-// changes -- no 64-bit pointer arithmetic in vector registers (hipcc turns plain pointer loads into a VGPR pointer pair per tile row)
+// the B fragments of one 64-deep k-tile of a kn8 weight ([K/8][N][8]), NT tiles of 16 rows: b[5 ks + j].  Buffer loads: the descriptor and the tile /
+// chunk offset `so` are wave-uniform (scalar registers), the ONE per-lane 32-bit offset `lo` ((k chunk g) * N + row nb + l16, times 16 bytes) never changes.
+// kstep = bytes between the two 32-deep halves of a tile = 4 N 16.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f16x8 ldb(__amdgpu_buffer_rsrc_t rs, unsigned lo, int so) {
     return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lo, so, 0));
 }
 template <int NT>
-__device__ __forceinline__ void load_b(f16x8 (&b)[10], __amdgpu_buffer_rsrc_t rs, unsigned lo, int so, int rstep) {
+__device__ __forceinline__ void load_b(f16x8 (&b)[10], __amdgpu_buffer_rsrc_t rs, unsigned lo, int so, int kstep) {
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-        for (int j = 0; j < NT; j++) b[ks * 5 + j] = ldb(rs, lo, so + j * rstep + ks * 64);
+        for (int j = 0; j < NT; j++) b[ks * 5 + j] = ldb(rs, lo, so + j * 256 + ks * kstep);
 }
-// GEGLU projection: tiles 0, 1 = value rows, tiles 2, 3 = the matching gate rows (gate_off bytes further down).  Same slot layout as five tiles (b[5 ks + j]),
-// and the fifth entry is WRITTEN too (a copy of the fourth): where a uniform run-time branch requests either kind of tile into one slot, both sides then
-// store the same ten entries in the same order -- otherwise hipcc's store sinking merges the tails of the two sides into a store through a pointer phi
-// and the whole slot array stays in scratch memory (480 bytes of private memory per lane, every fragment a scratch round trip)
-__device__ __forceinline__ void load_b_geglu(f16x8 (&b)[10], __amdgpu_buffer_rsrc_t rs, unsigned lo, int so, int rstep, int gate_off) {
+// GEGLU projection: tiles 0, 1 = value rows, tiles 2, 3 = the matching gate rows (gate_off bytes further along the row axis).  Same slot layout as five tiles
+// (b[5 ks + j]), and the fifth entry is WRITTEN too (a copy of the fourth): where a uniform run-time branch requests either kind of tile into one slot, both
+// sides then store the same ten entries in the same order -- otherwise hipcc's store sinking merges the tails of the two sides into a store through a
+// pointer phi and the whole slot array stays in scratch memory (480 bytes of private memory per lane, every fragment a scratch round trip)
+__device__ __forceinline__ void load_b_geglu(f16x8 (&b)[10], __amdgpu_buffer_rsrc_t rs, unsigned lo, int so, int kstep, int gate_off) {
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) b[ks * 5 + j] = ldb(rs, lo, so + (j & 1) * rstep + (j >> 1) * gate_off + ks * 64);
+        for (int j = 0; j < 4; j++) b[ks * 5 + j] = ldb(rs, lo, so + (j & 1) * 256 + (j >> 1) * gate_off + ks * kstep);
         b[ks * 5 + 4] = b[ks * 5 + 3];
     }
 }
@@ -330,7 +335,12 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     constexpr int IMG = KT * kTileBytes;
     constexpr int AH = NS - 1;                 // tiles requested ahead
     static_assert(C % 64 == 0 && NTW <= 5 && 2 * G2T * kTileBytes <= IMG && (NS == 2 || NS == 3) && PER % NS == 1 && AH <= G2T && AH <= KT, "shape");
-    constexpr int RS_C = 16 * C * 2, RS_F = 16 * F * 2, GATE = F * C * 2, CH1 = HC * C * 2, CH2 = HC * 2;
+    // kn8 byte strides: KS_* = between the two halves of a k-tile (4 k chunks), KT_* = between k-tiles (8 k chunks); N = C for the square weights and ff.net.2
+    // ([F/8][C][8]), N = 2F for ff.net.0.proj ([C/8][2F][8])
+    constexpr int KS_C = 4 * C * 16, KT_C = 8 * C * 16, KS_1 = 4 * 2 * F * 16, KT_1 = 8 * 2 * F * 16;
+    constexpr int GATE = F * 16;               // gate rows sit F rows behind the value rows
+    constexpr int CH1 = HC * 16;               // ff.net.0.proj: the rows of the next chunk
+    constexpr int CH2 = (HC / 8) * C * 16;     // ff.net.2: the k chunks of the next chunk of hidden columns
     const int tid = threadIdx.x;
     const int nblk = p.M >> 6;
 
@@ -341,20 +351,21 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     if ((int)blockIdx.x >= nblk) {
         extern __shared__ __attribute__((aligned(16))) char lds_pf[];
         char* dummy = lds_pf + __builtin_amdgcn_readfirstlane(tid >> 6) * 256;       // (256 bytes per wave)
-        touch_lines(p.wo1, C, C * 2, C * 2, tid, dummy);
-        touch_lines(p.wq2, C, C * 2, C * 2, tid, dummy);
+        touch_lines(p.wo1, 1, C * C * 2, 0, tid, dummy);
+        touch_lines(p.wq2, 1, C * C * 2, 0, tid, dummy);
         {
             constexpr int DP = (D + 15) / 16 * 16;
-            const int imgs = p.M / p.rows_per_img;
-            touch_lines(p.kp, 1, imgs * p.heads * TKT * 16 * DP * 2 * 2, 0, tid, dummy);     // kp and, right behind it, vtp
+            const int imgs = p.M / p.rows_per_img, bytes = imgs * p.heads * TKT * 16 * DP * 2;
+            touch_lines(p.kp, 1, bytes, 0, tid, dummy);
+            touch_lines(p.vtp, 1, bytes, 0, tid, dummy);
         }
-        touch_lines(p.wo2, C, C * 2, C * 2, tid, dummy);
+        touch_lines(p.wo2, 1, C * C * 2, 0, tid, dummy);
         for (int c = 0; c < NCHUNK; c++) {
-            touch_lines(p.w1 + (long)c * HC * C, HC, C * 2, C * 2, tid, dummy);
-            touch_lines(p.w1 + (long)(F + c * HC) * C, HC, C * 2, C * 2, tid, dummy);
-            touch_lines(p.w2 + c * HC, C, HC * 2, F * 2, tid, dummy);
+            touch_lines((const char*)p.w1 + c * CH1, C / 8, HC * 16, 2 * F * 16, tid, dummy);              // value rows of chunk c, every k chunk
+            touch_lines((const char*)p.w1 + GATE + c * CH1, C / 8, HC * 16, 2 * F * 16, tid, dummy);       // gate rows
+            touch_lines((const char*)p.w2 + c * CH2, 1, CH2, 0, tid, dummy);                                // ff.net.2 over this chunk's hidden columns
         }
-        if (p.wpo) touch_lines(p.wpo, C, C * 2, C * 2, tid, dummy);
+        if (p.wpo) touch_lines(p.wpo, 1, C * C * 2, 0, tid, dummy);
         return;
     }
 
@@ -387,10 +398,9 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     const int nb = wave * (C / 4);             // this wave's output columns of a C-wide contraction
 
     f16x8 bq[NS][10];
-    // per-lane weight offsets (bytes; the bases stay in scalar registers): row nb + l16 (+ 16 j), k offset 8 g
-    const unsigned lo_c = (unsigned)(((nb + l16) * C + g * 8) * 2);          // [C][C] weights
-    const unsigned lo_1 = (unsigned)(((wave * 32 + l16) * C + g * 8) * 2);   // w1 [2F][C]: + chunk * HC rows; gate rows F rows further
-    const unsigned lo_2 = (unsigned)(((nb + l16) * F + g * 8) * 2);          // w2 [C][F]: + chunk * HC columns
+    // per-lane weight offsets (bytes; the bases stay in scalar registers): k chunk g, row nb + l16 (+ 16 j)
+    const unsigned lo_c = (unsigned)((g * C + nb + l16) * 16);                   // [C/8][C][8] weights and ff.net.2 [F/8][C][8] (+ chunk * CH2)
+    const unsigned lo_1 = (unsigned)((g * 2 * F + wave * 32 + l16) * 16);        // ff.net.0.proj [C/8][2F][8]: + chunk * CH1; gate rows GATE further
     const __amdgpu_buffer_rsrc_t u_o1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.wo1, 0, C * C * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t u_q2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq2, 0, C * C * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t u_o2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.wo2, 0, C * C * 2, 0x00020000);
@@ -400,10 +410,10 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     const bool has_po = p.wpo != nullptr;
     // requests by position: a [C x C] contraction's tile t; the feed-forward's tile `pos` of chunk iteration cc -- positions 0 .. KT-1 = ff.net.0.proj of
     // chunk cc (value + gate rows), KT .. PER-1 = ff.net.2 over chunk cc - 1
-    auto ld_cc = [&](f16x8 (&b)[10], __amdgpu_buffer_rsrc_t rs, int t) __attribute__((always_inline)) { load_b<NTW>(b, rs, lo_c, t * 128, RS_C); };
+    auto ld_cc = [&](f16x8 (&b)[10], __amdgpu_buffer_rsrc_t rs, int t) __attribute__((always_inline)) { load_b<NTW>(b, rs, lo_c, t * KT_C, KS_C); };
     auto ld_ff = [&](f16x8 (&b)[10], int cc, int pos) __attribute__((always_inline)) {
-        if (pos < KT) load_b_geglu(b, u_1, lo_1, cc * CH1 + pos * 128, RS_C, GATE);
-        else load_b<NTW>(b, u_2, lo_2, (cc - 1) * CH2 + (pos - KT) * 128, RS_F);
+        if (pos < KT) load_b_geglu(b, u_1, lo_1, cc * CH1 + pos * KT_1, KS_1, GATE);
+        else load_b<NTW>(b, u_2, lo_c, (cc - 1) * CH2 + (pos - KT) * KT_C, KS_C);
     };
 
     static_for<AH>([&](auto tc) __attribute__((always_inline)) { ld_cc(bq[decltype(tc)::value % NS], u_o1, decltype(tc)::value); });      // the first tiles of the first contraction: in flight while the row block arrives
@@ -609,6 +619,14 @@ __global__ __launch_bounds__(256) void kv_pack_kernel(const f16* __restrict__ ba
     }
 }
 
+// [N][K] (k contiguous) -> kn8 [K/8][N][8]: one 16-byte chunk per thread
+__global__ __launch_bounds__(256) void kn8_pack_kernel(const f16x8* __restrict__ src, f16x8* __restrict__ dst, int N, int K8) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)N * K8) return;
+    const int kc = (int)(idx / N), n = (int)(idx - (long)kc * N);
+    dst[idx] = src[(long)n * K8 + kc];
+}
+
 }   // namespace osg_tb
 
 extern "C" {
@@ -618,6 +636,14 @@ int osg_tblock_tail_supported(int M, int rows_per_img, int C, int heads, int Tk)
 }
 
 size_t osg_tblock_kv_pack_elems(int imgs, int heads, int D) { return (size_t)imgs * heads * 80 * (size_t)((D + 15) / 16 * 16); }
+
+int osg_tblock_pack_weight(osg_ctx* ctx, const void* w_nk, int N, int K, void* w_kn8) {
+    if (N < 1 || K < 8 || K % 8) OSG_FAIL(ctx, "osg_tblock_pack_weight: K must be a multiple of 8");
+    const long n = (long)N * (K / 8);
+    hipLaunchKernelGGL(osg_tb::kn8_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->compute, (const f16x8*)w_nk, (f16x8*)w_kn8, N, K / 8);
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
 
 int osg_tblock_kv_pack_jobs(osg_ctx* ctx, const void* base, long ld, int imgs, int Tk, int heads, int njobs, const int* jobs_dev, void* dst) {
     if (Tk < 1 || Tk > 80 || njobs < 1 || imgs < 1 || heads < 1) OSG_FAIL(ctx, "osg_tblock_kv_pack_jobs: unsupported shape");

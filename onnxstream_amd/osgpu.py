@@ -29,7 +29,7 @@ EXPORTS = [
     "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_concat2", "osg_resize_nearest", "osg_gather_rows",
     "osg_maxpool_nhwc", "osg_convert", "osg_sampler_prepare", "osg_sampler_cfg_euler_a",
     "osg_range_push", "osg_range_pop", "osg_marker_record", "osg_copy_wait_marker", "osg_timer_mark", "osg_timer_between", "osg_set_stat_sinks", "osg_set_weight_prefetch", "osg_set_blocked_weight_hint", "osg_group_norm_stats_nhwc", "osg_qu8_conv2d_nhwc", "osg_qu8_conv2d_nhwc_t", "osg_qu8_conv_tap_sums", "osg_qu8_gemm", "osg_qu8_lut", "osg_qu8_binary", "osg_qu8_instance_norm", "osg_qu8_instance_norm_nhwc", "osg_qu8_affine_act", "osg_qu8_norm_affine_act_nhwc", "osg_qu8_softmax_last", "osg_kdbg_read",
-    "osg_tblock_tail_supported", "osg_tblock_tail", "osg_tblock_kv_pack_elems", "osg_tblock_kv_pack_jobs",
+    "osg_tblock_tail_supported", "osg_tblock_tail", "osg_tblock_kv_pack_elems", "osg_tblock_kv_pack_jobs", "osg_tblock_pack_weight",
 ]
 
 
@@ -130,6 +130,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_tblock_kv_pack_elems.argtypes = [ci, ci, ci]
     lib.osg_tblock_kv_pack_elems.restype = ctypes.c_size_t
     lib.osg_tblock_kv_pack_jobs.argtypes = [vp, vp, cl, ci, ci, ci, ci, vp, vp]
+    lib.osg_tblock_pack_weight.argtypes = [vp, vp, ci, ci, vp]
     return lib
 
 
@@ -333,9 +334,22 @@ class Gpu:
         self._ck(self.lib.osg_copy(self.ctx, vtp.ptr, dst.ptr + n * 2, n * 2))
         return kp, vtp
 
+    TBLOCK_WEIGHTS = ("wo1", "wq2", "wo2", "w1", "w2", "wpo")
+
+    def tblock_pack_weight(self, w_nk: DevBuf) -> DevBuf:
+        """[N, K] (k contiguous) -> the kn8 layout osg_tblock_tail streams, returned as a [K/8, N, 8] buffer"""
+        n, k = w_nk.shape
+        out = self.empty((k // 8, n, 8), w_nk.dtype)
+        self._ck(self.lib.osg_tblock_pack_weight(self.ctx, w_nk.ptr, n, k, out.ptr))
+        return out
+
+    def tblock_weights(self, w: dict) -> dict:
+        """host dict of a block's operands (weights [N, K]) -> device dict as tblock_tail wants it (weights packed)"""
+        return {n: (self.tblock_pack_weight(self.to_dev(t)) if n in self.TBLOCK_WEIGHTS else self.to_dev(t)) for n, t in w.items()}
+
     def tblock_tail(self, a1: DevBuf, x0: DevBuf, w: dict, kp: DevBuf, vtp: DevBuf, tk: int, heads: int, scale: float, rows_per_img: int, eps: float = 1e-5,
                     xin: Optional[DevBuf] = None, out2: Optional[DevBuf] = None, out2_col: int = 0, debug: bool = False, out: Optional[DevBuf] = None):
-        """osg_tblock_tail.  w: dict of DevBuf -- wo1 bo1 g2 be2 wq2 wo2 bo2 g3 be3 w1 b1 w2 b2 [wpo bpo]; weights [N,K].  Returns (out, [dumps])."""
+        """osg_tblock_tail.  w: dict of DevBuf -- wo1 bo1 g2 be2 wq2 wo2 bo2 g3 be3 w1 b1 w2 b2 [wpo bpo]; weights in the kn8 layout (tblock_weights).  Returns (out, [dumps])."""
         m, c = a1.shape
         a = TBlockTailArgs()
         a.a1, a.x0 = a1.ptr, x0.ptr

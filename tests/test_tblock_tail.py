@@ -95,7 +95,10 @@ def test_tblock_tail_stage_by_stage(gpu, M, imgs, Tk, proj):
     a1, x0, xin = rnd(rng, (M, C)), rnd(rng, (M, C)), rnd(rng, (M, C))
     k, v = rnd(rng, (imgs, Tk, C)), rnd(rng, (imgs, Tk, C))
     scale, eps = (C // heads) ** -0.5, 1e-5
-    dw = {n: gpu.to_dev(t) for n, t in w.items()}
+    dw = gpu.tblock_weights(w)
+    # the weight re-layout is pure data movement: bit-exact ([N, K] -> [K/8, N, 8])
+    assert np.array_equal(dw["w1"].numpy(), w["w1"].reshape(8 * C, C // 8, 8).transpose(1, 0, 2))
+    assert np.array_equal(dw["w2"].numpy(), w["w2"].reshape(C, 4 * C // 8, 8).transpose(1, 0, 2))
     if not proj:
         dw["wpo"] = dw["bpo"] = None
     kp, vtp = gpu.tblock_kv_pack(gpu.to_dev(k), gpu.to_dev(v), heads)
@@ -138,7 +141,7 @@ def test_tblock_tail_second_destination_and_row_pitch(gpu):
     w = make_block(rng, C)
     a1, x0, xin = rnd(rng, (M, C)), rnd(rng, (M, C)), rnd(rng, (M, C))
     k, v = rnd(rng, (imgs, Tk, C)), rnd(rng, (imgs, Tk, C))
-    dw = {n: gpu.to_dev(t) for n, t in w.items()}
+    dw = gpu.tblock_weights(w)
     kp, vtp = gpu.tblock_kv_pack(gpu.to_dev(k), gpu.to_dev(v), heads)
     wide = gpu.to_dev(np.full((M, 2 * C + 64), 7.0, f16))
     out, _ = gpu.tblock_tail(gpu.to_dev(a1), gpu.to_dev(x0), dw, kp, vtp, Tk, heads, 40 ** -0.5, M, xin=gpu.to_dev(xin), out2=wide, out2_col=C)

@@ -21,7 +21,7 @@ def main():
     sets = []
     w0 = t.make_block(rng, C)
     for i in range(nsets):
-        sets.append({n: gpu.to_dev(np.roll(v, i, axis=0)) for n, v in w0.items()})
+        sets.append(gpu.tblock_weights({n: np.roll(v, i, axis=0) for n, v in w0.items()}))
     a1, x0, xin = gpu.to_dev(t.rnd(rng, (M, C))), gpu.to_dev(t.rnd(rng, (M, C))), gpu.to_dev(t.rnd(rng, (M, C)))
     k, v = gpu.to_dev(t.rnd(rng, (imgs, Tk, C))), gpu.to_dev(t.rnd(rng, (imgs, Tk, C)))
     kp, vtp = gpu.tblock_kv_pack(k, v, heads)
