@@ -207,7 +207,8 @@ int osg_attention_strided(osg_ctx* ctx, osg_dtype dtype, const void* q, long q_t
  * with the row block resident in LDS and the GEGLU activation never formed.  All tensors f16; the seven weights in the kn8 layout of osg_tblock_pack_weight
  * ([K/8][N][8]; w1 from [8C][C] = value rows then gate rows, w2 from [C][4C]); a1 / x0 / xin dense [M][C]; out rows ldo apart (0 = C), out2 (may be NULL) a second copy rows ldo2 apart (the Concat
  * slot of a skip connection); kp / vtp from osg_tblock_kv_pack.  M rows = images x rows_per_img, a 64-row block lies inside one image.
- * dbg[0..6] (may be NULL): dense [M][C] dumps of x1, LN(x1), q, a2, x2, LN(x2), x3 (x3 only with wpo) -- the kernel tests read them. */
+ * dbg[0..6] (may be NULL): dense [M][C] dumps of x1, LN(x1), q, a2, x2, LN(x2), x3 (x3 only with wpo) -- the kernel tests read them; dbg[7] (may be NULL):
+ * [M/64][16] int64 wall-clock stamps (100 MHz) of every row block's stages -- tools/tblock_tail_probe.py reads them. */
 typedef struct {
   const void *a1, *x0;
   const void *wo1, *bo1;

@@ -52,6 +52,7 @@ struct TailParams {
     f16 *out, *out2;
     long ldo, ldo2;
     int M, rows_per_img, heads;
+    int pf_sleep0, pf_sleep;   // prefetching workgroups: pauses (x 64 cycles) behind the first contractions' weights and between the feed-forward chunks
     f16* dbg[8];
 };
 
@@ -119,15 +120,37 @@ __device__ __forceinline__ void mma_ktile(const char* At, int a_rd, const f16x8 
 // A whole contraction over KT k-tiles.  Every k-tile of the kernel has an index s in ONE kernel-wide sequence (SS = the index of this contraction's
 // first tile): tile s is consumed from register slot s % NS while the requests of the next NS - 1 tiles are in flight -- at tile s the request of tile
 // s + NS - 1 goes out, into the slot tile s - 1 has just left.  `load(b, t)` requests this contraction's tile t, `next(b, j)` tile j of whatever follows.
-template <int KT, int NT, int SS, int NS, typename Load, typename Next>
-__device__ __forceinline__ void gemm_stage(const char* A, int a_rd, f16x8 (&bq)[NS][10], f32x4 (&acc)[4][NT], Load&& load, Next&& next) {
+template <int KT, int NT, int SS, int NS, typename Load, typename Next, typename Mark>
+__device__ __forceinline__ void gemm_stage(const char* A, int a_rd, f16x8 (&bq)[NS][10], f32x4 (&acc)[4][NT], Load&& load, Next&& next, Mark&& mark) {
     static_for<KT>([&](auto tc) __attribute__((always_inline)) {
         constexpr int t = decltype(tc)::value;
+        mark(t);
         if constexpr (t + NS - 1 < KT) load(bq[(SS + t + NS - 1) % NS], t + NS - 1);
         else next(bq[(SS + t + NS - 1) % NS], t + NS - 1 - KT);
         __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks every request down to its first use: one exposed L2 round trip per fragment)
         mma_ktile<NT>(A + t * kTileBytes, a_rd, bq[(SS + t) % NS], acc);
         __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+template <int KT, int NT, int SS, int NS, typename Load, typename Next>
+__device__ __forceinline__ void gemm_stage(const char* A, int a_rd, f16x8 (&bq)[NS][10], f32x4 (&acc)[4][NT], Load&& load, Next&& next) {
+    gemm_stage<KT, NT, SS, NS>(A, a_rd, bq, acc, load, next, [](int) __attribute__((always_inline)) {});
+}
+
+// A [C x C] contraction whose KT weight tiles were ALL requested one contraction earlier (slot t = tile t): the weights of the four square contractions of a
+// block are cold when the launch starts and only ~200 KB each -- with one or two tiles in flight every one of their k-tiles waits a memory round trip
+// (~1 us per tile measured, against 0.4 us for the feed-forward's tiles the prefetching workgroups have long pulled into the L2).  `after(b, t)` runs
+// behind tile t's MFMAs: it requests tile t of the NEXT square contraction into the slot that has just been read.
+template <int KT, int NT, typename After, typename Mark>
+__device__ __forceinline__ void square_stage(const char* A, int a_rd, f16x8 (&bs)[KT][10], f32x4 (&acc)[4][NT], After&& after, Mark&& mark) {
+    static_for<KT>([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value;
+        mark(t);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_ktile<NT>(A + t * kTileBytes, a_rd, bs[t], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        after(bs[t], t);
     });
 }
 
@@ -351,8 +374,10 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     if ((int)blockIdx.x >= nblk) {
         extern __shared__ __attribute__((aligned(16))) char lds_pf[];
         char* dummy = lds_pf + __builtin_amdgcn_readfirstlane(tid >> 6) * 256;       // (256 bytes per wave)
-        touch_lines(p.wo1, 1, C * C * 2, 0, tid, dummy);
-        touch_lines(p.wq2, 1, C * C * 2, 0, tid, dummy);
+        // PACED: a request for everything at once queues the row blocks' own first requests behind 26 000 lines per XCD (the first contractions then
+        // wait longer than without any prefetch); the weights are asked for roughly at the rate the row blocks consume them, a few microseconds ahead
+        auto nap = [&](int n) __attribute__((always_inline)) { for (; n > 0; n -= 127) __builtin_amdgcn_s_sleep(127); };
+        touch_lines(p.wq2, 1, C * C * 2, 0, tid, dummy);        // (to_out1's own weights: the row blocks request them at entry themselves)
         {
             constexpr int DP = (D + 15) / 16 * 16;
             const int imgs = p.M / p.rows_per_img, bytes = imgs * p.heads * TKT * 16 * DP * 2;
@@ -360,12 +385,14 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
             touch_lines(p.vtp, 1, bytes, 0, tid, dummy);
         }
         touch_lines(p.wo2, 1, C * C * 2, 0, tid, dummy);
+        nap(p.pf_sleep0);
         for (int c = 0; c < NCHUNK; c++) {
             touch_lines((const char*)p.w1 + c * CH1, C / 8, HC * 16, 2 * F * 16, tid, dummy);              // value rows of chunk c, every k chunk
             touch_lines((const char*)p.w1 + GATE + c * CH1, C / 8, HC * 16, 2 * F * 16, tid, dummy);       // gate rows
             touch_lines((const char*)p.w2 + c * CH2, 1, CH2, 0, tid, dummy);                                // ff.net.2 over this chunk's hidden columns
+            if (c == NCHUNK / 2 && p.wpo) touch_lines(p.wpo, 1, C * C * 2, 0, tid, dummy);
+            nap(p.pf_sleep);
         }
-        if (p.wpo) touch_lines(p.wpo, 1, C * C * 2, 0, tid, dummy);
         return;
     }
 
@@ -396,8 +423,12 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     const int img = (int)(row0 / p.rows_per_img);
     const int a_rd = l16 * 128 + ((g ^ (l16 & 7)) << 4);
     const int nb = wave * (C / 4);             // this wave's output columns of a C-wide contraction
+    long long* const stamps = reinterpret_cast<long long*>(p.dbg[7]);      // dev probe: 16 wall-clock stamps (100 MHz) per row block, NULL in production
+    auto stamp = [&](int k) __attribute__((always_inline)) { if (stamps && tid == 0) stamps[(long)blockIdx.x * 32 + k] = wall_clock64(); };
+    stamp(0);
 
-    f16x8 bq[NS][10];
+    f16x8 bq[NS][10];      // feed-forward tiles: NS - 1 ahead
+    f16x8 bs[KT][10];      // to_out1's tiles: all of them, requested at entry (square_stage)
     // per-lane weight offsets (bytes; the bases stay in scalar registers): k chunk g, row nb + l16 (+ 16 j)
     const unsigned lo_c = (unsigned)((g * C + nb + l16) * 16);                   // [C/8][C][8] weights and ff.net.2 [F/8][C][8] (+ chunk * CH2)
     const unsigned lo_1 = (unsigned)((g * 2 * F + wave * 32 + l16) * 16);        // ff.net.0.proj [C/8][2F][8]: + chunk * CH1; gate rows GATE further
@@ -416,7 +447,7 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
         else load_b<NTW>(b, u_2, lo_c, (cc - 1) * CH2 + (pos - KT) * KT_C, KS_C);
     };
 
-    static_for<AH>([&](auto tc) __attribute__((always_inline)) { ld_cc(bq[decltype(tc)::value % NS], u_o1, decltype(tc)::value); });      // the first tiles of the first contraction: in flight while the row block arrives
+    static_for<KT>([&](auto tc) __attribute__((always_inline)) { ld_cc(bs[decltype(tc)::value], u_o1, decltype(tc)::value); });      // every tile of the first contraction: in flight while the row block arrives
 
     // ---- the row block: a1 -> P, x0 -> X (LDS-DMA, the swizzle on the source side as in gemm2_kernel) ----------------------------------
     {
@@ -435,30 +466,36 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    stamp(1);
 
     // ---- x1 = to_out(a1) + x0 ---------------------------------------------------------------------------------------------------------
     {
         f32x4 acc[4][NTW];
         zero_acc(acc);
-        gemm_stage<KT, NTW, 0, NS>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_cc(b, u_o1, t); },
-                                   [&](f16x8 (&b)[10], int j) __attribute__((always_inline)) { ld_cc(b, u_q2, j); });
+        square_stage<KT, NTW>(P, a_rd, bs, acc, [&](f16x8 (&)[10], int t) __attribute__((always_inline)) { if (t < AH) ld_cc(bq[t % NS], u_q2, t); },
+                              [&](int t) __attribute__((always_inline)) { stamp(16 + t); });
+        stamp(21);
         epi_to_lds<NTW, true>(acc, vec(V_BO1), nb, X, X, lane);
+        stamp(22);
     }
     __builtin_amdgcn_s_barrier();
+    stamp(2);
     dump_img<C>(X, p.dbg[0], row0, tid);
     ln_rows<C>(X, P, vec(V_G2), vec(V_BE2), p.eps2, tid);
     __builtin_amdgcn_s_barrier();
+    stamp(3);
     dump_img<C>(P, p.dbg[1], row0, tid);
 
     // ---- q = to_q(LN(x1)) ---------------------------------------------------------------------------------------------------------------
     {
         f32x4 acc[4][NTW];
         zero_acc(acc);
-        gemm_stage<KT, NTW, KT, NS>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_cc(b, u_q2, t); },
-                                    [&](f16x8 (&b)[10], int j) __attribute__((always_inline)) { ld_cc(b, u_o2, j); });
+        gemm_stage<KT, NTW, 0, NS>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_cc(b, u_q2, t); },
+                                   [&](f16x8 (&b)[10], int j) __attribute__((always_inline)) { ld_cc(b, u_o2, j); });
         epi_to_lds<NTW, false>(acc, vec(V_BQ2), nb, nullptr, R, lane);
     }
     __builtin_amdgcn_s_barrier();
+    stamp(4);
     dump_img<C>(R, p.dbg[2], row0, tid);
 
     // ---- a2 = cross-attention(q, K, V): heads split over the waves -------------------------------------------------------------------
@@ -469,20 +506,23 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
         cross_attention<D, TKT>(R, P, p.kp + img * per_img, p.vtp + img * per_img, wave * hpw, hpw, p.sc_log2e, p.Tk, lane);
     }
     __builtin_amdgcn_s_barrier();
+    stamp(5);
     dump_img<C>(P, p.dbg[3], row0, tid);
 
     // ---- x2 = to_out(a2) + x1 -----------------------------------------------------------------------------------------------------------
     {
         f32x4 acc[4][NTW];
         zero_acc(acc);
-        gemm_stage<KT, NTW, 2 * KT, NS>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_cc(b, u_o2, t); },
-                                        [&](f16x8 (&b)[10], int j) __attribute__((always_inline)) { ld_ff(b, 0, j); });
+        gemm_stage<KT, NTW, KT, NS>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_cc(b, u_o2, t); },
+                                    [&](f16x8 (&b)[10], int j) __attribute__((always_inline)) { ld_ff(b, 0, j); });
         epi_to_lds<NTW, true>(acc, vec(V_BO2), nb, X, X, lane);
     }
     __builtin_amdgcn_s_barrier();
+    stamp(6);
     dump_img<C>(X, p.dbg[4], row0, tid);
     ln_rows<C>(X, P, vec(V_G3), vec(V_BE3), p.eps3, tid);
     __builtin_amdgcn_s_barrier();
+    stamp(7);
     dump_img<C>(P, p.dbg[5], row0, tid);
 
     // ---- x3 = ff.net.2(GEGLU(ff.net.0.proj(LN(x2)))) + x2, the hidden activation 128 columns at a time ----------------------------------
@@ -490,7 +530,7 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     f32x4 accY[4][NTW];
     zero_acc(accY);
     {
-        constexpr int S0 = 3 * KT;                 // sequence index of G1(0)'s first k-tile
+        constexpr int S0 = 2 * KT;                 // sequence index (slot = index % NS) of G1(0)'s first k-tile: to_q and to_out2 came first (to_out1 has slots of its own)
         f32x4 accG[4][4];
         // GEGLU epilogue of chunk c into hidden buffer c & 1 (value tiles 0, 1; gate tiles 2, 3)
         auto geglu_store = [&](int c) __attribute__((always_inline)) {
@@ -515,6 +555,7 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
                                   [&](f16x8 (&b)[10], int j) __attribute__((always_inline)) { ld_ff(b, 1, j); });
         geglu_store(0);
         __builtin_amdgcn_s_barrier();
+        stamp(8);
         // iteration c >= 1: projection of chunk c, then ff.net.2 over chunk c - 1 beside the GEGLU arithmetic of chunk c.  Its tile `pos` sits in slot
         // (ST + pos) % NS; the request that goes out with it is position pos + AH of this iteration, or of the next one (the last iteration is followed by
         // positions KT .. PER-1 of a pseudo-iteration NCHUNK -- ff.net.2 over the last chunk -- and then by proj_out)
@@ -534,6 +575,7 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
                 mma_ktile<4>(P + t * kTileBytes, a_rd, bq[(ST + t) % NS], accG);
                 __builtin_amdgcn_sched_barrier(0);
             });
+            if (c == 3) stamp(24); else if (c == 4) stamp(28);
             const char* Hp = R + ((c - 1) & 1) * (G2T * kTileBytes);
             static_for<G2T>([&](auto uc) __attribute__((always_inline)) {
                 constexpr int u = decltype(uc)::value;
@@ -541,8 +583,11 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
                 __builtin_amdgcn_sched_barrier(0);
                 mma_ktile<NTW>(Hp + u * kTileBytes, a_rd, bq[(ST + KT + u) % NS], accY);
             });
+            if (c == 3) stamp(25); else if (c == 4) stamp(29);
             geglu_store(c);
+            if (c == 3) stamp(26); else if (c == 4) stamp(30);
             __builtin_amdgcn_s_barrier();
+            if (c == 2) stamp(23); else if (c == 3) stamp(27); else if (c == 4) stamp(31);
         };
         constexpr int B0 = (S0 + KT) % NS;          // slot of the first tile of iteration 1; iteration c starts at (B0 + (c - 1) PER) % NS = (B0 + c - 1) % NS
         int c = 1;
@@ -554,6 +599,7 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
         constexpr int REM = (NCHUNK - 1) % NS;      // iterations left over (their slots continue the rotation from B0)
         if constexpr (REM >= 1) ff_iter(std::integral_constant<int, B0 % NS>{}, c);
         if constexpr (REM >= 2) ff_iter(std::integral_constant<int, (B0 + 1) % NS>{}, c + 1);
+        stamp(9);
         // ff.net.2 over the last chunk (positions KT .. PER-1 of pseudo-iteration NCHUNK); the requests that go out with it are proj_out's first tiles
         {
             constexpr int ST = (S0 + KT + (NCHUNK - 1) * PER) % NS;        // slot of its first tile
@@ -568,6 +614,7 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
             });
         }
     }
+    stamp(10);
     f16x4 rg[4][NTW];                          // proj_out's residual x_in: requested now, behind the last weight tiles, consumed after the contraction
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -576,6 +623,7 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     if (!has_po) {
         if (p.out2) epi_to_global<NTW, true, true>(accY, vec(V_B2), nb, X, rg, p.out, p.ldo, p.out2, p.ldo2, row0, lane);
         else epi_to_global<NTW, true, false>(accY, vec(V_B2), nb, X, rg, p.out, p.ldo, nullptr, 0, row0, lane);
+        if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(13); }
         return;
     }
 #pragma unroll
@@ -585,15 +633,18 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     // x3 into P (every wave is past its last read of LN(x2): the barrier of the last chunk), then y = proj_out(x3) + x_in
     epi_to_lds<NTW, true>(accY, vec(V_B2), nb, X, P, lane);
     __builtin_amdgcn_s_barrier();
+    stamp(11);
     dump_img<C>(P, p.dbg[6], row0, tid);
     {
-        constexpr int SS = 3 * KT + KT + (NCHUNK - 1) * PER + G2T;
         f32x4 acc[4][NTW];
         zero_acc(acc);
+        constexpr int SS = 2 * KT + KT + (NCHUNK - 1) * PER + G2T;
         gemm_stage<KT, NTW, SS, NS>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_cc(b, u_po, t); },
                                     [&](f16x8 (&)[10], int) __attribute__((always_inline)) {});
+        stamp(12);
         if (p.out2) epi_to_global<NTW, false, true>(acc, vec(V_BPO), nb, nullptr, rg, p.out, p.ldo, p.out2, p.ldo2, row0, lane);
         else epi_to_global<NTW, false, false>(acc, vec(V_BPO), nb, nullptr, rg, p.out, p.ldo, nullptr, 0, row0, lane);
+        if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(13); }
     }
 }
 
@@ -675,14 +726,18 @@ int osg_tblock_tail(osg_ctx* ctx, const osg_tblock_tail_args* a) {
     p.ldo = a->ldo ? a->ldo : a->C; p.ldo2 = a->ldo2;
     p.M = a->M; p.rows_per_img = a->rows_per_img; p.heads = a->heads;
     for (int i = 0; i < 8; i++) p.dbg[i] = (f16*)a->dbg[i];
-    static const int ns = getenv("OSG_TBLOCK_SLOTS") ? atoi(getenv("OSG_TBLOCK_SLOTS")) : 3;            // dev knobs: register slots (2 | 3) and the
-    static const int pfw = getenv("OSG_TBLOCK_PREFETCH") ? atoi(getenv("OSG_TBLOCK_PREFETCH")) : 8;      // number of weight-prefetching workgroups (0 = none)
-    auto kern = ns == 2 ? osg_tb::tblock_tail_kernel<320, 40, 5, 2> : osg_tb::tblock_tail_kernel<320, 40, 5, 3>;
+    static const int pfw = getenv("OSG_TBLOCK_PREFETCH") ? atoi(getenv("OSG_TBLOCK_PREFETCH")) : 8;      // dev knobs: number of weight-prefetching workgroups (0 = none),
+    static const int pfs0 = getenv("OSG_TBLOCK_PF_SLEEP0") ? atoi(getenv("OSG_TBLOCK_PF_SLEEP0")) : 100;  // their pauses, x 64 cycles: behind the square weights ...
+    static const int pfs = getenv("OSG_TBLOCK_PF_SLEEP") ? atoi(getenv("OSG_TBLOCK_PF_SLEEP")) : 60;      // ... and behind every feed-forward chunk
+    p.pf_sleep0 = pfs0; p.pf_sleep = pfs;
+    // (two register slots for the feed-forward's tiles: three -- two tiles ahead -- measured no faster, profiles/r04_tblock_tail_probe_v3.txt, and with the
+    // square contractions' five slots beside them hipcc 7.2 crashes in its 'Rewrite AGPR-Copy-MFMA' pass)
+    auto kern = osg_tb::tblock_tail_kernel<320, 40, 5, 2>;
     constexpr int smem = 3 * 5 * osg_tb::kTileBytes + (9 * 320 + 8 * 320) * 2;   // three row-block images + the small operands
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[ns == 2]) {
+    static bool attr_set = false;
+    if (!attr_set) {
         OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set[ns == 2] = true;
+        attr_set = true;
     }
     const int nblk = a->M / 64;
     const int npf = nblk >= 64 ? pfw : 0;     // (a launch that leaves CUs idle anyway spends eight of them on pulling the weights into the eight L2s)

@@ -348,7 +348,7 @@ class Gpu:
         return {n: (self.tblock_pack_weight(self.to_dev(t)) if n in self.TBLOCK_WEIGHTS else self.to_dev(t)) for n, t in w.items()}
 
     def tblock_tail(self, a1: DevBuf, x0: DevBuf, w: dict, kp: DevBuf, vtp: DevBuf, tk: int, heads: int, scale: float, rows_per_img: int, eps: float = 1e-5,
-                    xin: Optional[DevBuf] = None, out2: Optional[DevBuf] = None, out2_col: int = 0, debug: bool = False, out: Optional[DevBuf] = None):
+                    xin: Optional[DevBuf] = None, out2: Optional[DevBuf] = None, out2_col: int = 0, debug: bool = False, out: Optional[DevBuf] = None, stamps: Optional[DevBuf] = None):
         """osg_tblock_tail.  w: dict of DevBuf -- wo1 bo1 g2 be2 wq2 wo2 bo2 g3 be3 w1 b1 w2 b2 [wpo bpo]; weights in the kn8 layout (tblock_weights).  Returns (out, [dumps])."""
         m, c = a1.shape
         a = TBlockTailArgs()
@@ -370,6 +370,8 @@ class Gpu:
             dumps = [self.empty((m, c), a1.dtype) for _ in range(7)]
             for i, dbuf in enumerate(dumps):
                 a.dbg[i] = dbuf.ptr
+        if stamps is not None:
+            a.dbg[7] = stamps.ptr
         self._ck(self.lib.osg_tblock_tail(self.ctx, ctypes.byref(a)))
         return out, dumps
 

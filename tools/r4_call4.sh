@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 4, GPU call 4: tail kernel v3 (kn8 weight layout)
+mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_tblock_tail.py -m gpu -x -q > gpurun_out/r4c4_tests.log 2>&1; tail -3 gpurun_out/r4c4_tests.log
+OSG_TBLOCK_SLOTS=2 timeout 600 python -m pytest tests/test_tblock_tail.py -m gpu -x -q > gpurun_out/r4c4_tests_ns2.log 2>&1; tail -2 gpurun_out/r4c4_tests_ns2.log
+for ns in 3 2; do for pf in 8 0; do
+  echo "== slots $ns prefetch workgroups $pf"; OSG_TBLOCK_SLOTS=$ns OSG_TBLOCK_PREFETCH=$pf REPS=2 SKIP_SEP=1 timeout 300 python tools/tblock_tail_probe.py 2>&1 | grep -v "^$"
+done; done > gpurun_out/r4c4_tail_probe.log 2>&1; cat gpurun_out/r4c4_tail_probe.log
+for i in 1 2; do
+  timeout 600 python bench.py --cpu-passes 0 --windows 3 > gpurun_out/r4c4_bench_fused_$i.json 2> gpurun_out/r4c4_bench_fused_$i.err; python -c "import json,sys; d=json.load(open('gpurun_out/r4c4_bench_fused_$i.json')); print('fused', d['ms_per_step'], d['config']['launches_per_step'], d['config']['unet_device_ms_per_step'], d['config']['windows_ms_per_step']['each'])"
+  timeout 600 python bench.py --cpu-passes 0 --windows 3 --no-tblock-fuse > gpurun_out/r4c4_bench_sep_$i.json 2> gpurun_out/r4c4_bench_sep_$i.err; python -c "import json,sys; d=json.load(open('gpurun_out/r4c4_bench_sep_$i.json')); print('separate', d['ms_per_step'], d['config']['launches_per_step'], d['config']['unet_device_ms_per_step'], d['config']['windows_ms_per_step']['each'])"
+done
+timeout 600 python bench.py --cpu-passes 0 --windows 0 --breakdown gpurun_out/r4c4_breakdown_fused.txt > /dev/null 2> gpurun_out/r4c4_bd.err; grep -n "TBlockTail\|KVPack" gpurun_out/r4c4_breakdown_fused.txt | head -8

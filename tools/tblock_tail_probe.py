@@ -43,6 +43,27 @@ def main():
                     n += 1
             ms = gpu.timer_stop()
             print(f"fused tail proj_out={int(proj)} {name}: {1000 * ms / n:.1f} us per launch ({n} launches)")
+    # ---- where a row block's time goes: wall-clock stamps of every stage (dbg[7]), cold weights
+    st = gpu.to_dev(np.zeros((M // 64, 32), np.int64))
+    names = ["rows landed", "to_out1", "LN", "to_q", "cross-attn", "to_out2", "LN", "GEGLU chunk 0", "chunks 1..9 (+ff2 0..8)", "ff2 chunk 9", "x3 -> LDS", "proj_out", "stores drained"]
+    acc = np.zeros(13)
+    inner = np.zeros(15)
+    nrep = 8
+    for i in range(nrep):
+        gpu.tblock_tail(a1, x0, sets[(7 * i + 3) % nsets], kp, vtp, Tk, heads, scale, M // imgs, xin=xin, out=out, stamps=st)
+        s = st.numpy().astype(np.float64)
+        acc += (s[:, 1:14] - s[:, 0:13]).mean(0) / 100.0      # 100 MHz -> us
+        tot = (s[:, 13] - s[:, 0]) / 100.0
+        inner += (s[:, 17:32] - s[:, 16:31]).mean(0) / 100.0
+        span = (s[:, 13].max() - s[:, 0].min()) / 100.0
+    print("stage (us, mean over the row blocks and %d launches):" % nrep)
+    for n, v in zip(names, acc / nrep):
+        print(f"  {n:28s} {v:7.2f}")
+    inames = ["to_out1 k-tile 0", "k-tile 1", "k-tile 2", "k-tile 3", "k-tile 4", "epilogue -> LDS", "(to chunk 2's barrier)", "chunk 3: ff.net.0.proj (5 k-tiles)", "chunk 3: ff.net.2 (2 k-tiles)", "chunk 3: GEGLU arithmetic + store", "chunk 3: barrier",
+              "chunk 4: ff.net.0.proj", "chunk 4: ff.net.2", "chunk 4: GEGLU", "chunk 4: barrier"]
+    for n, v in zip(inames, inner / nrep):
+        print(f"    {n:36s} {v:7.2f}")
+    print(f"  row block entry -> drained: mean {tot.mean():.1f}, min {tot.min():.1f}, max {tot.max():.1f}; first entry -> last drained {span:.1f} us (last launch)")
     if os.environ.get("SKIP_SEP"):
         return
     # the separate chain, same weights (hot and cold)
