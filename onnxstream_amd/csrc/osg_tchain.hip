@@ -576,6 +576,10 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             });
             if (c == 3) stamp(24); else if (c == 4) stamp(28);
+            // ff.net.2 over chunk c - 1, then the GEGLU arithmetic of chunk c.  (Slicing that arithmetic -- ~180 VALU / transcendental instructions per tile
+            // pair, independent of these MFMAs -- between the groups of four MFMAs was measured SLOWER: 2.72 instead of 0.93 + 1.18 us per chunk,
+            // profiles/r04_tblock_tail_stage_stamps_v5_geglu_interleaved_slower.txt -- one wave per SIMD issues in order, and the packed-f32 arithmetic takes the issue
+            // slots the MFMAs need; sched_group_barrier patterns were not honoured at all)
             const char* Hp = R + ((c - 1) & 1) * (G2T * kTileBytes);
             static_for<G2T>([&](auto uc) __attribute__((always_inline)) {
                 constexpr int u = decltype(uc)::value;
