@@ -336,7 +336,18 @@ def main():
     def make_pipe():
         return Txt2Img(b.LIB_HOST, model_dir, vae_dir, batched=True, device=gpu_index, fusion=args.fusion, autotune=not args.no_autotune)
     pipe = None
-    if dist is not None and not args.no_autotune:
+    frozen_ranks = dist is not None and not args.no_autotune and not os.environ.get("OSG_TUNE_CACHE") and os.path.exists(shipped_table)
+    if frozen_ranks:
+        # N > 1, no table named by the caller: every rank seeds a private copy of the SHIPPED table and plans on its own with OSG_TUNE_FROZEN = 1 -- a shape
+        # the table does not hold takes the cost model's first candidate (deterministic) instead of being timed, so all ranks make identical choices
+        # without rank 0 measuring anything while the others wait (round-3 review: share_tune_table serialised the start-up on rank 0)
+        import shutil
+        private = f"/tmp/osg_tune_{os.getuid()}_{os.getpid()}_rank{rank}.txt"
+        shutil.copy(shipped_table, private)
+        os.environ["OSG_TUNE_CACHE"] = private
+        os.environ["OSG_TUNE_FROZEN"] = "1"
+        tune_src = "shipped table onnxstream_amd/tune/mi355x.txt on every rank, frozen (missing shapes: deterministic cost-model choice, nothing timed)"
+    elif dist is not None and not args.no_autotune:
         # N > 1: every rank must make the SAME measured tile / split-K choices (else the same prompt gives different last bits on different
         # GPUs): rank 0 plans + tunes first, its table travels over RCCL, the other ranks start seeded from it and time nothing
         def tune_on_rank0():
@@ -525,18 +536,23 @@ def main():
         # only a counter file of THIS round whose own header says it was collected on the tuned plan (tools/pmc_round3.sh: same OSG_TUNE_CACHE table as the
         # timed run, eager passes of that plan) describes the kernels that are timed here; round 2's file was taken with autotune off and is NOT used any
         # more.  No such file => the three counter fields are null.
-        for cand in sorted((f for f in os.listdir(os.path.join(REPO, "profiles")) if f.startswith("r03_pmc") and f.endswith(".json")), reverse=True):
+        # round 4: ... AND whose `src_sha1` is the hash of the kernel / host sources of THIS tree (tools/src_hash.py; tools/pmc_round4.sh records it): counters of
+        # another tree's kernels are not reported as this run's (the round-3 file described a mid-round commit)
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import src_hash
+        tree = src_hash.src_sha1(REPO)
+        for cand in sorted((f for f in os.listdir(os.path.join(REPO, "profiles")) if f.startswith("r04_pmc") and f.endswith(".json")), reverse=True):
             try:
                 hdr = json.load(open(os.path.join(REPO, "profiles", cand)))
             except Exception:
                 continue
-            if hdr.get("tuned_plan") and "kernels" in hdr:
+            if hdr.get("tuned_plan") and "kernels" in hdr and hdr.get("src_sha1") == tree:
                 pmc_src, pmc_note = cand, hdr.get("note")
                 break
         if pmc_src and cfg.name == "sd15" and P == 1 and not args.no_autotune:   # (the counter file describes the tuned batch-2 pass of one prompt)
             tj = json.load(open(os.path.join(REPO, "profiles", pmc_src)))["kernels"]
-            sel = [v for k, v in tj.items() if "gemm2_kernel" in k or "conv3x3_kernel" in k or "conv_small" in k or "gemm_kernel" in k or "splitk_reduce" in k]
-            nd = sum(v["dispatches"] for k, v in tj.items() if ("gemm2_kernel" in k or "conv3x3_kernel" in k or "conv_small" in k or "gemm_kernel" in k))
+            sel = [v for k, v in tj.items() if "gemm2_kernel" in k or "conv3x3_kernel" in k or "conv_small" in k or "gemm_kernel" in k or "splitk_reduce" in k or "tblock_tail" in k]
+            nd = sum(v["dispatches"] for k, v in tj.items() if ("gemm2_kernel" in k or "conv3x3_kernel" in k or "conv_small" in k or "gemm_kernel" in k or "tblock_tail" in k))
             if nd:
                 traffic = (sum(2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0) for v in sel) * 1024.0) / nd
                 busy = sum(v.get("SQ_BUSY_CYCLES", 0.0) for v in sel)
@@ -548,7 +564,7 @@ def main():
                     "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": f"HBM-side bytes per contraction launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of profiles/{pmc_src}, split-K reduce launches folded in; {pmc_note})" if traffic is not None else None,
                     "counters": (f"profiles/{pmc_src}: eager passes of the tuned plan (same tune table as the timed hipGraph run), one counter set per rocprofv3 pass" if traffic is not None
-                                 else "null: no counter file of this round collected on the timed plan is committed (tools/pmc_round3.sh makes one)"),
+                                 else "null: no counter file collected on the timed plan of THIS tree is committed (tools/pmc_round4.sh makes one; its src_sha1 must match tools/src_hash.py)"),
                     "mfma_util": round(mfma_util, 4) if mfma_util is not None else None,
                     "hbm_gbs": round(hbm_gbs, 1) if hbm_gbs is not None else None, "hbm_frac": round(hbm_gbs / PEAK_HBM_GBS, 4) if hbm_gbs is not None else None,
                     "launches_per_step": g_n, "flop_per_launch": g_fl / max(g_n, 1), "avg_launch_us": g_ms * 1e3 / max(g_n, 1),

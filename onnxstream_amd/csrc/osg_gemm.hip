@@ -997,7 +997,7 @@ int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced) {
         } else {
             auto ranked = rank_v2(ctx, p.M, p.N, p.K, batch, allow_split);
             ch = ranked.empty() ? V2Choice{0, 4, 1} : ranked[0].second;
-            if (!ctx->capturing && tune_safe(p) && !ranked.empty()) {
+            if (!ctx->capturing && tune_safe(p) && !ranked.empty() && !osg_tune::frozen()) {
                 float best = -1.f;
                 for (auto& cand : ranked) {
                     const float us = osg_tune::time_us(ctx, [&] { return launch_v2_choice<CONV>(ctx, p, batch, cand.second); });
@@ -1433,7 +1433,7 @@ static int conv2d_route(osg_ctx* ctx, GemmParams& p, int N, int Cin, int Cout, i
             if (!osg_tune::lookup(key, &tc)) {
                 auto r3 = osg_conv3x3_rank(ctx, p);
                 tc = osg_tune::Choice{1, 0, 0, r3.empty() ? 1 : r3[0].second.second, r3.empty() ? 128 : r3[0].second.first, -1.f};
-                if (!ctx->capturing && tune_safe(p)) {
+                if (!ctx->capturing && tune_safe(p) && !osg_tune::frozen()) {
                     float best = -1.f;
                     static const bool dump3 = getenv("OSG_TUNE_DUMP") != nullptr;
                     for (auto& c : r3)

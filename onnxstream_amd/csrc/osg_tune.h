@@ -32,6 +32,9 @@ struct Choice {
 };
 
 bool lookup(const Key& k, Choice* out);
+// OSG_TUNE_FROZEN=1: a shape the table does not hold is NOT timed -- it takes the cost model's first candidate (deterministic, nothing stored).  What the ranks of
+// a multi-GPU job run with: every rank seeds the same shipped table and plans on its own, identically, without waiting for rank 0 to measure anything.
+inline bool frozen() { static const bool v = getenv("OSG_TUNE_FROZEN") && atoi(getenv("OSG_TUNE_FROZEN")) != 0; return v; }
 void store(const Key& k, const Choice& c);
 
 // microseconds per launch of f() (which enqueues the whole operation, reduce kernel included, and returns 0 on success); < 0 on failure
