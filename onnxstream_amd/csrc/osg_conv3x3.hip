@@ -465,7 +465,11 @@ int osg_group_norm_conv3x3(osg_ctx* ctx, const void* x, const void* gamma, const
     if (!osg_conv3x3_supported(N, H, W, Cin, Cout)) OSG_FAIL(ctx, "osg_group_norm_conv3x3: shape not supported (see osg_group_norm_conv3x3_supported)");
     if (bias && bias_dtype != OSG_F16 && bias_dtype != OSG_F32) OSG_FAIL(ctx, "osg_group_norm_conv3x3: invalid bias dtype");
     float* tab = nullptr;
-    if (osg_gn_table(ctx, x, gamma, beta, N, (long)H * W, Cin, groups, eps, &tab)) return 1;
+    static const bool once = getenv("OSG_GNCONV_TABLE_ONCE") != nullptr;    // dev probe (tools/gnconv_probe.py): time the convolution with the table already there
+    static float* tab_once = nullptr;
+    if (once && tab_once) tab = tab_once;
+    else if (osg_gn_table(ctx, x, gamma, beta, N, (long)H * W, Cin, groups, eps, &tab)) return 1;
+    if (once) tab_once = tab;
     GemmParams p{};
     p.A = (const f16*)x; p.Bt = (const f16*)w_ohwi; p.C = (f16*)y; p.bias = bias; p.residual = (const f16*)residual;
     p.M = N * H * W; p.N = Cout; p.K = 9 * Cin; p.lda = 0;

@@ -709,6 +709,8 @@ inline void splitk_route(osg_ctx* ctx, GemmParams& p, long n_tiles) {
     p.tickets = nullptr;
     p.xcd_local = 0;
     const int mode = splitk_ticket_mode();
+    static const int max_m = getenv("OSG_SPLITK_TICKET_MAXM") ? atoi(getenv("OSG_SPLITK_TICKET_MAXM")) : (1 << 30);   // (only launches of at most this many rows fold in the kernel)
+    if (p.M > max_m) return;
     if (mode == 0 || p.splits < 2 || p.N % 4 != 0 || p.splits > 16 || !ctx->tickets || n_tiles + 8 > osg_ctx::kTickets / 2) return;
     if (mode == 2 && !ctx->xcd_rr) return;
     p.tickets = ctx->tickets;
