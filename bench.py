@@ -229,6 +229,7 @@ def main():
     ap.add_argument("--steps-per-image", type=int, default=0, help="denoising steps per image (default 20; BASELINE config 4 = SDXL uses 10)")
     ap.add_argument("--side-stream", action="store_true", help="shortcut convolutions etc. on a second stream beside the main chain (parallel hipGraph branches; measured slower)")
     ap.add_argument("--no-ln-fold", action="store_true", help="standalone LayerNorm launches instead of folding every LayerNorm into the GEMM that consumes it (osg_gemm_ln, default)")
+    ap.add_argument("--small-linear", type=int, default=None, choices=[0, 1, 2], help="osg_linear_small launches for projections / 1x1 convolutions: 0 never (round 3: gemm2_kernel), 1 where measured faster (the Model's default), 2 every shape the kernel takes")
     ap.add_argument("--no-tblock-fuse", action="store_true", help="the tail of every transformer block as the seven launches of round 3 instead of one osg_tblock_tail launch where it takes the shape (round 4 default)")
     ap.add_argument("--no-concat-views", action="store_true", help="skip tensors through copy launches (Concat) instead of convolutions storing straight into their Concat slot (round 3 default)")
     ap.add_argument("--blocked-weights", action="store_true", help="resident weights in the blocked layout [N/16][K/64][16][64] for the direct-to-LDS kernels (experiment)")
@@ -372,6 +373,8 @@ def main():
         m._set_option("hip_concat_views", 0)
     if args.no_tblock_fuse:
         m._set_option("hip_fuse_tblock", 0)
+    if args.small_linear is not None:
+        m._set_option("hip_small_linear", args.small_linear)
     if args.gn_stats is not None:
         m._set_option("hip_gn_stats", args.gn_stats)
     if args.weight_prefetch:

@@ -230,6 +230,17 @@ typedef struct {
 } osg_tblock_tail_args;
 int osg_tblock_tail_supported(int M, int rows_per_img, int C, int heads, int Tk); /* 1 = osg_tblock_tail takes the shape */
 int osg_tblock_tail(osg_ctx* ctx, const osg_tblock_tail_args* a);
+/* The LEAN linear launch (osg_linsmall.hip): y[M,N] = [LayerNorm(x; gamma, beta, eps)] . W^T + bias + residual for the projections of the transformer blocks and
+ * the 1x1 convolutions (MatMul + Add (+ Add) onnxstream.cpp:5669-5861, :3906-4000; the LayerNorm chain :5237-5604; 1x1 Conv :4494-4707): the
+ * workgroup's whole row block in LDS, every operand requested at entry, weights streamed global -> registers from the kn8 layout of
+ * osg_tblock_pack_weight.  x rows ldx elements apart (0 = K), residual ldr (0 = N), y ldy (0 = N), optional second destination y2 / ldy2; bias / residual /
+ * gamma (+ beta) / y2 may be NULL.  f16 everywhere, f32 accumulation, one rounding.  rowstats (may be NULL): osg_gemm_rowstats' hand-over to an osg_gemm_ln
+ * that normalises this output, [M][N/32][2] floats.  osg_linear_small_supported: 1 when the shape is taken (K a multiple of 320 up to 2560, M and N multiples
+ * of the tile it picks); osg_linear_small_rowstats_supported: ... and its tile holds whole 32-column slots. */
+int osg_linear_small_supported(int M, int N, int K, int layer_norm);
+int osg_linear_small_rowstats_supported(int M, int N, int K);
+int osg_linear_small(osg_ctx* ctx, const void* x, long ldx, const void* w_kn8, const void* bias, const void* residual, long ldr, const void* gamma,
+                     const void* beta, float eps, void* y, long ldy, void* y2, long ldy2, int M, int N, int K, float* rowstats);
 /* A resident [N][K] weight (k contiguous: a MatMul's [K,N] after osg_transpose_kn_to_nk, a 1x1 convolution's OHWI) -> the layout osg_tblock_tail streams:
  * [K/8][N][8], i.e. for every 8-deep k chunk the N rows side by side -- an MFMA fragment request (lane = row, lane group = k chunk) is then four runs of
  * 256 contiguous bytes.  Done once per weight, when it becomes resident.  K % 8 == 0. */

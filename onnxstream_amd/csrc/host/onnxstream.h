@@ -566,6 +566,9 @@ public:
                                     // launch.  0 off, 1 every eligible GroupNorm, 2 (default) where the tensor has >= 8 M elements: in the throughput regime it pays (f16 VAE decoder
                                     // 4.61 -> 4.08 ms, SDXL UNet -1.1 %), on the SD 1.5 pass -- launches that last as long as one workgroup -- it is neutral (profiles/r03_gn_stats_ab.txt)
     bool m_hip_fuse_tblock = true;  // fusion level 2: the row-local tail of a transformer block (attn1.to_out .. ff.net.2 [.. proj_out]) as ONE launch where osg_tblock_tail takes the shape (round 4)
+    int m_hip_small_linear = 0;     // fusion level 2: projections and 1x1 convolutions as osg_linear_small launches (every operand requested at entry) instead of gemm2_kernel (round 4).
+                                    // 0 (default) never: inside the pass the TUNED gemm2_kernel launches are as fast or faster (5.65 vs 5.70 ms per step, profiles/r04_linear_small_ab.txt);
+                                    // 1 where the kernel probe measured it faster against the untuned choice: <= 1.7 GFLOP, K <= 1280, no LayerNorm in front; 2 every shape the kernel takes
     bool m_hip_concat_views = true; // fusion level 2: convolutions store skip tensors straight into their Concat slot (osg_conv2d_nhwc_v), no copy launch
     bool m_hip_side_stream = false; // contraction launches whose result is first read >= 3 steps later (a resnet's 1x1 shortcut convolution) run on a second
                                     // stream beside the main chain (parallel branches of the captured hipGraph); measured +0.25 ms per pass => opt-in

@@ -105,6 +105,8 @@ Plan::Plan(Model& model, HipBackend& backend, ConstPool& cpool, size_t batch) : 
     fuse_ln_gemm = m.m_hip_fuse_ln_gemm;
     concat_views = m.m_hip_concat_views;
     fuse_tblock = m.m_hip_fuse_tblock;
+    small_linear = m.m_hip_small_linear != 0;
+    small_linear_req = m.m_hip_small_linear;
     weight_prefetch = m.m_hip_weight_prefetch;
     blocked_weights = m.m_hip_blocked_weights;
     gn_stats_req = m.m_hip_gn_stats;
@@ -132,7 +134,7 @@ bool Plan::compatible(Model& mm, size_t batch) const {
     const bool want_stream = mm.m_hip_stream_weights || mm.m_cuda_options.m_vram_to_use > 0;
     if ((long)batch != N) return no("batch size");
     if (mm.m_use_fp16_arithmetic != fp16 || mm.m_use_uint8_arithmetic != u8 || mm.m_use_uint8_qdq != u8_qdq) return no("arithmetic type");
-    if (mm.m_hip_fusion_level != fusion_req || mm.m_hip_fuse_gn_conv != fuse_gn_conv || mm.m_hip_fuse_ln_gemm != fuse_ln_gemm || mm.m_hip_concat_views != concat_views || mm.m_hip_fuse_tblock != fuse_tblock || mm.m_hip_weight_prefetch != weight_prefetch || mm.m_hip_blocked_weights != blocked_weights || mm.m_hip_gn_stats != gn_stats_req ||
+    if (mm.m_hip_fusion_level != fusion_req || mm.m_hip_fuse_gn_conv != fuse_gn_conv || mm.m_hip_fuse_ln_gemm != fuse_ln_gemm || mm.m_hip_concat_views != concat_views || mm.m_hip_fuse_tblock != fuse_tblock || mm.m_hip_small_linear != small_linear_req || mm.m_hip_weight_prefetch != weight_prefetch || mm.m_hip_blocked_weights != blocked_weights || mm.m_hip_gn_stats != gn_stats_req ||
         mm.m_fuse_ops_in_attention != fuse_attn || mm.m_use_scaled_dp_attn_op != sdp_attn || mm.m_hip_autotune != autotune)
         return no("fusion / tuning options");
     if (want_stream != stream_weights || (size_t)mm.m_cuda_options.m_vram_to_use != vram_budget || (mm.m_hip_side_stream && !want_stream) != side_stream ||
@@ -2580,7 +2582,7 @@ struct Lowering {
     // Conv (reference :4494-4707 -> XnnPack::convolution :1292): group 1, dilation 1, pads re-centred (:1315-1329)
     // GEMM-shaped steps ([M,K] x [N,K]^T, plain epilogue) that can ALSO emit the partial row statistics of their output when a folded
     // LayerNorm turns out to consume it (osg_gemm_rowstats): keyed by the root val they write
-    struct RsProducer { size_t step; int a, w, bias, res, y; long M, N, K; };
+    struct RsProducer { size_t step; int a, w, bias, res, y; long M, N, K; bool lean = false; };   // (lean: an osg_linear_small launch, w = its kn8 weight)
     std::map<int, RsProducer> rs_producers;
     void note_rs_producer(int a, int w, int bias, int res, int y, long M, long Nn, long K) {
         if (P.fusion < 2 || !P.fuse_ln_gemm || Nn % 32 || K % 64 || Nn > 1280) return;
@@ -2605,6 +2607,16 @@ struct Lowering {
         const int a = r.a, w = r.w, bias = r.bias, res = r.res, y = r.y;
         const long M = r.M, Nn = r.N, K = r.K;
         const std::string what = st.what;
+        if (r.lean) {
+            const long ldx = V(a).ld;
+            st.run = [=, this] {
+                be.check(be.api.osg_linear_small(be.ctx, P.ptr(a), ldx, P.ptr(w), bias >= 0 ? P.ptr(bias) : nullptr, res >= 0 ? P.ptr(res) : nullptr, 0, nullptr, nullptr, 0.f, P.ptr(y), 0,
+                                                 nullptr, 0, (int)M, (int)Nn, (int)K, (float*)P.ptr(rs)),
+                         what.c_str());
+            };
+            rs_producers.erase(it);
+            return rs;
+        }
         st.run = [=, this] {
             be.check(be.api.osg_gemm_rowstats(be.ctx, P.ptr(a), P.ptr(w), bias >= 0 ? P.ptr(bias) : nullptr, bias >= 0 ? P.vals[bias].dtype : OSG_F16,
                                               res >= 0 ? P.ptr(res) : nullptr, P.ptr(y), (int)M, (int)Nn, (int)K, OSG_ACT_NONE, (float*)P.ptr(rs)),
@@ -2720,6 +2732,14 @@ struct Lowering {
         }
         auto co = std::make_shared<ConvOut>();
         co->dst = y;
+        if (KH == 1 && KW == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && ib < 0 && cact == OSG_ACT_NONE && V(x).ld == 0 && ls_ok(nb * Ho * Wo, Cout, Cin, false) &&
+            ls_operands_ok(x, w, bias, res)) {
+            // a 1x1 convolution IS a GEMM over the pixels (NHWC rows, OHWI == [N][K]): the lean linear launch, with the convolution's output views
+            co->no_sinks = true;
+            emit_linear_small("Conv [lean] " + op.m_name, x, w, bias, res, nullptr, y, nb * Ho * Wo, Cout, Cin, co);
+            conv_producers[P.root_of(y)] = ConvProducer{P.steps.size() - 1, co, y};
+            return;
+        }
         P.add_step("Conv " + op.m_name, reads, {y}, [=, this] {
             const ConvOut& o = *co;
             if (o.sink[0].off >= 0 || o.sink[1].off >= 0)
@@ -2793,8 +2813,53 @@ struct Lowering {
         P.steps.back().flops = 2.0 * M * Nn * K;
     }
 
+    struct LnFold { int x, g, b; float eps; long C; int rs; bool inl = false; };   // rs: partial row statistics handed over by the producer of x (-1: none); inl: the consumer is an osg_linear_small launch that normalises its rows itself (original weights, no fold, no statistics)
+    // ---- the lean linear launch (osg_linear_small, round 4): the projections of the transformer blocks and the 1x1 convolutions -- every operand requested at
+    // entry, the row block in LDS, weights streamed from the kn8 layout; LayerNorm (when one sits in front) done on the rows in LDS with the original weights
+    bool ls_ok(long M, long Nn, long K, bool ln) const {
+        // Measured (tools/linear_small_probe.py, profiles/r04_linear_small_probe_v1.txt; cold weights): at <= 1.7 GFLOP and K <= 1280 the lean launch is 1 - 2.4 us faster
+        // than gemm2_kernel (9.2 vs 11.6, 8.5 vs 9.2, 6.4 vs 7.7 us); beyond that every row block re-streaming its column tile's weights costs more than
+        // gemm2's tiles (K = 2560: 16.8 vs 10.8 us), and with the LayerNorm inside (the row block + gamma / beta exceed half the LDS: one workgroup per CU, two
+        // rounds of workgroups) it loses to the folded form by 2 - 14 us -- so LayerNorm consumers keep osg_gemm_ln (hip_small_linear = 2 routes them here too)
+        if (ln && m.m_hip_small_linear < 2) return false;
+        if (m.m_hip_small_linear < 2 && (K > 1280 || (double)M * Nn * K > 0.9e9)) return false;
+        return P.small_linear && P.fusion >= 2 && !P.stream_weights && !P.u8 && M > 0 && (double)M * Nn * K <= 2.6e9 && be.api.osg_linear_small_supported((int)M, (int)Nn, (int)K, ln ? 1 : 0) == 1;
+    }
+    bool ls_operands_ok(int a, int wnk, int bias, int res) {
+        if (V(a).dtype != OSG_F16 || V(wnk).dtype != OSG_F16 || !V(wnk).is_const || (V(a).ld % 8) != 0) return false;
+        if (bias >= 0 && V(bias).dtype != OSG_F16) return false;
+        if (res >= 0 && (V(res).dtype != OSG_F16 || V(res).ld != 0)) return false;
+        return true;
+    }
+    // co: where the result goes (a convolution's ConvOut: a Concat slot and / or the dense tensor); nullptr = y, dense
+    void emit_linear_small(const std::string& what, int a, int wnk, int bias, int res, const LnFold* ln, int y, long M, long Nn, long K, std::shared_ptr<ConvOut> co = nullptr) {
+        const int wk = weight_kn8(wnk);
+        const int g = ln ? ln->g : -1, b = ln ? ln->b : -1;
+        const float eps = ln ? ln->eps : 0.f;
+        const long ldx = V(a).ld;
+        std::vector<int> reads = {a, wk};
+        for (int r : {bias, res, g, b})
+            if (r >= 0) reads.push_back(r);
+        P.add_step(what, reads, {y}, [=, this] {
+            void* dst = co ? (char*)P.ptr(co->dst) + co->dst_off : P.ptr(y);
+            const long ldy = co ? co->dst_ld : 0;
+            void* dst2 = co && co->dst2 >= 0 ? (char*)P.ptr(co->dst2) + co->dst2_off : nullptr;
+            be.check(be.api.osg_linear_small(be.ctx, P.ptr(a), ldx, P.ptr(wk), bias >= 0 ? P.ptr(bias) : nullptr, res >= 0 ? P.ptr(res) : nullptr, 0,
+                                             g >= 0 ? P.ptr(g) : nullptr, b >= 0 ? P.ptr(b) : nullptr, eps, dst, ldy, dst2, co ? co->dst2_ld : 0, (int)M, (int)Nn, (int)K, nullptr),
+                     what.c_str());
+        });
+        P.steps.back().flops = 2.0 * M * Nn * K;
+        if (!ln && !co && V(y).ld == 0 && P.fuse_ln_gemm && Nn % 32 == 0 && Nn <= 1280 && be.api.osg_linear_small_rowstats_supported((int)M, (int)Nn, (int)K) == 1) {
+            RsProducer r{P.steps.size() - 1, a, wk, bias, res, y, M, Nn, K};
+            r.lean = true;
+            rs_producers[P.root_of(y)] = r;
+        }
+    }
+
     void emit_gemm(const std::string& what, int a, int wnk, int bias, int res, int y, long M, long Nn, long K, long batch, long sa, long sb,
                    long sc, int b_is_nk, osg_act act_ = OSG_ACT_NONE) {
+        if (b_is_nk && batch == 1 && act_ == OSG_ACT_NONE && V(y).ld == 0 && ls_ok(M, Nn, K, false) && ls_operands_ok(a, wnk, bias, res) && V(wnk).shape.size() == 2)
+            return emit_linear_small(what + " [lean]", a, wnk, bias, res, nullptr, y, M, Nn, K);
         std::vector<int> reads = {a, wnk};
         if (bias >= 0) reads.push_back(bias);
         if (res >= 0) reads.push_back(res);
@@ -2880,7 +2945,7 @@ struct Lowering {
             // concatenated [ntot, K] weight and [ntot] bias, built once from the resident per-op tensors
             int wcat = P.new_val("", {g.ntot, K}, OSG_F16, Lay::plain, false);
             V(wcat).is_const = true;
-            V(wcat).name = "merged|" + op.m_input[0].m_name + "|" + ops()[g.members[0]].m_name + "|" + std::to_string(g.members.size()) + (lnf ? "|ln" : "");
+            V(wcat).name = "merged|" + op.m_input[0].m_name + "|" + ops()[g.members[0]].m_name + "|" + std::to_string(g.members.size()) + (lnf && !lnf->inl ? "|ln" : "");   // (a folded copy has a tag of its own; the lean launch normalises the rows and reads the plain concatenation)
             bool fresh_w, fresh_b = false;
             V(wcat).dptr = P.const_alloc(V(wcat).name, (size_t)g.ntot * K * 2, &fresh_w);
             const bool has_bias = op.m_input.size() > 2 && !op.m_input[2].m_name.empty();
@@ -2906,7 +2971,10 @@ struct Lowering {
             ys.back() = g.ntot;
             g.y = P.new_val("", ys, OSG_F16, Lay::plain, V(a).batched);
             const long M = prod(as) / K * B(a);
-            if (lnf) {
+            if (lnf && lnf->inl) {
+                need(op, ls_operands_ok(a, wcat, bcat, -1), "invalid operands of a LayerNorm + merged Linear launch.");
+                emit_linear_small("Linear ln merged(" + std::to_string(g.members.size()) + ") [lean] " + op.m_name, a, wcat, bcat, -1, lnf, g.y, M, g.ntot, K);
+            } else if (lnf) {
                 auto [c1, c2] = ln_fold_weight(*lnf, wcat, bcat, P.ptr(wcat), V(wcat).name);   // the concatenated copy is private: fold in place
                 emit_gemm_ln("Linear ln+ merged(" + std::to_string(g.members.size()) + ") " + op.m_name, *lnf, wcat, c1, c2, -1, g.y, M, g.ntot, K, OSG_ACT_NONE);
             } else
@@ -2993,6 +3061,11 @@ struct Lowering {
         os.back() = Nn;
         int y = out_val(op, os, Lay::plain, V(a).batched);
         const long M = prod(as) / K * B(a);
+        if (lnf && lnf->inl) {
+            const int wnk = weight_nk(w);
+            need(op, ls_operands_ok(a, wnk, bias, res), "invalid operands of a LayerNorm + Linear launch.");
+            return emit_linear_small("Linear ln [lean] " + op.m_name, a, wnk, bias, res, lnf, y, M, Nn, K);
+        }
         if (lnf) {
             const int wnk = weight_nk(w);
             const int wf = private_copy(wnk, ln_tag(*lnf, bias));
@@ -3326,7 +3399,6 @@ struct Lowering {
     // up in ONE GEMM launch (a single Linear / Linear+GEGLU, or the members of one merged group: self-attention Q|K|V), the LayerNorm is
     // not launched at all -- gamma moves into the weight, beta and the mean correction into two fp32 epilogue vectors, the row
     // statistics are accumulated by the GEMM's math waves beside the MFMAs, from the A fragments they read anyway.  48 launches less in the SD 1.5 UNet.
-    struct LnFold { int x, g, b; float eps; long C; int rs; };   // rs: partial row statistics handed over by the producer of x (-1: none)
     std::map<std::string, LnFold> ln_deferred;   // LayerNorm output name -> what its consumers fold
     // ConstPool tag of a folded copy: it must name everything that went into the fold -- the LayerNorm's gamma and beta and the Linear's bias -- or a
     // weight tensor shared by two Linears behind different LayerNorms / with different biases would silently reuse the first fold (advisor, round 2)
@@ -3426,6 +3498,25 @@ struct Lowering {
         P.steps.back().flops = 2.0 * M * Nn * K;
     }
 
+    // every consumer of this LayerNorm (ln_can_fold has checked: plain osg.Linear ops, one launch) would be an osg_linear_small launch with LayerNorm
+    bool ln_consumers_lean(const Operation& op, int x, int g, int b) {
+        if (V(g).dtype != OSG_F16 || V(b).dtype != OSG_F16 || V(x).dtype != OSG_F16) return false;
+        const long C = V(x).shape.back(), M = P.total_elems(x) / C;
+        auto cit = consumers.find(op.m_output[0].m_name);
+        if (cit == consumers.end() || cit->second.empty()) return false;
+        long ntot = 0;
+        for (int c : cit->second) {
+            const Operation& co = ops()[c];
+            if (attr(co, "osg_geglu") || attr(co, "osg_act")) return false;
+            const Val* w = cval(co.m_input[1]);
+            if (!w || w->dtype != OSG_F16) return false;
+            ntot += w->shape[1];
+            auto git = group_of.find(c);
+            if (git != group_of.end()) ntot = groups[git->second.first].ntot;      // (all of them are the members of one merged group: ln_can_fold)
+        }
+        return ls_ok(M, ntot, C, true);
+    }
+
     void lower_layer_norm(const Operation& op) {
         int x = P.ensure_plain(in_val(op.m_input[0]));
         int g = in_val(op.m_input[1]), b = in_val(op.m_input[2]);
@@ -3433,6 +3524,12 @@ struct Lowering {
         const float eps = std::stof(*attr(op, "epsilon"));
         if (ln_can_fold(op, x, g, b, s.back())) {
             check_out(op, s);
+            if (ln_consumers_lean(op, x, g, b)) {     // the consuming launch normalises its rows itself: nothing to prepare here
+                LnFold f{x, g, b, eps, s.back(), -1};
+                f.inl = true;
+                ln_deferred[op.m_output[0].m_name] = f;
+                return;
+            }
             const int rs = upgrade_rs_producer(x, P.total_elems(x) / s.back(), s.back());
             ln_deferred[op.m_output[0].m_name] = LnFold{x, g, b, eps, s.back(), rs};
             return;

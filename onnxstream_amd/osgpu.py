@@ -29,7 +29,7 @@ EXPORTS = [
     "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_concat2", "osg_resize_nearest", "osg_gather_rows",
     "osg_maxpool_nhwc", "osg_convert", "osg_sampler_prepare", "osg_sampler_cfg_euler_a",
     "osg_range_push", "osg_range_pop", "osg_marker_record", "osg_copy_wait_marker", "osg_timer_mark", "osg_timer_between", "osg_set_stat_sinks", "osg_set_weight_prefetch", "osg_set_blocked_weight_hint", "osg_group_norm_stats_nhwc", "osg_qu8_conv2d_nhwc", "osg_qu8_conv2d_nhwc_t", "osg_qu8_conv_tap_sums", "osg_qu8_gemm", "osg_qu8_lut", "osg_qu8_binary", "osg_qu8_instance_norm", "osg_qu8_instance_norm_nhwc", "osg_qu8_affine_act", "osg_qu8_norm_affine_act_nhwc", "osg_qu8_softmax_last", "osg_kdbg_read",
-    "osg_tblock_tail_supported", "osg_tblock_tail", "osg_tblock_kv_pack_elems", "osg_tblock_kv_pack_jobs", "osg_tblock_pack_weight",
+    "osg_tblock_tail_supported", "osg_tblock_tail", "osg_tblock_kv_pack_elems", "osg_tblock_kv_pack_jobs", "osg_tblock_pack_weight", "osg_linear_small_supported", "osg_linear_small_rowstats_supported", "osg_linear_small",
 ]
 
 
@@ -131,6 +131,9 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_tblock_kv_pack_elems.restype = ctypes.c_size_t
     lib.osg_tblock_kv_pack_jobs.argtypes = [vp, vp, cl, ci, ci, ci, ci, vp, vp]
     lib.osg_tblock_pack_weight.argtypes = [vp, vp, ci, ci, vp]
+    lib.osg_linear_small_supported.argtypes = [ci] * 4
+    lib.osg_linear_small_rowstats_supported.argtypes = [ci] * 3
+    lib.osg_linear_small.argtypes = [vp, vp, cl, vp, vp, vp, cl, vp, vp, cf, vp, cl, vp, cl, ci, ci, ci, vp]
     return lib
 
 
@@ -333,6 +336,16 @@ class Gpu:
         self._ck(self.lib.osg_copy(self.ctx, kp.ptr, dst.ptr, n * 2))
         self._ck(self.lib.osg_copy(self.ctx, vtp.ptr, dst.ptr + n * 2, n * 2))
         return kp, vtp
+
+    def linear_small(self, x: DevBuf, w_kn8: DevBuf, bias: Optional[DevBuf] = None, residual: Optional[DevBuf] = None, gamma: Optional[DevBuf] = None,
+                     beta: Optional[DevBuf] = None, eps: float = 1e-5, out2: Optional[DevBuf] = None, out2_col: int = 0, rowstats: Optional[DevBuf] = None):
+        """osg_linear_small: x [M, K], w_kn8 [K/8, N, 8] (tblock_pack_weight of the [N, K] weight) -> y [M, N]; optional LayerNorm of x, second destination"""
+        m, k = x.shape
+        n = w_kn8.shape[1]
+        y = self.empty((m, n), x.dtype)
+        y2, ld2 = (out2.ptr + out2_col * 2, out2.shape[-1]) if out2 is not None else (None, 0)
+        self._ck(self.lib.osg_linear_small(self.ctx, x.ptr, k, w_kn8.ptr, self._p(bias), self._p(residual), n, self._p(gamma), self._p(beta), eps, y.ptr, n, y2, ld2, m, n, k, self._p(rowstats)))
+        return y
 
     TBLOCK_WEIGHTS = ("wo1", "wq2", "wo2", "w1", "w2", "wpo")
 

@@ -125,6 +125,19 @@ def test_sd15_unet_tuned_plan_reference_parity(sd15_dir, tmp_path):
     _triangulated(got, sd15_dir, sd_unet.unet_inputs(sd_unet.SD15, 42), "SD1.5 UNet full size, tuned plan (shipped table)")
 
 
+def test_sd15_unet_lean_linears_reference_parity(sd15_dir):
+    """Opt-in hip_small_linear = 2: 90 projections / 1x1 convolutions of the pass run as osg_linear_small launches (osg_linsmall.hip: the row block in LDS, every operand
+    requested at entry, LayerNorm on the rows in LDS with the unfolded weights) instead of gemm2_kernel.  Same bound against the reference, eager == captured."""
+    from onnxstream_amd import build as b
+    a, c = sd_unet.unet_inputs(sd_unet.SD15, 42), sd_unet.unet_inputs(sd_unet.SD15, 43)
+    o = _run(b.LIB_HOST, sd15_dir, [a, c], runs=2, options=(("hip_small_linear", 2),))
+    assert np.array_equal(o[0][0], o[1][0]) and np.array_equal(o[0][1], o[1][1])
+    assert np.isfinite(o[0][0]).all()
+    if not oref.available():
+        pytest.skip("oracle/_ref not present: reproducibility checked, reference parity skipped")
+    _triangulated(o[0][0], sd15_dir, a, "SD1.5 UNet full size, lean linear launches (hip_small_linear=2)")
+
+
 @pytest.fixture(scope="module")
 def sd15_w8_dir():
     d = os.path.join(os.environ.get("OSA_SYNTH_DIR", "/tmp/onnxstream_amd_synth"), "sd15_w8") + "/"

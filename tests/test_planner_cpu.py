@@ -529,6 +529,32 @@ def test_a_second_call_with_the_same_inputs_does_not_plan_again(stub_backend, mo
         m.close()
 
 
+def test_lean_linear_route_plan(stub_backend):
+    """hip_small_linear: 0 (default) no osg_linear_small launch; 1 the shapes the kernel probe measured faster (<= 1.7 GFLOP, K <= 1280, no LayerNorm in front);
+    2 every shape the kernel takes -- LayerNorms in front of them are then done inside the launch (no folded weight copies, no row statistics from the producer),
+    the LayerNorm + GEGLU projections keep osg_gemm_ln and get their row statistics from a lean producer.  Same number of launches in every mode."""
+    d = os.path.join(os.environ.get("OSA_SYNTH_DIR", "/tmp/onnxstream_amd_synth"), "sd15") + "/"
+    if not os.path.exists(d + ".complete"):
+        os.makedirs(d, exist_ok=True)
+        sd_unet.build_unet(DirSink(d), sd_unet.SD15)
+        open(d + ".complete", "w").write("ok")
+    ins = sd_unet.unet_inputs(sd_unet.SD15, 42)
+    counts = {}
+    for mode in (0, 1, 2):
+        m, info = _plan(d, ins, (("hip_small_linear", mode),), pushes=2)
+        steps, vals, arena = _parse(info)
+        m.close()
+        assert len(steps) == 275
+        _check_arena(steps, vals, arena)
+        what = [s["what"] for s in steps]
+        counts[mode] = sum("[lean]" in w for w in what)
+        if mode == 2:
+            assert sum(w.startswith("Linear ln ") and "[lean]" in w for w in what) >= 20          # LayerNorm inside the launch
+            assert not any("ln+" in w and "GEGLU" not in w for w in what)                          # what still folds a LayerNorm is the GEGLU projection only ...
+            assert sum("[lean] +rowstats" in w for w in what) == 11                                # ... fed by the lean attn2.to_out launches of the 640- and 1280-wide blocks
+    assert counts[0] == 0 and 0 < counts[1] < counts[2] and counts[2] >= 85
+
+
 def test_group_norm_statistics_from_producers_plan(stub_backend):
     """hip_gn_stats = 1: in the full-size SD 1.5 plan the 31 GroupNorms of the 64 x 64 and 32 x 32 levels read what 33 convolutions add up in their epilogues
     (two of them through both destinations: the dense tensor for the next block, the Concat slot for the up path); with the default (large tensors only) and with 0 the plan has none."""
