@@ -206,9 +206,10 @@ int osg_attention_strided(osg_ctx* ctx, osg_dtype dtype, const void* q, long q_t
  *   y  = x3 . Wpo^T + bpo + xin                 the 1x1 proj_out Conv (:4494-4707) + the spatial residual; only when wpo != NULL, else y = x3
  * with the row block resident in LDS and the GEGLU activation never formed.  All tensors f16; the seven weights in the kn8 layout of osg_tblock_pack_weight
  * ([K/8][N][8]; w1 from [8C][C] = value rows then gate rows, w2 from [C][4C]); a1 / x0 / xin dense [M][C]; out rows ldo apart (0 = C), out2 (may be NULL) a second copy rows ldo2 apart (the Concat
- * slot of a skip connection); kp / vtp from osg_tblock_kv_pack.  M rows = images x rows_per_img, a 64-row block lies inside one image.
+ * slot of a skip connection); kp / vtp from osg_tblock_kv_pack.  M rows = images x rows_per_img, a row block (64 or 32 rows) lies inside one image.
+ * rows_per_block: 0 = the library picks (32-row blocks while 64-row blocks would leave CUs without one), 32 / 64 = forced (tests, probes).
  * dbg[0..6] (may be NULL): dense [M][C] dumps of x1, LN(x1), q, a2, x2, LN(x2), x3 (x3 only with wpo) -- the kernel tests read them; dbg[7] (may be NULL):
- * [M/64][16] int64 wall-clock stamps (100 MHz) of every row block's stages -- tools/tblock_tail_probe.py reads them. */
+ * [M/32][32] int64 wall-clock stamps (100 MHz) of every row block's stages -- tools/tblock_tail_probe.py reads them. */
 typedef struct {
   const void *a1, *x0;
   const void *wo1, *bo1;
@@ -227,6 +228,7 @@ typedef struct {
   long ldo, ldo2;
   int M, rows_per_img, C, heads;
   void* dbg[8];
+  int rows_per_block;
 } osg_tblock_tail_args;
 int osg_tblock_tail_supported(int M, int rows_per_img, int C, int heads, int Tk); /* 1 = osg_tblock_tail takes the shape */
 int osg_tblock_tail(osg_ctx* ctx, const osg_tblock_tail_args* a);

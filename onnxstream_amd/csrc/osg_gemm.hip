@@ -746,6 +746,76 @@ __global__ __launch_bounds__(256) void conv_small_cin_kernel(GemmParams p, int K
     }
 }
 
+// The SD / SDXL conv_in and the VAE decoder's first convolution (3x3, Cin = 4: K = 36) on the matrix cores: the vector kernel above spends 288 FMAs + 288
+// f16 -> f32 conversions per (pixel, 8 channels) and took 31 us for 0.2 GFLOP at 2 x 64 x 64 -> 320 (profiles/r04_breakdown_tail_v4_fastbox.txt), a
+// twentieth of a pass's convolution time for a ten-thousandth of its work.  Here K is padded to 64 (two v_mfma_f32_16x16x32_f16 steps, the second one holds tap
+// 8 and zeros): the filter bank sits in LDS as [Cout][64 + 8] with the padding zeroed, a lane builds its A fragment -- pixel l & 15, taps 2g and 2g + 1 -- from
+// three 8-byte loads, and each wave walks every other 16-channel tile of its 16 pixels.  Same epilogue operands as conv_small_cin_kernel.
+__global__ __launch_bounds__(256) void conv_cin4_mfma_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char cin4_lds[];
+    constexpr int WLD = 144;                         // bytes per filter row in LDS: 64 halves + 8 of padding (conflict-free 16-byte fragment reads)
+    const int N = p.N, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    float* const bsm = reinterpret_cast<float*>(cin4_lds + (size_t)N * WLD);          // bias as f32 [N]
+    for (int i = tid; i < N * 8; i += 256) {         // (row n, 16-byte chunk c): k = 8c .. 8c + 7 of a 36-deep row, rows 72 bytes apart in memory
+        const int n = i >> 3, c = i & 7;
+        f16x4 lo = f16x4{0, 0, 0, 0}, hi = f16x4{0, 0, 0, 0};
+        const f16* src = p.Bt + (long)n * 36 + c * 8;
+        if (c < 5) lo = *reinterpret_cast<const f16x4*>(src);
+        if (c < 4) hi = *reinterpret_cast<const f16x4*>(src + 4);
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+        *reinterpret_cast<f16x8*>(cin4_lds + n * WLD + c * 16) = v;
+    }
+    for (int n = tid; n < N; n += 256) bsm[n] = !p.bias ? 0.f : p.bias_f32 ? ((const float*)p.bias)[n] : (float)((const f16*)p.bias)[n];
+    // this lane's pixel and its A fragments
+    const int m = blockIdx.x * 32 + (wave & 1) * 16 + l16;
+    const bool live = m < p.M;
+    const int mc = live ? m : p.M - 1;
+    const int hw = p.Ho * p.Wo;
+    const int n_img = mc / hw, r2 = mc - n_img * hw, ho = r2 / p.Wo, wo = r2 - ho * p.Wo;
+    const f16* xin = p.A + (long)n_img * p.H * p.W * 4;
+    auto tap = [&](int t) __attribute__((always_inline)) {
+        const int hi = ho * p.sh - p.pt + t / 3, wi = wo * p.sw - p.pl + t % 3;
+        const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        const f16x4 v = *reinterpret_cast<const f16x4*>(xin + ((long)(ok ? hi : 0) * p.W + (ok ? wi : 0)) * 4);
+        return ok ? v : f16x4{0, 0, 0, 0};
+    };
+    const f16x4 t0 = tap(2 * g), t1 = tap(2 * g + 1), t8 = tap(8);
+    f16x8 a0, a1;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        a0[e] = t0[e]; a0[4 + e] = t1[e];
+        a1[e] = g == 0 ? t8[e] : (f16)0; a1[4 + e] = (f16)0;
+    }
+    __syncthreads();
+    const long ldc = p.ldc ? p.ldc : (long)N;
+    const int img_row = m / p.rb_rows;
+    for (int j = wave >> 1; j < N / 16; j += 2) {
+        const char* wrow = cin4_lds + (j * 16 + l16) * WLD + g * 16;
+        const f16x8 b0 = *reinterpret_cast<const f16x8*>(wrow), b1 = *reinterpret_cast<const f16x8*>(wrow + 64);
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0, a0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1, a1, acc, 0, 0, 0);
+        if (!live) continue;
+        const int n = j * 16 + g * 4;                // the lane holds channels n .. n + 3 of pixel m
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bsm + n);
+        f16x4 rb = f16x4{0, 0, 0, 0}, rs = f16x4{0, 0, 0, 0};
+        if (p.rowbias) rb = *reinterpret_cast<const f16x4*>(p.rowbias + (long)img_row * p.rb_ld + n);
+        if (p.residual) rs = *reinterpret_cast<const f16x4*>(p.residual + (long)m * N + n);
+        f16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float v = acc[r] + bv[r];
+            if (p.rowbias) v += (float)rb[r];
+            if (p.residual) v += (float)rs[r];
+            o[r] = (f16)osg_apply_act(v, p.act);
+        }
+        *reinterpret_cast<f16x4*>(p.C + (long)m * ldc + n) = o;
+        if (p.C2) *reinterpret_cast<f16x4*>(p.C2 + (long)m * p.ldc2 + n) = o;
+    }
+}
+
 // sum the split-K slabs, fuse bias/residual/activation, round once to f16
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, f16* __restrict__ C,
                                                             const void* __restrict__ bias, int bias_f32,
@@ -1409,6 +1479,19 @@ int osg_conv2d_nhwc_v(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* 
 
 static int conv2d_route(osg_ctx* ctx, GemmParams& p, int N, int Cin, int Cout, int KH, int KW, int sh, int sw, int pt, int pl, int pb, int pr) {
     (void)N;
+    static const bool cin4_off = getenv("OSG_CONV_CIN4_VALU") != nullptr;     // (A/B: the vector kernel)
+    if (!cin4_off && Cin == 4 && KH == 3 && KW == 3 && Cout % 16 == 0 && (size_t)Cout * (144 + 4) <= 160 * 1024 && (p.ldc % 4) == 0 && (p.ldc2 % 4) == 0 &&
+        (!p.rowbias || p.rb_ld % 4 == 0)) {
+        const size_t smem = (size_t)Cout * (144 + 4);
+        static size_t attr_smem = 0;
+        if (smem > 64 * 1024 && smem > attr_smem) {
+            OSG_HIP(ctx, hipFuncSetAttribute((const void*)conv_cin4_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            attr_smem = smem;
+        }
+        hipLaunchKernelGGL(conv_cin4_mfma_kernel, dim3((p.M + 31) / 32), dim3(256), smem, ctx->compute, p);
+        OSG_LAUNCH_CHECK(ctx);
+        return 0;
+    }
     if (Cin < 8 && Cout % 8 == 0 && Cout / 8 <= 256 && (size_t)p.K * Cout * 2 <= 64 * 1024) {
         const int ppb = 256 / (Cout / 8);
         hipLaunchKernelGGL(conv_small_cin_kernel, dim3((p.M + 4 * ppb - 1) / (4 * ppb)), dim3(256), (size_t)p.K * Cout * 2, ctx->compute, p, KH, ppb);

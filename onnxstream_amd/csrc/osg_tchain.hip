@@ -70,10 +70,13 @@ __device__ __forceinline__ void static_for_impl(Fn&& f) {
 template <int N, typename Fn>
 __device__ __forceinline__ void static_for(Fn&& f) { static_for_impl<0, N>(f); }
 
-constexpr int kTileBytes = 8192;   // one k-tile of a row block: 64 rows x 128 B (64 halves), chunk c of row r at slot c ^ (r & 7)
+// one k-tile of a row block of 16 RT rows: rows x 128 B (64 halves), chunk c of row r at slot c ^ (r & 7).  RT = 16-row tiles per wave: 4 (64-row blocks) or 2 (32)
+template <int RT>
+constexpr int kTileBytes = RT * 2048;
 
-// byte offset of element (m, n), n % 4 == 0, inside a swizzled [64 x C] LDS image
-__device__ __forceinline__ int img_off(int m, int n) { return (n >> 6) * kTileBytes + m * 128 + ((((n & 63) >> 3) ^ (m & 7)) << 4) + (n & 7) * 2; }
+// byte offset of element (m, n), n % 4 == 0, inside a swizzled [16 RT x C] LDS image
+template <int RT>
+__device__ __forceinline__ int img_off(int m, int n) { return (n >> 6) * kTileBytes<RT> + m * 128 + ((((n & 63) >> 3) ^ (m & 7)) << 4) + (n & 7) * 2; }
 
 // the B fragments of one 64-deep k-tile of a kn8 weight ([K/8][N][8]), NT tiles of 16 rows: b[5 ks + j].  Buffer loads: the descriptor and the tile /
 // chunk offset `so` are wave-uniform (scalar registers), the ONE per-lane 32-bit offset `lo` ((k chunk g) * N + row nb + l16, times 16 bytes) never changes.
@@ -103,61 +106,61 @@ __device__ __forceinline__ void load_b_geglu(f16x8 (&b)[10], __amdgpu_buffer_rsr
 }
 
 // one k-tile of a [64 x 16 NT] wave tile: A fragments from the swizzled LDS image, B fragments from a register slot
-template <int NT>
-__device__ __forceinline__ void mma_ktile(const char* At, int a_rd, const f16x8 (&b)[10], f32x4 (&acc)[4][NT]) {
+template <int RT, int NT>
+__device__ __forceinline__ void mma_ktile(const char* At, int a_rd, const f16x8 (&b)[10], f32x4 (&acc)[RT][NT]) {
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
-        f16x8 a[4];
+        f16x8 a[RT];
 #pragma unroll
-        for (int i = 0; i < 4; i++) a[i] = *reinterpret_cast<const f16x8*>(At + ((a_rd + i * 2048) ^ (ks << 6)));
+        for (int i = 0; i < RT; i++) a[i] = *reinterpret_cast<const f16x8*>(At + ((a_rd + i * 2048) ^ (ks << 6)));
 #pragma unroll
         for (int j = 0; j < NT; j++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[ks * 5 + j], a[i], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < RT; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[ks * 5 + j], a[i], acc[i][j], 0, 0, 0);
     }
 }
 
 // A whole contraction over KT k-tiles.  Every k-tile of the kernel has an index s in ONE kernel-wide sequence (SS = the index of this contraction's
 // first tile): tile s is consumed from register slot s % NS while the requests of the next NS - 1 tiles are in flight -- at tile s the request of tile
 // s + NS - 1 goes out, into the slot tile s - 1 has just left.  `load(b, t)` requests this contraction's tile t, `next(b, j)` tile j of whatever follows.
-template <int KT, int NT, int SS, int NS, typename Load, typename Next, typename Mark>
-__device__ __forceinline__ void gemm_stage(const char* A, int a_rd, f16x8 (&bq)[NS][10], f32x4 (&acc)[4][NT], Load&& load, Next&& next, Mark&& mark) {
+template <int RT, int KT, int NT, int SS, int NS, typename Load, typename Next, typename Mark>
+__device__ __forceinline__ void gemm_stage(const char* A, int a_rd, f16x8 (&bq)[NS][10], f32x4 (&acc)[RT][NT], Load&& load, Next&& next, Mark&& mark) {
     static_for<KT>([&](auto tc) __attribute__((always_inline)) {
         constexpr int t = decltype(tc)::value;
         mark(t);
         if constexpr (t + NS - 1 < KT) load(bq[(SS + t + NS - 1) % NS], t + NS - 1);
         else next(bq[(SS + t + NS - 1) % NS], t + NS - 1 - KT);
         __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks every request down to its first use: one exposed L2 round trip per fragment)
-        mma_ktile<NT>(A + t * kTileBytes, a_rd, bq[(SS + t) % NS], acc);
+        mma_ktile<RT, NT>(A + t * kTileBytes<RT>, a_rd, bq[(SS + t) % NS], acc);
         __builtin_amdgcn_sched_barrier(0);
     });
 }
 
-template <int KT, int NT, int SS, int NS, typename Load, typename Next>
-__device__ __forceinline__ void gemm_stage(const char* A, int a_rd, f16x8 (&bq)[NS][10], f32x4 (&acc)[4][NT], Load&& load, Next&& next) {
-    gemm_stage<KT, NT, SS, NS>(A, a_rd, bq, acc, load, next, [](int) __attribute__((always_inline)) {});
+template <int RT, int KT, int NT, int SS, int NS, typename Load, typename Next>
+__device__ __forceinline__ void gemm_stage(const char* A, int a_rd, f16x8 (&bq)[NS][10], f32x4 (&acc)[RT][NT], Load&& load, Next&& next) {
+    gemm_stage<RT, KT, NT, SS, NS>(A, a_rd, bq, acc, load, next, [](int) __attribute__((always_inline)) {});
 }
 
 // A [C x C] contraction whose KT weight tiles were ALL requested one contraction earlier (slot t = tile t): the weights of the four square contractions of a
 // block are cold when the launch starts and only ~200 KB each -- with one or two tiles in flight every one of their k-tiles waits a memory round trip
 // (~1 us per tile measured, against 0.4 us for the feed-forward's tiles the prefetching workgroups have long pulled into the L2).  `after(b, t)` runs
 // behind tile t's MFMAs: it requests tile t of the NEXT square contraction into the slot that has just been read.
-template <int KT, int NT, typename After, typename Mark>
-__device__ __forceinline__ void square_stage(const char* A, int a_rd, f16x8 (&bs)[KT][10], f32x4 (&acc)[4][NT], After&& after, Mark&& mark) {
+template <int RT, int KT, int NT, typename After, typename Mark>
+__device__ __forceinline__ void square_stage(const char* A, int a_rd, f16x8 (&bs)[KT][10], f32x4 (&acc)[RT][NT], After&& after, Mark&& mark) {
     static_for<KT>([&](auto tc) __attribute__((always_inline)) {
         constexpr int t = decltype(tc)::value;
         mark(t);
         __builtin_amdgcn_sched_barrier(0);
-        mma_ktile<NT>(A + t * kTileBytes, a_rd, bs[t], acc);
+        mma_ktile<RT, NT>(A + t * kTileBytes<RT>, a_rd, bs[t], acc);
         __builtin_amdgcn_sched_barrier(0);
         after(bs[t], t);
     });
 }
 
-template <int NT>
-__device__ __forceinline__ void zero_acc(f32x4 (&acc)[4][NT]) {
+template <int RT, int NT>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[RT][NT]) {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < RT; i++)
 #pragma unroll
         for (int j = 0; j < NT; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
@@ -165,16 +168,16 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[4][NT]) {
 // acc + bias (+ residual from the LDS image `res`) -> f16 -> the LDS image `dst`.  res may be dst: a lane reads exactly the bytes it overwrites.
 // bias: this op's [C] vector in the LDS copy of the block's small operands (zeros when the op has none) -- a load from global memory here would be a cold
 // round trip on the critical path of every stage, and (vector-memory results return in order) a wait for every weight tile requested before it
-template <int NT, bool RES>
-__device__ __forceinline__ void epi_to_lds(const f32x4 (&acc)[4][NT], const char* bias, int nb, const char* res, char* dst, int lane) {
+template <int RT, int NT, bool RES>
+__device__ __forceinline__ void epi_to_lds(const f32x4 (&acc)[RT][NT], const char* bias, int nb, const char* res, char* dst, int lane) {
     const int l16 = lane & 15, g4 = (lane >> 4) * 4;
 #pragma unroll
     for (int j = 0; j < NT; j++) {
         const int n = nb + j * 16 + g4;
         const f16x4 bv = *reinterpret_cast<const f16x4*>(bias + n * 2);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int off = img_off(i * 16 + l16, n);
+        for (int i = 0; i < RT; i++) {
+            const int off = img_off<RT>(i * 16 + l16, n);
             f16x4 rv = f16x4{0, 0, 0, 0};
             if constexpr (RES) rv = *reinterpret_cast<const f16x4*>(res + off);
             f16x4 o;
@@ -186,8 +189,8 @@ __device__ __forceinline__ void epi_to_lds(const f32x4 (&acc)[4][NT], const char
 }
 
 // acc + bias + residual (an LDS image, or fragments `rg` fetched from global rows by the caller) -> f16 -> global rows (and, OUT2, a second destination)
-template <int NT, bool RES_LDS, bool OUT2>
-__device__ __forceinline__ void epi_to_global(const f32x4 (&acc)[4][NT], const char* bias, int nb, const char* res_lds, const f16x4 (&rg)[4][NT],
+template <int RT, int NT, bool RES_LDS, bool OUT2>
+__device__ __forceinline__ void epi_to_global(const f32x4 (&acc)[RT][NT], const char* bias, int nb, const char* res_lds, const f16x4 (&rg)[RT][NT],
                                               f16* __restrict__ out, long ldo, f16* __restrict__ out2, long ldo2, long row0, int lane) {
     const int l16 = lane & 15, g4 = (lane >> 4) * 4;
 #pragma unroll
@@ -195,10 +198,10 @@ __device__ __forceinline__ void epi_to_global(const f32x4 (&acc)[4][NT], const c
         const int n = nb + j * 16 + g4;
         const f16x4 bv = *reinterpret_cast<const f16x4*>(bias + n * 2);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < RT; i++) {
             const int m = i * 16 + l16;
             f16x4 rv = rg[i][j];
-            if constexpr (RES_LDS) rv = *reinterpret_cast<const f16x4*>(res_lds + img_off(m, n));
+            if constexpr (RES_LDS) rv = *reinterpret_cast<const f16x4*>(res_lds + img_off<RT>(m, n));
             f16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; r++) o[r] = (f16)((acc[i][j][r] + (float)bv[r]) + (float)rv[r]);
@@ -208,23 +211,24 @@ __device__ __forceinline__ void epi_to_global(const f32x4 (&acc)[4][NT], const c
     }
 }
 
-// LayerNorm of the 64 rows of image X into image P: layer_norm_kernel's arithmetic (osg_norm.hip), four adjacent lanes per row
-template <int C>
+// LayerNorm of the 16 RT rows of image X into image P: layer_norm_kernel's arithmetic (osg_norm.hip), LPR = 256 / rows adjacent lanes per row
+template <int RT, int C>
 __device__ __forceinline__ void ln_rows(const char* X, char* P, const char* gamma, const char* beta, float eps, int tid) {   // (gamma, beta: LDS copies)
-    constexpr int NCH = C / 8, PER = NCH / 4;
-    static_assert(NCH % 4 == 0, "row chunks split over four lanes");
-    const int row = tid >> 2, part = tid & 3;
+    constexpr int NCH = C / 8, LPR = 16 / RT, PER = NCH / LPR;
+    static_assert(NCH % LPR == 0 && (LPR == 4 || LPR == 8), "row chunks split over the lanes of a row");
+    const int row = tid / LPR, part = tid % LPR;
     float v[PER][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < PER; i++) {
-        const int c = part + 4 * i;
-        const f16x8 t = *reinterpret_cast<const f16x8*>(X + (c >> 3) * kTileBytes + row * 128 + (((c & 7) ^ (row & 7)) << 4));
+        const int c = part + LPR * i;
+        const f16x8 t = *reinterpret_cast<const f16x8*>(X + (c >> 3) * kTileBytes<RT> + row * 128 + (((c & 7) ^ (row & 7)) << 4));
 #pragma unroll
         for (int e = 0; e < 8; e++) { v[i][e] = (float)t[e]; s += v[i][e]; }
     }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
+    if constexpr (LPR == 8) s += __shfl_xor(s, 4, 64);
     const float mean = s / (float)C;
     float q = 0.f;
 #pragma unroll
@@ -233,32 +237,33 @@ __device__ __forceinline__ void ln_rows(const char* X, char* P, const char* gamm
         for (int e = 0; e < 8; e++) { const float d = v[i][e] - mean; q += d * d; }
     q += __shfl_xor(q, 1, 64);
     q += __shfl_xor(q, 2, 64);
+    if constexpr (LPR == 8) q += __shfl_xor(q, 4, 64);
     const float rstd = 1.0f / sqrtf(q / (float)C + eps);
 #pragma unroll
     for (int i = 0; i < PER; i++) {
-        const int c = part + 4 * i;
+        const int c = part + LPR * i;
         const f16x8 gm = *reinterpret_cast<const f16x8*>(gamma + c * 16);
         const f16x8 bt = *reinterpret_cast<const f16x8*>(beta + c * 16);
         f16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; e++) o[e] = (f16)((v[i][e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
-        *reinterpret_cast<f16x8*>(P + (c >> 3) * kTileBytes + row * 128 + (((c & 7) ^ (row & 7)) << 4)) = o;
+        *reinterpret_cast<f16x8*>(P + (c >> 3) * kTileBytes<RT> + row * 128 + (((c & 7) ^ (row & 7)) << 4)) = o;
     }
 }
 
-template <int C>
+template <int RT, int C>
 __device__ __forceinline__ void dump_img(const char* img, f16* __restrict__ dst, long row0, int tid) {
     if (!dst) return;
     constexpr int NCH = C / 8;
-    for (int idx = tid; idx < 64 * NCH; idx += 256) {
+    for (int idx = tid; idx < 16 * RT * NCH; idx += 256) {
         const int row = idx / NCH, c = idx - row * NCH;
         *reinterpret_cast<f16x8*>(dst + (row0 + row) * C + c * 8) =
-            *reinterpret_cast<const f16x8*>(img + (c >> 3) * kTileBytes + row * 128 + (((c & 7) ^ (row & 7)) << 4));
+            *reinterpret_cast<const f16x8*>(img + (c >> 3) * kTileBytes<RT> + row * 128 + (((c & 7) ^ (row & 7)) << 4));
     }
 }
 
 // cross-attention of this wave's heads over the 64 rows: Q from image `Qi`, output into image `Oi`.  Packs: K [head][TKT*16][DP], V^T [head][DP][TKT*16]
-template <int D, int TKT>
+template <int RT, int D, int TKT>
 __device__ __forceinline__ void cross_attention(const char* Qi, char* Oi, const f16* __restrict__ kp, const f16* __restrict__ vtp, int head0, int nheads, float c, int Tk, int lane) {
     constexpr int DS = (D + 15) / 16, DP = DS * 16, TKP = TKT * 16;
     const int l16 = lane & 15, g = lane >> 4;
@@ -276,14 +281,14 @@ __device__ __forceinline__ void cross_attention(const char* Qi, char* Oi, const 
 #pragma unroll
             for (int tt = 0; tt < TKT; tt++) vf[dt][tt] = *reinterpret_cast<const f16x4*>(vh + (dt * 16 + l16) * TKP + tt * 16 + g * 4);
 #pragma unroll 1
-        for (int mi = 0; mi < 4; mi++) {
+        for (int mi = 0; mi < RT; mi++) {
             const int m = mi * 16 + l16;
             f16x4 qf[DS];
 #pragma unroll
             for (int ds = 0; ds < DS; ds++) {
                 const int dd = ds * 16 + g * 4;
                 const bool ok = dd < D;                          // (D % 4 == 0: a fragment is all inside or all outside the head)
-                const f16x4 t = *reinterpret_cast<const f16x4*>(Qi + img_off(m, h * D + (ok ? dd : 0)));
+                const f16x4 t = *reinterpret_cast<const f16x4*>(Qi + img_off<RT>(m, h * D + (ok ? dd : 0)));
                 qf[ds] = ok ? t : f16x4{0, 0, 0, 0};
             }
             f32x4 s[TKT];
@@ -328,7 +333,7 @@ __device__ __forceinline__ void cross_attention(const char* Qi, char* Oi, const 
                     f16x4 ov;
 #pragma unroll
                     for (int r = 0; r < 4; r++) ov[r] = (f16)(o[r] * inv);
-                    *reinterpret_cast<f16x4*>(Oi + img_off(m, h * D + dd)) = ov;
+                    *reinterpret_cast<f16x4*>(Oi + img_off<RT>(m, h * D + dd)) = ov;
                 }
             }
         }
@@ -347,17 +352,19 @@ __device__ __forceinline__ void touch_lines(const void* base, int rows, int row_
 }
 
 // NS = register slots for weight tiles (2: one tile ahead, 3: two tiles ahead)
-template <int C, int D, int TKT, int NS>
-__global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
+template <int RT, int C, int D, int TKT, int NS>
+__global__ __launch_bounds__(256, RT == 2 && NS == 2 ? 2 : 1) void tblock_tail_kernel(TailParams p) {   // (32-row blocks: two workgroups fit a CU -- 72 KB of LDS, <= 256 registers)
+    constexpr int RB = 16 * RT;                // rows of a row block
+    constexpr int TB = kTileBytes<RT>;
     constexpr int KT = C / 64;                 // k-tiles of a C-deep contraction
     constexpr int NTW = C / 64;                // 16-column tiles per wave when four waves split C output columns
     constexpr int F = 4 * C;                   // GEGLU hidden width
     constexpr int HC = 128, NCHUNK = F / HC;   // hidden columns per chunk
     constexpr int G2T = HC / 64;               // k-tiles of ff.net.2 per chunk
     constexpr int PER = KT + G2T;              // k-tiles per chunk iteration
-    constexpr int IMG = KT * kTileBytes;
+    constexpr int IMG = KT * TB;
     constexpr int AH = NS - 1;                 // tiles requested ahead
-    static_assert(C % 64 == 0 && NTW <= 5 && 2 * G2T * kTileBytes <= IMG && (NS == 2 || NS == 3) && PER % NS == 1 && AH <= G2T && AH <= KT, "shape");
+    static_assert(C % 64 == 0 && NTW <= 5 && 2 * G2T * TB <= IMG && (RT == 2 || RT == 4) && (NS == 2 || NS == 3) && PER % NS == 1 && AH <= G2T && AH <= KT, "shape");
     // kn8 byte strides: KS_* = between the two halves of a k-tile (4 k chunks), KT_* = between k-tiles (8 k chunks); N = C for the square weights and ff.net.2
     // ([F/8][C][8]), N = 2F for ff.net.0.proj ([C/8][2F][8])
     constexpr int KS_C = 4 * C * 16, KT_C = 8 * C * 16, KS_1 = 4 * 2 * F * 16, KT_1 = 8 * 2 * F * 16;
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     constexpr int CH1 = HC * 16;               // ff.net.0.proj: the rows of the next chunk
     constexpr int CH2 = (HC / 8) * C * 16;     // ff.net.2: the k chunks of the next chunk of hidden columns
     const int tid = threadIdx.x;
-    const int nblk = p.M >> 6;
+    const int nblk = p.M / RB;
 
     // ---- the workgroups behind the row blocks do no arithmetic: each pulls the block's weights into the L2 of ITS XCD (workgroup i runs on XCD i mod 8),
     // in the order the row blocks will want them.  A launch's weights are cold (the L2s are invalidated between launches, a pass streams 1.7 GB through
@@ -419,7 +426,7 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, g = lane >> 4;
-    const long row0 = (long)blockIdx.x * 64;
+    const long row0 = (long)blockIdx.x * RB;
     const int img = (int)(row0 / p.rows_per_img);
     const int a_rd = l16 * 128 + ((g ^ (l16 & 7)) << 4);
     const int nb = wave * (C / 4);             // this wave's output columns of a C-wide contraction
@@ -451,17 +458,17 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
 
     // ---- the row block: a1 -> P, x0 -> X (LDS-DMA, the swizzle on the source side as in gemm2_kernel) ----------------------------------
     {
-        __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a1 + row0 * C), 0, 64 * C * 2, 0x00020000);
-        __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x0 + row0 * C), 0, 64 * C * 2, 0x00020000);
+        __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a1 + row0 * C), 0, RB * C * 2, 0x00020000);
+        __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x0 + row0 * C), 0, RB * C * 2, 0x00020000);
         const int rsub = lane >> 3, gch = (lane & 7) ^ rsub;
 #pragma unroll
         for (int kt = 0; kt < KT; kt++)
 #pragma unroll
-            for (int qq = 0; qq < 2; qq++) {
+            for (int qq = 0; qq < RT / 2; qq++) {
                 const int q8 = qq * 4 + wave;                               // 8-row group inside the tile
                 const unsigned off = (unsigned)(((q8 * 8 + rsub) * C + kt * 64 + gch * 8) * 2);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(P + kt * kTileBytes + q8 * 1024), 16, off, 0, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr)(X + kt * kTileBytes + q8 * 1024), 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(P + kt * TB + q8 * 1024), 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr)(X + kt * TB + q8 * 1024), 16, off, 0, 0, 0);
             }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -470,88 +477,88 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
 
     // ---- x1 = to_out(a1) + x0 ---------------------------------------------------------------------------------------------------------
     {
-        f32x4 acc[4][NTW];
+        f32x4 acc[RT][NTW];
         zero_acc(acc);
-        square_stage<KT, NTW>(P, a_rd, bs, acc, [&](f16x8 (&)[10], int t) __attribute__((always_inline)) { if (t < AH) ld_cc(bq[t % NS], u_q2, t); },
+        square_stage<RT, KT, NTW>(P, a_rd, bs, acc, [&](f16x8 (&)[10], int t) __attribute__((always_inline)) { if (t < AH) ld_cc(bq[t % NS], u_q2, t); },
                               [&](int t) __attribute__((always_inline)) { stamp(16 + t); });
         stamp(21);
-        epi_to_lds<NTW, true>(acc, vec(V_BO1), nb, X, X, lane);
+        epi_to_lds<RT, NTW, true>(acc, vec(V_BO1), nb, X, X, lane);
         stamp(22);
     }
     __builtin_amdgcn_s_barrier();
     stamp(2);
-    dump_img<C>(X, p.dbg[0], row0, tid);
-    ln_rows<C>(X, P, vec(V_G2), vec(V_BE2), p.eps2, tid);
+    dump_img<RT, C>(X, p.dbg[0], row0, tid);
+    ln_rows<RT, C>(X, P, vec(V_G2), vec(V_BE2), p.eps2, tid);
     __builtin_amdgcn_s_barrier();
     stamp(3);
-    dump_img<C>(P, p.dbg[1], row0, tid);
+    dump_img<RT, C>(P, p.dbg[1], row0, tid);
 
     // ---- q = to_q(LN(x1)) ---------------------------------------------------------------------------------------------------------------
     {
-        f32x4 acc[4][NTW];
+        f32x4 acc[RT][NTW];
         zero_acc(acc);
-        gemm_stage<KT, NTW, 0, NS>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_cc(b, u_q2, t); },
+        gemm_stage<RT, KT, NTW, 0, NS>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_cc(b, u_q2, t); },
                                    [&](f16x8 (&b)[10], int j) __attribute__((always_inline)) { ld_cc(b, u_o2, j); });
-        epi_to_lds<NTW, false>(acc, vec(V_BQ2), nb, nullptr, R, lane);
+        epi_to_lds<RT, NTW, false>(acc, vec(V_BQ2), nb, nullptr, R, lane);
     }
     __builtin_amdgcn_s_barrier();
     stamp(4);
-    dump_img<C>(R, p.dbg[2], row0, tid);
+    dump_img<RT, C>(R, p.dbg[2], row0, tid);
 
     // ---- a2 = cross-attention(q, K, V): heads split over the waves -------------------------------------------------------------------
     {
         constexpr int DS = (D + 15) / 16, DP = DS * 16, TKP = TKT * 16;
         const int hpw = p.heads >> 2;
         const long per_img = (long)p.heads * TKP * DP;
-        cross_attention<D, TKT>(R, P, p.kp + img * per_img, p.vtp + img * per_img, wave * hpw, hpw, p.sc_log2e, p.Tk, lane);
+        cross_attention<RT, D, TKT>(R, P, p.kp + img * per_img, p.vtp + img * per_img, wave * hpw, hpw, p.sc_log2e, p.Tk, lane);
     }
     __builtin_amdgcn_s_barrier();
     stamp(5);
-    dump_img<C>(P, p.dbg[3], row0, tid);
+    dump_img<RT, C>(P, p.dbg[3], row0, tid);
 
     // ---- x2 = to_out(a2) + x1 -----------------------------------------------------------------------------------------------------------
     {
-        f32x4 acc[4][NTW];
+        f32x4 acc[RT][NTW];
         zero_acc(acc);
-        gemm_stage<KT, NTW, KT, NS>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_cc(b, u_o2, t); },
+        gemm_stage<RT, KT, NTW, KT, NS>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_cc(b, u_o2, t); },
                                     [&](f16x8 (&b)[10], int j) __attribute__((always_inline)) { ld_ff(b, 0, j); });
-        epi_to_lds<NTW, true>(acc, vec(V_BO2), nb, X, X, lane);
+        epi_to_lds<RT, NTW, true>(acc, vec(V_BO2), nb, X, X, lane);
     }
     __builtin_amdgcn_s_barrier();
     stamp(6);
-    dump_img<C>(X, p.dbg[4], row0, tid);
-    ln_rows<C>(X, P, vec(V_G3), vec(V_BE3), p.eps3, tid);
+    dump_img<RT, C>(X, p.dbg[4], row0, tid);
+    ln_rows<RT, C>(X, P, vec(V_G3), vec(V_BE3), p.eps3, tid);
     __builtin_amdgcn_s_barrier();
     stamp(7);
-    dump_img<C>(P, p.dbg[5], row0, tid);
+    dump_img<RT, C>(P, p.dbg[5], row0, tid);
 
     // ---- x3 = ff.net.2(GEGLU(ff.net.0.proj(LN(x2)))) + x2, the hidden activation 128 columns at a time ----------------------------------
     // k-tile sequence: G1(0) | G1(1) G2(0) | G1(2) G2(1) | ... | G1(NCHUNK-1) G2(NCHUNK-2) | G2(NCHUNK-1); G1 = KT tiles (4 fragments each), G2 = G2T tiles (NTW)
-    f32x4 accY[4][NTW];
+    f32x4 accY[RT][NTW];
     zero_acc(accY);
     {
         constexpr int S0 = 2 * KT;                 // sequence index (slot = index % NS) of G1(0)'s first k-tile: to_q and to_out2 came first (to_out1 has slots of its own)
-        f32x4 accG[4][4];
+        f32x4 accG[RT][4];
         // GEGLU epilogue of chunk c into hidden buffer c & 1 (value tiles 0, 1; gate tiles 2, 3)
         auto geglu_store = [&](int c) __attribute__((always_inline)) {
-            char* H = R + (c & 1) * (G2T * kTileBytes);
+            char* H = R + (c & 1) * (G2T * TB);
 #pragma unroll
             for (int jt = 0; jt < 2; jt++) {
                 const int hc = wave * 32 + jt * 16 + g * 4;          // column inside the chunk
                 const f16x4 bv = *reinterpret_cast<const f16x4*>(vec(V_B1) + (c * HC + hc) * 2);
                 const f16x4 bg = *reinterpret_cast<const f16x4*>(vec(V_B1) + (F + c * HC + hc) * 2);
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
+                for (int i = 0; i < RT; i++) {
                     f16x4 o;
 #pragma unroll
                     for (int r = 0; r < 4; r++) o[r] = (f16)((accG[i][jt][r] + (float)bv[r]) * osg_gelu_erf(accG[i][2 + jt][r] + (float)bg[r]));
-                    *reinterpret_cast<f16x4*>(H + img_off(i * 16 + l16, hc)) = o;
+                    *reinterpret_cast<f16x4*>(H + img_off<RT>(i * 16 + l16, hc)) = o;
                 }
             }
         };
         // chunk 0: projection only (its last AH requests are the first tiles of iteration 1)
         zero_acc(accG);
-        gemm_stage<KT, 4, S0, NS>(P, a_rd, bq, accG, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_ff(b, 0, t); },
+        gemm_stage<RT, KT, 4, S0, NS>(P, a_rd, bq, accG, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_ff(b, 0, t); },
                                   [&](f16x8 (&b)[10], int j) __attribute__((always_inline)) { ld_ff(b, 1, j); });
         geglu_store(0);
         __builtin_amdgcn_s_barrier();
@@ -572,7 +579,7 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
                 constexpr int t = decltype(tc)::value;
                 request(bq[(ST + t + AH) % NS], t + AH);
                 __builtin_amdgcn_sched_barrier(0);
-                mma_ktile<4>(P + t * kTileBytes, a_rd, bq[(ST + t) % NS], accG);
+                mma_ktile<RT, 4>(P + t * TB, a_rd, bq[(ST + t) % NS], accG);
                 __builtin_amdgcn_sched_barrier(0);
             });
             if (c == 3) stamp(24); else if (c == 4) stamp(28);
@@ -580,12 +587,12 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
             // pair, independent of these MFMAs -- between the groups of four MFMAs was measured SLOWER: 2.72 instead of 0.93 + 1.18 us per chunk,
             // profiles/r04_tblock_tail_stage_stamps_v5_geglu_interleaved_slower.txt -- one wave per SIMD issues in order, and the packed-f32 arithmetic takes the issue
             // slots the MFMAs need; sched_group_barrier patterns were not honoured at all)
-            const char* Hp = R + ((c - 1) & 1) * (G2T * kTileBytes);
+            const char* Hp = R + ((c - 1) & 1) * (G2T * TB);
             static_for<G2T>([&](auto uc) __attribute__((always_inline)) {
                 constexpr int u = decltype(uc)::value;
                 request(bq[(ST + KT + u + AH) % NS], KT + u + AH);
                 __builtin_amdgcn_sched_barrier(0);
-                mma_ktile<NTW>(Hp + u * kTileBytes, a_rd, bq[(ST + KT + u) % NS], accY);
+                mma_ktile<RT, NTW>(Hp + u * TB, a_rd, bq[(ST + KT + u) % NS], accY);
             });
             if (c == 3) stamp(25); else if (c == 4) stamp(29);
             geglu_store(c);
@@ -607,47 +614,47 @@ __global__ __launch_bounds__(256) void tblock_tail_kernel(TailParams p) {
         // ff.net.2 over the last chunk (positions KT .. PER-1 of pseudo-iteration NCHUNK); the requests that go out with it are proj_out's first tiles
         {
             constexpr int ST = (S0 + KT + (NCHUNK - 1) * PER) % NS;        // slot of its first tile
-            const char* Hp = R + ((NCHUNK - 1) & 1) * (G2T * kTileBytes);
+            const char* Hp = R + ((NCHUNK - 1) & 1) * (G2T * TB);
             static_for<G2T>([&](auto uc) __attribute__((always_inline)) {
                 constexpr int u = decltype(uc)::value;
                 if constexpr (u + AH < G2T) ld_ff(bq[(ST + u + AH) % NS], NCHUNK, KT + u + AH);
                 else if (has_po) ld_cc(bq[(ST + u + AH) % NS], u_po, u + AH - G2T);
                 __builtin_amdgcn_sched_barrier(0);
-                mma_ktile<NTW>(Hp + u * kTileBytes, a_rd, bq[(ST + u) % NS], accY);
+                mma_ktile<RT, NTW>(Hp + u * TB, a_rd, bq[(ST + u) % NS], accY);
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
     }
     stamp(10);
-    f16x4 rg[4][NTW];                          // proj_out's residual x_in: requested now, behind the last weight tiles, consumed after the contraction
+    f16x4 rg[RT][NTW];                          // proj_out's residual x_in: requested now, behind the last weight tiles, consumed after the contraction
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < RT; i++)
 #pragma unroll
         for (int j = 0; j < NTW; j++) rg[i][j] = f16x4{0, 0, 0, 0};
     if (!has_po) {
-        if (p.out2) epi_to_global<NTW, true, true>(accY, vec(V_B2), nb, X, rg, p.out, p.ldo, p.out2, p.ldo2, row0, lane);
-        else epi_to_global<NTW, true, false>(accY, vec(V_B2), nb, X, rg, p.out, p.ldo, nullptr, 0, row0, lane);
+        if (p.out2) epi_to_global<RT, NTW, true, true>(accY, vec(V_B2), nb, X, rg, p.out, p.ldo, p.out2, p.ldo2, row0, lane);
+        else epi_to_global<RT, NTW, true, false>(accY, vec(V_B2), nb, X, rg, p.out, p.ldo, nullptr, 0, row0, lane);
         if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(13); }
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < RT; i++)
 #pragma unroll
         for (int j = 0; j < NTW; j++) rg[i][j] = *reinterpret_cast<const f16x4*>(p.xin + (row0 + i * 16 + l16) * C + nb + j * 16 + g * 4);
     // x3 into P (every wave is past its last read of LN(x2): the barrier of the last chunk), then y = proj_out(x3) + x_in
-    epi_to_lds<NTW, true>(accY, vec(V_B2), nb, X, P, lane);
+    epi_to_lds<RT, NTW, true>(accY, vec(V_B2), nb, X, P, lane);
     __builtin_amdgcn_s_barrier();
     stamp(11);
-    dump_img<C>(P, p.dbg[6], row0, tid);
+    dump_img<RT, C>(P, p.dbg[6], row0, tid);
     {
-        f32x4 acc[4][NTW];
+        f32x4 acc[RT][NTW];
         zero_acc(acc);
         constexpr int SS = 2 * KT + KT + (NCHUNK - 1) * PER + G2T;
-        gemm_stage<KT, NTW, SS, NS>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_cc(b, u_po, t); },
+        gemm_stage<RT, KT, NTW, SS, NS>(P, a_rd, bq, acc, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_cc(b, u_po, t); },
                                     [&](f16x8 (&)[10], int) __attribute__((always_inline)) {});
         stamp(12);
-        if (p.out2) epi_to_global<NTW, false, true>(acc, vec(V_BPO), nb, nullptr, rg, p.out, p.ldo, p.out2, p.ldo2, row0, lane);
-        else epi_to_global<NTW, false, false>(acc, vec(V_BPO), nb, nullptr, rg, p.out, p.ldo, nullptr, 0, row0, lane);
+        if (p.out2) epi_to_global<RT, NTW, false, true>(acc, vec(V_BPO), nb, nullptr, rg, p.out, p.ldo, p.out2, p.ldo2, row0, lane);
+        else epi_to_global<RT, NTW, false, false>(acc, vec(V_BPO), nb, nullptr, rg, p.out, p.ldo, nullptr, 0, row0, lane);
         if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(13); }
     }
 }
@@ -687,7 +694,7 @@ __global__ __launch_bounds__(256) void kn8_pack_kernel(const f16x8* __restrict__
 extern "C" {
 
 int osg_tblock_tail_supported(int M, int rows_per_img, int C, int heads, int Tk) {
-    return C == 320 && heads == 8 && M > 0 && M % 64 == 0 && rows_per_img % 64 == 0 && Tk >= 1 && Tk <= 80;
+    return C == 320 && heads == 8 && M > 0 && M % 32 == 0 && rows_per_img % 32 == 0 && Tk >= 1 && Tk <= 80;
 }
 
 size_t osg_tblock_kv_pack_elems(int imgs, int heads, int D) { return (size_t)imgs * heads * 80 * (size_t)((D + 15) / 16 * 16); }
@@ -734,18 +741,37 @@ int osg_tblock_tail(osg_ctx* ctx, const osg_tblock_tail_args* a) {
     static const int pfs0 = getenv("OSG_TBLOCK_PF_SLEEP0") ? atoi(getenv("OSG_TBLOCK_PF_SLEEP0")) : 100;  // their pauses, x 64 cycles: behind the square weights ...
     static const int pfs = getenv("OSG_TBLOCK_PF_SLEEP") ? atoi(getenv("OSG_TBLOCK_PF_SLEEP")) : 60;      // ... and behind every feed-forward chunk
     p.pf_sleep0 = pfs0; p.pf_sleep = pfs;
-    // (two register slots for the feed-forward's tiles: three -- two tiles ahead -- measured no faster, profiles/r04_tblock_tail_probe_v3.txt, and with the
-    // square contractions' five slots beside them hipcc 7.2 crashes in its 'Rewrite AGPR-Copy-MFMA' pass)
-    auto kern = osg_tb::tblock_tail_kernel<320, 40, 5, 2>;
-    constexpr int smem = 3 * 5 * osg_tb::kTileBytes + (9 * 320 + 8 * 320) * 2;   // three row-block images + the small operands
-    static bool attr_set = false;
-    if (!attr_set) {
-        OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
+    // Rows per block: 64 rows give every weight fragment four row tiles of MFMA work, but M = 8 192 rows (SD 1.5 at 64x64, cond + uncond) are then 128 workgroups
+    // on 256 CUs; 32-row blocks put one workgroup on every CU at twice the weight traffic out of the L2s.  OSG_TBLOCK_ROWS = 32 | 64 overrides the choice.
+    // (Two register slots for the feed-forward's tiles: three -- two tiles ahead -- measured no faster, profiles/r04_tblock_tail_probe_v3.txt, and with the
+    // square contractions' five slots beside them hipcc 7.2 crashes in its 'Rewrite AGPR-Copy-MFMA' pass.)
+    static const int rows_env = getenv("OSG_TBLOCK_ROWS") ? atoi(getenv("OSG_TBLOCK_ROWS")) : 0;
+    int rows = a->rows_per_block == 32 || a->rows_per_block == 64 ? a->rows_per_block : rows_env == 32 || rows_env == 64 ? rows_env : (a->M / 64 < 2 * ctx->num_cu ? 32 : 64);
+    if (a->rows_per_block != 0 && a->rows_per_block != 32 && a->rows_per_block != 64) OSG_FAIL(ctx, "osg_tblock_tail: rows_per_block must be 0, 32 or 64");
+    if (a->M % 64 || a->rows_per_img % 64) {
+        if (a->rows_per_block == 64) OSG_FAIL(ctx, "osg_tblock_tail: 64-row blocks need M and rows_per_img to be multiples of 64");
+        rows = 32;
     }
-    const int nblk = a->M / 64;
-    const int npf = nblk >= 64 ? pfw : 0;     // (a launch that leaves CUs idle anyway spends eight of them on pulling the weights into the eight L2s)
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nblk + npf)), dim3(256), smem, ctx->compute, p);
+    const int nblk = a->M / rows;
+    // eight more workgroups pull the weights into the eight L2s -- where the launch leaves CUs free for them (64-row blocks at M = 8 192); beside one row block per CU
+    // they cost more than they bring (32-row blocks, 256 + 8 workgroups: 76.7 against 71.2 us per launch, profiles/r04_tblock_tail_rows_probe.txt)
+    const int npf = nblk >= 64 && nblk + pfw <= ctx->num_cu ? pfw : 0;
+    auto launch = [&](auto kern, int smem, bool& attr_set) -> int {
+        if (!attr_set) {
+            OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)(nblk + npf)), dim3(256), smem, ctx->compute, p);
+        return 0;
+    };
+    constexpr int vec_bytes = (9 * 320 + 8 * 320) * 2;     // the small operands behind the three row-block images
+    static bool attr64 = false, attr32 = false, attr32n3 = false;
+    static const bool ns3 = getenv("OSG_TBLOCK_NS") && atoi(getenv("OSG_TBLOCK_NS")) == 3;     // dev knob: two weight tiles ahead (32-row blocks only)
+    int rc;
+    if (rows == 64) rc = launch(osg_tb::tblock_tail_kernel<4, 320, 40, 5, 2>, 3 * 5 * osg_tb::kTileBytes<4> + vec_bytes, attr64);
+    else if (ns3) rc = launch(osg_tb::tblock_tail_kernel<2, 320, 40, 5, 3>, 3 * 5 * osg_tb::kTileBytes<2> + vec_bytes, attr32n3);
+    else rc = launch(osg_tb::tblock_tail_kernel<2, 320, 40, 5, 2>, 3 * 5 * osg_tb::kTileBytes<2> + vec_bytes, attr32);
+    if (rc) return rc;
     OSG_LAUNCH_CHECK(ctx);
     return 0;
 }

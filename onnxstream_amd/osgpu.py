@@ -43,7 +43,7 @@ class TBlockTailArgs(ctypes.Structure):
     _fields_ = [("a1", _vp), ("x0", _vp), ("wo1", _vp), ("bo1", _vp), ("g2", _vp), ("be2", _vp), ("eps2", _cf), ("wq2", _vp), ("bq2", _vp),
                 ("kp", _vp), ("vtp", _vp), ("scale", _cf), ("Tk", _ci), ("wo2", _vp), ("bo2", _vp), ("g3", _vp), ("be3", _vp), ("eps3", _cf),
                 ("w1", _vp), ("b1", _vp), ("w2", _vp), ("b2", _vp), ("wpo", _vp), ("bpo", _vp), ("xin", _vp), ("out", _vp), ("out2", _vp),
-                ("ldo", _cl), ("ldo2", _cl), ("M", _ci), ("rows_per_img", _ci), ("C", _ci), ("heads", _ci), ("dbg", _vp * 8)]
+                ("ldo", _cl), ("ldo2", _cl), ("M", _ci), ("rows_per_img", _ci), ("C", _ci), ("heads", _ci), ("dbg", _vp * 8), ("rows_per_block", _ci)]
 
 
 def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
@@ -361,7 +361,7 @@ class Gpu:
         return {n: (self.tblock_pack_weight(self.to_dev(t)) if n in self.TBLOCK_WEIGHTS else self.to_dev(t)) for n, t in w.items()}
 
     def tblock_tail(self, a1: DevBuf, x0: DevBuf, w: dict, kp: DevBuf, vtp: DevBuf, tk: int, heads: int, scale: float, rows_per_img: int, eps: float = 1e-5,
-                    xin: Optional[DevBuf] = None, out2: Optional[DevBuf] = None, out2_col: int = 0, debug: bool = False, out: Optional[DevBuf] = None, stamps: Optional[DevBuf] = None):
+                    xin: Optional[DevBuf] = None, out2: Optional[DevBuf] = None, out2_col: int = 0, debug: bool = False, out: Optional[DevBuf] = None, stamps: Optional[DevBuf] = None, rows_per_block: int = 0):
         """osg_tblock_tail.  w: dict of DevBuf -- wo1 bo1 g2 be2 wq2 wo2 bo2 g3 be3 w1 b1 w2 b2 [wpo bpo]; weights in the kn8 layout (tblock_weights).  Returns (out, [dumps])."""
         m, c = a1.shape
         a = TBlockTailArgs()
@@ -378,6 +378,7 @@ class Gpu:
         if out2 is not None:
             a.out2, a.ldo2 = out2.ptr + out2_col * 2, out2.shape[-1]
         a.M, a.rows_per_img, a.C, a.heads = m, rows_per_img, c, heads
+        a.rows_per_block = rows_per_block
         dumps = []
         if debug:
             dumps = [self.empty((m, c), a1.dtype) for _ in range(7)]

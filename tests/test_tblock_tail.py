@@ -86,8 +86,11 @@ def chain_numpy(a1, x0, w, k, v, heads, scale, imgs, eps, xin):
 STAGES = ["x1", "ln2", "q", "a2", "x2", "ln3", "x3"]
 
 
-@pytest.mark.parametrize("M,imgs,Tk,proj", [(128, 2, 77, True), (256, 2, 77, False), (512, 1, 80, True), (192, 3, 50, True), (8192, 2, 77, True)])
-def test_tblock_tail_stage_by_stage(gpu, M, imgs, Tk, proj):
+@pytest.mark.parametrize("rows", [64, 32])
+@pytest.mark.parametrize("M,imgs,Tk,proj", [(128, 2, 77, True), (256, 2, 77, False), (512, 1, 80, True), (192, 3, 50, True), (8192, 2, 77, True), (96, 3, 77, True)])
+def test_tblock_tail_stage_by_stage(gpu, M, imgs, Tk, proj, rows):
+    if rows == 64 and (M // imgs) % 64:
+        pytest.skip("64-row blocks lie inside one image")
     C, heads = 320, 8
     assert gpu.lib.osg_tblock_tail_supported(M, M // imgs, C, heads, Tk) == 1
     rng = np.random.default_rng(M + Tk)
@@ -111,7 +114,7 @@ def test_tblock_tail_stage_by_stage(gpu, M, imgs, Tk, proj):
     want_vt[:, :, :D, :Tk] = v.reshape(imgs, Tk, heads, D).transpose(0, 2, 3, 1)
     assert np.array_equal(kpn, want_kp) and np.array_equal(vtn, want_vt)
 
-    out, dumps = gpu.tblock_tail(gpu.to_dev(a1), gpu.to_dev(x0), dw, kp, vtp, Tk, heads, scale, M // imgs, eps, xin=gpu.to_dev(xin) if proj else None, debug=True)
+    out, dumps = gpu.tblock_tail(gpu.to_dev(a1), gpu.to_dev(x0), dw, kp, vtp, Tk, heads, scale, M // imgs, eps, xin=gpu.to_dev(xin) if proj else None, debug=True, rows_per_block=rows)
     got = {n: dumps[i].numpy() for i, n in enumerate(STAGES)}
     if proj:
         got["y"] = out.numpy()
@@ -134,7 +137,8 @@ def test_tblock_tail_stage_by_stage(gpu, M, imgs, Tk, proj):
     assert rel_max(got["x1"], sep["x1"]) <= 5e-4, msg
 
 
-def test_tblock_tail_second_destination_and_row_pitch(gpu):
+@pytest.mark.parametrize("rows", [0, 32, 64])
+def test_tblock_tail_second_destination_and_row_pitch(gpu, rows):
     """out2 / ldo2 (a skip connection's Concat slot) receives the same bits as out"""
     C, heads, M, imgs, Tk = 320, 8, 128, 1, 77
     rng = np.random.default_rng(5)
@@ -144,15 +148,17 @@ def test_tblock_tail_second_destination_and_row_pitch(gpu):
     dw = gpu.tblock_weights(w)
     kp, vtp = gpu.tblock_kv_pack(gpu.to_dev(k), gpu.to_dev(v), heads)
     wide = gpu.to_dev(np.full((M, 2 * C + 64), 7.0, f16))
-    out, _ = gpu.tblock_tail(gpu.to_dev(a1), gpu.to_dev(x0), dw, kp, vtp, Tk, heads, 40 ** -0.5, M, xin=gpu.to_dev(xin), out2=wide, out2_col=C)
+    out, _ = gpu.tblock_tail(gpu.to_dev(a1), gpu.to_dev(x0), dw, kp, vtp, Tk, heads, 40 ** -0.5, M, xin=gpu.to_dev(xin), out2=wide, out2_col=C, rows_per_block=rows)
     o, wd = out.numpy(), wide.numpy()
     assert np.array_equal(wd[:, C:2 * C], o)
     assert (wd[:, :C] == 7).all() and (wd[:, 2 * C:] == 7).all()
-    out_b, _ = gpu.tblock_tail(gpu.to_dev(a1), gpu.to_dev(x0), dw, kp, vtp, Tk, heads, 40 ** -0.5, M, xin=gpu.to_dev(xin))
+    out_b, _ = gpu.tblock_tail(gpu.to_dev(a1), gpu.to_dev(x0), dw, kp, vtp, Tk, heads, 40 ** -0.5, M, xin=gpu.to_dev(xin), rows_per_block=rows)
     assert np.array_equal(out_b.numpy(), o)           # relaunch: same bits
 
 
 def test_tblock_tail_rejects_what_it_does_not_take(gpu):
     assert gpu.lib.osg_tblock_tail_supported(8192, 4096, 640, 8, 77) == 0
     assert gpu.lib.osg_tblock_tail_supported(100, 100, 320, 8, 77) == 0
+    assert gpu.lib.osg_tblock_tail_supported(96, 32, 320, 8, 77) == 1
+    assert gpu.lib.osg_tblock_tail_supported(96, 48, 320, 8, 77) == 0
     assert gpu.lib.osg_tblock_tail_supported(128, 64, 320, 8, 81) == 0

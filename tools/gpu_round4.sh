@@ -1,0 +1,59 @@
+#!/bin/bash
+# Dev tool (GPU box), round 4: ONE parameterised runner instead of a one-shot script per gpurun call.  usage: gpu_round4.sh <recipe> [args]; several recipes: "a,b,c"
+#   tests            the whole GPU suite + smoke()
+#   bench            the default bench line + per-launch breakdown           -> gpurun_out/r04_bench.json, r04_breakdown.txt
+#   ab "<A>" "<B>"   bench.py with flag set A vs flag set B, alternating 2x   (e.g. ab "" "--no-tblock-fuse")
+#   configs          the other BASELINE configs: SDXL, 4 prompts, W8A16, W8A16 resident codes, W8A8 VAE
+#   tworank          the N = 2 flow on one GPU (OSA_BENCH_ONE_GPU=1, gloo): line format, frozen shipped tune table on both ranks
+#   prof             rocprofv3 --kernel-trace --stats of the bench command + the in-graph timeline (tools/graph_trace.py)
+#   pmc              per-kernel counters of the timed plan, each set in its own --pmc pass (tools/pmc_round4.sh)
+#   tailprobe        osg_tblock_tail: per-launch time (cold / hot weights) + stage stamps for 64- / 32-row blocks, 1 / 2 weight tiles ahead, with / without prefetching workgroups
+#   tailtests        the tail kernel's tests + the golden chains
+#   abenv "<env A>" "<env B>" ...  bench.py under each environment (X=1 Y=2 strings; use a dummy variable for 'default'), alternating 2x
+mkdir -p gpurun_out; export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-.}
+T=gpurun_out/r04
+line() { python -c "import json,sys; d=json.load(open('$1')); c=d['config']; print('$2', 'ms_per_step', d['ms_per_step'], 'value', d['value'], d['unit'], 'launches', c.get('launches_per_step'), 'unet_device_ms', c.get('unet_device_ms_per_step'), 'windows', (c.get('windows_ms_per_step') or {}).get('each'), 'frac', (d.get('roofline') or {}).get('frac'))"; }
+IFS=',' read -ra RECIPES <<< "$1"; shift; ARGS=("$@")
+for R in "${RECIPES[@]}"; do case $R in
+tests)
+  timeout 1200 python -m pytest tests -m gpu -x -q > ${T}_pytest_gpu.log 2>&1; tail -3 ${T}_pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > ${T}_smoke.log 2>&1; tail -2 ${T}_smoke.log ;;
+bench)
+  export OSG_TUNE_CACHE=/tmp/osg_tune_cache.txt; rm -f $OSG_TUNE_CACHE; cp onnxstream_amd/tune/mi355x.txt $OSG_TUNE_CACHE
+  timeout 900 python bench.py --breakdown ${T}_breakdown.txt > ${T}_bench.json 2> ${T}_bench.err; cat ${T}_bench.json; tail -2 ${T}_bench.err; head -16 ${T}_breakdown.txt ;;
+ab)
+  for i in 1 2; do
+    timeout 600 python bench.py --cpu-passes 0 --windows 2 ${ARGS[0]} > ${T}_ab_A_$i.json 2> ${T}_ab_A_$i.err; line ${T}_ab_A_$i.json "A [${ARGS[0]}]"
+    timeout 600 python bench.py --cpu-passes 0 --windows 2 ${ARGS[1]} > ${T}_ab_B_$i.json 2> ${T}_ab_B_$i.err; line ${T}_ab_B_$i.json "B [${ARGS[1]}]"
+  done ;;
+configs)
+  timeout 900 python bench.py --config SDXL --steps-per-image 10 --steps 20 --warmup 2 --cpu-passes 0 > ${T}_bench_sdxl.json 2> ${T}_bench_sdxl.err; line ${T}_bench_sdxl.json "SDXL 1024x1024 10-step"
+  timeout 600 python bench.py --prompts-per-gpu 4 --cpu-passes 0 > ${T}_bench_p4.json 2> ${T}_bench_p4.err; line ${T}_bench_p4.json "4 prompts per GPU"
+  timeout 600 python bench.py --quant-weights --cpu-passes 0 > ${T}_bench_w8a16.json 2> ${T}_bench_w8a16.err; line ${T}_bench_w8a16.json "W8A16 (dequantised at load)"
+  timeout 600 python bench.py --quant-weights --w8-resident --cpu-passes 0 > ${T}_bench_w8res.json 2> ${T}_bench_w8res.err; line ${T}_bench_w8res.json "W8A16 resident codes"
+  timeout 300 python bench.py --config VAE_QU8 --steps 20 --warmup 3 > ${T}_bench_vae_qu8.json 2> ${T}_bench_vae_qu8.err; cut -c1-300 ${T}_bench_vae_qu8.json ;;
+tworank)
+  OSA_BENCH_ONE_GPU=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --steps 20 --warmup 2 --cpu-passes 0 --profile-reps 0 > ${T}_two_rank.json 2> ${T}_two_rank.err
+  echo "two ranks on one GPU: exit $?"; tail -3 ${T}_two_rank.err; cut -c1-700 ${T}_two_rank.json ;;
+prof)
+  export OSG_TUNE_CACHE=/tmp/osg_tune_cache.txt; [ -s $OSG_TUNE_CACHE ] || cp onnxstream_amd/tune/mi355x.txt $OSG_TUNE_CACHE
+  rm -rf /tmp/prof_f
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_f -o fin -- python bench.py --steps 20 --warmup 2 --cpu-passes 0 --profile-reps 1 --windows 0 > ${T}_rocprof.log 2>&1
+  echo "rocprofv3 exit $?"; grep -c "Memory access fault" ${T}_rocprof.log
+  for f in $(find /tmp/prof_f -name "*kernel_stats.csv"); do cp $f ${T}_rocprofv3_kernel_stats.csv; done
+  python tools/graph_trace.py $(find /tmp/prof_f -name "*kernel_trace.csv" | head -1) > ${T}_graph_timeline.txt 2>&1; head -24 ${T}_graph_timeline.txt ;;
+pmc)
+  export OSG_TUNE_CACHE=/tmp/osg_tune_cache.txt; [ -s $OSG_TUNE_CACHE ] || cp onnxstream_amd/tune/mi355x.txt $OSG_TUNE_CACHE
+  bash tools/pmc_round4.sh r04_tuned_plan 2>&1 | tail -30 ;;
+tailprobe)
+  for cfg in "64 2 8" "32 2 8" "32 2 0" "32 3 8" "32 3 0" "64 2 0"; do set -- $cfg; echo "== rows per block $1, weight tiles in flight $(($2 - 1)), prefetching workgroups $3"
+    ROWS=$1 OSG_TBLOCK_NS=$2 OSG_TBLOCK_PREFETCH=$3 REPS=2 timeout 300 python tools/tblock_tail_probe.py 2>&1 | grep -v "^$"; done > ${T}_tail_probe.log 2>&1; cat ${T}_tail_probe.log ;;
+kerneltests)   # kerneltests "<pytest -k expression>": part of tests/test_gpu_kernels.py
+  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "${ARGS[0]}" > ${T}_kernel_tests.log 2>&1; tail -4 ${T}_kernel_tests.log ;;
+tailtests)
+  timeout 900 python -m pytest tests/test_tblock_tail.py tests/test_golden.py -m gpu -x -q -k "tblock or chains" > ${T}_tail_tests.log 2>&1; tail -4 ${T}_tail_tests.log ;;
+abenv)   # abenv "<env A>" "<env B>" [more env sets ...]: bench.py under each environment, alternating 2x
+  for i in 1 2; do n=0; for e in "${ARGS[@]}"; do n=$((n + 1))
+    env $e timeout 600 python bench.py --cpu-passes 0 --windows 2 > ${T}_abenv_${n}_$i.json 2> ${T}_abenv_${n}_$i.err; line ${T}_abenv_${n}_$i.json "[$e]"; done; done ;;
+*) echo "unknown recipe $R" ;;
+esac; done

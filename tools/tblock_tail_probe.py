@@ -17,6 +17,8 @@ def main():
     C, heads, M, imgs, Tk = 320, 8, 8192, 2, 77
     nsets = int(os.environ.get("NSETS", "96"))
     reps = int(os.environ.get("REPS", "3"))
+    rows = int(os.environ.get("ROWS", "0"))        # rows per block: 0 = the library's choice, 32, 64
+    print(f"rows per block: {rows or 'library choice'}")
     rng = np.random.default_rng(0)
     sets = []
     w0 = t.make_block(rng, C)
@@ -30,7 +32,7 @@ def main():
     for proj in (True, False):
         for name, ns in (("cold", nsets), ("hot", 1)):
             for _ in range(2):
-                gpu.tblock_tail(a1, x0, sets[0] if proj else {**sets[0], 'wpo': None, 'bpo': None}, kp, vtp, Tk, heads, scale, M // imgs, xin=xin if proj else None, out=out)
+                gpu.tblock_tail(a1, x0, sets[0] if proj else {**sets[0], 'wpo': None, 'bpo': None}, kp, vtp, Tk, heads, scale, M // imgs, xin=xin if proj else None, out=out, rows_per_block=rows)
             gpu.sync()
             gpu.timer_start()
             n = 0
@@ -39,19 +41,20 @@ def main():
                     w = dict(sets[i % ns])
                     if not proj:
                         w["wpo"] = w["bpo"] = None
-                    gpu.tblock_tail(a1, x0, w, kp, vtp, Tk, heads, scale, M // imgs, xin=xin if proj else None, out=out)
+                    gpu.tblock_tail(a1, x0, w, kp, vtp, Tk, heads, scale, M // imgs, xin=xin if proj else None, out=out, rows_per_block=rows)
                     n += 1
             ms = gpu.timer_stop()
             print(f"fused tail proj_out={int(proj)} {name}: {1000 * ms / n:.1f} us per launch ({n} launches)")
     # ---- where a row block's time goes: wall-clock stamps of every stage (dbg[7]), cold weights
-    st = gpu.to_dev(np.zeros((M // 64, 32), np.int64))
+    st = gpu.to_dev(np.zeros((M // 32, 32), np.int64))
     names = ["rows landed", "to_out1", "LN", "to_q", "cross-attn", "to_out2", "LN", "GEGLU chunk 0", "chunks 1..9 (+ff2 0..8)", "ff2 chunk 9", "x3 -> LDS", "proj_out", "stores drained"]
     acc = np.zeros(13)
     inner = np.zeros(15)
     nrep = 8
     for i in range(nrep):
-        gpu.tblock_tail(a1, x0, sets[(7 * i + 3) % nsets], kp, vtp, Tk, heads, scale, M // imgs, xin=xin, out=out, stamps=st)
+        gpu.tblock_tail(a1, x0, sets[(7 * i + 3) % nsets], kp, vtp, Tk, heads, scale, M // imgs, xin=xin, out=out, stamps=st, rows_per_block=rows)
         s = st.numpy().astype(np.float64)
+        s = s[s[:, 0] != 0]                                    # (M / 32 slots: 64-row blocks fill the first half)
         acc += (s[:, 1:14] - s[:, 0:13]).mean(0) / 100.0      # 100 MHz -> us
         tot = (s[:, 13] - s[:, 0]) / 100.0
         inner += (s[:, 17:32] - s[:, 16:31]).mean(0) / 100.0
@@ -64,7 +67,7 @@ def main():
     for n, v in zip(inames, inner / nrep):
         print(f"    {n:36s} {v:7.2f}")
     print(f"  row block entry -> drained: mean {tot.mean():.1f}, min {tot.min():.1f}, max {tot.max():.1f}; first entry -> last drained {span:.1f} us (last launch)")
-    if os.environ.get("SKIP_SEP"):
+    if os.environ.get("SKIP_SEP", "1" if rows else ""):
         return
     # the separate chain, same weights (hot and cold)
     q3shape = (imgs, M // imgs, C)
