@@ -232,6 +232,24 @@ typedef struct {
 } osg_tblock_tail_args;
 int osg_tblock_tail_supported(int M, int rows_per_img, int C, int heads, int Tk); /* 1 = osg_tblock_tail takes the shape */
 int osg_tblock_tail(osg_ctx* ctx, const osg_tblock_tail_args* a);
+/* Cross-attention with its query projection inside (osg_tchain.hip), for the levels the tail above does not take (C = 640 / 1280, 8 heads):
+ *   out[:, h D .. h D + D) = softmax(scale (LayerNorm(x; gamma, beta, eps) . Wq_h^T + bq_h) k_h^T) v_h        per head h, D = C / heads
+ * = the 9-op LayerNorm chain (onnxstream.cpp:5237-5604) + MatMul (:5669-5861) + AttentionFusedOps (:6696-6929) of attn2, one workgroup per (32 rows, head).
+ * x [M][C] rows ldx elements apart (0 = C), wq in the kn8 layout of osg_tblock_pack_weight (from [C][C] = [N][K]), bq may be NULL, kp / vtp from
+ * osg_tblock_kv_pack(_jobs) with head dim D, out [M][C] rows ldo apart (0 = C).  M = images x rows_per_img, both multiples of 32; Tk <= 80.
+ * f16 everywhere, f32 accumulation, q rounded to f16 as the separate launch rounds it.  dbg_q (may be NULL): dense [M][C] dump of q (tests). */
+typedef struct {
+  const void* x; long ldx;
+  const void *gamma, *beta; float eps;
+  const void *wq, *bq;
+  const void *kp, *vtp;
+  float scale; int Tk;
+  void* out; long ldo;
+  int M, rows_per_img, C, heads;
+  void* dbg_q;
+} osg_qattn_args;
+int osg_qattn_supported(int M, int rows_per_img, int C, int heads, int Tk);
+int osg_qattn(osg_ctx* ctx, const osg_qattn_args* a);
 /* The LEAN linear launch (osg_linsmall.hip): y[M,N] = [LayerNorm(x; gamma, beta, eps)] . W^T + bias + residual for the projections of the transformer blocks and
  * the 1x1 convolutions (MatMul + Add (+ Add) onnxstream.cpp:5669-5861, :3906-4000; the LayerNorm chain :5237-5604; 1x1 Conv :4494-4707): the
  * workgroup's whole row block in LDS, every operand requested at entry, weights streamed global -> registers from the kn8 layout of
@@ -250,7 +268,7 @@ int osg_tblock_pack_weight(osg_ctx* ctx, const void* w_nk, int N, int K, void* w
 /* K / V of cross-attentions re-packed for osg_tblock_tail, several blocks per launch.  All of them are column ranges of ONE matrix `base` ([imgs * Tk] rows
  * ld apart -- the merged K|V projection of the text context): job j = jobs_dev[4 j .. 4 j + 3] = {column of K, column of V, head dim D, element offset of
  * its packs inside dst}; head h sits h D columns further in.  At dst + offset: kp [img][head][80][DP], then vtp [img][head][DP][80] (V transposed),
- * DP = D rounded up to 16, zero padding.  osg_tblock_kv_pack_elems = f16 elements of EACH of the two packs of a job. */
+ * DP = D rounded up to 16, zero padding.  ld, the columns and D are multiples of 8 (16-byte chunks).  osg_tblock_kv_pack_elems = f16 elements of EACH of the two packs of a job. */
 size_t osg_tblock_kv_pack_elems(int imgs, int heads, int D);
 int osg_tblock_kv_pack_jobs(osg_ctx* ctx, const void* base, long ld, int imgs, int Tk, int heads, int njobs, const int* jobs_dev, void* dst);
 /* ScaledDotProductAttention == the reference's pseudo-op of that name (formed at run time from Transpose/MatMul/Div/Add/Softmax/MatMul or

@@ -275,6 +275,7 @@ struct Plan {
     bool fuse_ln_gemm = false;
     bool concat_views = true;     // m_hip_concat_views
     bool fuse_tblock = true;      // m_hip_fuse_tblock
+    bool fuse_qattn = true;       // m_hip_fuse_qattn
     bool small_linear = false;    // m_hip_small_linear != 0
     int small_linear_req = 0;     // m_hip_small_linear as requested
     bool in_flight = false;       // a pass of this plan may still be running on the device (set while execute() / replay() are between enqueue and wait)

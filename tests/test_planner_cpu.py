@@ -164,7 +164,7 @@ def test_full_size_sd15_plan(stub_backend):
         sd_unet.build_unet(DirSink(d), sd_unet.SD15)
         open(d + ".complete", "w").write("ok")
     ins = sd_unet.unet_inputs(sd_unet.SD15, 42)
-    m, info = _plan(d, ins, (("hip_side_stream", 1), ("hip_fuse_ln_gemm", 0), ("hip_fuse_tblock", 0)), pushes=2)
+    m, info = _plan(d, ins, (("hip_side_stream", 1), ("hip_fuse_ln_gemm", 0), ("hip_fuse_tblock", 0), ("hip_fuse_qattn", 0)), pushes=2)
     steps, vals, arena = _parse(info)
     m.close()
     assert len(steps) == 352                                    # (366 before round 3; the two time-embedding Gemm + SiLU pairs are one launch each; the 12 skip-connection Concats are no launches any more, see below)
@@ -176,7 +176,7 @@ def test_full_size_sd15_plan(stub_backend):
     assert arena < 400 * 2 ** 20                                # activations of a batch-2 pass pack into well under 400 MiB
     kinds = [s["what"].split(" ", 1)[0].split("+")[0] for s in steps]
     assert kinds.count("Attention") == 32 and kinds.count("GroupNorm") == 61 and kinds.count("LayerNorm") == 48
-    m, info = _plan(d, ins, (("hip_fuse_tblock", 0),), pushes=2)   # round 3's default plan: every LayerNorm folded into its consuming GEMM
+    m, info = _plan(d, ins, (("hip_fuse_tblock", 0), ("hip_fuse_qattn", 0)), pushes=2)   # round 3's default plan: every LayerNorm folded into its consuming GEMM
     steps_3 = _parse(info)[0]
     m.close()
     assert len(steps_3) == 304
@@ -186,13 +186,21 @@ def test_full_size_sd15_plan(stub_backend):
     m, info = _plan(d, ins, (), pushes=2)
     steps_d, vals_d, arena_d = _parse(info)
     m.close()
-    assert len(steps_d) == 304 - 5 * 6 + 1
+    # ... and at the other levels (640 / 1280 channels, where a row block's weights are too many) LayerNorm + to_q + cross-attention are one launch (osg_qattn):
+    # 11 blocks x (2 -> 1); their K / V come out of the same re-packing launch
+    assert len(steps_d) == 304 - 5 * 6 + 1 - 11
     tails = [s for s in steps_d if s["what"].startswith("TBlockTail+proj_out ")]
-    packs = [s for s in steps_d if s["what"].startswith("KVPack x5 ")]
-    assert len(tails) == 5 and len(packs) == 1 and all(s["i"] > packs[0]["i"] for s in tails)
-    assert all(packs[0]["writes"][0] in s["reads"] for s in tails)             # every tail reads the one pack buffer, which therefore lives until the last of them
-    assert vals_d[packs[0]["writes"][0]]["last"] == max(s["i"] for s in tails)
-    assert [s["what"].split(" ", 1)[0] for s in steps_d].count("Attention") == 32 - 5
+    qatts = [s for s in steps_d if s["what"].startswith("QAttention ")]
+    packs = [s for s in steps_d if s["what"].startswith("KVPack x16 ")]
+    assert len(tails) == 5 and len(qatts) == 11 and len(packs) == 1 and all(s["i"] > packs[0]["i"] for s in tails + qatts)
+    assert all(packs[0]["writes"][0] in s["reads"] for s in tails + qatts)     # every one of them reads the one pack buffer, which therefore lives until the last of them
+    assert vals_d[packs[0]["writes"][0]]["last"] == max(s["i"] for s in tails + qatts)
+    assert [s["what"].split(" ", 1)[0] for s in steps_d].count("Attention") == 32 - 16
+    assert not any("attn2/to_q" in s["what"] for s in steps_d)
+    m, info = _plan(d, ins, (("hip_fuse_qattn", 0),), pushes=2)
+    steps_q = _parse(info)[0]
+    m.close()
+    assert len(steps_q) == 304 - 5 * 6 + 1 and sum(s["what"].startswith("KVPack x5 ") for s in steps_q) == 1
     _check_arena(steps_d, vals_d, arena_d)
     # round 3: every skip-connection Concat of the up path is gone -- both of its operands come straight out of convolutions, which store into their
     # column slice of the concatenated buffer themselves (osg_conv2d_nhwc_v): 24 convolutions carry the mark, the only Concat launch left is the
@@ -210,7 +218,7 @@ def test_full_size_sd15_plan(stub_backend):
     assert len(cat_vals) == 12 and all(len(v) == 2 for v in cat_vals.values())
     for v, writers in cat_vals.items():
         assert vals_d[v]["first"] == min(writers) and vals_d[v]["last"] > max(writers)
-    m, info = _plan(d, ins, (("hip_concat_views", 0), ("hip_fuse_tblock", 0)), pushes=2)
+    m, info = _plan(d, ins, (("hip_concat_views", 0), ("hip_fuse_tblock", 0), ("hip_fuse_qattn", 0)), pushes=2)
     steps_o = _parse(info)[0]
     m.close()
     assert len(steps_o) == 316 and [s["what"].split(" ", 1)[0] for s in steps_o].count("Concat") == 13
@@ -544,15 +552,15 @@ def test_lean_linear_route_plan(stub_backend):
         m, info = _plan(d, ins, (("hip_small_linear", mode),), pushes=2)
         steps, vals, arena = _parse(info)
         m.close()
-        assert len(steps) == 275
+        assert len(steps) == 264
         _check_arena(steps, vals, arena)
         what = [s["what"] for s in steps]
         counts[mode] = sum("[lean]" in w for w in what)
         if mode == 2:
-            assert sum(w.startswith("Linear ln ") and "[lean]" in w for w in what) >= 20          # LayerNorm inside the launch
+            assert sum(w.startswith("Linear ln ") and "[lean]" in w for w in what) >= 16          # LayerNorm inside the launch (the attn2.to_q ones are part of QAttention launches)
             assert not any("ln+" in w and "GEGLU" not in w for w in what)                          # what still folds a LayerNorm is the GEGLU projection only ...
             assert sum("[lean] +rowstats" in w for w in what) == 11                                # ... fed by the lean attn2.to_out launches of the 640- and 1280-wide blocks
-    assert counts[0] == 0 and 0 < counts[1] < counts[2] and counts[2] >= 85
+    assert counts[0] == 0 and 0 < counts[1] < counts[2] and counts[2] >= 75
 
 
 def test_group_norm_statistics_from_producers_plan(stub_backend):
@@ -571,6 +579,7 @@ def test_group_norm_statistics_from_producers_plan(stub_backend):
         if on is not None:
             m._set_option("hip_gn_stats", on)
         m._set_option("hip_fuse_tblock", 0)       # (a block tail fused into one launch cannot add statistics up: tested below)
+        m._set_option("hip_fuse_qattn", 0)
         m.read_file(d + "model.txt")
         for i in (sd_unet.unet_inputs(cfg, 42), sd_unet.unet_inputs(cfg, 43)):
             for k, v in i.items():
@@ -602,7 +611,7 @@ def test_group_norm_statistics_from_producers_plan(stub_backend):
     m.run()
     what = [s["what"] for s in _parse(m.hip_plan_info())[0]]
     m.close()
-    assert len(what) == 275 and 10 <= sum(w.startswith("GroupNorm stats<") for w in what) < 31
+    assert len(what) == 264 and 10 <= sum(w.startswith("GroupNorm stats<") for w in what) < 31
     assert all(w.startswith("Conv ") for w in what if "+gnstats" in w) and not any("+gnstats" in w for w in what if w.startswith("TBlockTail"))
 
 

@@ -9,6 +9,7 @@
 #   pmc              per-kernel counters of the timed plan, each set in its own --pmc pass (tools/pmc_round4.sh)
 #   tailprobe        osg_tblock_tail: per-launch time (cold / hot weights) + stage stamps for 64- / 32-row blocks, 1 / 2 weight tiles ahead, with / without prefetching workgroups
 #   tailtests        the tail kernel's tests + the golden chains
+#   qattn            osg_qattn: tests, golden chains, probe against the separate launches
 #   abenv "<env A>" "<env B>" ...  bench.py under each environment (X=1 Y=2 strings; use a dummy variable for 'default'), alternating 2x
 mkdir -p gpurun_out; export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-.}
 T=gpurun_out/r04
@@ -50,6 +51,9 @@ tailprobe)
     ROWS=$1 OSG_TBLOCK_NS=$2 OSG_TBLOCK_PREFETCH=$3 REPS=2 timeout 300 python tools/tblock_tail_probe.py 2>&1 | grep -v "^$"; done > ${T}_tail_probe.log 2>&1; cat ${T}_tail_probe.log ;;
 kerneltests)   # kerneltests "<pytest -k expression>": part of tests/test_gpu_kernels.py
   timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "${ARGS[0]}" > ${T}_kernel_tests.log 2>&1; tail -4 ${T}_kernel_tests.log ;;
+qattn)   # osg_qattn: its tests, the golden chains, the probe
+  timeout 900 python -m pytest tests/test_qattn.py tests/test_golden.py -m gpu -x -q -k "qattn or chains" > ${T}_qattn_tests.log 2>&1; tail -12 ${T}_qattn_tests.log
+  timeout 300 python tools/qattn_probe.py > ${T}_qattn_probe.log 2>&1; cat ${T}_qattn_probe.log ;;
 tailtests)
   timeout 900 python -m pytest tests/test_tblock_tail.py tests/test_golden.py -m gpu -x -q -k "tblock or chains" > ${T}_tail_tests.log 2>&1; tail -4 ${T}_tail_tests.log ;;
 abenv)   # abenv "<env A>" "<env B>" [more env sets ...]: bench.py under each environment, alternating 2x
