@@ -777,9 +777,9 @@ __global__ __launch_bounds__(256) void qattn_kernel(QAttnParams p) {
 #pragma unroll
         for (int j = 0; j < NT; j++) bb[j] = ldb(u_w, lo, (wave * KSW + s) * KSTEP + j * 256);
     };
-    static_for<PD>([&](auto sc) __attribute__((always_inline)) { request(b[decltype(sc)::value], decltype(sc)::value); });
 
-    // ---- the rows (LDS-DMA, swizzle on the source side) and the LayerNorm vectors -------------------------------------------------------------
+    // ---- the rows (LDS-DMA, swizzle on the source side) and the LayerNorm vectors FIRST, the first PD k-steps of weight fragments right behind them:
+    // vector-memory results return in order, so "all but the last PD NT requests have landed" = the rows are in LDS -- LayerNorm runs while the weights fly
     {
         __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + row0 * p.ldx), 0, (int)((RB - 1) * p.ldx * 2 + C * 2), 0x00020000);
         const int rsub = lane >> 3, gch = (lane & 7) ^ rsub;
@@ -789,12 +789,22 @@ __global__ __launch_bounds__(256) void qattn_kernel(QAttnParams p) {
             const unsigned off = (unsigned)(((q8 * 8 + rsub) * p.ldx + kt * 64 + gch * 8) * 2);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr)(XI + kt * TB + q8 * 1024), 16, off, 0, 0, 0);
         }
-        for (int i = tid; i < 2 * C / 8; i += 256) {
-            const f16* src = i < C / 8 ? p.gamma + i * 8 : p.beta + (i - C / 8) * 8;
-            *reinterpret_cast<f16x8*>(VEC + i * 16) = *reinterpret_cast<const f16x8*>(src);
+        constexpr int NV = (2 * C / 8 + 255) / 256;
+        f16x8 vv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            const int c = min(tid + i * 256, 2 * C / 8 - 1);
+            vv[i] = *reinterpret_cast<const f16x8*>((c < C / 8 ? p.gamma + c * 8 : p.beta + (c - C / 8) * 8));
         }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<PD>([&](auto sc) __attribute__((always_inline)) { request(b[decltype(sc)::value], decltype(sc)::value); });
+        __builtin_amdgcn_sched_barrier(0);
+        static_assert(PD * NT <= 63, "vmcnt");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * NT) : "memory");
+#pragma unroll
+        for (int i = 0; i < NV; i++)
+            if (tid + i * 256 < 2 * C / 8) *reinterpret_cast<f16x8*>(VEC + (tid + i * 256) * 16) = vv[i];
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     ln_rows_wide<RT, C>(XI, VEC, VEC + C * 2, p.eps, tid);
     __builtin_amdgcn_s_barrier();
