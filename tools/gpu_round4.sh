@@ -4,7 +4,7 @@
 #   bench            the default bench line + per-launch breakdown           -> gpurun_out/r04_bench.json, r04_breakdown.txt
 #   ab "<A>" "<B>"   bench.py with flag set A vs flag set B, alternating 2x   (e.g. ab "" "--no-tblock-fuse")
 #   configs          the other BASELINE configs: SDXL, 4 prompts, W8A16, W8A16 resident codes, W8A8 VAE
-#   tworank          the N = 2 flow on one GPU (OSA_BENCH_ONE_GPU=1, gloo): line format, frozen shipped tune table on both ranks
+#   tworank          the N = 2 flow on one GPU (OSA_BENCH_ONE_GPU=1, gloo), as the driver launches it (no OSG_TUNE_CACHE in the environment): line format, frozen shipped tune table on both ranks
 #   prof             rocprofv3 --kernel-trace --stats of the bench command + the in-graph timeline (tools/graph_trace.py)
 #   pmc              per-kernel counters of the timed plan, each set in its own --pmc pass (tools/pmc_round4.sh)
 #   tailprobe        osg_tblock_tail: per-launch time (cold / hot weights) + stage stamps for 64- / 32-row blocks, 1 / 2 weight tiles ahead, with / without prefetching workgroups
@@ -34,7 +34,7 @@ configs)
   timeout 600 python bench.py --quant-weights --w8-resident --cpu-passes 0 > ${T}_bench_w8res.json 2> ${T}_bench_w8res.err; line ${T}_bench_w8res.json "W8A16 resident codes"
   timeout 300 python bench.py --config VAE_QU8 --steps 20 --warmup 3 > ${T}_bench_vae_qu8.json 2> ${T}_bench_vae_qu8.err; cut -c1-300 ${T}_bench_vae_qu8.json ;;
 tworank)
-  OSA_BENCH_ONE_GPU=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --steps 20 --warmup 2 --cpu-passes 0 --profile-reps 0 > ${T}_two_rank.json 2> ${T}_two_rank.err
+  OSA_BENCH_ONE_GPU=1 timeout 900 env -u OSG_TUNE_CACHE -u OSG_TUNE_FROZEN python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --steps 20 --warmup 2 --cpu-passes 0 --profile-reps 0 > ${T}_two_rank.json 2> ${T}_two_rank.err
   echo "two ranks on one GPU: exit $?"; tail -3 ${T}_two_rank.err; cut -c1-700 ${T}_two_rank.json ;;
 prof)
   export OSG_TUNE_CACHE=/tmp/osg_tune_cache.txt; [ -s $OSG_TUNE_CACHE ] || cp onnxstream_amd/tune/mi355x.txt $OSG_TUNE_CACHE
@@ -56,6 +56,9 @@ qattn)   # osg_qattn: its tests, the golden chains, the probe
   timeout 300 python tools/qattn_probe.py > ${T}_qattn_probe.log 2>&1; cat ${T}_qattn_probe.log ;;
 tailtests)
   timeout 900 python -m pytest tests/test_tblock_tail.py tests/test_golden.py -m gpu -x -q -k "tblock or chains" > ${T}_tail_tests.log 2>&1; tail -4 ${T}_tail_tests.log ;;
+p4rows)   # 4 prompts per GPU (M = 32 768 rows at the 64x64 level): 64- vs 32-row blocks in the tail kernel
+  for i in 1 2; do for r in 64 32; do
+    OSG_TBLOCK_ROWS=$r timeout 600 python bench.py --prompts-per-gpu 4 --cpu-passes 0 --windows 2 > ${T}_p4rows_${r}_$i.json 2> ${T}_p4rows_${r}_$i.err; line ${T}_p4rows_${r}_$i.json "[4 prompts, $r-row blocks]"; done; done ;;
 abenv)   # abenv "<env A>" "<env B>" [more env sets ...]: bench.py under each environment, alternating 2x
   for i in 1 2; do n=0; for e in "${ARGS[@]}"; do n=$((n + 1))
     env $e timeout 600 python bench.py --cpu-passes 0 --windows 2 > ${T}_abenv_${n}_$i.json 2> ${T}_abenv_${n}_$i.err; line ${T}_abenv_${n}_$i.json "[$e]"; done; done ;;
