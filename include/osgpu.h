@@ -232,7 +232,7 @@ typedef struct {
 } osg_tblock_tail_args;
 int osg_tblock_tail_supported(int M, int rows_per_img, int C, int heads, int Tk); /* 1 = osg_tblock_tail takes the shape */
 int osg_tblock_tail(osg_ctx* ctx, const osg_tblock_tail_args* a);
-/* Cross-attention with its query projection inside (osg_tchain.hip), for the levels the tail above does not take (C = 640 / 1280, 8 heads):
+/* Cross-attention with its query projection inside (osg_tchain.hip), for the levels the tail above does not take (C = 640 / 1280; 8 heads, or SDXL's 10 / 20 heads of 64):
  *   out[:, h D .. h D + D) = softmax(scale (LayerNorm(x; gamma, beta, eps) . Wq_h^T + bq_h) k_h^T) v_h        per head h, D = C / heads
  * = the 9-op LayerNorm chain (onnxstream.cpp:5237-5604) + MatMul (:5669-5861) + AttentionFusedOps (:6696-6929) of attn2, one workgroup per (32 rows, head).
  * x [M][C] rows ldx elements apart (0 = C), wq in the kn8 layout of osg_tblock_pack_weight (from [C][C] = [N][K]), bq may be NULL, kp / vtp from

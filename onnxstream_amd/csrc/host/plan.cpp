@@ -3786,6 +3786,11 @@ struct Lowering {
             a.scale = scale; a.Tk = (int)Tk;
             a.out = P.ptr(y); a.ldo = C;
             a.M = (int)M; a.rows_per_img = (int)T; a.C = (int)C; a.heads = (int)heads;
+            {   // (workgroups of different heads read the same rows of x while others already store their columns of the output: the two must not share memory)
+                const char *xb = (const char*)a.x, *yb = (const char*)a.out, *pb = (const char*)P.ptr(pack);
+                const size_t nbytes = (size_t)M * C * 2, pbytes = P.val_bytes(pack);
+                if ((xb < yb + nbytes && yb < xb + nbytes) || (pb < yb + nbytes && yb < pb + pbytes)) throw std::runtime_error(what + ": output overlaps an operand (arena packing)");
+            }
             be.check(be.api.osg_qattn(be.ctx, &a), what.c_str());
         });
         P.steps.back().flops = 2.0 * M * C * C + 4.0 * nb * heads * T * Tk * (C / heads);

@@ -464,6 +464,7 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
 #pragma unroll
                 for (int j = 0; j < TN; j++) red[(i * TN + j) * 64] = acc[i][j];
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (a bare s_barrier does not wait for the LDS writes above: osg_tchain.hip lds_barrier)
         __builtin_amdgcn_s_barrier();
         if (grp == 1) return;
 #pragma unroll

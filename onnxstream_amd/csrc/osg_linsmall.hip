@@ -20,6 +20,16 @@
 
 namespace osg_ls {
 
+// Workgroup barrier behind LDS writes.  A bare s_barrier does not wait for the wave's own outstanding LDS operations (gfx90a and later back off at barriers, so
+// hipcc inserts no s_waitcnt in front of one), and LDS requests of different SIMDs are not served in issue order: without the wait a wave past the barrier can
+// read what another wave has issued but the LDS has not yet written -- seen as run-to-run differences of osg_qattn at 10 heads of 64 on cold operands
+// (profiles/r04_qattn_lds_barrier_race.txt).  lgkmcnt only: vector-memory requests (weight fragments in flight) are deliberately NOT waited for.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+
 struct LinParams {
     const f16* x; long ldx;
     const f16* w;                 // kn8 [K/8][N][8]
@@ -160,10 +170,10 @@ __global__ __launch_bounds__(256) void linear_small_kernel(LinParams p) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();
     if constexpr (LN) {
         ln_rows_inplace<BM>(lds, GB, GB + K * 2, K, p.eps, tid);
-        __builtin_amdgcn_s_barrier();
+        lds_barrier();
     }
 
     // ---- the contraction: groups of D k steps; a slot is refilled with the step D further on as soon as its MFMAs are issued ----------------------

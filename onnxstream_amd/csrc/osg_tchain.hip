@@ -58,6 +58,16 @@ struct TailParams {
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
+// Workgroup barrier behind LDS writes.  A bare s_barrier does not wait for the wave's own outstanding LDS operations (gfx90a and later back off at barriers, so
+// hipcc inserts no s_waitcnt in front of one), and LDS requests of different SIMDs are not served in issue order: without the wait a wave past the barrier can
+// read what another wave has issued but the LDS has not yet written -- seen as run-to-run differences of osg_qattn at 10 heads of 64 on cold operands
+// (profiles/r04_qattn_lds_barrier_race.txt).  lgkmcnt only: vector-memory requests (weight fragments in flight) are deliberately NOT waited for.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): loop indices that ARE constants (not merely become constants once an unrolling pass
 // has run): the register slots bq[s % NS] below must be addressed with literal indices, or the array is left in scratch memory
 template <int I, int N, typename Fn>
@@ -511,7 +521,7 @@ __global__ __launch_bounds__(256, RT == 2 && NS == 2 ? 2 : 1) void tblock_tail_k
             }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();
     stamp(1);
 
     // ---- x1 = to_out(a1) + x0 ---------------------------------------------------------------------------------------------------------
@@ -524,11 +534,11 @@ __global__ __launch_bounds__(256, RT == 2 && NS == 2 ? 2 : 1) void tblock_tail_k
         epi_to_lds<RT, NTW, true>(acc, vec(V_BO1), nb, X, X, lane);
         stamp(22);
     }
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();
     stamp(2);
     dump_img<RT, C>(X, p.dbg[0], row0, tid);
     ln_rows<RT, C>(X, P, vec(V_G2), vec(V_BE2), p.eps2, tid);
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();
     stamp(3);
     dump_img<RT, C>(P, p.dbg[1], row0, tid);
 
@@ -540,7 +550,7 @@ __global__ __launch_bounds__(256, RT == 2 && NS == 2 ? 2 : 1) void tblock_tail_k
                                    [&](f16x8 (&b)[10], int j) __attribute__((always_inline)) { ld_cc(b, u_o2, j); });
         epi_to_lds<RT, NTW, false>(acc, vec(V_BQ2), nb, nullptr, R, lane);
     }
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();
     stamp(4);
     dump_img<RT, C>(R, p.dbg[2], row0, tid);
 
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(256, RT == 2 && NS == 2 ? 2 : 1) void tblock_tail_k
         const long per_img = (long)p.heads * TKP * DP;
         cross_attention<RT, D, TKT>(R, P, p.kp + img * per_img, p.vtp + img * per_img, wave * hpw, hpw, p.sc_log2e, p.Tk, lane);
     }
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();
     stamp(5);
     dump_img<RT, C>(P, p.dbg[3], row0, tid);
 
@@ -563,11 +573,11 @@ __global__ __launch_bounds__(256, RT == 2 && NS == 2 ? 2 : 1) void tblock_tail_k
                                     [&](f16x8 (&b)[10], int j) __attribute__((always_inline)) { ld_ff(b, 0, j); });
         epi_to_lds<RT, NTW, true>(acc, vec(V_BO2), nb, X, X, lane);
     }
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();
     stamp(6);
     dump_img<RT, C>(X, p.dbg[4], row0, tid);
     ln_rows<RT, C>(X, P, vec(V_G3), vec(V_BE3), p.eps3, tid);
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();
     stamp(7);
     dump_img<RT, C>(P, p.dbg[5], row0, tid);
 
@@ -600,7 +610,7 @@ __global__ __launch_bounds__(256, RT == 2 && NS == 2 ? 2 : 1) void tblock_tail_k
         gemm_stage<RT, KT, 4, S0, NS>(P, a_rd, bq, accG, [&](f16x8 (&b)[10], int t) __attribute__((always_inline)) { ld_ff(b, 0, t); },
                                   [&](f16x8 (&b)[10], int j) __attribute__((always_inline)) { ld_ff(b, 1, j); });
         geglu_store(0);
-        __builtin_amdgcn_s_barrier();
+        lds_barrier();
         stamp(8);
         // iteration c >= 1: projection of chunk c, then ff.net.2 over chunk c - 1 beside the GEGLU arithmetic of chunk c.  Its tile `pos` sits in slot
         // (ST + pos) % NS; the request that goes out with it is position pos + AH of this iteration, or of the next one (the last iteration is followed by
@@ -636,7 +646,7 @@ __global__ __launch_bounds__(256, RT == 2 && NS == 2 ? 2 : 1) void tblock_tail_k
             if (c == 3) stamp(25); else if (c == 4) stamp(29);
             geglu_store(c);
             if (c == 3) stamp(26); else if (c == 4) stamp(30);
-            __builtin_amdgcn_s_barrier();
+            lds_barrier();
             if (c == 2) stamp(23); else if (c == 3) stamp(27); else if (c == 4) stamp(31);
         };
         constexpr int B0 = (S0 + KT) % NS;          // slot of the first tile of iteration 1; iteration c starts at (B0 + (c - 1) PER) % NS = (B0 + c - 1) % NS
@@ -682,7 +692,7 @@ __global__ __launch_bounds__(256, RT == 2 && NS == 2 ? 2 : 1) void tblock_tail_k
         for (int j = 0; j < NTW; j++) rg[i][j] = *reinterpret_cast<const f16x4*>(p.xin + (row0 + i * 16 + l16) * C + nb + j * 16 + g * 4);
     // x3 into P (every wave is past its last read of LN(x2): the barrier of the last chunk), then y = proj_out(x3) + x_in
     epi_to_lds<RT, NTW, true>(accY, vec(V_B2), nb, X, P, lane);
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();
     stamp(11);
     dump_img<RT, C>(P, p.dbg[6], row0, tid);
     {
@@ -805,9 +815,9 @@ __global__ __launch_bounds__(256) void qattn_kernel(QAttnParams p) {
         for (int i = 0; i < NV; i++)
             if (tid + i * 256 < 2 * C / 8) *reinterpret_cast<f16x8*>(VEC + (tid + i * 256) * 16) = vv[i];
     }
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();
     ln_rows_wide<RT, C>(XI, VEC, VEC + C * 2, p.eps, tid);
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();
 
     // ---- partial q_h over this wave's k-steps ----------------------------------------------------------------------------------------------
     f32x4 acc[RT][NT];
@@ -847,7 +857,7 @@ __global__ __launch_bounds__(256) void qattn_kernel(QAttnParams p) {
                 for (int tt = 0; tt < TKT; tt++) vf[dt][tt] = *reinterpret_cast<const f16x4*>(vh + (dt * 16 + l16) * TKP + tt * 16 + g * 4);
         }
     }
-    __builtin_amdgcn_s_barrier();              // every wave is past its last read of the rows
+    lds_barrier();              // every wave is past its last read of the rows
     {
         float* PS = reinterpret_cast<float*>(XI) + wave * (RB * D);
 #pragma unroll
@@ -855,7 +865,7 @@ __global__ __launch_bounds__(256) void qattn_kernel(QAttnParams p) {
 #pragma unroll
             for (int j = 0; j < NT; j++) *reinterpret_cast<f32x4*>(PS + (i * 16 + l16) * D + j * 16 + g * 4) = acc[i][j];
     }
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();
     for (int idx = tid; idx < RB * D / 4; idx += 256) {
         const int m = idx / (D / 4), n = (idx - m * (D / 4)) * 4;
         const float* ps = reinterpret_cast<const float*>(XI) + m * D + n;
@@ -872,7 +882,7 @@ __global__ __launch_bounds__(256) void qattn_kernel(QAttnParams p) {
         *reinterpret_cast<f16x4*>(QI + img_off<RT>(m, n)) = o;
         if (p.dbg_q) *reinterpret_cast<f16x4*>(p.dbg_q + (row0 + m) * C + h * D + n) = o;
     }
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();
     if (!att) return;
 
     // ---- attention of row tile `wave` (cross_attention's arithmetic) ------------------------------------------------------------------------
@@ -1014,7 +1024,13 @@ int osg_tblock_tail(osg_ctx* ctx, const osg_tblock_tail_args* a) {
 }
 
 int osg_qattn_supported(int M, int rows_per_img, int C, int heads, int Tk) {
-    return (C == 640 || C == 1280) && heads == 8 && M > 0 && M % 32 == 0 && rows_per_img % 32 == 0 && Tk >= 1 && Tk <= 80;
+    // (SD 1.5 / 2.x: 8 heads of 80 / 160; SDXL: 10 / 20 heads of 64)
+    const bool shape = (C == 640 && (heads == 8 || heads == 10)) || (C == 1280 && (heads == 8 || heads == 20));
+    // one workgroup per (32 rows, head) re-reads the rows and a head's weight slice: it pays while the launch is a handful of workgroups per CU (SD 1.5's 32x32 level:
+    // 512); at SDXL's sizes (2 560 / 1 280 workgroups) the tiled GEMM + the attention launch are faster (profiles/r04_sdxl_qattn_ab.txt: 32.6 against 30.5 ms per step)
+    static const bool any_size = getenv("OSG_QATTN_ANY_SIZE") != nullptr;     // dev knob (tools/qattn_repro.py)
+    if (!any_size && (long)(M / 32) * heads > 512) return 0;
+    return shape && M > 0 && M % 32 == 0 && rows_per_img % 32 == 0 && Tk >= 1 && Tk <= 80;
 }
 
 int osg_qattn(osg_ctx* ctx, const osg_qattn_args* a) {
@@ -1040,10 +1056,12 @@ int osg_qattn(osg_ctx* ctx, const osg_qattn_args* a) {
         hipLaunchKernelGGL(kern, dim3((unsigned)(a->M / 32), (unsigned)a->heads), dim3(256), smem, ctx->compute, p);
         return 0;
     };
-    static bool attr640 = false, attr1280 = false;
+    static bool attr640 = false, attr1280 = false, attr640x = false, attr1280x = false;
     int rc;
-    if (a->C == 640) rc = launch(osg_tb::qattn_kernel<640, 80>, 10 * 4096 + 2 * 4096 + 2 * 640 * 2, attr640);
-    else rc = launch(osg_tb::qattn_kernel<1280, 160>, 20 * 4096 + 3 * 4096 + 2 * 1280 * 2, attr1280);
+    if (a->C == 640 && a->heads == 8) rc = launch(osg_tb::qattn_kernel<640, 80>, 10 * 4096 + 2 * 4096 + 2 * 640 * 2, attr640);
+    else if (a->C == 640) rc = launch(osg_tb::qattn_kernel<640, 64>, 10 * 4096 + 1 * 4096 + 2 * 640 * 2, attr640x);
+    else if (a->heads == 8) rc = launch(osg_tb::qattn_kernel<1280, 160>, 20 * 4096 + 3 * 4096 + 2 * 1280 * 2, attr1280);
+    else rc = launch(osg_tb::qattn_kernel<1280, 64>, 20 * 4096 + 1 * 4096 + 2 * 1280 * 2, attr1280x);
     if (rc) return rc;
     OSG_LAUNCH_CHECK(ctx);
     return 0;

@@ -32,7 +32,7 @@ SPECIAL = {
     "osg_group_norm_conv3x3_supported": "{ (void)N; (void)H; (void)W; (void)Cin; (void)Cout; return 0; }",
     # (shape predicates and sizes the PLANNER branches on: the real library's answers, so the CPU tests see the plan a GPU box would build)
     "osg_tblock_tail_supported": "{ return C == 320 && heads == 8 && M > 0 && M % 32 == 0 && rows_per_img % 32 == 0 && Tk >= 1 && Tk <= 80; }",
-    "osg_qattn_supported": "{ return (C == 640 || C == 1280) && heads == 8 && M > 0 && M % 32 == 0 && rows_per_img % 32 == 0 && Tk >= 1 && Tk <= 80; }",
+    "osg_qattn_supported": "{ return ((C == 640 && (heads == 8 || heads == 10)) || (C == 1280 && (heads == 8 || heads == 20))) && (long)(M / 32) * heads <= 512 && M > 0 && M % 32 == 0 && rows_per_img % 32 == 0 && Tk >= 1 && Tk <= 80; }",
     "osg_linear_small_supported": """{
     (void)layer_norm;
     if (M <= 0 || N <= 0 || K <= 0 || K % 320 || K > 2560) return 0;

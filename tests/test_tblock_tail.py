@@ -154,6 +154,12 @@ def test_tblock_tail_second_destination_and_row_pitch(gpu, rows):
     assert (wd[:, :C] == 7).all() and (wd[:, 2 * C:] == 7).all()
     out_b, _ = gpu.tblock_tail(gpu.to_dev(a1), gpu.to_dev(x0), dw, kp, vtp, Tk, heads, 40 ** -0.5, M, xin=gpu.to_dev(xin), rows_per_block=rows)
     assert np.array_equal(out_b.numpy(), o)           # relaunch: same bits
+    # ... also with the operands evicted from the caches in between (workgroup barriers behind LDS writes: a missing wait shows on cold operands only)
+    scratch = gpu.empty((64 * 1024 * 1024,), f16)
+    for fillv in (1, 2, 3):
+        gpu._ck(gpu.lib.osg_memset(gpu.ctx, scratch.ptr, fillv, 128 * 1024 * 1024))
+        out_c, _ = gpu.tblock_tail(gpu.to_dev(a1), gpu.to_dev(x0), dw, kp, vtp, Tk, heads, 40 ** -0.5, M, xin=gpu.to_dev(xin), rows_per_block=rows)
+        assert np.array_equal(out_c.numpy(), o)
 
 
 def test_tblock_tail_rejects_what_it_does_not_take(gpu):

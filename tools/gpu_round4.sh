@@ -59,6 +59,10 @@ tailtests)
 p4rows)   # 4 prompts per GPU (M = 32 768 rows at the 64x64 level): 64- vs 32-row blocks in the tail kernel
   for i in 1 2; do for r in 64 32; do
     OSG_TBLOCK_ROWS=$r timeout 600 python bench.py --prompts-per-gpu 4 --cpu-passes 0 --windows 2 > ${T}_p4rows_${r}_$i.json 2> ${T}_p4rows_${r}_$i.err; line ${T}_p4rows_${r}_$i.json "[4 prompts, $r-row blocks]"; done; done ;;
+sdxlab)   # SDXL: the default plan against --no-qattn-fuse, alternating 2x; then the full-size SDXL parity test
+  for i in 1 2; do for f in "" "--no-qattn-fuse"; do
+    timeout 900 python bench.py --config SDXL --steps-per-image 10 --steps 20 --warmup 2 --cpu-passes 0 --windows 2 $f > ${T}_sdxlab_$i.json 2> ${T}_sdxlab_$i.err; line ${T}_sdxlab_$i.json "SDXL [$f]"; done; done
+  timeout 900 python -m pytest tests/test_fullsize.py -m gpu -x -q -s -k "sdxl" > ${T}_sdxl_fullsize.log 2>&1; tail -4 ${T}_sdxl_fullsize.log ;;
 abenv)   # abenv "<env A>" "<env B>" [more env sets ...]: bench.py under each environment, alternating 2x
   for i in 1 2; do n=0; for e in "${ARGS[@]}"; do n=$((n + 1))
     env $e timeout 600 python bench.py --cpu-passes 0 --windows 2 > ${T}_abenv_${n}_$i.json 2> ${T}_abenv_${n}_$i.err; line ${T}_abenv_${n}_$i.json "[$e]"; done; done ;;
