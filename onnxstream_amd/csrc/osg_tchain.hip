@@ -12,7 +12,8 @@
 //   [ y  = proj_out(x3) + x_in                            (the 1x1 Conv :4494-4707 behind the block, + the spatial residual Add) ]
 //
 // The round-3 plan ran this as 7 launches (141 us at the 64x64 level for 27.6 GFLOP = 11 us of matrix work; every launch lasts as long as ONE
-// workgroup).  Here ONE workgroup owns 64 token rows from a1 to y:
+// workgroup).  Here ONE workgroup owns a block of token rows from a1 to y -- 64 rows in the text below (RT = 4 row tiles per wave), 32 in the
+// variant the library picks while 64-row blocks would leave CUs without one (RT = 2: 50 KB of code instead of 84, one workgroup per CU at M = 8 192):
 //   * the row block lives in LDS between the contractions (three [64 x C] f16 images in the k-tiled, XOR-swizzled layout gemm2_kernel uses for its A
 //     tiles: fragment reads are the same conflict-free ds_read_b128), the [64 x 4C] GEGLU activation is never formed: it is produced 128 columns at a
 //     time and contracted against the matching 128-deep slice of ff.net.2 on the spot (accumulators of x3 stay in registers across the chunks);
@@ -28,6 +29,8 @@
 // launches it replaced (profiles/r04_tblock_tail_v1_ab.txt), whatever the prefetch depth.
 // Numerics: f32 accumulation in the order of gemm2_kernel's one-slice form, one RNE rounding per reference op boundary that survives fusion level 2
 // (x1, LN, q, a2, x2, LN, h, x3, y), scores / probabilities in f32 as attn_kernel keeps them.
+// Second kernel of this file: qattn_kernel -- LayerNorm + attn2.to_q + cross-attention of the 640- / 1280-wide blocks, one workgroup per (32 rows, head); see there.
+// Every workgroup barrier of this file is lds_barrier() (s_waitcnt lgkmcnt(0) + s_barrier): a bare s_barrier does not wait for LDS writes on gfx950.
 #include "osg_common.h"
 
 #include <cstdlib>
