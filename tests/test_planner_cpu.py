@@ -132,6 +132,35 @@ def test_every_golden_graph_plans_at_every_fusion_level(stub_backend, name):
     assert counts["f2+ln"] <= counts["f2"] and counts["f2+side"] == counts["f2"]
 
 
+def test_transformer_chain_plans(stub_backend):
+    """The two real-width transformer chains (tests/golden_cases.py CHAINS): at fusion level 2 the 320-wide one is proj_in, Q|K|V, self-attention and ONE osg_tblock_tail
+    launch; the 640-wide one keeps its launches except LayerNorm + attn2.to_q + cross-attention, which are ONE osg_qattn launch; each reads a K / V pack made by one
+    KVPack launch.  With the two fusions off the round-3 launches are back, and nothing else changes."""
+    want = {"transformer_block_320": ("TBlockTail+proj_out ", 7), "transformer_block_640": ("QAttention ", 2)}        # (prefix of the fused launch, launches it replaces)
+    for name, (prefix, replaced) in want.items():
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+        ins = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+        with tempfile.TemporaryDirectory() as d:
+            d += "/"
+            gc.emit(gc.by_name(name), DirSink(d))
+            m, info = _plan(d, ins, ())
+            steps, vals, arena = _parse(info)
+            m.close()
+            _check_arena(steps, vals, arena)
+            what = [s["what"] for s in steps]
+            fused = [s for s in steps if s["what"].startswith(prefix)]
+            packs = [s for s in steps if s["what"].startswith("KVPack x1 ")]
+            assert len(fused) == 1 and len(packs) == 1 and packs[0]["i"] < fused[0]["i"] and packs[0]["writes"][0] in fused[0]["reads"], what
+            assert sum(w.startswith("Attention ") for w in what) == 1                   # the self-attention
+            m, info = _plan(d, ins, (("hip_fuse_tblock", 0), ("hip_fuse_qattn", 0)))
+            steps0 = _parse(info)[0]
+            m.close()
+            what0 = [s["what"] for s in steps0]
+            assert not any(w.startswith(("TBlockTail", "QAttention", "KVPack")) for w in what0)
+            assert sum(w.startswith("Attention ") for w in what0) == 2
+            assert len(steps0) == len(steps) - 2 + replaced, (name, len(steps0), len(steps))     # (- 2: the fused launch and the KVPack launch)
+
+
 def test_unet_plan_structure(stub_backend):
     """The miniature UNet: what the fusion level 2 plan is made of, and what the opt-in variants change."""
     ins = sd_unet.unet_inputs(sd_unet.TINY, 42)
