@@ -136,6 +136,15 @@ def transformer_block_640(g):
     return {"x": _rn(23, (1, 640, 8, 8)), "ctx": _rn(24, (1, 77, 768))}
 
 
+def transformer_block_1280(g):
+    """... and at the 16x16 / 8x8 levels' widths (1280 channels, 8 heads of 160): osg_qattn's second instantiation, the five-deep weight ring"""
+    cfg = sd_unet.UNetConfig(block_out=(1280, 1280), heads=8, ctx_dim=768, ctx_len=77, latent=8, groups=32, name="case1280")
+    x = g.input("x", (1, 1280, 8, 8))
+    c = g.input("ctx", (1, 77, 768))
+    sd_unet._UNet(g, cfg).transformer2d("/tr", x, c, 1)
+    return {"x": _rn(25, (1, 1280, 8, 8)), "ctx": _rn(26, (1, 77, 768))}
+
+
 def upsample_concat(g):
     x = g.input("x", (1, 32, 6, 6))
     s = g.input("skip", (1, 32, 12, 12))
@@ -174,7 +183,7 @@ def shape_gather_chain(g):
 CASES = [conv3x3, conv3x3_stride2, conv1x1_nobias, conv_in_4ch, conv_ragged, linear_bias, gemm_temb, group_norm_silu, layer_norm,
          self_attention, cross_attention, geglu_ff, resnet_block, transformer_block, upsample_concat, time_embedding, shape_gather_chain]
 # longer chains at real widths (15 rounding points deep): held to the whole-net bound of tests/test_golden.py, not the single-pattern one
-CHAINS = [transformer_block_320, transformer_block_640]
+CHAINS = [transformer_block_320, transformer_block_640, transformer_block_1280]
 # whole (miniature) networks: SD1.5-shaped and SDXL-shaped UNets, the VAE decoder (single 32-wide attention head + 3 resolutions)
 UNETS = {"unet_tiny": sd_unet.TINY, "unet_tinyxl": sd_unet.TINY_XL, "vae_tiny": sd_vae.TINY_VAE,
          # W8A16 (BASELINE config 3, UNet half): uint8 weights + per-tensor scale/zero-point in model.txt, dequantised at load

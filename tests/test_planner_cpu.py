@@ -136,7 +136,7 @@ def test_transformer_chain_plans(stub_backend):
     """The two real-width transformer chains (tests/golden_cases.py CHAINS): at fusion level 2 the 320-wide one is proj_in, Q|K|V, self-attention and ONE osg_tblock_tail
     launch; the 640-wide one keeps its launches except LayerNorm + attn2.to_q + cross-attention, which are ONE osg_qattn launch; each reads a K / V pack made by one
     KVPack launch.  With the two fusions off the round-3 launches are back, and nothing else changes."""
-    want = {"transformer_block_320": ("TBlockTail+proj_out ", 7), "transformer_block_640": ("QAttention ", 2)}        # (prefix of the fused launch, launches it replaces)
+    want = {"transformer_block_320": ("TBlockTail+proj_out ", 7), "transformer_block_640": ("QAttention ", 2), "transformer_block_1280": ("QAttention ", 2)}        # (prefix of the fused launch, launches it replaces)
     for name, (prefix, replaced) in want.items():
         z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
         ins = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
