@@ -260,7 +260,7 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP backend has no CPU fallback")
-    # OSA_BENCH_ONE_GPU=1 (dev check of the N > 1 flow on a 1-GPU box, tools/gpu_round4.sh tworank): every rank drives cuda:0 and the process group is
+    # OSA_BENCH_ONE_GPU=1 (dev check of the N > 1 flow on a 1-GPU box, tools/gpu_round.sh tworank): every rank drives cuda:0 and the process group is
     # gloo over host tensors (RCCL refuses two ranks on one device).  Never set by the driver; the line it prints says so ("dev_one_gpu").
     one_gpu = os.environ.get("OSA_BENCH_ONE_GPU") == "1"
     gpu_index = 0 if one_gpu else local_rank

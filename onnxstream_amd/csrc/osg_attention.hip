@@ -16,6 +16,8 @@
 // Head dims are zero-padded in LDS/registers to a multiple of 32 (QK^T) / 16 (PV): 40->64/48, 80->96/80, 160->160.
 #include "osg_common.h"
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -280,6 +282,319 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     }
 }
 
+// =====================================================================================================================================
+// v2 (round 5) -- the UNet's attention shapes (no mask, head dim 40 / 64 / 80 / 160).  Same mapping and the same online softmax as attn_kernel,
+// but the per-tile instruction count of a wave is roughly halved (the kernel is issue-bound: ~380 instructions per 64-key tile and wave around 28 MFMAs):
+//   * K / V tiles arrive by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction) into an NST-deep ring -- no staging registers, no ds_write pass,
+//     ONE barrier per tile; rows past Tkv are zero-filled by the descriptor's bounds check (out-of-range offset);
+//   * the LDS image of a tile is the DENSE [64 keys][D] row-major copy (lane-linear, as the DMA requires; for D = 64 / 80 / 160 the 16-byte chunks of a K row
+//     are XOR-swizzled / rotated by row so that the b128 fragment reads spread over the banks -- applied to the per-lane SOURCE address).  V stays row-major
+//     and is read with the transposing LDS read (ds_read_b64_tr_b16: a 16-lane group hands in 4 rows x 16 columns and each lane gets ONE column's 4 rows),
+//     which yields exactly the V^T fragment the P V step needs in the k order the probabilities already have -- the 8 ds_write_b16 per chunk of v1 are gone;
+//   * head dims that are not a multiple of 32 finish Q K^T with ONE v_mfma_f32_16x16x16_f16 (d = 32..47 for D = 40) instead of a 32-deep step over zero
+//     padding; what the fragment reads beyond a row's D halves is the next row's data, multiplied by the zeros of the Q fragment;
+//   * the row sums come off the matrix pipe: an MFMA with an all-ones A operand adds up the (f16) probabilities of every query column -- 16 v_add_f32 per
+//     query tile and key tile become 2 MFMAs, and the sum is the sum of exactly the values P V multiplies;
+//   * XCD-local placement: the flat grid is remapped so that all query blocks of one (image, head) run on ONE XCD (its L2 then holds that head's K / V once;
+//     with blockIdx.y = head every XCD pulled every head: 94.5 MB fetched per launch against 21 MB of operands, profiles/r04_pmc_tuned_plan.json).
+template <int D>
+__device__ __forceinline__ int attn2_kpos(int row, int ch) {       // 16-byte chunk `ch` of K row `row` lives at chunk position ... of the row's LDS image
+    if constexpr (D == 64) return ch ^ (row & 7);
+    else if constexpr (D == 80) { const int v = ch + ((row >> 3) & 1); return v >= 10 ? v - 10 : v; }
+    else if constexpr (D == 160) { const int v = ch + ((row >> 2) & 3); return v >= 20 ? v - 20 : v; }
+    else return ch;
+}
+template <int D>
+__device__ __forceinline__ int attn2_kunpos(int row, int pp) {     // ... and the inverse (which chunk does position pp hold)
+    if constexpr (D == 64) return pp ^ (row & 7);
+    else if constexpr (D == 80) { const int v = pp - ((row >> 3) & 1); return v < 0 ? v + 10 : v; }
+    else if constexpr (D == 160) { const int v = pp - ((row >> 2) & 3); return v < 0 ? v + 20 : v; }
+    else return pp;
+}
+template <class F, int... I>
+__device__ __forceinline__ void attn2_static_for(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N>
+__device__ __forceinline__ void attn2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// the transposing LDS read as inline asm: through the builtin, hipcc 7.2 puts an s_waitcnt vmcnt(0) in front of every such read (it cannot tell the read from the
+// LDS-DMA writes in flight), which would serialise the ring.  The caller waits (counted lgkmcnt) before it uses the result.
+typedef __fp16 attn2_hx4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+template <int OFF>
+__device__ __forceinline__ attn2_hx4 attn2_tr_read(unsigned lds_addr) {
+    attn2_hx4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
+    return v;
+}
+
+template <int D, int QT, int NST>
+__global__ __launch_bounds__(256) void attn2_kernel(AttnParams p, int nqb) {
+    constexpr int DCH = D / 8;                  // 16-byte chunks per K / V row
+    constexpr int ROWB = D * 2;                 // bytes per row of the LDS image
+    constexpr int TILE_B = 64 * ROWB;           // one operand's tile: 64 keys (= DCH KiB)
+    constexpr int STAGE_B = 2 * TILE_B;         // K tile, then V tile
+    constexpr int K32 = D / 32, REM = D % 32;
+    static_assert(REM == 0 || REM == 8 || REM == 16, "attn2: head dim = 32 a (+ 8 | 16)");
+    constexpr bool TAIL = REM != 0;
+    constexpr int DT = (D + 15) / 16;
+    constexpr int NT = 4, NS = 2;               // 16-key score tiles / 32-deep P V steps per 64-key tile
+    constexpr int NINST = 2 * DCH;              // 1-KiB DMA pieces per tile: K's DCH, then V's DCH
+    constexpr int MAXP = (NINST + 3) / 4;       // ... per wave (waves 0 .. NINST % 4 - 1 issue one more than the others when 4 does not divide NINST)
+    constexpr int NLO = NINST / 4;              // pieces per tile of the waves that issue fewer
+    static_assert((NLO + 1) * (NST - 2) <= 63, "vmcnt is a 6-bit counter");
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) char asmem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef attn2_hx4 hx4;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 15, g = lane >> 4;
+    // flat workgroup index -> (image, head, query block): a contiguous run of indices per XCD (workgroup b runs on XCD b % 8)
+    int L;
+    {
+        const int total = gridDim.x, bid = blockIdx.x, x = bid & 7, i = bid >> 3, q = total >> 3, r = total & 7;
+        L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int bh = L / nqb, qb = L - bh * nqb;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+    const int q0 = qb * (64 * QT) + wave * (16 * QT);
+
+    const f16* __restrict__ Q = p.q + b * p.q_batch + h * p.q_head;
+    const f16* __restrict__ K = p.k + b * p.k_batch + (h / p.kv_div) * p.k_head;
+    const f16* __restrict__ V = p.v + b * p.v_batch + (h / p.kv_div) * p.v_head;
+    f16* __restrict__ O = p.o + b * p.o_batch + h * p.o_head;
+
+    // buffer descriptors over this head's K / V rows; validity of a row is decided per lane (out-of-range offset => the DMA writes zeros)
+    const long kext = ((long)(p.Tkv - 1) * p.k_tok + D) * 2, vext = ((long)(p.Tkv - 1) * p.v_tok + D) * 2;
+    __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (int)(kext < 0x7ffffff0L ? kext : 0x7ffffff0L), 0x00020000);
+    __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, (int)(vext < 0x7ffffff0L ? vext : 0x7ffffff0L), 0x00020000);
+
+    // this wave's DMA pieces: piece i = wave + 4 j covers bytes [i KiB, (i + 1) KiB) of the stage; lane l fills slot (i % DCH) * 64 + l of that operand's tile
+    int p_off[MAXP], p_row[MAXP];
+#pragma unroll
+    for (int j = 0; j < MAXP; j++) {
+        const int i = wave + 4 * j;
+        const bool isv = i >= DCH;
+        const int c = (isv ? i - DCH : i) * 64 + lane;
+        const int row = c / DCH, pp = c - row * DCH;
+        const int ch = isv ? pp : attn2_kunpos<D>(row, pp);
+        p_row[j] = row;
+        p_off[j] = (int)(((long)row * (isv ? p.v_tok : p.k_tok) + ch * 8) * 2);
+    }
+    const int n_w = (NINST - wave + 3) / 4;     // pieces this wave issues per tile
+    const int ntiles = (p.Tkv + 63) >> 6;
+    auto issue_tile = [&](int kt) {
+        char* st = asmem + (kt % NST) * STAGE_B;
+        const int kv0 = kt << 6, left = p.Tkv - kv0;
+        const int sk = (int)((long)kv0 * p.k_tok * 2), sv = (int)((long)kv0 * p.v_tok * 2);
+#pragma unroll
+        for (int j = 0; j < MAXP; j++) {
+            const int i = wave + 4 * j;
+            if (i < NINST) {
+                const unsigned off = p_row[j] < left ? (unsigned)p_off[j] : OOB;
+                if (i < DCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr)(st + i * 1024), 16, off, sk, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr)(st + i * 1024), 16, off, sv, 0, 0);
+            }
+        }
+    };
+
+    // Q fragments (operand B: lane holds Q[q][ks*32 + g*8 .. +7]; the 16-deep tail: Q[q][K32*32 + g*4 .. +3], zero past D)
+    f16x8 qf[QT][K32 ? K32 : 1];
+    f16x4 qtail[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; qt++) {
+        const int q = q0 + qt * 16 + lq;
+        const f16* qrow = Q + (long)min(q, p.Tq - 1) * p.q_tok;
+#pragma unroll
+        for (int ks = 0; ks < K32; ks++) qf[qt][ks] = *reinterpret_cast<const f16x8*>(qrow + ks * 32 + g * 8);
+        if constexpr (TAIL) {
+            const int d = K32 * 32 + g * 4;
+            f16x4 v = *reinterpret_cast<const f16x4*>(qrow + min(d, D - 4));
+            if (d >= D) v = f16x4{0, 0, 0, 0};
+            qtail[qt] = v;
+        }
+    }
+    // (rows past Tq compute on a copy of the last row and are not stored)
+    if (tid < 16) reinterpret_cast<float*>(asmem + NST * STAGE_B)[tid] = 0.f;   // the pad behind the last stage (read by the last row's overhang)
+#pragma unroll
+    for (int s2 = 0; s2 < NST - 1; s2++)
+        if (s2 < ntiles) issue_tile(s2);
+
+    f32x4 oacc[QT][DT], lacc[QT];
+    float m_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; qt++) {
+        m_run[qt] = -INFINITY;
+        lacc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) oacc[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const f16x8 ones = {(f16)1, (f16)1, (f16)1, (f16)1, (f16)1, (f16)1, (f16)1, (f16)1};
+
+    // fragment addressing inside a stage (constant over the tiles)
+    int kofs[K32 ? K32 : 1];
+#pragma unroll
+    for (int ks = 0; ks < K32; ks++) kofs[ks] = lq * ROWB + attn2_kpos<D>(lq, ks * 4 + g) * 16;
+    const int ktail = lq * ROWB + (REM == 8 ? (K32 * 4 + (g >> 1)) : attn2_kpos<D>(lq, K32 * 4 + (g >> 1))) * 16 + (g & 1) * 8;
+    const int vofs = TILE_B + (g * 4 + (lq >> 2)) * ROWB + (lq & 3) * 8;
+    const float c = p.scale_log2e;
+
+    for (int kt = 0; kt < ntiles; kt++) {
+        // my pieces of tile kt have landed: the NST - 2 tiles requested after it may stay in flight (fewer at the end of the sweep)
+        if (NST == 2 || kt + NST - 2 >= ntiles) attn2_wait_vm<0>();
+        else if (n_w == NLO) attn2_wait_vm<NLO * (NST - 2)>();
+        else attn2_wait_vm<(NLO + 1) * (NST - 2)>();
+        __builtin_amdgcn_s_barrier();                         // everyone's have; tile kt-1's stage is free
+        if (kt + NST - 1 < ntiles) issue_tile(kt + NST - 1);
+        const char* St = asmem + (kt % NST) * STAGE_B;
+        const int kv0 = kt << 6;
+
+        // ---- S^T = K Q^T -------------------------------------------------------------------------------
+        f32x4 s[QT][NT];
+#pragma unroll
+        for (int qt = 0; qt < QT; qt++)
+#pragma unroll
+            for (int t = 0; t < NT; t++) s[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+#pragma unroll
+            for (int ks = 0; ks < K32; ks++) {
+                const f16x8 kf = *reinterpret_cast<const f16x8*>(St + t * 16 * ROWB + kofs[ks]);
+#pragma unroll
+                for (int qt = 0; qt < QT; qt++) s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][ks], s[qt][t], 0, 0, 0);
+            }
+            if constexpr (TAIL) {
+                const f16x4 kf = *reinterpret_cast<const f16x4*>(St + t * 16 * ROWB + ktail);
+#pragma unroll
+                for (int qt = 0; qt < QT; qt++) s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qtail[qt], s[qt][t], 0, 0, 0);
+            }
+        }
+
+        // ---- online softmax (log2 domain), as attn_kernel: raw running maximum, the scale rides in the fma that feeds v_exp_f32 ----
+        const bool full = kv0 + 64 <= p.Tkv;
+        f16x8 pf[QT][NS];
+#pragma unroll
+        for (int qt = 0; qt < QT; qt++) {
+            float mx = -INFINITY;
+            if (full) {
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) mx = fmaxf(mx, s[qt][t][r]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int kv = kv0 + t * 16 + g * 4 + r;
+                        const float x = kv < p.Tkv ? s[qt][t][r] : -INFINITY;
+                        s[qt][t][r] = x;
+                        mx = fmaxf(mx, x);
+                    }
+            }
+            mx = row4_max(mx);
+            const float m_new = fmaxf(m_run[qt], mx);
+            const float mc = -m_new * c;
+            if (__builtin_amdgcn_ballot_w64(m_new != m_run[qt]) != 0) {   // (exactly 1 everywhere otherwise)
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * c);
+#pragma unroll
+                for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) oacc[qt][dt][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 4; r++) lacc[qt][r] *= alpha;
+            }
+            m_run[qt] = m_new;
+#pragma unroll
+            for (int st = 0; st < NS; st++) {
+                f16x8 pv;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    pv[r] = (f16)__builtin_amdgcn_exp2f(fmaf(s[qt][2 * st][r], c, mc));
+                    pv[4 + r] = (f16)__builtin_amdgcn_exp2f(fmaf(s[qt][2 * st + 1][r], c, mc));
+                }
+                pf[qt][st] = pv;
+            }
+        }
+
+        // ---- O^T += V^T P, l += 1^T P ---------------------------------------------------------------------
+#pragma unroll
+        for (int st = 0; st < NS; st++)
+#pragma unroll
+            for (int qt = 0; qt < QT; qt++) lacc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[qt][st], lacc[qt], 0, 0, 0);
+        // V^T fragments: k slots g*8 + 0..3 <-> keys st*32 + g*4 + 0..3, slots g*8 + 4..7 <-> keys st*32 + 16 + g*4 + 0..3 (the order of pf); the reads of
+        // row block dt + 1 are in flight while block dt's MFMAs issue (LDS returns in order: a counted wait)
+        {
+            const unsigned va = (unsigned)(size_t)(lds_ptr)(St + vofs);
+            hx4 vr[2][NS][2];
+            auto vread = [&](auto dtc) {
+                constexpr int dt = decltype(dtc)::value;
+                vr[dt & 1][0][0] = attn2_tr_read<0 * ROWB + dt * 32>(va);
+                vr[dt & 1][0][1] = attn2_tr_read<16 * ROWB + dt * 32>(va);
+                vr[dt & 1][1][0] = attn2_tr_read<32 * ROWB + dt * 32>(va);
+                vr[dt & 1][1][1] = attn2_tr_read<48 * ROWB + dt * 32>(va);
+            };
+            auto vstep = [&](auto dtc) {
+                constexpr int dt = decltype(dtc)::value;
+                hx4 &a0 = vr[dt & 1][0][0], &a1 = vr[dt & 1][0][1], &a2 = vr[dt & 1][1][0], &a3 = vr[dt & 1][1][1];
+                if constexpr (dt + 1 < DT) {
+                    vread(std::integral_constant<int, dt + 1>{});
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)::"memory");
+                } else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)::"memory");
+#pragma unroll
+                for (int st = 0; st < NS; st++) {
+                    const hx4 lo = vr[dt & 1][st][0], hi = vr[dt & 1][st][1];
+                    const f16x8 vf = {(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
+#pragma unroll
+                    for (int qt = 0; qt < QT; qt++)
+                        oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][st], oacc[qt][dt], 0, 0, 0);
+                }
+            };
+            vread(std::integral_constant<int, 0>{});
+            attn2_static_for(vstep, std::make_integer_sequence<int, DT>{});
+        }
+    }
+
+    // ---- epilogue: O[q][d..d+3] = O^T / l -----------------------------------------------------------------
+#pragma unroll
+    for (int qt = 0; qt < QT; qt++) {
+        const int q = q0 + qt * 16 + lq;
+        if (q >= p.Tq) continue;
+        const float inv = 1.0f / lacc[qt][0];
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) {
+            const int d = dt * 16 + g * 4;
+            if (d >= D) continue;
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r] = (f16)(oacc[qt][dt][r] * inv);
+            *reinterpret_cast<f16x4*>(O + (long)q * p.o_tok + d) = o;
+        }
+    }
+}
+
+template <int D, int NST>
+int launch_attn2(osg_ctx* ctx, const AttnParams& p, int batch) {
+    static const int force_qt = getenv("OSG_ATTN_QT") ? atoi(getenv("OSG_ATTN_QT")) : 0;
+    constexpr size_t smem = (size_t)NST * 2 * 64 * D * 2 + 64;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    const long blocks128 = (long)((p.Tq + 127) / 128) * batch * p.heads;
+    const bool qt2 = p.Tq >= 1024 && force_qt != 1 && (blocks128 >= 2L * ctx->num_cu || force_qt == 2);
+    auto k1 = attn2_kernel<D, 1, NST>;
+    auto k2 = attn2_kernel<D, 2, NST>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        OSG_HIP(ctx, hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        OSG_HIP(ctx, hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    const int nqb = qt2 ? (p.Tq + 127) / 128 : (p.Tq + 63) / 64;
+    dim3 grid((unsigned)((long)nqb * batch * p.heads));
+    if (qt2) hipLaunchKernelGGL(k2, grid, dim3(256), smem, ctx->compute, p, nqb);
+    else hipLaunchKernelGGL(k1, grid, dim3(256), smem, ctx->compute, p, nqb);
+    OSG_LAUNCH_CHECK(ctx);
+    return 0;
+}
+
 template <int DP, int DT>
 int launch_attn(osg_ctx* ctx, const AttnParams& p, int batch) {
     static const int force_qt = getenv("OSG_ATTN_QT") ? atoi(getenv("OSG_ATTN_QT")) : 0;
@@ -309,6 +624,14 @@ int launch_attn(osg_ctx* ctx, const AttnParams& p, int batch) {
 
 int dispatch_attn(osg_ctx* ctx, const AttnParams& p, int batch) {
     const int D = p.D;
+    // the UNet's shapes: v2 (OSG_ATTN_V1=1: the round-2 kernel, for A/B).  K / V rows must be 16-byte aligned (checked by the callers); the DMA offsets are 32-bit
+    static const int v1 = getenv("OSG_ATTN_V1") ? atoi(getenv("OSG_ATTN_V1")) : 0;
+    if (!v1 && !p.mask && (long)p.Tkv * max(p.k_tok, p.v_tok) * 2 < 0x7fffffffL) {
+        if (D == 40) return launch_attn2<40, 3>(ctx, p, batch);
+        if (D == 64) return launch_attn2<64, 3>(ctx, p, batch);
+        if (D == 80) return launch_attn2<80, 3>(ctx, p, batch);
+        if (D == 160) return launch_attn2<160, 2>(ctx, p, batch);
+    }
     if (D <= 32) return launch_attn<32, 2>(ctx, p, batch);
     if (D <= 48) return launch_attn<64, 3>(ctx, p, batch);
     if (D <= 64) return launch_attn<64, 4>(ctx, p, batch);

@@ -478,6 +478,18 @@ def test_attention(gpu, heads, Tq, Tkv, D):
         assert rel_max(got, sliced) <= 6e-3
 
 
+@pytest.mark.parametrize("heads,Tq,Tkv,D", [(64, 1030, 200, 40), (64, 1024, 77, 64), (72, 1024, 130, 80), (64, 1030, 70, 160), (3, 100, 130, 40), (2, 70, 1, 80),
+                                            (2, 200, 129, 64), (1, 17, 300, 160)])
+def test_attention_dma_kernel_ragged_shapes(gpu, heads, Tq, Tkv, D):
+    """attn2_kernel (round 5: K / V through LDS-DMA, transposing V reads, row sums on the matrix pipe): the 128-row form (>= 512 blocks of 128 rows) and the
+    64-row form on ragged query / key counts -- partial last key tile (rows past Tkv zero-filled by the DMA), query rows past Tq, one key only."""
+    rng = np.random.default_rng(Tq * 7 + Tkv + D)
+    q, k, v = rnd(rng, (heads, Tq, D)), rnd(rng, (heads, Tkv, D)), rnd(rng, (heads, Tkv, D))
+    want = ref.attention_exact(q, k, v, D ** -0.5)
+    got = gpu.attention(gpu.to_dev(q), gpu.to_dev(k), gpu.to_dev(v), D ** -0.5, k_is_dt=False).numpy()
+    assert rel_max(got, want) <= 2e-3
+
+
 def test_attention_spike_rows(gpu):
     """Force the online-softmax rescale branch: one key dominates a late tile for some query rows."""
     rng = np.random.default_rng(3)

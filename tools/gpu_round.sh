@@ -1,5 +1,6 @@
 #!/bin/bash
-# Dev tool (GPU box), round 4: ONE parameterised runner instead of a one-shot script per gpurun call.  usage: gpu_round4.sh <recipe> [args]; several recipes: "a,b,c"
+# Dev tool (GPU box), rounds 4-5: ONE parameterised runner instead of a one-shot script per gpurun call.  usage: gpu_round.sh <recipe> [args]; several recipes: "a,b,c"
+# (output prefix gpurun_out/$ROUND, default r05)
 #   tests            the whole GPU suite + smoke()
 #   bench            the default bench line + per-launch breakdown           -> gpurun_out/r04_bench.json, r04_breakdown.txt
 #   ab "<A>" "<B>"   bench.py with flag set A vs flag set B, alternating 2x   (e.g. ab "" "--no-tblock-fuse")
@@ -12,7 +13,7 @@
 #   qattn            osg_qattn: tests, golden chains, probe against the separate launches
 #   abenv "<env A>" "<env B>" ...  bench.py under each environment (X=1 Y=2 strings; use a dummy variable for 'default'), alternating 2x
 mkdir -p gpurun_out; export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-.}
-T=gpurun_out/r04
+T=gpurun_out/${ROUND:-r05}; export OSA_REQUIRE_ORACLE=1
 line() { python -c "import json,sys; d=json.load(open('$1')); c=d['config']; print('$2', 'ms_per_step', d['ms_per_step'], 'value', d['value'], d['unit'], 'launches', c.get('launches_per_step'), 'unet_device_ms', c.get('unet_device_ms_per_step'), 'windows', (c.get('windows_ms_per_step') or {}).get('each'), 'frac', (d.get('roofline') or {}).get('frac'))"; }
 IFS=',' read -ra RECIPES <<< "$1"; shift; ARGS=("$@")
 for R in "${RECIPES[@]}"; do case $R in
@@ -45,7 +46,7 @@ prof)
   python tools/graph_trace.py $(find /tmp/prof_f -name "*kernel_trace.csv" | head -1) > ${T}_graph_timeline.txt 2>&1; head -24 ${T}_graph_timeline.txt ;;
 pmc)
   export OSG_TUNE_CACHE=/tmp/osg_tune_cache.txt; [ -s $OSG_TUNE_CACHE ] || cp onnxstream_amd/tune/mi355x.txt $OSG_TUNE_CACHE
-  bash tools/pmc_round4.sh r04_tuned_plan 2>&1 | tail -30 ;;
+  bash tools/pmc_round4.sh ${ROUND:-r05}_tuned_plan 2>&1 | tail -30 ;;
 tailprobe)
   for cfg in "64 2 8" "32 2 8" "32 2 0" "32 3 8" "32 3 0" "64 2 0"; do set -- $cfg; echo "== rows per block $1, weight tiles in flight $(($2 - 1)), prefetching workgroups $3"
     ROWS=$1 OSG_TBLOCK_NS=$2 OSG_TBLOCK_PREFETCH=$3 REPS=2 timeout 300 python tools/tblock_tail_probe.py 2>&1 | grep -v "^$"; done > ${T}_tail_probe.log 2>&1; cat ${T}_tail_probe.log ;;
@@ -66,5 +67,11 @@ sdxlab)   # SDXL: the default plan against --no-qattn-fuse, alternating 2x; then
 abenv)   # abenv "<env A>" "<env B>" [more env sets ...]: bench.py under each environment, alternating 2x
   for i in 1 2; do n=0; for e in "${ARGS[@]}"; do n=$((n + 1))
     env $e timeout 600 python bench.py --cpu-passes 0 --windows 2 > ${T}_abenv_${n}_$i.json 2> ${T}_abenv_${n}_$i.err; line ${T}_abenv_${n}_$i.json "[$e]"; done; done ;;
+attn)   # attention: kernel tests + golden chains, then the probe with the round-2 kernel (OSG_ATTN_V1=1) and the round-5 kernel
+  timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_sdpa.py tests/test_golden.py -m gpu -x -q -k "attention or sdpa or chains" > ${T}_attn_tests.log 2>&1; tail -5 ${T}_attn_tests.log
+  for v in 1 0; do OSG_ATTN_V1=$v timeout 300 python tools/attn_probe.py 2>&1 | sed "s/^/[OSG_ATTN_V1=$v] /"; done > ${T}_attn_probe.txt; cat ${T}_attn_probe.txt ;;
+abenv1)   # like abenv, one round only
+  n=0; for e in "${ARGS[@]}"; do n=$((n + 1))
+    env $e timeout 600 python bench.py --cpu-passes 0 --windows 2 > ${T}_abenv1_${n}.json 2> ${T}_abenv1_${n}.err; line ${T}_abenv1_${n}.json "[$e]"; done ;;
 *) echo "unknown recipe $R" ;;
 esac; done
