@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnParams p, int nqb) {
     constexpr int NINST = 2 * DCH;              // 1-KiB DMA pieces per tile: K's DCH, then V's DCH
     constexpr int MAXP = (NINST + 3) / 4;       // ... per wave (waves 0 .. NINST % 4 - 1 issue one more than the others when 4 does not divide NINST)
     constexpr int NLO = NINST / 4;              // pieces per tile of the waves that issue fewer
-    static_assert((NLO + 1) * (NST - 2) <= 63, "vmcnt is a 6-bit counter");
+    static_assert(NST >= 3 && (NLO + 1) * (NST - 2) <= 63, "three stages at least (the tile being read, the next one, one in flight); vmcnt is a 6-bit counter");
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) char asmem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -438,40 +438,40 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnParams p, int nqb) {
     const int vofs = TILE_B + (g * 4 + (lq >> 2)) * ROWB + (lq & 3) * 8;
     const float c = p.scale_log2e;
 
-    for (int kt = 0; kt < ntiles; kt++) {
-        // my pieces of tile kt have landed: the NST - 2 tiles requested after it may stay in flight (fewer at the end of the sweep)
-        if (NST == 2 || kt + NST - 2 >= ntiles) attn2_wait_vm<0>();
-        else if (n_w == NLO) attn2_wait_vm<NLO * (NST - 2)>();
-        else attn2_wait_vm<(NLO + 1) * (NST - 2)>();
-        __builtin_amdgcn_s_barrier();                         // everyone's have; tile kt-1's stage is free
-        if (kt + NST - 1 < ntiles) issue_tile(kt + NST - 1);
-        const char* St = asmem + (kt % NST) * STAGE_B;
-        const int kv0 = kt << 6;
-
-        // ---- S^T = K Q^T -------------------------------------------------------------------------------
-        f32x4 s[QT][NT];
+    // ---- the sweep, software-pipelined over the key tiles: while the VALU runs the softmax of tile kt, the matrix pipe already works on S^T of tile kt + 1
+    // (two score register sets).  The loop is unrolled so that the stage of a tile and the score set are compile-time: LDS addresses are one VGPR + immediates.
+    auto qk = [&](auto stc, f32x4 (&s)[QT][NT]) {
+        constexpr int stg = decltype(stc)::value;
+        const char* St = asmem + stg * STAGE_B;
 #pragma unroll
         for (int qt = 0; qt < QT; qt++)
 #pragma unroll
             for (int t = 0; t < NT; t++) s[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (all 32-deep steps of all four score tiles first, then the 16-deep tails: a v_mfma_f32_16x16x16_f16 issued right behind the v_mfma_f32_16x16x32_f16
+        // that produces its accumulator read the accumulator before it was written -- hipcc 7.2 pads no wait states between the two opcodes; with four or more
+        // MFMAs in between the producer has retired.  sched_barrier: the scheduler must not pull a tail forward.)
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
+        for (int ks = 0; ks < K32; ks++)
 #pragma unroll
-            for (int ks = 0; ks < K32; ks++) {
+            for (int t = 0; t < NT; t++) {
                 const f16x8 kf = *reinterpret_cast<const f16x8*>(St + t * 16 * ROWB + kofs[ks]);
 #pragma unroll
                 for (int qt = 0; qt < QT; qt++) s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][ks], s[qt][t], 0, 0, 0);
             }
-            if constexpr (TAIL) {
-                const f16x4 kf = *reinterpret_cast<const f16x4*>(St + t * 16 * ROWB + ktail);
+        if constexpr (TAIL) {
+            f16x4 kt4[NT];
 #pragma unroll
-                for (int qt = 0; qt < QT; qt++) s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf, qtail[qt], s[qt][t], 0, 0, 0);
-            }
+            for (int t = 0; t < NT; t++) kt4[t] = *reinterpret_cast<const f16x4*>(St + t * 16 * ROWB + ktail);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int qt = 0; qt < QT; qt++) s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(kt4[t], qtail[qt], s[qt][t], 0, 0, 0);
         }
-
-        // ---- online softmax (log2 domain), as attn_kernel: raw running maximum, the scale rides in the fma that feeds v_exp_f32 ----
+    };
+    // online softmax (log2 domain), as attn_kernel: raw running maximum, the scale rides in the fma that feeds v_exp_f32
+    auto softmax = [&](f32x4 (&s)[QT][NT], int kv0, f16x8 (&pf)[QT][NS]) {
         const bool full = kv0 + 64 <= p.Tkv;
-        f16x8 pf[QT][NS];
 #pragma unroll
         for (int qt = 0; qt < QT; qt++) {
             float mx = -INFINITY;
@@ -515,44 +515,70 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnParams p, int nqb) {
                 pf[qt][st] = pv;
             }
         }
-
-        // ---- O^T += V^T P, l += 1^T P ---------------------------------------------------------------------
+    };
+    // O^T += V^T P, l += 1^T P.  V^T fragments: k slots g*8 + 0..3 <-> keys st*32 + g*4 + 0..3, slots g*8 + 4..7 <-> keys st*32 + 16 + g*4 + 0..3 (the order of
+    // pf); the reads of row block dt + 1 are in flight while block dt's MFMAs issue (LDS returns in order: a counted wait)
+    auto pvstep = [&](auto stc, f16x8 (&pf)[QT][NS]) {
+        constexpr int stg = decltype(stc)::value;
 #pragma unroll
         for (int st = 0; st < NS; st++)
 #pragma unroll
             for (int qt = 0; qt < QT; qt++) lacc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[qt][st], lacc[qt], 0, 0, 0);
-        // V^T fragments: k slots g*8 + 0..3 <-> keys st*32 + g*4 + 0..3, slots g*8 + 4..7 <-> keys st*32 + 16 + g*4 + 0..3 (the order of pf); the reads of
-        // row block dt + 1 are in flight while block dt's MFMAs issue (LDS returns in order: a counted wait)
-        {
-            const unsigned va = (unsigned)(size_t)(lds_ptr)(St + vofs);
-            hx4 vr[2][NS][2];
-            auto vread = [&](auto dtc) {
-                constexpr int dt = decltype(dtc)::value;
-                vr[dt & 1][0][0] = attn2_tr_read<0 * ROWB + dt * 32>(va);
-                vr[dt & 1][0][1] = attn2_tr_read<16 * ROWB + dt * 32>(va);
-                vr[dt & 1][1][0] = attn2_tr_read<32 * ROWB + dt * 32>(va);
-                vr[dt & 1][1][1] = attn2_tr_read<48 * ROWB + dt * 32>(va);
-            };
-            auto vstep = [&](auto dtc) {
-                constexpr int dt = decltype(dtc)::value;
-                hx4 &a0 = vr[dt & 1][0][0], &a1 = vr[dt & 1][0][1], &a2 = vr[dt & 1][1][0], &a3 = vr[dt & 1][1][1];
-                if constexpr (dt + 1 < DT) {
-                    vread(std::integral_constant<int, dt + 1>{});
-                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)::"memory");
-                } else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)::"memory");
+        // (the stage's base rides in the 16-bit immediate where it fits, in the address register otherwise)
+        constexpr int SB = stg * STAGE_B, IMM = (SB + 48 * ROWB + DT * 32 < 65536) ? SB : 0;
+        const unsigned va = (unsigned)(size_t)(lds_ptr)(asmem + vofs + (SB - IMM));
+        hx4 vr[2][NS][2];
+        auto vread = [&](auto dtc) {
+            constexpr int dt = decltype(dtc)::value;
+            vr[dt & 1][0][0] = attn2_tr_read<IMM + 0 * ROWB + dt * 32>(va);
+            vr[dt & 1][0][1] = attn2_tr_read<IMM + 16 * ROWB + dt * 32>(va);
+            vr[dt & 1][1][0] = attn2_tr_read<IMM + 32 * ROWB + dt * 32>(va);
+            vr[dt & 1][1][1] = attn2_tr_read<IMM + 48 * ROWB + dt * 32>(va);
+        };
+        auto vstep = [&](auto dtc) {
+            constexpr int dt = decltype(dtc)::value;
+            hx4 &a0 = vr[dt & 1][0][0], &a1 = vr[dt & 1][0][1], &a2 = vr[dt & 1][1][0], &a3 = vr[dt & 1][1][1];
+            if constexpr (dt + 1 < DT) {
+                vread(std::integral_constant<int, dt + 1>{});
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)::"memory");
+            } else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)::"memory");
 #pragma unroll
-                for (int st = 0; st < NS; st++) {
-                    const hx4 lo = vr[dt & 1][st][0], hi = vr[dt & 1][st][1];
-                    const f16x8 vf = {(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
+            for (int st = 0; st < NS; st++) {
+                const hx4 lo = vr[dt & 1][st][0], hi = vr[dt & 1][st][1];
+                const f16x8 vf = {(f16)lo[0], (f16)lo[1], (f16)lo[2], (f16)lo[3], (f16)hi[0], (f16)hi[1], (f16)hi[2], (f16)hi[3]};
 #pragma unroll
-                    for (int qt = 0; qt < QT; qt++)
-                        oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][st], oacc[qt][dt], 0, 0, 0);
-                }
-            };
-            vread(std::integral_constant<int, 0>{});
-            attn2_static_for(vstep, std::make_integer_sequence<int, DT>{});
-        }
-    }
+                for (int qt = 0; qt < QT; qt++)
+                    oacc[qt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[qt][st], oacc[qt][dt], 0, 0, 0);
+            }
+        };
+        vread(std::integral_constant<int, 0>{});
+        attn2_static_for(vstep, std::make_integer_sequence<int, DT>{});
+    };
+    // before tile kt + 1 is read: my pieces of it have landed (the NST - 3 tiles requested after it may stay in flight), then everyone's have -- and
+    // everyone is done with tile kt - 1, whose stage takes tile kt + NST - 1
+    auto sync_issue = [&](int kt) {
+        if (NST == 3 || kt + 2 >= ntiles) attn2_wait_vm<0>();
+        else if (n_w == NLO) attn2_wait_vm<NLO * (NST - 3)>();
+        else attn2_wait_vm<(NLO + 1) * (NST - 3)>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NST - 1 < ntiles) issue_tile(kt + NST - 1);
+    };
+    f32x4 sA[QT][NT], sB[QT][NT];
+    sync_issue(-1);                                   // tile 0 (no issue: tiles 0 .. NST - 2 are already requested)
+    qk(std::integral_constant<int, 0>{}, sA);
+    constexpr int U = (NST % 2) ? 2 * NST : NST;      // unroll: stage and score set repeat with this period
+    auto step = [&](auto ic, int kt) {
+        constexpr int i = decltype(ic)::value;
+        f32x4 (&sc)[QT][NT] = (i & 1) ? sB : sA;
+        f32x4 (&sn)[QT][NT] = (i & 1) ? sA : sB;
+        f16x8 pf[QT][NS];
+        sync_issue(kt);
+        if (kt + 1 < ntiles) qk(std::integral_constant<int, (i + 1) % NST>{}, sn);
+        softmax(sc, kt << 6, pf);
+        pvstep(std::integral_constant<int, i % NST>{}, pf);
+    };
+    for (int kt0 = 0; kt0 < ntiles; kt0 += U)
+        attn2_static_for([&](auto ic) { if (kt0 + decltype(ic)::value < ntiles) step(ic, kt0 + decltype(ic)::value); }, std::make_integer_sequence<int, U>{});
 
     // ---- epilogue: O[q][d..d+3] = O^T / l -----------------------------------------------------------------
 #pragma unroll
@@ -627,10 +653,10 @@ int dispatch_attn(osg_ctx* ctx, const AttnParams& p, int batch) {
     // the UNet's shapes: v2 (OSG_ATTN_V1=1: the round-2 kernel, for A/B).  K / V rows must be 16-byte aligned (checked by the callers); the DMA offsets are 32-bit
     static const int v1 = getenv("OSG_ATTN_V1") ? atoi(getenv("OSG_ATTN_V1")) : 0;
     if (!v1 && !p.mask && (long)p.Tkv * max(p.k_tok, p.v_tok) * 2 < 0x7fffffffL) {
-        if (D == 40) return launch_attn2<40, 3>(ctx, p, batch);
-        if (D == 64) return launch_attn2<64, 3>(ctx, p, batch);
+        if (D == 40) return launch_attn2<40, 4>(ctx, p, batch);
+        if (D == 64) return launch_attn2<64, 4>(ctx, p, batch);
         if (D == 80) return launch_attn2<80, 3>(ctx, p, batch);
-        if (D == 160) return launch_attn2<160, 2>(ctx, p, batch);
+        if (D == 160) return launch_attn2<160, 3>(ctx, p, batch);
     }
     if (D <= 32) return launch_attn<32, 2>(ctx, p, batch);
     if (D <= 48) return launch_attn<64, 3>(ctx, p, batch);
