@@ -287,30 +287,17 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 // but the per-tile instruction count of a wave is roughly halved (the kernel is issue-bound: ~380 instructions per 64-key tile and wave around 28 MFMAs):
 //   * K / V tiles arrive by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction) into an NST-deep ring -- no staging registers, no ds_write pass,
 //     ONE barrier per tile; rows past Tkv are zero-filled by the descriptor's bounds check (out-of-range offset);
-//   * the LDS image of a tile is the DENSE [64 keys][D] row-major copy (lane-linear, as the DMA requires; for D = 64 / 80 / 160 the 16-byte chunks of a K row
-//     are XOR-swizzled / rotated by row so that the b128 fragment reads spread over the banks -- applied to the per-lane SOURCE address).  V stays row-major
-//     and is read with the transposing LDS read (ds_read_b64_tr_b16: a 16-lane group hands in 4 rows x 16 columns and each lane gets ONE column's 4 rows),
-//     which yields exactly the V^T fragment the P V step needs in the k order the probabilities already have -- the 8 ds_write_b16 per chunk of v1 are gone;
-//   * head dims that are not a multiple of 32 finish Q K^T with ONE v_mfma_f32_16x16x16_f16 (d = 32..47 for D = 40) instead of a 32-deep step over zero
-//     padding; what the fragment reads beyond a row's D halves is the next row's data, multiplied by the zeros of the Q fragment;
+//   * the LDS image of a tile is the row-major [64 keys][RSC 16-byte chunks] copy (lane-linear, as the DMA requires), rows PADDED to RSC = 2 (mod 4) chunks --
+//     6 for D = 40, 10 for 64 / 80, 22 for 160 (the pad lanes request an out-of-range offset: zeros).  With that stride both fragment reads are free of bank
+//     conflicts without a swizzle: ds_read_b128 is serviced in the lane groups {0-3, 12-15, 20-27} ..., i.e. rows {0-3, 12-15} at chunk c with rows 4-11 at
+//     chunk c + 1, whose 16-byte slots (row RSC + chunk) mod 16 are then all distinct; the transposing read's 32-lane groups cover 8 rows x 32 bytes at
+//     distinct multiples of 32 bytes mod 256.  (Dense 80-byte rows: half of all LDS cycles were conflicts, profiles/r05_pmc_attention_v2.txt.)  V stays
+//     row-major and is read with the transposing LDS read (ds_read_b64_tr_b16: a 16-lane group hands in 4 rows x 16 columns and each lane gets ONE column's
+//     4 rows), which yields exactly the V^T fragment the P V step needs in the k order the probabilities already have -- the 8 ds_write_b16 per chunk of v1 are gone;
 //   * the row sums come off the matrix pipe: an MFMA with an all-ones A operand adds up the (f16) probabilities of every query column -- 16 v_add_f32 per
 //     query tile and key tile become 2 MFMAs, and the sum is the sum of exactly the values P V multiplies;
 //   * XCD-local placement: the flat grid is remapped so that all query blocks of one (image, head) run on ONE XCD (its L2 then holds that head's K / V once;
 //     with blockIdx.y = head every XCD pulled every head: 94.5 MB fetched per launch against 21 MB of operands, profiles/r04_pmc_tuned_plan.json).
-template <int D>
-__device__ __forceinline__ int attn2_kpos(int row, int ch) {       // 16-byte chunk `ch` of K row `row` lives at chunk position ... of the row's LDS image
-    if constexpr (D == 64) return ch ^ (row & 7);
-    else if constexpr (D == 80) { const int v = ch + ((row >> 3) & 1); return v >= 10 ? v - 10 : v; }
-    else if constexpr (D == 160) { const int v = ch + ((row >> 2) & 3); return v >= 20 ? v - 20 : v; }
-    else return ch;
-}
-template <int D>
-__device__ __forceinline__ int attn2_kunpos(int row, int pp) {     // ... and the inverse (which chunk does position pp hold)
-    if constexpr (D == 64) return pp ^ (row & 7);
-    else if constexpr (D == 80) { const int v = pp - ((row >> 3) & 1); return v < 0 ? v + 10 : v; }
-    else if constexpr (D == 160) { const int v = pp - ((row >> 2) & 3); return v < 0 ? v + 20 : v; }
-    else return pp;
-}
 template <class F, int... I>
 __device__ __forceinline__ void attn2_static_for(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N>
@@ -328,18 +315,20 @@ __device__ __forceinline__ attn2_hx4 attn2_tr_read(unsigned lds_addr) {
 template <int D, int QT, int NST>
 __global__ __launch_bounds__(256) void attn2_kernel(AttnParams p, int nqb) {
     constexpr int DCH = D / 8;                  // 16-byte chunks per K / V row
-    constexpr int ROWB = D * 2;                 // bytes per row of the LDS image
-    constexpr int TILE_B = 64 * ROWB;           // one operand's tile: 64 keys (= DCH KiB)
+    constexpr int RSC = DCH + ((6 - DCH % 4) % 4);   // ... of the LDS image: the next count = 2 (mod 4), see the header
+    constexpr int ROWB = RSC * 16;              // bytes per row of the LDS image
+    constexpr int TILE_B = 64 * ROWB;           // one operand's tile: 64 keys (= RSC KiB)
     constexpr int STAGE_B = 2 * TILE_B;         // K tile, then V tile
     constexpr int K32 = D / 32, REM = D % 32;
     static_assert(REM == 0 || REM == 8 || REM == 16, "attn2: head dim = 32 a (+ 8 | 16)");
+    static_assert(RSC % 4 == 2 && RSC >= DCH && (REM == 0 || RSC * 8 >= K32 * 32 + 16), "row pitch");
     constexpr bool TAIL = REM != 0;
     constexpr int DT = (D + 15) / 16;
+    static_assert(DT * 16 <= RSC * 8, "the P V row blocks read inside the padded row");
     constexpr int NT = 4, NS = 2;               // 16-key score tiles / 32-deep P V steps per 64-key tile
-    constexpr int NINST = 2 * DCH;              // 1-KiB DMA pieces per tile: K's DCH, then V's DCH
-    constexpr int MAXP = (NINST + 3) / 4;       // ... per wave (waves 0 .. NINST % 4 - 1 issue one more than the others when 4 does not divide NINST)
-    constexpr int NLO = NINST / 4;              // pieces per tile of the waves that issue fewer
-    static_assert(NST >= 3 && (NLO + 1) * (NST - 2) <= 63, "three stages at least (the tile being read, the next one, one in flight); vmcnt is a 6-bit counter");
+    constexpr int NINST = 2 * RSC;              // 1-KiB DMA pieces per tile: K's RSC, then V's RSC
+    constexpr int MAXP = NINST / 4;             // ... per wave (RSC is even: the same count for every wave)
+    static_assert(NST >= 3 && MAXP * (NST - 2) <= 63, "three stages at least (the tile being read, the next one, one in flight); vmcnt is a 6-bit counter");
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) char asmem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -368,53 +357,48 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnParams p, int nqb) {
     __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (int)(kext < 0x7ffffff0L ? kext : 0x7ffffff0L), 0x00020000);
     __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, (int)(vext < 0x7ffffff0L ? vext : 0x7ffffff0L), 0x00020000);
 
-    // this wave's DMA pieces: piece i = wave + 4 j covers bytes [i KiB, (i + 1) KiB) of the stage; lane l fills slot (i % DCH) * 64 + l of that operand's tile
+    // this wave's DMA pieces: piece i = wave + 4 j covers bytes [i KiB, (i + 1) KiB) of the stage; lane l fills slot (i % RSC) * 64 + l of that operand's tile
     int p_off[MAXP], p_row[MAXP];
 #pragma unroll
     for (int j = 0; j < MAXP; j++) {
         const int i = wave + 4 * j;
-        const bool isv = i >= DCH;
-        const int c = (isv ? i - DCH : i) * 64 + lane;
-        const int row = c / DCH, pp = c - row * DCH;
-        const int ch = isv ? pp : attn2_kunpos<D>(row, pp);
-        p_row[j] = row;
-        p_off[j] = (int)(((long)row * (isv ? p.v_tok : p.k_tok) + ch * 8) * 2);
+        const bool isv = i >= RSC;
+        const int c = (isv ? i - RSC : i) * 64 + lane;
+        const int row = c / RSC, pp = c - row * RSC;
+        p_row[j] = pp < DCH ? row : 64;             // (a pad chunk is never in range)
+        p_off[j] = (int)(((long)row * (isv ? p.v_tok : p.k_tok) + pp * 8) * 2);
     }
-    const int n_w = (NINST - wave + 3) / 4;     // pieces this wave issues per tile
     const int ntiles = (p.Tkv + 63) >> 6;
-    auto issue_tile = [&](int kt) {
+    auto issue_tile = [&](int kt) __attribute__((always_inline)) {
         char* st = asmem + (kt % NST) * STAGE_B;
-        const int kv0 = kt << 6, left = p.Tkv - kv0;
+        const int kv0 = kt << 6, left = min(p.Tkv - kv0, 64);
         const int sk = (int)((long)kv0 * p.k_tok * 2), sv = (int)((long)kv0 * p.v_tok * 2);
 #pragma unroll
         for (int j = 0; j < MAXP; j++) {
             const int i = wave + 4 * j;
-            if (i < NINST) {
-                const unsigned off = p_row[j] < left ? (unsigned)p_off[j] : OOB;
-                if (i < DCH) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr)(st + i * 1024), 16, off, sk, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr)(st + i * 1024), 16, off, sv, 0, 0);
-            }
+            const unsigned off = p_row[j] < left ? (unsigned)p_off[j] : OOB;
+            if (i < RSC) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr)(st + i * 1024), 16, off, sk, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr)(st + i * 1024), 16, off, sv, 0, 0);
         }
     };
 
-    // Q fragments (operand B: lane holds Q[q][ks*32 + g*8 .. +7]; the 16-deep tail: Q[q][K32*32 + g*4 .. +3], zero past D)
+    // Q fragments (operand B: lane holds Q[q][ks*32 + g*8 .. +7]; a partial last step: zero past D)
     f16x8 qf[QT][K32 ? K32 : 1];
-    f16x4 qtail[QT];
+    f16x8 qtail[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; qt++) {
         const int q = q0 + qt * 16 + lq;
         const f16* qrow = Q + (long)min(q, p.Tq - 1) * p.q_tok;
 #pragma unroll
         for (int ks = 0; ks < K32; ks++) qf[qt][ks] = *reinterpret_cast<const f16x8*>(qrow + ks * 32 + g * 8);
-        if constexpr (TAIL) {
-            const int d = K32 * 32 + g * 4;
-            f16x4 v = *reinterpret_cast<const f16x4*>(qrow + min(d, D - 4));
-            if (d >= D) v = f16x4{0, 0, 0, 0};
+        if constexpr (TAIL) {   // the last, partial 32-deep step: Q[q][K32*32 + g*8 .. +7], zero past D
+            const int d = K32 * 32 + g * 8;
+            f16x8 v = *reinterpret_cast<const f16x8*>(qrow + min(d, D - 8));
+            if (d >= D) v = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
             qtail[qt] = v;
         }
     }
     // (rows past Tq compute on a copy of the last row and are not stored)
-    if (tid < 16) reinterpret_cast<float*>(asmem + NST * STAGE_B)[tid] = 0.f;   // the pad behind the last stage (read by the last row's overhang)
 #pragma unroll
     for (int s2 = 0; s2 < NST - 1; s2++)
         if (s2 < ntiles) issue_tile(s2);
@@ -431,51 +415,44 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnParams p, int nqb) {
     const f16x8 ones = {(f16)1, (f16)1, (f16)1, (f16)1, (f16)1, (f16)1, (f16)1, (f16)1};
 
     // fragment addressing inside a stage (constant over the tiles)
-    int kofs[K32 ? K32 : 1];
+    int kofs[K32 + 1];
 #pragma unroll
-    for (int ks = 0; ks < K32; ks++) kofs[ks] = lq * ROWB + attn2_kpos<D>(lq, ks * 4 + g) * 16;
-    const int ktail = lq * ROWB + (REM == 8 ? (K32 * 4 + (g >> 1)) : attn2_kpos<D>(lq, K32 * 4 + (g >> 1))) * 16 + (g & 1) * 8;
+    for (int ks = 0; ks < K32 + 1; ks++) kofs[ks] = lq * ROWB + (ks * 4 + g) * 16;
     const int vofs = TILE_B + (g * 4 + (lq >> 2)) * ROWB + (lq & 3) * 8;
     const float c = p.scale_log2e;
 
     // ---- the sweep, software-pipelined over the key tiles: while the VALU runs the softmax of tile kt, the matrix pipe already works on S^T of tile kt + 1
     // (two score register sets).  The loop is unrolled so that the stage of a tile and the score set are compile-time: LDS addresses are one VGPR + immediates.
-    auto qk = [&](auto stc, f32x4 (&s)[QT][NT]) {
+    auto qk = [&](auto stc, f32x4 (&s)[QT][NT]) __attribute__((always_inline)) {
         constexpr int stg = decltype(stc)::value;
         const char* St = asmem + stg * STAGE_B;
 #pragma unroll
         for (int qt = 0; qt < QT; qt++)
 #pragma unroll
             for (int t = 0; t < NT; t++) s[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // (all 32-deep steps of all four score tiles first, then the 16-deep tails: a v_mfma_f32_16x16x16_f16 issued right behind the v_mfma_f32_16x16x32_f16
-        // that produces its accumulator read the accumulator before it was written -- hipcc 7.2 pads no wait states between the two opcodes; with four or more
-        // MFMAs in between the producer has retired.  sched_barrier: the scheduler must not pull a tail forward.)
+        // A head dim that is not a multiple of 32 ends with a partial step whose Q fragment is zero past D; the K fragment of that step reads on into the row's
+        // zero pad and, past the row pitch, into the next row (finite data times zero).  It is a 32-deep MFMA like the others: v_mfma_f32_16x16x16_f16 occupies
+        // the matrix pipe just as long (measured), its 64-bit fragment reads were merged into ds_read2_b64 -- 4-way bank conflicts, ALL the conflict cycles of the
+        // kernel -- and hipcc 7.2 pads no wait states between a 32-deep MFMA and a 16-deep one that reads its accumulator (wrong scores when they were adjacent).
 #pragma unroll
-        for (int ks = 0; ks < K32; ks++)
+        for (int ks = 0; ks < K32 + (TAIL ? 1 : 0); ks++)
 #pragma unroll
             for (int t = 0; t < NT; t++) {
                 const f16x8 kf = *reinterpret_cast<const f16x8*>(St + t * 16 * ROWB + kofs[ks]);
 #pragma unroll
-                for (int qt = 0; qt < QT; qt++) s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[qt][ks], s[qt][t], 0, 0, 0);
+                for (int qt = 0; qt < QT; qt++) s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, ks < K32 ? qf[qt][ks < K32 ? ks : 0] : qtail[qt], s[qt][t], 0, 0, 0);
             }
-        if constexpr (TAIL) {
-            f16x4 kt4[NT];
-#pragma unroll
-            for (int t = 0; t < NT; t++) kt4[t] = *reinterpret_cast<const f16x4*>(St + t * 16 * ROWB + ktail);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < NT; t++)
-#pragma unroll
-                for (int qt = 0; qt < QT; qt++) s[qt][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(kt4[t], qtail[qt], s[qt][t], 0, 0, 0);
-        }
     };
     // online softmax (log2 domain), as attn_kernel: raw running maximum, the scale rides in the fma that feeds v_exp_f32
-    auto softmax = [&](f32x4 (&s)[QT][NT], int kv0, f16x8 (&pf)[QT][NS]) {
-        const bool full = kv0 + 64 <= p.Tkv;
+    // (fullc: every key of the tile exists -- all tiles but a ragged last one.  The rescale of the accumulators stays behind a ballot: unconditional it is 25
+    // VALU instructions per tile in a kernel bound by VALU issue -- measured 103.3 vs 101.4 us, although the branch-free step let the scheduler lay the
+    // softmax between the next tile's MFMAs.)
+    auto softmax = [&](auto fullc, f32x4 (&s)[QT][NT], int kv0, f16x8 (&pf)[QT][NS]) __attribute__((always_inline)) {
+        constexpr bool full = decltype(fullc)::value;
 #pragma unroll
         for (int qt = 0; qt < QT; qt++) {
             float mx = -INFINITY;
-            if (full) {
+            if constexpr (full) {
 #pragma unroll
                 for (int t = 0; t < NT; t++)
 #pragma unroll
@@ -494,7 +471,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnParams p, int nqb) {
             mx = row4_max(mx);
             const float m_new = fmaxf(m_run[qt], mx);
             const float mc = -m_new * c;
-            if (__builtin_amdgcn_ballot_w64(m_new != m_run[qt]) != 0) {   // (exactly 1 everywhere otherwise)
+            if (__builtin_amdgcn_ballot_w64(m_new != m_run[qt]) != 0) {   // (exactly 1 everywhere otherwise; the maxima settle after a few tiles)
                 const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * c);
 #pragma unroll
                 for (int dt = 0; dt < DT; dt++)
@@ -518,7 +495,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnParams p, int nqb) {
     };
     // O^T += V^T P, l += 1^T P.  V^T fragments: k slots g*8 + 0..3 <-> keys st*32 + g*4 + 0..3, slots g*8 + 4..7 <-> keys st*32 + 16 + g*4 + 0..3 (the order of
     // pf); the reads of row block dt + 1 are in flight while block dt's MFMAs issue (LDS returns in order: a counted wait)
-    auto pvstep = [&](auto stc, f16x8 (&pf)[QT][NS]) {
+    auto pvstep = [&](auto stc, f16x8 (&pf)[QT][NS]) __attribute__((always_inline)) {
         constexpr int stg = decltype(stc)::value;
 #pragma unroll
         for (int st = 0; st < NS; st++)
@@ -528,20 +505,22 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnParams p, int nqb) {
         constexpr int SB = stg * STAGE_B, IMM = (SB + 48 * ROWB + DT * 32 < 65536) ? SB : 0;
         const unsigned va = (unsigned)(size_t)(lds_ptr)(asmem + vofs + (SB - IMM));
         hx4 vr[2][NS][2];
-        auto vread = [&](auto dtc) {
+        auto vread = [&](auto dtc) __attribute__((always_inline)) {
             constexpr int dt = decltype(dtc)::value;
             vr[dt & 1][0][0] = attn2_tr_read<IMM + 0 * ROWB + dt * 32>(va);
             vr[dt & 1][0][1] = attn2_tr_read<IMM + 16 * ROWB + dt * 32>(va);
             vr[dt & 1][1][0] = attn2_tr_read<IMM + 32 * ROWB + dt * 32>(va);
             vr[dt & 1][1][1] = attn2_tr_read<IMM + 48 * ROWB + dt * 32>(va);
         };
-        auto vstep = [&](auto dtc) {
+        auto vstep = [&](auto dtc) __attribute__((always_inline)) {
             constexpr int dt = decltype(dtc)::value;
             hx4 &a0 = vr[dt & 1][0][0], &a1 = vr[dt & 1][0][1], &a2 = vr[dt & 1][1][0], &a3 = vr[dt & 1][1][1];
             if constexpr (dt + 1 < DT) {
                 vread(std::integral_constant<int, dt + 1>{});
                 asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)::"memory");
             } else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)::"memory");
+            // (two 16-deep MFMAs fed by one transposing read each would save the v_mov_b64 that glues two 64-bit results into the 128-bit operand below -- 18 VALU
+            // instructions per tile -- but measured 109 vs 98 us: a v_mfma_f32_16x16x16_f16 occupies the matrix pipe as long as the 32-deep one)
 #pragma unroll
             for (int st = 0; st < NS; st++) {
                 const hx4 lo = vr[dt & 1][st][0], hi = vr[dt & 1][st][1];
@@ -556,10 +535,9 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnParams p, int nqb) {
     };
     // before tile kt + 1 is read: my pieces of it have landed (the NST - 3 tiles requested after it may stay in flight), then everyone's have -- and
     // everyone is done with tile kt - 1, whose stage takes tile kt + NST - 1
-    auto sync_issue = [&](int kt) {
+    auto sync_issue = [&](int kt) __attribute__((always_inline)) {
         if (NST == 3 || kt + 2 >= ntiles) attn2_wait_vm<0>();
-        else if (n_w == NLO) attn2_wait_vm<NLO * (NST - 3)>();
-        else attn2_wait_vm<(NLO + 1) * (NST - 3)>();
+        else attn2_wait_vm<MAXP * (NST - 3)>();
         __builtin_amdgcn_s_barrier();
         if (kt + NST - 1 < ntiles) issue_tile(kt + NST - 1);
     };
@@ -567,18 +545,38 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnParams p, int nqb) {
     sync_issue(-1);                                   // tile 0 (no issue: tiles 0 .. NST - 2 are already requested)
     qk(std::integral_constant<int, 0>{}, sA);
     constexpr int U = (NST % 2) ? 2 * NST : NST;      // unroll: stage and score set repeat with this period
-    auto step = [&](auto ic, int kt) {
+    // a step of the sweep: tiles 0 .. ntiles - 2 (full tiles with a successor), then the last one (maybe ragged, nothing to prefetch)
+    auto step = [&](auto ic, int kt) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
         f32x4 (&sc)[QT][NT] = (i & 1) ? sB : sA;
         f32x4 (&sn)[QT][NT] = (i & 1) ? sA : sB;
         f16x8 pf[QT][NS];
         sync_issue(kt);
-        if (kt + 1 < ntiles) qk(std::integral_constant<int, (i + 1) % NST>{}, sn);
-        softmax(sc, kt << 6, pf);
+        qk(std::integral_constant<int, (i + 1) % NST>{}, sn);
+        softmax(std::true_type{}, sc, kt << 6, pf);
         pvstep(std::integral_constant<int, i % NST>{}, pf);
     };
-    for (int kt0 = 0; kt0 < ntiles; kt0 += U)
-        attn2_static_for([&](auto ic) { if (kt0 + decltype(ic)::value < ntiles) step(ic, kt0 + decltype(ic)::value); }, std::make_integer_sequence<int, U>{});
+    auto last = [&](auto ic, int kt) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        f32x4 (&sc)[QT][NT] = (i & 1) ? sB : sA;
+        f16x8 pf[QT][NS];
+        if ((p.Tkv & 63) == 0) softmax(std::true_type{}, sc, kt << 6, pf);
+        else softmax(std::false_type{}, sc, kt << 6, pf);
+        pvstep(std::integral_constant<int, i % NST>{}, pf);
+    };
+    // main loop: U unconditional steps per trip (guards inside the unrolled body make the register allocator shuffle the score sets at every join: 50 v_mov_b64
+    // per tile were measured in such a build); what is left -- fewer than U steps and the last tile -- runs once, through guarded copies of the same code
+    int kt = 0;
+    for (; kt + U < ntiles; kt += U)
+        attn2_static_for([&](auto ic) __attribute__((always_inline)) { step(ic, kt + decltype(ic)::value); }, std::make_integer_sequence<int, U>{});
+    bool done = false;
+    attn2_static_for([&](auto ic) __attribute__((always_inline)) {
+        const int k2 = kt + decltype(ic)::value;
+        if (!done) {
+            if (k2 + 1 < ntiles) step(ic, k2);
+            else { last(ic, k2); done = true; }
+        }
+    }, std::make_integer_sequence<int, U>{});
 
     // ---- epilogue: O[q][d..d+3] = O^T / l -----------------------------------------------------------------
 #pragma unroll
@@ -601,7 +599,8 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnParams p, int nqb) {
 template <int D, int NST>
 int launch_attn2(osg_ctx* ctx, const AttnParams& p, int batch) {
     static const int force_qt = getenv("OSG_ATTN_QT") ? atoi(getenv("OSG_ATTN_QT")) : 0;
-    constexpr size_t smem = (size_t)NST * 2 * 64 * D * 2 + 64;
+    constexpr int RSC = D / 8 + ((6 - (D / 8) % 4) % 4);
+    constexpr size_t smem = (size_t)NST * 2 * 64 * RSC * 16;
     static_assert(smem <= 160 * 1024, "LDS budget");
     const long blocks128 = (long)((p.Tq + 127) / 128) * batch * p.heads;
     const bool qt2 = p.Tq >= 1024 && force_qt != 1 && (blocks128 >= 2L * ctx->num_cu || force_qt == 2);
@@ -654,7 +653,7 @@ int dispatch_attn(osg_ctx* ctx, const AttnParams& p, int batch) {
     static const int v1 = getenv("OSG_ATTN_V1") ? atoi(getenv("OSG_ATTN_V1")) : 0;
     if (!v1 && !p.mask && (long)p.Tkv * max(p.k_tok, p.v_tok) * 2 < 0x7fffffffL) {
         if (D == 40) return launch_attn2<40, 4>(ctx, p, batch);
-        if (D == 64) return launch_attn2<64, 4>(ctx, p, batch);
+        if (D == 64) return launch_attn2<64, 3>(ctx, p, batch);
         if (D == 80) return launch_attn2<80, 3>(ctx, p, batch);
         if (D == 160) return launch_attn2<160, 3>(ctx, p, batch);
     }

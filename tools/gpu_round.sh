@@ -69,7 +69,7 @@ abenv)   # abenv "<env A>" "<env B>" [more env sets ...]: bench.py under each en
     env $e timeout 600 python bench.py --cpu-passes 0 --windows 2 > ${T}_abenv_${n}_$i.json 2> ${T}_abenv_${n}_$i.err; line ${T}_abenv_${n}_$i.json "[$e]"; done; done ;;
 attn)   # attention: kernel tests + golden chains, then the probe with the round-2 kernel (OSG_ATTN_V1=1) and the round-5 kernel
   timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_sdpa.py tests/test_golden.py -m gpu -x -q -k "attention or sdpa or chains" > ${T}_attn_tests.log 2>&1; tail -5 ${T}_attn_tests.log
-  for v in 1 0; do OSG_ATTN_V1=$v timeout 300 python tools/attn_probe.py 2>&1 | sed "s/^/[OSG_ATTN_V1=$v] /"; done > ${T}_attn_probe.txt; cat ${T}_attn_probe.txt ;;
+  for v in "OSG_ATTN_V1=1" "OSG_ATTN_V1=0" ${ARGS[@]}; do env $v timeout 300 python tools/attn_probe.py 2>&1 | sed "s/^/[$v] /"; done > ${T}_attn_probe.txt; cat ${T}_attn_probe.txt ;;
 abenv1)   # like abenv, one round only
   n=0; for e in "${ARGS[@]}"; do n=$((n + 1))
     env $e timeout 600 python bench.py --cpu-passes 0 --windows 2 > ${T}_abenv1_${n}.json 2> ${T}_abenv1_${n}.err; line ${T}_abenv1_${n}.json "[$e]"; done ;;

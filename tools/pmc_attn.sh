@@ -16,8 +16,8 @@ for d in ("/tmp/pmc_attn", "/tmp/pmc_attn2"):
     n = collections.Counter()
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "attn_kernel" not in r["Kernel_Name"]: continue
-            k = r["Kernel_Name"][28:60]
+            if "attn" not in r["Kernel_Name"] or "kernel" not in r["Kernel_Name"]: continue
+            k = r["Kernel_Name"].split("(")[0].split("::")[-1][-44:] + " grid " + r.get("Grid_Size", "?")
             out[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
     for k, v in out.items():
         disp = max(c for (kk, _), c in n.items() if kk == k)
