@@ -227,15 +227,12 @@ def main():
     ap.add_argument("--cpu-passes", type=int, default=4, help="reference CPU passes in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--profile-reps", type=int, default=3)
     ap.add_argument("--steps-per-image", type=int, default=0, help="denoising steps per image (default 20; BASELINE config 4 = SDXL uses 10)")
-    ap.add_argument("--side-stream", action="store_true", help="shortcut convolutions etc. on a second stream beside the main chain (parallel hipGraph branches; measured slower)")
     ap.add_argument("--no-ln-fold", action="store_true", help="standalone LayerNorm launches instead of folding every LayerNorm into the GEMM that consumes it (osg_gemm_ln, default)")
-    ap.add_argument("--small-linear", type=int, default=None, choices=[0, 1, 2], help="osg_linear_small launches for projections / 1x1 convolutions: 0 never (round 3: gemm2_kernel), 1 where measured faster (the Model's default), 2 every shape the kernel takes")
     ap.add_argument("--no-qattn-fuse", action="store_true", help="LayerNorm-folded attn2.to_q and the cross-attention as two launches (round 3) instead of one osg_qattn launch where it takes the shape (round 4 default)")
     ap.add_argument("--no-tblock-fuse", action="store_true", help="the tail of every transformer block as the seven launches of round 3 instead of one osg_tblock_tail launch where it takes the shape (round 4 default)")
     ap.add_argument("--no-concat-views", action="store_true", help="skip tensors through copy launches (Concat) instead of convolutions storing straight into their Concat slot (round 3 default)")
-    ap.add_argument("--blocked-weights", action="store_true", help="resident weights in the blocked layout [N/16][K/64][16][64] for the direct-to-LDS kernels (experiment)")
-    ap.add_argument("--weight-prefetch", action="store_true", help="every contraction launch also touches the next contraction's weights (memory-side cache warm-up; experiment)")
     ap.add_argument("--gn-stats", type=int, default=None, choices=[0, 1, 2], help="GroupNorm statistics from the producing convolutions' epilogues: 0 never, 1 every eligible GroupNorm, 2 only tensors of >= 8 M elements (the Model's default: pays in the throughput regime, neutral on the SD 1.5 pass, profiles/r03_gn_stats_ab.txt)")
+    ap.add_argument("--frozen-table", action="store_true", help="N = 1 as the ranks of an N > 1 job run: the shipped tune table, OSG_TUNE_FROZEN=1 (a shape it does not hold takes the cost model's first candidate, nothing is timed) -- the same plan at every N")
     ap.add_argument("--no-autotune", action="store_true", help="tile / split-K configurations from the cost model only (no measured choice in the first pass)")
     ap.add_argument("--host-loop", action="store_true", help="pipeline mode: CFG + Euler-A on the host with one round trip per step (the reference app's shape) instead of the device loop")
     ap.add_argument("--prompts-per-gpu", type=int, default=1, help="prompts denoised together on each GPU (2P samples per UNet pass: the reference's --num batching)")
@@ -328,7 +325,7 @@ def main():
     tune_src = "none (cost model)" if args.no_autotune else ("OSG_TUNE_CACHE of the caller" if os.environ.get("OSG_TUNE_CACHE") else
                                                              ("shipped table onnxstream_amd/tune/mi355x.txt, missing shapes measured now (cold operands)" if os.path.exists(shipped_table)
                                                               else "measured in the plan-building pass (cold operands)"))
-    if not args.no_autotune and not os.environ.get("OSG_TUNE_CACHE") and dist is None:
+    if not args.no_autotune and not os.environ.get("OSG_TUNE_CACHE") and dist is None and not args.frozen_table:
         import shutil
         private = f"/tmp/osg_tune_{os.getuid()}_{os.getpid()}.txt"
         if os.path.exists(shipped_table):
@@ -338,7 +335,7 @@ def main():
     def make_pipe():
         return Txt2Img(b.LIB_HOST, model_dir, vae_dir, batched=True, device=gpu_index, fusion=args.fusion, autotune=not args.no_autotune)
     pipe = None
-    frozen_ranks = dist is not None and not args.no_autotune and not os.environ.get("OSG_TUNE_CACHE") and os.path.exists(shipped_table)
+    frozen_ranks = (dist is not None or args.frozen_table) and not args.no_autotune and (args.frozen_table or not os.environ.get("OSG_TUNE_CACHE")) and os.path.exists(shipped_table)
     if frozen_ranks:
         # N > 1, no table named by the caller: every rank seeds a private copy of the SHIPPED table and plans on its own with OSG_TUNE_FROZEN = 1 -- a shape
         # the table does not hold takes the cost model's first candidate (deterministic) instead of being timed, so all ranks make identical choices
@@ -376,16 +373,8 @@ def main():
         m._set_option("hip_fuse_tblock", 0)
     if args.no_qattn_fuse:
         m._set_option("hip_fuse_qattn", 0)
-    if args.small_linear is not None:
-        m._set_option("hip_small_linear", args.small_linear)
     if args.gn_stats is not None:
         m._set_option("hip_gn_stats", args.gn_stats)
-    if args.weight_prefetch:
-        m._set_option("hip_weight_prefetch", 1)
-    if args.blocked_weights:
-        m._set_option("hip_blocked_weights", 1)
-    if args.side_stream:
-        m._set_option("hip_side_stream", 1)
     L = cfg.latent
     P = max(1, args.prompts_per_gpu if args.mode == "pipeline" and not cfg.sdxl_add_embed else 1)
     lat_shape = (P, cfg.in_ch, L, L)
@@ -517,6 +506,12 @@ def main():
         assert rank != 0 or (allr.shape[0] == world and np.isfinite(allr).all())
     ms_per_step = wall * 1e3 / args.steps
     images_per_s = world * P / (STEPS_PER_IMAGE * ms_per_step * 1e-3)
+    # shapes the measured-choice table did not hold (timed live at N = 1, cost-model choice under OSG_TUNE_FROZEN): 0 means N = 1 and N > 1 time the same plan
+    try:
+        import ctypes
+        tune_misses = int(ctypes.CDLL(b.LIB_GPU).osg_tune_misses()) if not args.no_autotune else None
+    except Exception:
+        tune_misses = None
 
     line = None
     if rank == 0:
@@ -595,13 +590,15 @@ def main():
         line = {
             "metric": "sd15_unet_step_latency_ms+images_per_sec_512x512_20step" if cfg.name == "sd15" else f"{cfg.name}_unet_step_latency_ms+images_per_sec_{STEPS_PER_IMAGE}step", "value": round(images_per_s, 4), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            # the headline-of-record against box-to-box / window-to-window spread: the median of the further one-image windows (config.windows_ms_per_step)
+            "ms_per_step_window_median": round(float(np.median(win_ms)), 4) if win_ms else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": (f"{cfg.name} {8 * cfg.latent}x{8 * cfg.latent} {STEPS_PER_IMAGE}-step txt2img ({'W8A16' if args.quant_weights else 'W16A16'}): per step the UNet over cond+uncond (2x4x{cfg.latent}x{cfg.latent} latents, ctx 77x{cfg.ctx_dim}) "
                                     f"as one batch-2 pass + CFG 7 + Euler-Ancestral update ({'on the host, one round trip per step' if args.host_loop else 'on the device, one host sync per image'}), VAE decode after the last step of every image (inside the timed region), "
                                     f"weights resident; ms_per_step = wall / K with the decode amortised; images/s = gpus x prompts_per_gpu / (steps_per_image x ms_per_step)")
                                    if vae_dir else (f"{cfg.name} UNet denoising step: cond+uncond 2x4x{cfg.latent}x{cfg.latent} latents, W16A16, "
                                                     f"weights resident, mode={args.mode}; NO VAE decode"),
-                       "mode": args.mode, "sampler": "host" if args.host_loop else "device", "autotune": not args.no_autotune, "tune_table": tune_src, "vae_decode_in_timed_region": bool(vae_dir), "images_completed": images_timed, "clamp": bool(args.clamp), "latent_absmax": round(latent_absmax, 3),
+                       "mode": args.mode, "sampler": "host" if args.host_loop else "device", "autotune": not args.no_autotune, "tune_table": tune_src, "tune_table_frozen": bool(frozen_ranks), "tune_table_misses": tune_misses, "vae_decode_in_timed_region": bool(vae_dir), "images_completed": images_timed, "clamp": bool(args.clamp), "latent_absmax": round(latent_absmax, 3),
                        "prompts_per_gpu": P, "unet_passes_per_step": 2 * P, "steps_per_image": STEPS_PER_IMAGE, "launches_per_step": kernels,
                        "vae_launches": vae_kernels, "fusion_level": args.fusion, "unet_device_ms_per_step": round(dev_ms, 4),
                        "parallelism": f"replica x{world}" + (" (dev_one_gpu: all ranks on cuda:0, gloo)" if one_gpu else ""),

@@ -74,6 +74,9 @@ void* osg_stream(const osg_ctx* ctx);     /* the compute hipStream_t (for caller
  * and later launches (graph captures included) reuse the fastest; the choice is shared by every context of the process on that device.
  * Takes the seat of XNNPACK's per-operator microkernel selection at xnn_create_* time (onnxstream.cpp:1104-1182).  Default off. */
 int osg_set_autotune(osg_ctx* ctx, int on);
+/* Shapes an autotuning context looked up in the measured-choice table (OSG_TUNE_CACHE) and did not find, since the process started: with OSG_TUNE_FROZEN=1 such a
+ * shape runs the cost model's first candidate untimed -- a job whose ranks must time the SAME plan (bench.py --gpus N) wants this to be 0. */
+int osg_tune_misses(void);
 
 /* ---- memory / transfers (CublasOps buffer pool + cudaMemcpyAsync precedent, onnxstream.cpp:141-230,325,347) --- */
 int osg_malloc(osg_ctx* ctx, size_t bytes, void** dptr);
@@ -250,17 +253,6 @@ typedef struct {
 } osg_qattn_args;
 int osg_qattn_supported(int M, int rows_per_img, int C, int heads, int Tk);
 int osg_qattn(osg_ctx* ctx, const osg_qattn_args* a);
-/* The LEAN linear launch (osg_linsmall.hip): y[M,N] = [LayerNorm(x; gamma, beta, eps)] . W^T + bias + residual for the projections of the transformer blocks and
- * the 1x1 convolutions (MatMul + Add (+ Add) onnxstream.cpp:5669-5861, :3906-4000; the LayerNorm chain :5237-5604; 1x1 Conv :4494-4707): the
- * workgroup's whole row block in LDS, every operand requested at entry, weights streamed global -> registers from the kn8 layout of
- * osg_tblock_pack_weight.  x rows ldx elements apart (0 = K), residual ldr (0 = N), y ldy (0 = N), optional second destination y2 / ldy2; bias / residual /
- * gamma (+ beta) / y2 may be NULL.  f16 everywhere, f32 accumulation, one rounding.  rowstats (may be NULL): osg_gemm_rowstats' hand-over to an osg_gemm_ln
- * that normalises this output, [M][N/32][2] floats.  osg_linear_small_supported: 1 when the shape is taken (K a multiple of 320 up to 2560, M and N multiples
- * of the tile it picks); osg_linear_small_rowstats_supported: ... and its tile holds whole 32-column slots. */
-int osg_linear_small_supported(int M, int N, int K, int layer_norm);
-int osg_linear_small_rowstats_supported(int M, int N, int K);
-int osg_linear_small(osg_ctx* ctx, const void* x, long ldx, const void* w_kn8, const void* bias, const void* residual, long ldr, const void* gamma,
-                     const void* beta, float eps, void* y, long ldy, void* y2, long ldy2, int M, int N, int K, float* rowstats);
 /* A resident [N][K] weight (k contiguous: a MatMul's [K,N] after osg_transpose_kn_to_nk, a 1x1 convolution's OHWI) -> the layout osg_tblock_tail streams:
  * [K/8][N][8], i.e. for every 8-deep k chunk the N rows side by side -- an MFMA fragment request (lane = row, lane group = k chunk) is then four runs of
  * 256 contiguous bytes.  Done once per weight, when it becomes resident.  K % 8 == 0. */
@@ -301,24 +293,9 @@ int osg_group_norm_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void
  * (a multiple of 128).  The kernel's epilogue serves the sinks where it can (one k-slice, 4-aligned shapes), a small launch of its own otherwise.
  * osg_group_norm_stats_nhwc then normalises from the table in ONE streaming launch (the reference's GroupNorm = InstanceNormalization over [1,G,L]
  * + affine, onnxstream.cpp:4788-5055, as osg_group_norm_nhwc).  f16 only. */
-/* Weight prefetch (round 3): the NEXT contraction launch on this context (osg_gemm*, osg_conv2d_nhwc*; the direct-to-LDS kernels) also touches one dword per
- * 64 bytes of [weights, weights + bytes) -- the weights of the contraction AFTER it -- so that launch finds them in the memory-side cache.  Launches that cannot
- * serve it leave it pending for the next one; bytes 0 clears. */
-int osg_set_weight_prefetch(osg_ctx* ctx, const void* weights, size_t bytes);
-/* Blocked weights (round 3): the caller vouches that `weights` -- the [N][K] f16 weight of the contraction launches that follow, until the next call -- is RESIDENT
- * and constant; the direct-to-LDS kernels then read a copy laid out [N/16][K/64][16][64] (made once per weight, kept by the context, dropped with osg_free of the
- * weight): a wave's tile load is one 1-KiB burst instead of eight 128-byte pieces K*2 bytes apart.  NULL: off. */
-int osg_set_blocked_weight_hint(osg_ctx* ctx, const void* weights);
 int osg_set_stat_sinks(osg_ctx* ctx, void* table0, int groups0, int cpg0, int ch_off0, void* table1, int groups1, int cpg1, int ch_off1, int rows_per_image);
 int osg_group_norm_stats_nhwc(osg_ctx* ctx, const void* x, const void* gamma, const void* beta, void* y, int N, long HW, int C, int G, float eps, osg_act act,
                               const void* stat_table);
-/* Fused  GroupNorm(+SiLU) -> Conv3x3 / stride 1 / pad 1  (the resnet block's norm -> nonlinearity -> conv, reference ops
- * Reshape, InstanceNormalization :4788, Reshape, Mul, Add, Sigmoid :4376, Mul, Conv :4494): the normalised activation is produced
- * on chip inside the convolution's tile loaders and never stored.  Shapes: see osg_group_norm_conv3x3_supported (1 = taken). */
-int osg_group_norm_conv3x3_supported(int N, int H, int W, int Cin, int Cout);
-int osg_group_norm_conv3x3(osg_ctx* ctx, const void* x, const void* gamma, const void* beta, int groups, float eps, osg_act act_pre,
-                           const void* w_ohwi, const void* bias, osg_dtype bias_dtype, const void* image_bias, long image_bias_ld,
-                           const void* residual, void* y, int N, int H, int W, int Cin, int Cout);
 /* Fused LayerNorm over the last axis == ReduceMean,Sub,Pow,ReduceMean,Add,Sqrt,Div,Mul,Add (onnxstream.cpp:5237-5604). */
 int osg_layer_norm(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* gamma, const void* beta, void* y, long rows, int C,
                    float eps);
@@ -334,15 +311,6 @@ int osg_binary(osg_ctx* ctx, osg_dtype dtype, osg_binary_kind kind, const void* 
                const long* b_shape, void* y, int rank);
 /* GEGLU: x:[rows,2C] -> y:[rows,C] = x[:, :C] * gelu_erf(x[:, C:]) (Slice,Slice,Div,Erf,Add,Mul,Mul,Mul). */
 int osg_geglu(osg_ctx* ctx, osg_dtype dtype, const void* x, void* y, long rows, long C);
-
-/* ---- side branch (new): independent launches beside the main chain ------------------------------------------------------ */
-/* Between osg_side_begin and osg_side_end every launch of this context goes to a second stream (with its own split-K workspace) that
- * starts after everything enqueued so far; osg_side_join makes the main stream wait for all side work enqueued so far.  Inside a
- * capture the fork / join become parallel branches of the hipGraph.  Sections do not nest; the caller guarantees that the main chain
- * neither overwrites a side launch's operands nor reads its results before the join. */
-int osg_side_begin(osg_ctx* ctx);
-int osg_side_end(osg_ctx* ctx);
-int osg_side_join(osg_ctx* ctx);
 
 /* ---- denoising-loop glue on the device -------------------------------------------------------- */
 /* CFGDenoiser input side (src/sd.cpp:1427-1470): sample[2p] = sample[2p+1] = x[p] * c_in for p < prompts (L floats each, fp32);

@@ -19,15 +19,15 @@ namespace onnxstream {
     X(osg_device_count) X(osg_init) X(osg_destroy) X(osg_last_error) X(osg_device_name) X(osg_stream) \
     X(osg_set_autotune) X(osg_malloc) X(osg_free) X(osg_upload) X(osg_upload_sync) X(osg_host_register) \
     X(osg_host_unregister) X(osg_upload_pinned) X(osg_upload_pinned_async) X(osg_copy_fence) X(osg_download) X(osg_copy) X(osg_memset) X(osg_sync) \
-    X(osg_graph_begin) X(osg_graph_end) X(osg_graph_launch) X(osg_graph_destroy) X(osg_side_begin) X(osg_side_end) \
-    X(osg_side_join) X(osg_timer_start) X(osg_timer_stop) X(osg_conv2d_nhwc) X(osg_conv2d_nhwc_rb) X(osg_conv2d_nhwc_v) X(osg_set_stat_sinks) X(osg_set_weight_prefetch) X(osg_set_blocked_weight_hint) X(osg_group_norm_stats_nhwc) X(osg_gemm) \
+    X(osg_graph_begin) X(osg_graph_end) X(osg_graph_launch) X(osg_graph_destroy) \
+    X(osg_timer_start) X(osg_timer_stop) X(osg_conv2d_nhwc) X(osg_conv2d_nhwc_rb) X(osg_conv2d_nhwc_v) X(osg_set_stat_sinks) X(osg_group_norm_stats_nhwc) X(osg_gemm) \
     X(osg_gemm_ln) X(osg_gemm_rowstats) X(osg_gemm_w8) X(osg_conv2d_nhwc_w8) X(osg_transpose_kn_to_nk) X(osg_attention) \
-    X(osg_attention_strided) X(osg_sdpa) X(osg_rms_norm) X(osg_rope) X(osg_instance_norm) X(osg_group_norm_nhwc) X(osg_group_norm_conv3x3_supported) X(osg_group_norm_conv3x3) X(osg_layer_norm) \
+    X(osg_attention_strided) X(osg_sdpa) X(osg_rms_norm) X(osg_rope) X(osg_instance_norm) X(osg_group_norm_nhwc) X(osg_layer_norm) \
     X(osg_reduce_mean_last) X(osg_softmax_last) X(osg_unary) X(osg_binary) X(osg_geglu) X(osg_transpose) \
     X(osg_copy_2d) X(osg_concat2) X(osg_resize_nearest) X(osg_gather_rows) X(osg_maxpool_nhwc) X(osg_convert) \
     X(osg_sampler_prepare) X(osg_sampler_cfg_euler_a) X(osg_qu8_conv2d_nhwc) X(osg_qu8_conv2d_nhwc_t) X(osg_qu8_conv_tap_sums) X(osg_qu8_gemm) X(osg_qu8_lut) X(osg_qu8_binary) \
     X(osg_qu8_instance_norm) X(osg_qu8_instance_norm_nhwc) X(osg_qu8_affine_act) X(osg_qu8_norm_affine_act_nhwc) X(osg_qu8_softmax_last) X(osg_range_push) X(osg_range_pop) X(osg_marker_record) \
-    X(osg_copy_wait_marker) X(osg_timer_mark) X(osg_timer_between) X(osg_tblock_tail_supported) X(osg_tblock_tail) X(osg_tblock_kv_pack_elems) X(osg_tblock_kv_pack_jobs) X(osg_tblock_pack_weight) X(osg_qattn_supported) X(osg_qattn) X(osg_linear_small_supported) X(osg_linear_small_rowstats_supported) X(osg_linear_small)
+    X(osg_copy_wait_marker) X(osg_timer_mark) X(osg_timer_between) X(osg_tblock_tail_supported) X(osg_tblock_tail) X(osg_tblock_kv_pack_elems) X(osg_tblock_kv_pack_jobs) X(osg_tblock_pack_weight) X(osg_qattn_supported) X(osg_qattn)
 
 struct OsgApi {
 #define OSG_FN(name) decltype(&::name) name = nullptr;

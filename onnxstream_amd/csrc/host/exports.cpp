@@ -233,19 +233,14 @@ void model_set_option(Handle* h, char* name, unsigned int value) {
     else if (n == "hip_fusion_level") m.m_hip_fusion_level = (int)value;
     else if (n == "hip_use_graph") m.m_hip_use_graph = b;
     else if (n == "hip_autotune") m.m_hip_autotune = b;
-    else if (n == "hip_side_stream") m.m_hip_side_stream = b;
     else if (n == "hip_fuse_ln_gemm") m.m_hip_fuse_ln_gemm = b;
     else if (n == "hip_concat_views") m.m_hip_concat_views = b;
     else if (n == "hip_fuse_tblock") m.m_hip_fuse_tblock = b;
     else if (n == "hip_fuse_qattn") m.m_hip_fuse_qattn = b;
-    else if (n == "hip_small_linear") m.m_hip_small_linear = (int)value;
     else if (n == "hip_gn_stats") m.m_hip_gn_stats = (int)value;
-    else if (n == "hip_weight_prefetch") m.m_hip_weight_prefetch = b;
-    else if (n == "hip_blocked_weights") m.m_hip_blocked_weights = b;
     else if (n == "hip_stream_weights") m.m_hip_stream_weights = b;
     else if (n == "hip_w8_resident") m.m_hip_w8_resident = b;
     else if (n == "hip_resident_outputs") m.m_hip_resident_outputs = b;
-    else if (n == "hip_fuse_gn_conv") m.m_hip_fuse_gn_conv = b;
     else {
         const char* err = "model_set_option: 'name' not found.";
         printf("=== ERROR === %s\n", err);

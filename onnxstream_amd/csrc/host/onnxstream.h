@@ -560,19 +560,12 @@ public:
     bool m_hip_use_graph = true;   // replay a pass as one hipGraph from the third run on
     bool m_hip_fuse_ln_gemm = true;  // fusion level 2: a LayerNorm whose only consumers are Linear ops is folded into their GEMM (osg_gemm_ln, row
                                      // statistics handed over by the producing GEMM): 48 launches less in the SD 1.5 UNet, measured -1 % per step (round 2) => on
-    bool m_hip_blocked_weights = false; // resident f16 weights read by the direct-to-LDS kernels in the blocked layout [N/16][K/64][16][64] (osg_set_blocked_weight_hint; a second copy per weight)
-    bool m_hip_weight_prefetch = false; // every contraction launch also pulls the NEXT contraction's weights towards the memory-side cache (osg_set_weight_prefetch)
     int m_hip_gn_stats = 2;         // fusion level 2: a GroupNorm over what convolutions store reads its statistics from their epilogues (osg_set_stat_sinks) and is one streaming
                                     // launch.  0 off, 1 every eligible GroupNorm, 2 (default) where the tensor has >= 8 M elements: in the throughput regime it pays (f16 VAE decoder
                                     // 4.61 -> 4.08 ms, SDXL UNet -1.1 %), on the SD 1.5 pass -- launches that last as long as one workgroup -- it is neutral (profiles/r03_gn_stats_ab.txt)
     bool m_hip_fuse_qattn = true;   // fusion level 2: LayerNorm + attn2.to_q + cross-attention as ONE launch where osg_qattn takes the shape (C = 640 / 1280; round 4)
     bool m_hip_fuse_tblock = true;  // fusion level 2: the row-local tail of a transformer block (attn1.to_out .. ff.net.2 [.. proj_out]) as ONE launch where osg_tblock_tail takes the shape (round 4)
-    int m_hip_small_linear = 0;     // fusion level 2: projections and 1x1 convolutions as osg_linear_small launches (every operand requested at entry) instead of gemm2_kernel (round 4).
-                                    // 0 (default) never: inside the pass the TUNED gemm2_kernel launches are as fast or faster (5.65 vs 5.70 ms per step, profiles/r04_linear_small_ab.txt);
-                                    // 1 where the kernel probe measured it faster against the untuned choice: <= 1.7 GFLOP, K <= 1280, no LayerNorm in front; 2 every shape the kernel takes
     bool m_hip_concat_views = true; // fusion level 2: convolutions store skip tensors straight into their Concat slot (osg_conv2d_nhwc_v), no copy launch
-    bool m_hip_side_stream = false; // contraction launches whose result is first read >= 3 steps later (a resnet's 1x1 shortcut convolution) run on a second
-                                    // stream beside the main chain (parallel branches of the captured hipGraph); measured +0.25 ms per pass => opt-in
     bool m_hip_autotune = false;   // true: the first (eager) pass TIMES the legal tile / split-K configurations of every GEMM / convolution shape
                                    // (osg_set_autotune) -- faster, but the choice (hence the fp32 summation order, hence the last bits) depends on a
                                    // timer unless OSG_TUNE_CACHE seeds it; default: the deterministic cost-model choice
@@ -583,8 +576,6 @@ public:
     bool m_hip_w8_resident = false;     // true: uint8 weights of Conv/MatMul/Gemm stay uint8 in HBM (half the footprint and weight traffic) and are
                                         // dequantised on chip by the osg_*_w8 kernels -- same VALUES as the reference's load-time dequantisation
                                         // (:2887-2891); false (default, currently the faster path: halo conv + merged projections): dequantise once at load
-    bool m_hip_fuse_gn_conv = false;    // GroupNorm(+SiLU) applied inside the 3x3 convolution's tile loaders (osg_group_norm_conv3x3): bit-identical,
-                                        // removes a pass over the tensor, but measured slower than the separate launches -> opt-in
     bool m_hip_stream_weights = false;  // true: weights are re-streamed through pinned buffers every pass (WeightsProvider mode)
     size_t hip_last_kernel_count() const;
     size_t hip_plans_built() const { return m_plans_built; }   // how many times run() had to (re-)plan since the Model was created

@@ -101,18 +101,13 @@ Plan::Plan(Model& model, HipBackend& backend, ConstPool& cpool, size_t batch) : 
     budgeted = vram_budget > 0;
     if (budgeted) stream_weights = true;
     w8_resident = m.m_hip_w8_resident && !stream_weights;
-    fuse_gn_conv = m.m_hip_fuse_gn_conv;
     fuse_ln_gemm = m.m_hip_fuse_ln_gemm;
     concat_views = m.m_hip_concat_views;
     fuse_tblock = m.m_hip_fuse_tblock;
     fuse_qattn = m.m_hip_fuse_qattn;
-    small_linear = m.m_hip_small_linear != 0;
-    small_linear_req = m.m_hip_small_linear;
-    weight_prefetch = m.m_hip_weight_prefetch;
-    blocked_weights = m.m_hip_blocked_weights;
     gn_stats_req = m.m_hip_gn_stats;
     gn_stats_min_elems = m.m_hip_gn_stats == 2 ? (8L << 20) : 0;
-    gn_stats_on = m.m_hip_gn_stats != 0 && !stream_weights && m.m_hip_fusion_level >= 2 && !m.m_hip_fuse_gn_conv && !m.m_use_uint8_arithmetic && !m.m_range_data_calibrate;
+    gn_stats_on = m.m_hip_gn_stats != 0 && !stream_weights && m.m_hip_fusion_level >= 2 && !m.m_use_uint8_arithmetic && !m.m_range_data_calibrate;
     u8 = m.m_use_uint8_arithmetic;
     u8_qdq = m.m_use_uint8_qdq;
     autotune = m.m_hip_autotune;
@@ -120,7 +115,6 @@ Plan::Plan(Model& model, HipBackend& backend, ConstPool& cpool, size_t batch) : 
     fuse_attn = m.m_fuse_ops_in_attention;
     sdp_attn = m.m_use_scaled_dp_attn_op;
     outputs_convert_set = m.m_outputs_convert_set;
-    side_stream = m.m_hip_side_stream && !stream_weights;
     extra_outputs = m.m_extra_outputs;
     recycle = m.m_support_dynamic_shapes && !stream_weights;
     resident_outputs = m.m_hip_resident_outputs && m.m_support_dynamic_shapes && !stream_weights && !m.m_outputs_convert_set.empty();
@@ -135,10 +129,10 @@ bool Plan::compatible(Model& mm, size_t batch) const {
     const bool want_stream = mm.m_hip_stream_weights || mm.m_cuda_options.m_vram_to_use > 0;
     if ((long)batch != N) return no("batch size");
     if (mm.m_use_fp16_arithmetic != fp16 || mm.m_use_uint8_arithmetic != u8 || mm.m_use_uint8_qdq != u8_qdq) return no("arithmetic type");
-    if (mm.m_hip_fusion_level != fusion_req || mm.m_hip_fuse_gn_conv != fuse_gn_conv || mm.m_hip_fuse_ln_gemm != fuse_ln_gemm || mm.m_hip_concat_views != concat_views || mm.m_hip_fuse_tblock != fuse_tblock || mm.m_hip_fuse_qattn != fuse_qattn || mm.m_hip_small_linear != small_linear_req || mm.m_hip_weight_prefetch != weight_prefetch || mm.m_hip_blocked_weights != blocked_weights || mm.m_hip_gn_stats != gn_stats_req ||
+    if (mm.m_hip_fusion_level != fusion_req || mm.m_hip_fuse_ln_gemm != fuse_ln_gemm || mm.m_hip_concat_views != concat_views || mm.m_hip_fuse_tblock != fuse_tblock || mm.m_hip_fuse_qattn != fuse_qattn || mm.m_hip_gn_stats != gn_stats_req ||
         mm.m_fuse_ops_in_attention != fuse_attn || mm.m_use_scaled_dp_attn_op != sdp_attn || mm.m_hip_autotune != autotune)
         return no("fusion / tuning options");
-    if (want_stream != stream_weights || (size_t)mm.m_cuda_options.m_vram_to_use != vram_budget || (mm.m_hip_side_stream && !want_stream) != side_stream ||
+    if (want_stream != stream_weights || (size_t)mm.m_cuda_options.m_vram_to_use != vram_budget ||
         (mm.m_hip_w8_resident && !want_stream) != w8_resident)
         return no("weight residency options");
     if (mm.m_extra_outputs != extra_outputs || mm.m_outputs_convert_set != outputs_convert_set ||
@@ -770,7 +764,6 @@ struct Lowering {
             if (has_type("osg.SiLU")) { index_graph(); cse_silu(); }
             if (has_type("osg.SiLU") && has_type("Gemm")) { index_graph(); fuse_gemm_act(); }   // (after the CSE: the 22 SiLUs behind the time embedding are one by now)
             if (has_type("Conv")) { index_graph(); fuse_image_bias(); }
-            if (has_type("osg.GroupNorm")) { index_graph(); fuse_group_norm_conv(); }   // last: the conv's epilogue inputs (residual, image bias) are final by now
         } else if (m.m_fuse_ops_in_attention && has_type("Softmax")) {
             index_graph(); fuse_attention(false);
         }
@@ -1276,47 +1269,6 @@ struct Lowering {
         }
     }
 
-    // osg.GroupNorm(+SiLU) -> Conv 3x3/s1/p1  ==> the normalisation rides in the convolution's tile loaders (osg_group_norm_conv3x3):
-    // the normalised activation is never written.  Runs after the residual / image-bias fusions so the conv's epilogue inputs are final.
-    void fuse_group_norm_conv() {
-        // measured SLOWER than GroupNorm + conv as separate launches (tools/gnconv_probe.py: 51 vs 42 us at 64x64x320): the loader waves
-        // spend ~100 VALU instructions per 1-KiB patch piece on the affine + SiLU and become the critical path.  Opt-in only.
-        if (P.stream_weights || !m.m_hip_fuse_gn_conv) return;
-        for (size_t i = 0; i < ops().size(); i++) {
-            if (!is((int)i, "osg.GroupNorm")) continue;
-            Operation& gn = ops()[i];
-            int ci = sole_consumer(gn.m_output[0]);
-            if (!is(ci, "Conv")) continue;
-            Operation& cv = ops()[ci];
-            if (cv.m_input.empty() || cv.m_input[0].m_name != gn.m_output[0].m_name || attr(cv, "osg_act")) continue;
-            bool other_use = false;   // the normalised tensor must not also be the residual / image bias of the same conv
-            for (size_t k = 1; k < cv.m_input.size(); k++) other_use |= cv.m_input[k].m_name == gn.m_output[0].m_name;
-            if (other_use) continue;
-            const Val* w = cval(cv.m_input[1]);
-            const auto& xs = gn.m_input[0].m_shape;
-            if (!w || w->dtype != OSG_F16 || w->shape.size() != 4 || xs.size() != 4 || xs[0] != 1) continue;
-            if (w->shape[2] != 3 || w->shape[3] != 3) continue;
-            auto* st = attr(cv, "strides");
-            auto* pd = attr(cv, "pads");
-            if (st && int_list(*st) != std::vector<int>{1, 1}) continue;
-            if (!pd || int_list(*pd) != std::vector<int>{1, 1, 1, 1}) continue;
-            const Val* gam = cval(gn.m_input[1]);
-            const Val* bet = cval(gn.m_input[2]);
-            if (!gam || !bet || gam->dtype != OSG_F16 || bet->dtype != OSG_F16) continue;
-            if (!be.api.osg_group_norm_conv3x3_supported((int)N, (int)xs[2], (int)xs[3], (int)xs[1], (int)w->shape[0])) continue;
-            Operation f = cv;
-            f.m_input[0] = gn.m_input[0];
-            while (f.m_input.size() < 5) f.m_input.push_back(Tensor());
-            f.m_input.push_back(gn.m_input[1]);
-            f.m_input.push_back(gn.m_input[2]);
-            f.m_attributes.emplace_back("osg_prenorm", *attr(gn, "silu"));
-            f.m_attributes.emplace_back("osg_pre_groups", *attr(gn, "groups"));
-            f.m_attributes.emplace_back("osg_pre_eps", *attr(gn, "epsilon"));
-            dead[i] = 1;
-            ops()[ci] = std::move(f);
-        }
-    }
-
     // osg.Linear(x, W[K,2C], b) -> osg.GEGLU  ==> the GEGLU rides in the GEMM epilogue (value/gate columns pair-interleaved at plan time)
     void fuse_linear_geglu() {
         if (P.stream_weights) return;   // needs a re-ordered resident copy of the weight
@@ -1407,7 +1359,7 @@ struct Lowering {
                     const Operation& co = ops()[c0];
                     const Val* w = cval(co.m_input[1]);
                     const auto& rs = ops()[r0].m_output[0].m_shape;
-                    bool ok = co.m_input.size() == 4 && attr(co, "osg_residual") && !attr(co, "osg_image_bias") && !attr(co, "osg_prenorm") && !attr(co, "osg_act") &&
+                    bool ok = co.m_input.size() == 4 && attr(co, "osg_residual") && !attr(co, "osg_image_bias") && !attr(co, "osg_act") &&
                               co.m_input[0].m_name == ops()[t0].m_output[0].m_name && w && w->dtype == OSG_F16 && w->shape == Shape{C, C, 1, 1} && vok(co.m_input[2], C, true) &&
                               rs.size() == 4 && rs[0] == 1 && (long)(rs[1] * rs[2]) == T && (long)rs[3] == C && act(co.m_input[3]) && co.m_input[3].m_name != co.m_input[0].m_name;
                     for (auto& a : co.m_attributes) {
@@ -1568,6 +1520,7 @@ struct Lowering {
             int ri = other(ops()[ad], op.m_output[0].m_name);
             const Tensor& r = ops()[ad].m_input[ri];
             if (!act(r) || r.m_shape != op.m_output[0].m_shape || r.m_name == op.m_output[0].m_name) continue;
+            if (conv && op.m_output[0].m_shape.size() != 4) continue;   // (a Conv1D is lifted to 2-D inside lower_conv: its residual stays an Add)
             // the residual must already exist when the fused op runs: its producer has to precede `ad` (always true in a
             // topologically sorted file) -- the fused op takes the place of the Add.
             Operation f = op;
@@ -2586,7 +2539,15 @@ struct Lowering {
         if (P.u8) return lower_u8(op);
         if (t == "Gather") return lower_gather(op);
         if (t == "Cast") return lower_cast(op);
-        if (t == "Conv") return lower_conv(op);
+        if (t == "Conv") {
+            conv1d_out = Conv1dOut{};
+            lower_conv(op);
+            if (conv1d_out.y >= 0) {   // Conv1D: NHWC [1, Lo, 1, O] -> plain [1, O, Lo, 1] = the graph's [1, O, Lo]
+                check_out(op, {1, conv1d_out.Cout, conv1d_out.Lo});
+                P.alias(P.ensure_plain(conv1d_out.y), {1, conv1d_out.Cout, conv1d_out.Lo}, Lay::plain, op.m_output[0].m_name);
+            }
+            return;
+        }
         if (t == "MatMul") return lower_matmul(op);
         if (t == "osg.Linear") return lower_linear(op);
         if (t == "Gemm") return lower_gemm(op);
@@ -2626,7 +2587,7 @@ struct Lowering {
     // Conv (reference :4494-4707 -> XnnPack::convolution :1292): group 1, dilation 1, pads re-centred (:1315-1329)
     // GEMM-shaped steps ([M,K] x [N,K]^T, plain epilogue) that can ALSO emit the partial row statistics of their output when a folded
     // LayerNorm turns out to consume it (osg_gemm_rowstats): keyed by the root val they write
-    struct RsProducer { size_t step; int a, w, bias, res, y; long M, N, K; bool lean = false; };   // (lean: an osg_linear_small launch, w = its kn8 weight)
+    struct RsProducer { size_t step; int a, w, bias, res, y; long M, N, K; };
     std::map<int, RsProducer> rs_producers;
     void note_rs_producer(int a, int w, int bias, int res, int y, long M, long Nn, long K) {
         if (P.fusion < 2 || !P.fuse_ln_gemm || Nn % 32 || K % 64 || Nn > 1280) return;
@@ -2651,16 +2612,6 @@ struct Lowering {
         const int a = r.a, w = r.w, bias = r.bias, res = r.res, y = r.y;
         const long M = r.M, Nn = r.N, K = r.K;
         const std::string what = st.what;
-        if (r.lean) {
-            const long ldx = V(a).ld;
-            st.run = [=, this] {
-                be.check(be.api.osg_linear_small(be.ctx, P.ptr(a), ldx, P.ptr(w), bias >= 0 ? P.ptr(bias) : nullptr, res >= 0 ? P.ptr(res) : nullptr, 0, nullptr, nullptr, 0.f, P.ptr(y), 0,
-                                                 nullptr, 0, (int)M, (int)Nn, (int)K, (float*)P.ptr(rs)),
-                         what.c_str());
-            };
-            rs_producers.erase(it);
-            return rs;
-        }
         st.run = [=, this] {
             be.check(be.api.osg_gemm_rowstats(be.ctx, P.ptr(a), P.ptr(w), bias >= 0 ? P.ptr(bias) : nullptr, bias >= 0 ? P.vals[bias].dtype : OSG_F16,
                                               res >= 0 ? P.ptr(res) : nullptr, P.ptr(y), (int)M, (int)Nn, (int)K, OSG_ACT_NONE, (float*)P.ptr(rs)),
@@ -2685,12 +2636,12 @@ struct Lowering {
     std::map<int, ConvProducer> conv_producers;   // root val of a convolution's output -> its step
     std::set<size_t> viewed_steps;                // steps whose destinations were redirected (their launch must stay the view-aware one)
 
+    struct Conv1dOut { int y = -1; long Cout = 0, Lo = 0; } conv1d_out;
     void lower_conv(const Operation& op) {
         const bool has_res = attr(op, "osg_residual") != nullptr;
         const bool has_ib = attr(op, "osg_image_bias") != nullptr;
-        const bool has_pre = attr(op, "osg_prenorm") != nullptr;
         const osg_act cact = attr(op, "osg_act") ? OSG_ACT_SILU : OSG_ACT_NONE;
-        const size_t nin = has_pre ? (op.m_input.size() == 7 ? (has_ib ? 5 : has_res ? 4 : !op.m_input[2].m_name.empty() ? 3 : 2) : 0) : op.m_input.size();
+        const size_t nin = op.m_input.size();
         need(op, nin == 2 || nin == 3 || (has_res && nin == 4) || (has_ib && nin == 5), "wrong number of inputs.");
         need(op, op.m_output.size() == 1, "wrong number of outputs.");
         std::vector<int> dil = {1, 1}, ks, pads = {0, 0, 0, 0}, strides = {1, 1};
@@ -2701,12 +2652,26 @@ struct Lowering {
             else if (a.first == "kernel_shape") ks = int_list(a.second);
             else if (a.first == "pads") pads = int_list(a.second);
             else if (a.first == "strides") strides = int_list(a.second);
-            else if (a.first == "osg_residual" || a.first == "osg_image_bias" || a.first == "osg_prenorm" || a.first == "osg_pre_groups" ||
-                     a.first == "osg_pre_eps" || a.first == "osg_act") {}
+            else if (a.first == "osg_residual" || a.first == "osg_image_bias" || a.first == "osg_act") {}
             else throw std::invalid_argument(op.m_type + ": unrecognized attribute: " + a.first + ".");
         }
         int x = in_val(op.m_input[0]);
-        need(op, V(x).shape.size() == 4, "Conv1D / non 4-D input not implemented on the HIP backend.");
+        // Conv1D (reference :4521-4544): run as the 2-D convolution over [N, C, L, 1] -- dilations / kernel_shape gain a 1, pads [b, e] become [b, 0, e, 0], the
+        // stride is repeated -- and the [N, O, Lo, 1] result is handed on as [N, O, Lo]
+        const bool is1d = V(x).shape.size() == 3;
+        if (is1d) {
+            need(op, !has_res && !has_ib, "Conv1D with fused epilogue inputs not implemented on the HIP backend.");
+            bool have_pads = false, have_strides = false, have_dil = false;
+            for (auto& a : op.m_attributes) { have_pads |= a.first == "pads"; have_strides |= a.first == "strides"; have_dil |= a.first == "dilations"; }
+            if (have_dil) { need(op, dil.size() == 1, "invalid dilations attribute value."); dil.push_back(1); }
+            if (!ks.empty()) { need(op, ks.size() == 1, "invalid kernel_shape attribute value."); ks.push_back(1); }
+            if (have_pads) { need(op, pads.size() == 2, "invalid pads attribute value."); pads = {pads[0], 0, pads[1], 0}; }
+            if (have_strides) { need(op, strides.size() == 1, "invalid strides attribute value."); strides.push_back(strides[0]); }
+            Shape s4 = V(x).shape;
+            s4.push_back(1);
+            x = P.alias(P.ensure_plain(x), s4, Lay::plain);
+        }
+        need(op, V(x).shape.size() == 4, "invalid shape of input.");
         for (int d : dil) need(op, d == 1, "dilations != 1 not supported (not implemented).");
         need(op, group == 1, "group != 1 not supported (not implemented).");
         need(op, pads.size() == 4 && strides.size() == 2, "invalid pads/strides.");
@@ -2736,31 +2701,14 @@ struct Lowering {
             need(op, V(ib).numel() == Cout && V(ib).dtype == OSG_F16 && V(ib).batched == V(x).batched, "invalid image bias.");
             ib_ld = V(ib).ld ? V(ib).ld : Cout;
         }
-        int y = out_val(op, {1, Cout, Ho, Wo}, Lay::nhwc, V(x).batched);
+        int y = is1d ? P.new_val("", {1, Cout, Ho, Wo}, OSG_F16, Lay::nhwc, V(x).batched) : out_val(op, {1, Cout, Ho, Wo}, Lay::nhwc, V(x).batched);
+        if (is1d) conv1d_out = Conv1dOut{y, Cout, Ho};   // (lower() hands the [1, O, Lo, 1] result on as the graph's [1, O, Lo] once the launch is planned)
         const long nb = B(x);
         const int sh = strides[0], sw = strides[1];
         std::vector<int> reads = {x, w};
         if (bias >= 0) reads.push_back(bias);
         if (res >= 0) reads.push_back(res);
         if (ib >= 0) reads.push_back(ib);
-        if (has_pre) {
-            const int gam = in_val(op.m_input[5]), bet = in_val(op.m_input[6]);
-            const int G = std::stoi(*attr(op, "osg_pre_groups"));
-            const float eps = std::stof(*attr(op, "osg_pre_eps"));
-            const int pact = *attr(op, "osg_prenorm") == "1" ? OSG_ACT_SILU : OSG_ACT_NONE;
-            need(op, V(gam).numel() == Cin && V(bet).numel() == Cin && V(w).dtype == OSG_F16, "invalid fused GroupNorm operands.");
-            reads.push_back(gam);
-            reads.push_back(bet);
-            P.add_step("Conv gn+ " + op.m_name, reads, {y}, [=, this] {
-                be.check(be.api.osg_group_norm_conv3x3(be.ctx, P.ptr(x), P.ptr(gam), P.ptr(bet), G, eps, (osg_act)pact, P.ptr(w),
-                                                       bias >= 0 ? P.ptr(bias) : nullptr, bias >= 0 ? P.vals[bias].dtype : OSG_F16,
-                                                       ib >= 0 ? P.ptr(ib) : nullptr, ib_ld, res >= 0 ? P.ptr(res) : nullptr, P.ptr(y), (int)nb,
-                                                       (int)H, (int)W, (int)Cin, (int)Cout),
-                         "Conv");
-            });
-            P.steps.back().flops = 2.0 * nb * Ho * Wo * Cout * KH * KW * Cin;
-            return;
-        }
         if (V(w).dtype == OSG_U8) {
             const float qs = V(w).qscale;
             const int qz = V(w).qzp;
@@ -2776,14 +2724,6 @@ struct Lowering {
         }
         auto co = std::make_shared<ConvOut>();
         co->dst = y;
-        if (KH == 1 && KW == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && ib < 0 && cact == OSG_ACT_NONE && V(x).ld == 0 && ls_ok(nb * Ho * Wo, Cout, Cin, false) &&
-            ls_operands_ok(x, w, bias, res)) {
-            // a 1x1 convolution IS a GEMM over the pixels (NHWC rows, OHWI == [N][K]): the lean linear launch, with the convolution's output views
-            co->no_sinks = true;
-            emit_linear_small("Conv [lean] " + op.m_name, x, w, bias, res, nullptr, y, nb * Ho * Wo, Cout, Cin, co);
-            conv_producers[P.root_of(y)] = ConvProducer{P.steps.size() - 1, co, y};
-            return;
-        }
         P.add_step("Conv " + op.m_name, reads, {y}, [=, this] {
             const ConvOut& o = *co;
             if (o.sink[0].off >= 0 || o.sink[1].off >= 0)
@@ -2857,53 +2797,10 @@ struct Lowering {
         P.steps.back().flops = 2.0 * M * Nn * K;
     }
 
-    struct LnFold { int x, g, b; float eps; long C; int rs; bool inl = false; };   // rs: partial row statistics handed over by the producer of x (-1: none); inl: the consumer is an osg_linear_small launch that normalises its rows itself (original weights, no fold, no statistics)
-    // ---- the lean linear launch (osg_linear_small, round 4): the projections of the transformer blocks and the 1x1 convolutions -- every operand requested at
-    // entry, the row block in LDS, weights streamed from the kn8 layout; LayerNorm (when one sits in front) done on the rows in LDS with the original weights
-    bool ls_ok(long M, long Nn, long K, bool ln) const {
-        // Measured (tools/linear_small_probe.py, profiles/r04_linear_small_probe_v1.txt; cold weights): at <= 1.7 GFLOP and K <= 1280 the lean launch is 1 - 2.4 us faster
-        // than gemm2_kernel (9.2 vs 11.6, 8.5 vs 9.2, 6.4 vs 7.7 us); beyond that every row block re-streaming its column tile's weights costs more than
-        // gemm2's tiles (K = 2560: 16.8 vs 10.8 us), and with the LayerNorm inside (the row block + gamma / beta exceed half the LDS: one workgroup per CU, two
-        // rounds of workgroups) it loses to the folded form by 2 - 14 us -- so LayerNorm consumers keep osg_gemm_ln (hip_small_linear = 2 routes them here too)
-        if (ln && m.m_hip_small_linear < 2) return false;
-        if (m.m_hip_small_linear < 2 && (K > 1280 || (double)M * Nn * K > 0.9e9)) return false;
-        return P.small_linear && P.fusion >= 2 && !P.stream_weights && !P.u8 && M > 0 && (double)M * Nn * K <= 2.6e9 && be.api.osg_linear_small_supported((int)M, (int)Nn, (int)K, ln ? 1 : 0) == 1;
-    }
-    bool ls_operands_ok(int a, int wnk, int bias, int res) {
-        if (V(a).dtype != OSG_F16 || V(wnk).dtype != OSG_F16 || !V(wnk).is_const || (V(a).ld % 8) != 0) return false;
-        if (bias >= 0 && V(bias).dtype != OSG_F16) return false;
-        if (res >= 0 && (V(res).dtype != OSG_F16 || V(res).ld != 0)) return false;
-        return true;
-    }
-    // co: where the result goes (a convolution's ConvOut: a Concat slot and / or the dense tensor); nullptr = y, dense
-    void emit_linear_small(const std::string& what, int a, int wnk, int bias, int res, const LnFold* ln, int y, long M, long Nn, long K, std::shared_ptr<ConvOut> co = nullptr) {
-        const int wk = weight_kn8(wnk);
-        const int g = ln ? ln->g : -1, b = ln ? ln->b : -1;
-        const float eps = ln ? ln->eps : 0.f;
-        const long ldx = V(a).ld;
-        std::vector<int> reads = {a, wk};
-        for (int r : {bias, res, g, b})
-            if (r >= 0) reads.push_back(r);
-        P.add_step(what, reads, {y}, [=, this] {
-            void* dst = co ? (char*)P.ptr(co->dst) + co->dst_off : P.ptr(y);
-            const long ldy = co ? co->dst_ld : 0;
-            void* dst2 = co && co->dst2 >= 0 ? (char*)P.ptr(co->dst2) + co->dst2_off : nullptr;
-            be.check(be.api.osg_linear_small(be.ctx, P.ptr(a), ldx, P.ptr(wk), bias >= 0 ? P.ptr(bias) : nullptr, res >= 0 ? P.ptr(res) : nullptr, 0,
-                                             g >= 0 ? P.ptr(g) : nullptr, b >= 0 ? P.ptr(b) : nullptr, eps, dst, ldy, dst2, co ? co->dst2_ld : 0, (int)M, (int)Nn, (int)K, nullptr),
-                     what.c_str());
-        });
-        P.steps.back().flops = 2.0 * M * Nn * K;
-        if (!ln && !co && V(y).ld == 0 && P.fuse_ln_gemm && Nn % 32 == 0 && Nn <= 1280 && be.api.osg_linear_small_rowstats_supported((int)M, (int)Nn, (int)K) == 1) {
-            RsProducer r{P.steps.size() - 1, a, wk, bias, res, y, M, Nn, K};
-            r.lean = true;
-            rs_producers[P.root_of(y)] = r;
-        }
-    }
+    struct LnFold { int x, g, b; float eps; long C; int rs; };   // rs: partial row statistics handed over by the producer of x (-1: none)
 
     void emit_gemm(const std::string& what, int a, int wnk, int bias, int res, int y, long M, long Nn, long K, long batch, long sa, long sb,
                    long sc, int b_is_nk, osg_act act_ = OSG_ACT_NONE) {
-        if (b_is_nk && batch == 1 && act_ == OSG_ACT_NONE && V(y).ld == 0 && ls_ok(M, Nn, K, false) && ls_operands_ok(a, wnk, bias, res) && V(wnk).shape.size() == 2)
-            return emit_linear_small(what + " [lean]", a, wnk, bias, res, nullptr, y, M, Nn, K);
         std::vector<int> reads = {a, wnk};
         if (bias >= 0) reads.push_back(bias);
         if (res >= 0) reads.push_back(res);
@@ -2989,7 +2886,7 @@ struct Lowering {
             // concatenated [ntot, K] weight and [ntot] bias, built once from the resident per-op tensors
             int wcat = P.new_val("", {g.ntot, K}, OSG_F16, Lay::plain, false);
             V(wcat).is_const = true;
-            V(wcat).name = "merged|" + op.m_input[0].m_name + "|" + ops()[g.members[0]].m_name + "|" + std::to_string(g.members.size()) + (lnf && !lnf->inl ? "|ln" : "");   // (a folded copy has a tag of its own; the lean launch normalises the rows and reads the plain concatenation)
+            V(wcat).name = "merged|" + op.m_input[0].m_name + "|" + ops()[g.members[0]].m_name + "|" + std::to_string(g.members.size()) + (lnf ? "|ln" : "");   // (a folded copy has a tag of its own)
             bool fresh_w, fresh_b = false;
             V(wcat).dptr = P.const_alloc(V(wcat).name, (size_t)g.ntot * K * 2, &fresh_w);
             const bool has_bias = op.m_input.size() > 2 && !op.m_input[2].m_name.empty();
@@ -3015,10 +2912,7 @@ struct Lowering {
             ys.back() = g.ntot;
             g.y = P.new_val("", ys, OSG_F16, Lay::plain, V(a).batched);
             const long M = prod(as) / K * B(a);
-            if (lnf && lnf->inl) {
-                need(op, ls_operands_ok(a, wcat, bcat, -1), "invalid operands of a LayerNorm + merged Linear launch.");
-                emit_linear_small("Linear ln merged(" + std::to_string(g.members.size()) + ") [lean] " + op.m_name, a, wcat, bcat, -1, lnf, g.y, M, g.ntot, K);
-            } else if (lnf) {
+            if (lnf) {
                 auto [c1, c2] = ln_fold_weight(*lnf, wcat, bcat, P.ptr(wcat), V(wcat).name);   // the concatenated copy is private: fold in place
                 emit_gemm_ln("Linear ln+ merged(" + std::to_string(g.members.size()) + ") " + op.m_name, *lnf, wcat, c1, c2, -1, g.y, M, g.ntot, K, OSG_ACT_NONE);
             } else
@@ -3105,11 +2999,6 @@ struct Lowering {
         os.back() = Nn;
         int y = out_val(op, os, Lay::plain, V(a).batched);
         const long M = prod(as) / K * B(a);
-        if (lnf && lnf->inl) {
-            const int wnk = weight_nk(w);
-            need(op, ls_operands_ok(a, wnk, bias, res), "invalid operands of a LayerNorm + Linear launch.");
-            return emit_linear_small("Linear ln [lean] " + op.m_name, a, wnk, bias, res, lnf, y, M, Nn, K);
-        }
         if (lnf) {
             const int wnk = weight_nk(w);
             const int wf = private_copy(wnk, ln_tag(*lnf, bias));
@@ -3542,25 +3431,6 @@ struct Lowering {
         P.steps.back().flops = 2.0 * M * Nn * K;
     }
 
-    // every consumer of this LayerNorm (ln_can_fold has checked: plain osg.Linear ops, one launch) would be an osg_linear_small launch with LayerNorm
-    bool ln_consumers_lean(const Operation& op, int x, int g, int b) {
-        if (V(g).dtype != OSG_F16 || V(b).dtype != OSG_F16 || V(x).dtype != OSG_F16) return false;
-        const long C = V(x).shape.back(), M = P.total_elems(x) / C;
-        auto cit = consumers.find(op.m_output[0].m_name);
-        if (cit == consumers.end() || cit->second.empty()) return false;
-        long ntot = 0;
-        for (int c : cit->second) {
-            const Operation& co = ops()[c];
-            if (attr(co, "osg_geglu") || attr(co, "osg_act")) return false;
-            const Val* w = cval(co.m_input[1]);
-            if (!w || w->dtype != OSG_F16) return false;
-            ntot += w->shape[1];
-            auto git = group_of.find(c);
-            if (git != group_of.end()) ntot = groups[git->second.first].ntot;      // (all of them are the members of one merged group: ln_can_fold)
-        }
-        return ls_ok(M, ntot, C, true);
-    }
-
     void lower_layer_norm(const Operation& op) {
         int x = P.ensure_plain(in_val(op.m_input[0]));
         int g = in_val(op.m_input[1]), b = in_val(op.m_input[2]);
@@ -3568,12 +3438,6 @@ struct Lowering {
         const float eps = std::stof(*attr(op, "epsilon"));
         if (ln_can_fold(op, x, g, b, s.back())) {
             check_out(op, s);
-            if (ln_consumers_lean(op, x, g, b)) {     // the consuming launch normalises its rows itself: nothing to prepare here
-                LnFold f{x, g, b, eps, s.back(), -1};
-                f.inl = true;
-                ln_deferred[op.m_output[0].m_name] = f;
-                return;
-            }
             const int rs = upgrade_rs_producer(x, P.total_elems(x) / s.back(), s.back());
             ln_deferred[op.m_output[0].m_name] = LnFold{x, g, b, eps, s.back(), rs};
             return;
@@ -4341,7 +4205,7 @@ void Plan::build() {
     const bool cacheable = m.m_support_dynamic_shapes && !stream_weights && !budgeted;
     if (cacheable) {
         key = std::to_string(fusion) + "|" + std::to_string(m.m_hip_fusion_level) + (u8 ? "|u8" : "|f") + (fp16 ? "h" : "-") + (w8_resident ? "8" : "-") + (fuse_attn ? "a" : "-") +
-              (sdp_attn ? "s" : "-") + (fuse_ln_gemm ? "l" : "-") + (fuse_gn_conv ? "g" : "-") + "|" + std::to_string(m.m_attention_fused_ops_parts) + "|" + std::to_string(m.m_ops.size()) + "|";
+              (sdp_attn ? "s" : "-") + (fuse_ln_gemm ? "l" : "-") + "|" + std::to_string(m.m_attention_fused_ops_parts) + "|" + std::to_string(m.m_ops.size()) + "|";
         for (auto& e : extra_outputs) key += e + ",";
         key += "|";
         if (m.m_requires_upcast)
@@ -4523,26 +4387,6 @@ void Plan::build() {
         }
     }
 
-    // ---- side branch: a contraction whose result is first read three or more steps later (a resnet's 1x1 shortcut convolution: GroupNorm,
-    // conv1, GroupNorm sit between it and conv2's residual input) runs on the second stream, joined right before that reader ------------
-    if (side_stream && fusion >= 2) {
-        std::vector<int> first_read(vals.size(), 1 << 30), writers(vals.size(), 0);
-        for (size_t si = 0; si < steps.size(); si++) {
-            for (int v : steps[si].reads) { int r = root_of(v); first_read[r] = std::min(first_read[r], (int)si); }
-            for (int v : steps[si].writes) writers[root_of(v)]++;
-        }
-        for (size_t si = 0; si < steps.size(); si++) {
-            Step& s = steps[si];
-            if (s.flops <= 0 || s.writes.size() != 1) continue;
-            const int w = root_of(s.writes[0]);
-            if (vals[w].pinned || vals[w].dptr || writers[w] != 1) continue;
-            const int j = first_read[w];
-            if (j >= (int)steps.size() || j - (int)si < 3) continue;
-            s.side_join = j;
-            steps[j].join_before = true;
-        }
-    }
-
     if (u8) {
         // the last step that reads a value whose (scale, zero point) are only known per run; the output dequantisation of a pass-through of
         // such a value counts too.  Also every step that is not safe inside a capture: none besides these (tables are built at plan time).
@@ -4559,8 +4403,6 @@ void Plan::build() {
                 Val& r = vals[root_of(v)];
                 r.first = std::min(r.first, (int)si);
                 r.last = std::max(r.last, (int)si);
-                // a side launch may still be running until its join: its operands and result stay untouched (and unreused) until then
-                if (steps[si].side_join >= 0) r.last = std::max(r.last, steps[si].side_join);
             }
     struct Block { size_t off, size; };
     std::vector<Block> free_list;
@@ -4644,28 +4486,6 @@ void Plan::build() {
     }
     arena_bytes = top ? top : 256;
     if (gn_stats_bytes) { gn_stats = (char*)be.malloc(gn_stats_bytes); owned.push_back(gn_stats); }   // (zeroed at the start of every pass: zero_gn_stats)
-    // ---- weight prefetch (m_hip_weight_prefetch): every contraction step announces the weights of the contraction step after it to its own launch, whose
-    // workgroups touch them before they start on their tiles (include/osgpu.h osg_set_weight_prefetch).  Resident weights only (a fixed address).
-    if ((weight_prefetch || blocked_weights) && !stream_weights && !u8) {
-        const void* next_ptr = nullptr;
-        size_t next_bytes = 0;
-        for (size_t si = steps.size(); si-- > 0;) {
-            Step& st = steps[si];
-            if (st.flops <= 0) continue;
-            st.pf_ptr = next_ptr;
-            st.pf_bytes = next_bytes;
-            int wv = -1;
-            size_t wb = 0;
-            for (int v : st.reads) {
-                const Val& vv = vals[root_of(v)];
-                if (!vv.is_const || !vv.dptr) continue;
-                const size_t b = val_bytes(v);
-                if (b > wb) { wb = b; wv = v; }
-            }
-            if (wv >= 0 && vals[root_of(wv)].dtype == OSG_F16) st.w_ptr = ptr(wv);
-            if (wv >= 0 && wb >= 65536) { next_ptr = ptr(wv); next_bytes = wb; }      // (a step without weights -- attention -- passes the announcement on)
-        }
-    }
     if (recycle) {
         arena = pooled_malloc(arena_bytes);
         arena_pooled = true;
@@ -4714,20 +4534,7 @@ void Plan::run_steps(size_t begin, size_t end) {
             Range(HipBackend& b_, bool on_, const char* n) : b(b_), on(on_) { if (on) b.api.osg_range_push(n); }
             ~Range() { if (on) b.api.osg_range_pop(); }
         } range(be, roctx_on, s.what.c_str());
-        if (s.join_before) be.check(be.api.osg_side_join(be.ctx), "osg_side_join");
-        if (s.flops > 0 && weight_prefetch) be.check(be.api.osg_set_weight_prefetch(be.ctx, s.pf_ptr, s.pf_bytes), "osg_set_weight_prefetch");
-        if (s.flops > 0 && blocked_weights) be.check(be.api.osg_set_blocked_weight_hint(be.ctx, s.w_ptr), "osg_set_blocked_weight_hint");
-        if (s.side_join >= 0) {
-            be.check(be.api.osg_side_begin(be.ctx), "osg_side_begin");
-            try {
-                s.run();
-            } catch (...) {
-                be.api.osg_side_end(be.ctx);
-                throw;
-            }
-            be.check(be.api.osg_side_end(be.ctx), "osg_side_end");
-        } else
-            s.run();
+        s.run();
         // OSG_PLAN_TRACE=1 (debugging aid, eager passes only): name every step on stderr and wait for it -- a device fault then points at its launch
         static const bool trace = std::getenv("OSG_PLAN_TRACE") != nullptr;
         if (trace && !in_capture) {
@@ -4735,7 +4542,6 @@ void Plan::run_steps(size_t begin, size_t end) {
             be.check(be.api.osg_sync(be.ctx), "osg_sync");
         }
     }
-    be.check(be.api.osg_side_join(be.ctx), "osg_side_join");
 }
 
 void Plan::execute(const std::function<void()>& while_device_runs) {
@@ -5199,7 +5005,7 @@ std::string Plan::info() const {
     char buf[128];
     for (size_t i = 0; i < steps.size(); i++) {
         const Step& s = steps[i];
-        snprintf(buf, sizeof buf, "step %zu side_join=%d join_before=%d reads=", i, s.side_join, s.join_before ? 1 : 0);
+        snprintf(buf, sizeof buf, "step %zu reads=", i);
         out += buf;
         for (size_t k = 0; k < s.reads.size(); k++) out += (k ? "," : "") + std::to_string(root_of(s.reads[k]));
         out += " writes=";

@@ -62,11 +62,6 @@ struct Step {
     std::function<void()> run;
     std::vector<int> reads, writes;
     double flops = 0;             // algorithmic 2*MAC count of a contraction step (0 for memory-bound steps)
-    const void* pf_ptr = nullptr; // m_hip_weight_prefetch: the weights of the NEXT contraction step, announced to this step's launch (osg_set_weight_prefetch)
-    size_t pf_bytes = 0;
-    const void* w_ptr = nullptr;  // m_hip_blocked_weights: this contraction step's resident weight (osg_set_blocked_weight_hint)
-    int side_join = -1;           // >= 0: runs on the side stream; index of the first step that reads its result (joined right before)
-    bool join_before = false;     // the main stream waits for the side stream before this step
 };
 
 struct Lowering;
@@ -180,7 +175,7 @@ struct Plan {
     // eager pass with HIP events around every step, `reps` times; "ms<TAB>flops<TAB>bytes<TAB>what" per line (ms = mean)
     std::string profile(int reps);
     // plan introspection for the CPU tests of the host logic (tests/test_planner_cpu.py): one line per step
-    //   "step <i> side_join=<j> join_before=<0|1> reads=<v,...> writes=<v,...> | <what>"   (val ids are ROOT vals)
+    //   "step <i> reads=<v,...> writes=<v,...> | <what>"   (val ids are ROOT vals)
     // and per arena val  "val <id> offset=<o> bytes=<b> first=<f> last=<l>", then "arena <bytes>".
     std::string info() const;
     bool compatible(Model& m, size_t batch) const;
@@ -271,22 +266,16 @@ struct Plan {
     std::set<std::string> outputs_convert_set;
     bool u8 = false;               // m_use_uint8_arithmetic: uint8 activations (the reference's W8A8 path, VAE decoder)
     bool stream_weights = false;
-    bool fuse_gn_conv = false;
     bool fuse_ln_gemm = false;
     bool concat_views = true;     // m_hip_concat_views
     bool fuse_tblock = true;      // m_hip_fuse_tblock
     bool fuse_qattn = true;       // m_hip_fuse_qattn
-    bool small_linear = false;    // m_hip_small_linear != 0
-    int small_linear_req = 0;     // m_hip_small_linear as requested
     bool in_flight = false;       // a pass of this plan may still be running on the device (set while execute() / replay() are between enqueue and wait)
-    bool weight_prefetch = false; // m_hip_weight_prefetch
-    bool blocked_weights = false; // m_hip_blocked_weights
     bool gn_stats_on = false;
     int gn_stats_req = 2;          // m_hip_gn_stats as requested (0 off, 1 all eligible, 2 large tensors only)
     long gn_stats_min_elems = 0;   // m_hip_gn_stats: GroupNorm statistics from the producing convolutions' epilogues (plan.cpp lower_group_norm)
     char* gn_stats = nullptr;      // the pass's statistics block: one [N][G][2] int64 table per such GroupNorm, zeroed at the start of every pass
     size_t gn_stats_bytes = 0;
-    bool side_stream = false;      // contraction steps whose result is not needed by the next steps run on a second stream (m_hip_side_stream)
     void zero_gn_stats();
     void run_steps(size_t begin = 0, size_t end = (size_t)-1);   // steps [begin, end) honouring the side-stream marks
     // uint8 plans: steps [0, dyn_end) read values quantised per run (a pushed input and what merely re-arranges its codes): they run eagerly every

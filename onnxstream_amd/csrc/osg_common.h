@@ -17,26 +17,11 @@ struct osg_ctx {
     hipEvent_t ev_copy2 = nullptr;
     int copy_streams = 2, copy_rr = 0;
     bool copy_dirty[2] = {false, false};
-    // side branch (osg_side_begin/end/join): a second compute stream with its own split-K workspace.  While a side section is open,
-    // `compute`/`ws`/`ws2` ARE the side stream's (the fields are swapped), so every launch site works unchanged.
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    void* ws_s = nullptr;
-    size_t ws_s_bytes = 0;
-    void* ws2_s = nullptr;
-    size_t ws2_s_bytes = 0;
-    bool in_side = false, side_dirty = false;
     hipEvent_t ev_copy = nullptr;       // copy stream -> compute stream dependency
     // GroupNorm statistics sinks (osg_set_stat_sinks): taken by the next osg_conv2d_nhwc_v; sink_fused = the launch that ran served them in its epilogue
     struct PendingSink { long long* table = nullptr; int groups = 0, cpg = 0, ch_off = 0; } pending_sink[2];
     int pending_hw = 0;
     bool tuning = false, sink_fused = false;
-    // blocked weights (experiment): the planner names the resident weight of the next contraction; the launchers swap in a blocked copy (made once, kept here)
-    const void* blk_hint = nullptr;
-    struct BlkCopy { void* copy; int n, k; };
-    std::map<const void*, BlkCopy> blk_cache;
-    const void* pending_pf = nullptr;   // osg_set_weight_prefetch: taken by the next contraction launch that can serve it
-    size_t pending_pf_bytes = 0;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     // pinned double-buffered staging for host->device streaming (weights provider path)
     static constexpr int kStages = 2;

@@ -64,15 +64,6 @@ struct Geo {
         for (int d = 1; d <= D - 2; d++) n += WLB + patch_loads((t - d + 18) % 9);
         return n;
     }
-    // PRE (fused GroupNorm + SiLU on the input): the next slab's patch comes through REGISTERS -- all NPW pieces plus the slab's
-    // affine-table rows are issued at tap 0, transformed and written to LDS two pieces per tap from tap 2 on
-    static constexpr int NTAB = 4 * TI;                     // 16-byte table loads per lane per slab (ca, cb: 8 floats each, per image)
-    static constexpr int pre_loads(int t) { return t == 0 ? NPW + NTAB : 0; }
-    static constexpr int allowed_outstanding_pre(int t) {
-        int n = 0;
-        for (int d = 1; d <= D - 2; d++) n += WLB + pre_loads((t - d + 18) % 9);
-        return n;
-    }
 };
 
 // W_: image width (= tile width); BN: output channels per tile; WGM x WGN: grid of the 4 MATH waves.
@@ -81,7 +72,7 @@ struct Geo {
 // the time whatever the ring depth; with the DMA issue moved to waves that do nothing else, the math waves' stream is
 // ds_read + MFMA only and the two streams overlap on the SIMD.
 // (the body is a __device__ function: hipcc emits no host stub for a __global__ template whose body holds a generic lambda)
-template <int W_, int BN, int WGM, int WGN, int MODE, bool PRE, int NLW>
+template <int W_, int BN, int WGM, int WGN, int MODE, int NLW>
 __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
     using G = Geo<W_, BN, NLW>;
     constexpr int TI = G::TI, TH = G::TH, PW = G::PW, PPI = G::PPI, PP = G::PP, NPW = G::NPW, PATCH_BYTES = G::PATCH_BYTES;
@@ -150,8 +141,7 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
         for (int j = 0; j < WLB; j++) {
             const int nl = (j * NLW + wave) * 8 + rsub;
             const int n = n0 + nl;
-            if (p.b_blk) b_off[j] = (nl < BN && n < p.N) ? (unsigned)((long)(n >> 4) * (p.K >> 6) * 2048 + (n & 15) * 128 + gch * 16) : OOB;
-            else b_off[j] = (nl < BN && n < p.N) ? (unsigned)(((long)n * p.K + gch * 8) * 2) : OOB;
+            b_off[j] = (nl < BN && n < p.N) ? (unsigned)(((long)n * p.K + gch * 8) * 2) : OOB;
         }
         auto issue_patch_piece = [&](int pc, int slab, char* buf) {     // slab may be past the end: dummy (zero-filling) load
             if (MODE >= 3 && MODE != 6) return;
@@ -161,62 +151,18 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
         auto issue_weights = [&](int stage, int tap, int slab) {
             if (MODE >= 3 && MODE != 6) return;
             const unsigned kill = (slab < slab_e && MODE != 2) ? 0u : OOB;
-            const int soff = p.b_blk ? (tap * (p.Cin >> 6) + slab) * 2048 : (tap * p.Cin + slab * 64) * 2;
+            const int soff = (tap * p.Cin + slab * 64) * 2;
             char* dst = bst0 + stage * BST_BYTES;
 #pragma unroll
             for (int j = 0; j < WLB; j++)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(dst + (j * NLW + wave) * 1024), 16, b_off[j] | kill, soff, 0, 0);
         };
-        // ---- PRE: register-staged patch with the GroupNorm affine + SiLU applied on the way into LDS -----------------------------
-        typedef int v4i __attribute__((ext_vector_type(4)));
-        v4i preg[PRE ? NPW : 1];
-        f32x4 tca[PRE ? 2 * TI : 1], tcb[PRE ? 2 * TI : 1];      // ca / cb of this lane's 8 channels, per image of the tile
-        auto pre_issue = [&](int slab) {                         // all pieces of `slab` + its table rows -> registers
-            const unsigned kill = slab < slab_e ? 0u : OOB;
-#pragma unroll
-            for (int pc = 0; pc < NPW; pc++) preg[pc] = __builtin_amdgcn_raw_buffer_load_b128(rsA, pa_off[pc] | kill, slab * 128, 0);
-            const int sl = slab < slab_e ? slab : slab_b;        // (past the end: any valid row, the values are not used)
-#pragma unroll
-            for (int ti = 0; ti < TI; ti++) {
-                const int img = min(img0 + ti, p.pre_imgs - 1);
-                const float* row = p.pre_tab + ((long)img * 2) * p.Cin + sl * 64 + gch * 8;
-                tca[2 * ti] = *reinterpret_cast<const f32x4*>(row);
-                tca[2 * ti + 1] = *reinterpret_cast<const f32x4*>(row + 4);
-                tcb[2 * ti] = *reinterpret_cast<const f32x4*>(row + p.Cin);
-                tcb[2 * ti + 1] = *reinterpret_cast<const f32x4*>(row + p.Cin + 4);
-            }
-        };
-        auto pre_commit = [&](int pc, int slab, char* buf) {     // y = act(x * ca + cb) for image pixels, 0 for the halo; one ds_write_b128
-            const bool valid = pa_off[pc] != OOB && slab < slab_e;
-            const int ti = TI == 1 ? 0 : ((pc * NLW + wave) * 8 + rsub) / PPI;
-            f16x8 xv;
-            __builtin_memcpy(&xv, &preg[pc], 16);
-            f16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const float ca = TI == 1 ? tca[e >> 2][e & 3] : (ti ? tca[2 + (e >> 2)][e & 3] : tca[e >> 2][e & 3]);
-                const float cb = TI == 1 ? tcb[e >> 2][e & 3] : (ti ? tcb[2 + (e >> 2)][e & 3] : tcb[e >> 2][e & 3]);
-                const float v = osg_apply_act((float)xv[e] * ca + cb, p.pre_act);
-                o[e] = valid ? (f16)v : (f16)0;
-            }
-            *reinterpret_cast<f16x8*>(buf + (pc * NLW + wave) * 1024 + lane * 16) = o;
-        };
-
         // prologue == units -D .. -1 of the steady state (D = NSTW - 1 units of weights in flight)
         issue_weights(0, 0, slab_b);
-        if constexpr (PRE) {
-            pre_issue(slab_b);
-        } else {
 #pragma unroll
-            for (int pc = 0; pc < NPW; pc++) issue_patch_piece(pc, slab_b, patch0);
-        }
+        for (int pc = 0; pc < NPW; pc++) issue_patch_piece(pc, slab_b, patch0);
 #pragma unroll
         for (int d = 1; d < D; d++) issue_weights(d, d % 9, slab_b + d / 9);
-        if constexpr (PRE) {
-#pragma unroll
-            for (int pc = 0; pc < NPW; pc++) pre_commit(pc, slab_b, patch0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
         wait_vmcnt<(D - 1) * WLB>();                         // unit 0's weights + the first patch have landed
         __builtin_amdgcn_s_barrier();
         int ust = 0;                                         // weight stage of the current unit
@@ -225,26 +171,13 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
             static_for<0, 9>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 // after this wait + barrier the tiles of unit u+1 are resident too: what the previous D-2 units issued may stay in flight
-                if constexpr (PRE) {
-                    if constexpr (t == 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // next slab's patch fully written
-                    wait_vmcnt<G::allowed_outstanding_pre(t)>();
-                } else {
-                    wait_vmcnt<G::allowed_outstanding(t)>();
-                }
+                wait_vmcnt<G::allowed_outstanding(t)>();
                 if (MODE != 5) __builtin_amdgcn_s_barrier();
                 constexpr int td = (t + D) % 9;
                 int std_ = ust + D;
                 std_ = std_ >= NSTW ? std_ - NSTW : std_;
                 issue_weights(std_, td, slab + (t + D) / 9);   // into the stage unit u-1 just released
-                if constexpr (PRE) {
-                    if constexpr (t == 0) pre_issue(slab + 1);
-                    if constexpr (t >= 2) {
-                        if constexpr (2 * (t - 2) < NPW) pre_commit(2 * (t - 2), slab + 1, patch_next);
-                        if constexpr (2 * (t - 2) + 1 < NPW) pre_commit(2 * (t - 2) + 1, slab + 1, patch_next);
-                    }
-                } else {
-                    static_for<0, G::patch_loads(t)>([&](auto pc) { issue_patch_piece(t * PPT + decltype(pc)::value, slab + 1, patch_next); });
-                }
+                static_for<0, G::patch_loads(t)>([&](auto pc) { issue_patch_piece(t * PPT + decltype(pc)::value, slab + 1, patch_next); });
                 ust = ust + 1 == NSTW ? 0 : ust + 1;
             });
         }
@@ -366,24 +299,33 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
         __builtin_amdgcn_s_barrier();           // (the loader waves have left: the four math waves) every one is done with patches and weight stages
         stat_lds = reinterpret_cast<float*>(smem3) + (wave8 & 3) * (WN * 2);
     }
+    if constexpr (MODE == 0) {
+        if (p.splits > 1 && p.fold_acc) {
+            // split-K over slabs, folded by the last workgroup to arrive at the tile (osg_gemm_common.h splitk_fold_acc; only the 4 math waves are still here:
+            // tid 0..255): it then runs the fused epilogue of an unsplit launch
+            if (!splitk_fold_acc<TM, TN>(p, acc, m_tile * p.nt + n_tile, zs, reinterpret_cast<int*>(smem3), tid)) return;
+            EpiOps<TM, TN, true, false> none;
+            none.have = false;
+            gemm_epilogue_fast<TM, TN, true, false>(p, acc, m0, n0, wm0, wn0, lane, 0, none, nullptr);
+            return;
+        }
+    }
     gemm_epilogue<TM, TN, true, EPRE>(p, acc, m0, n0, wm0, wn0, lane, 0, zs, epre, stat_lds);
     kdbg_stamp(p, 5);
     if (p.kdbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); kdbg_stamp(p, 6); }
-    // split-K over slabs: the last block to arrive at the tile folds the slabs (only the 4 math waves are still here: tid 0..255)
-    if (p.splits > 1 && p.tickets) splitk_finish<128, BN>(p, m0, n0, m_tile * p.nt + n_tile, 0, zs, reinterpret_cast<int*>(smem3), tid, 256);
 }
 
-template <int W_, int BN, int WGM, int WGN, int MODE, bool PRE, int NLW>
+template <int W_, int BN, int WGM, int WGN, int MODE, int NLW>
 __global__ __launch_bounds__(256 + 64 * NLW) void conv3x3_kernel(GemmParams p) {
-    conv3x3_body<W_, BN, WGM, WGN, MODE, PRE, NLW>(p);
+    conv3x3_body<W_, BN, WGM, WGN, MODE, NLW>(p);
 }
 
-template <int W_, int BN, int WGM, int WGN, int MODE = 0, bool PRE = false, int NLW = 4>
+template <int W_, int BN, int WGM, int WGN, int MODE = 0, int NLW = 4>
 int launch3(osg_ctx* ctx, GemmParams& p) {
     constexpr size_t smem = Geo<W_, BN, NLW>::SMEM;
     static_assert(smem <= 160 * 1024, "LDS budget");
     static_assert(Geo<W_, BN, NLW>::OK, "pipeline depth out of range");
-    auto kern = conv3x3_kernel<W_, BN, WGM, WGN, MODE, PRE, NLW>;
+    auto kern = conv3x3_kernel<W_, BN, WGM, WGN, MODE, NLW>;
     static bool attr_set = false;
     if (!attr_set) {
         OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -392,10 +334,10 @@ int launch3(osg_ctx* ctx, GemmParams& p) {
     p.mt = (p.M + 127) / 128;
     p.nt = (p.N + BN - 1) / BN;
     p.tiles_total = p.mt * p.nt;
-    if (p.xcd_local && !p.tickets) p.xcd_local = 0;
+    if (MODE != 0) p.fold_acc = 0;
+    if (!p.fold_acc) p.xcd_local = 0;
     p.no_epre = osg_mm::no_epi_prefetch();
     p.kdbg = kdbg_buffer(ctx, (long)(p.xcd_local ? (p.tiles_total + 7) / 8 * 8 * p.splits : p.tiles_total * p.splits));
-    if (osg_mm::apply_blocked_weight(ctx, p, 1)) return 1;
     const osg_mm::StatSink sinks_in[2] = {p.sink[0], p.sink[1]};
     if (p.sink[0].table || p.sink[1].table) {   // (see launch_v2 in osg_gemm.hip)
         const bool ok = !ctx->tuning && p.splits == 1 && MODE == 0 && (p.N & 3) == 0 && ((p.ldc | p.ldc2) & 3) == 0 && p.sink_hw > 0 && p.sink_hw % 128 == 0 && p.M % p.sink_hw == 0;
@@ -410,7 +352,7 @@ int launch3(osg_ctx* ctx, GemmParams& p) {
 
 template <int W_>
 int launch3_bn(osg_ctx* ctx, GemmParams& p, int bn, int nl) {
-    if (W_ == 64 && bn == 80 && !p.pre_tab) {   // experiments (tools/gemm_probe.py): 1 = loads + barriers only, 2 = no global loads (compute on stale LDS)
+    if (W_ == 64 && bn == 80) {   // experiments (tools/gemm_probe.py): 1 = loads + barriers only, 2 = no global loads (compute on stale LDS)
         const char* e = getenv("OSG_CONV3X3_DBG");
         const int dbg = e ? atoi(e) : 0;
         if (dbg == 1) return launch3<64, 80, 4, 1, 1>(ctx, p);
@@ -421,16 +363,11 @@ int launch3_bn(osg_ctx* ctx, GemmParams& p, int bn, int nl) {
         if (dbg == 6) return launch3<64, 80, 4, 1, 6>(ctx, p);
         if (dbg == 7) return launch3<64, 80, 4, 1, 7>(ctx, p);
     }
-    if (p.pre_tab) {
-        if (bn == 80) return launch3<W_, 80, 4, 1, 0, true>(ctx, p);
-        if (bn == 160) return launch3<W_, 160, 2, 2, 0, true>(ctx, p);
-        return launch3<W_, 128, 2, 2, 0, true>(ctx, p);
-    }
     if (nl == 8) {   // 8 loader waves (768 threads): a measured candidate only (osg_tune.h) -- the same arithmetic, twice the DMA issue slots
         // (where the wider stages leave the LDS ring too short -- W = 8 with BN = 160 -- the 4-loader kernel runs instead)
-        if (bn == 80) { if constexpr (Geo<W_, 80, 8>::OK) return launch3<W_, 80, 4, 1, 0, false, 8>(ctx, p); }
-        else if (bn == 160) { if constexpr (Geo<W_, 160, 8>::OK) return launch3<W_, 160, 2, 2, 0, false, 8>(ctx, p); }
-        else { if constexpr (Geo<W_, 128, 8>::OK) return launch3<W_, 128, 2, 2, 0, false, 8>(ctx, p); }
+        if (bn == 80) { if constexpr (Geo<W_, 80, 8>::OK) return launch3<W_, 80, 4, 1, 0, 8>(ctx, p); }
+        else if (bn == 160) { if constexpr (Geo<W_, 160, 8>::OK) return launch3<W_, 160, 2, 2, 0, 8>(ctx, p); }
+        else { if constexpr (Geo<W_, 128, 8>::OK) return launch3<W_, 128, 2, 2, 0, 8>(ctx, p); }
     }
     if (bn == 80) return launch3<W_, 80, 4, 1>(ctx, p);
     if (bn == 160) return launch3<W_, 160, 2, 2>(ctx, p);
@@ -438,8 +375,6 @@ int launch3_bn(osg_ctx* ctx, GemmParams& p, int bn, int nl) {
 }
 
 }  // namespace
-
-int osg_gn_table(osg_ctx* ctx, const void* x, const void* gamma, const void* beta, int N, long HW, int C, int G, float eps, float** tab_out);
 
 int osg_conv3x3_supported(int N, int H, int W, int Cin, int Cout) {
     if (!(W == 64 || W == 32 || W == 16 || W == 8)) return 0;
@@ -449,41 +384,6 @@ int osg_conv3x3_supported(int N, int H, int W, int Cin, int Cout) {
     if ((double)N * H * W * Cin * 2.0 >= 2147483648.0 || (double)Cout * 9.0 * Cin * 2.0 >= 2147483648.0) return 0;
     return 1;
 }
-
-extern "C" {
-
-int osg_group_norm_conv3x3_supported(int N, int H, int W, int Cin, int Cout) { return osg_conv3x3_supported(N, H, W, Cin, Cout); }
-
-// y = Conv3x3/s1/p1( act_pre( GroupNorm(x) ) ) (+bias, per-image bias, residual): the resnet block's  GroupNorm -> SiLU -> Conv
-// with the normalised activation never written to memory -- statistics + affine table (2 small launches), then the halo-reuse
-// convolution whose loader waves apply  act(x*ca[c] + cb[c])  to each input-patch pixel on its way into LDS (zero halo AFTER
-// the activation, as the reference pads the normalised tensor).  The f16 values the MFMAs read are exactly those the separate
-// osg_group_norm_nhwc would have stored.
-int osg_group_norm_conv3x3(osg_ctx* ctx, const void* x, const void* gamma, const void* beta, int groups, float eps, osg_act act_pre,
-                           const void* w_ohwi, const void* bias, osg_dtype bias_dtype, const void* image_bias, long image_bias_ld,
-                           const void* residual, void* y, int N, int H, int W, int Cin, int Cout) {
-    if (!osg_conv3x3_supported(N, H, W, Cin, Cout)) OSG_FAIL(ctx, "osg_group_norm_conv3x3: shape not supported (see osg_group_norm_conv3x3_supported)");
-    if (bias && bias_dtype != OSG_F16 && bias_dtype != OSG_F32) OSG_FAIL(ctx, "osg_group_norm_conv3x3: invalid bias dtype");
-    float* tab = nullptr;
-    static const bool once = getenv("OSG_GNCONV_TABLE_ONCE") != nullptr;    // dev probe (tools/gnconv_probe.py): time the convolution with the table already there
-    static float* tab_once = nullptr;
-    if (once && tab_once) tab = tab_once;
-    else if (osg_gn_table(ctx, x, gamma, beta, N, (long)H * W, Cin, groups, eps, &tab)) return 1;
-    if (once) tab_once = tab;
-    GemmParams p{};
-    p.A = (const f16*)x; p.Bt = (const f16*)w_ohwi; p.C = (f16*)y; p.bias = bias; p.residual = (const f16*)residual;
-    p.M = N * H * W; p.N = Cout; p.K = 9 * Cin; p.lda = 0;
-    p.bias_f32 = bias_dtype == OSG_F32; p.act = OSG_ACT_NONE;
-    p.a_bytes_l = (long)N * H * W * Cin * 2;
-    p.rowbias = (const f16*)image_bias; p.rb_rows = H * W; p.rb_ld = image_bias_ld;
-    p.H = H; p.W = W; p.Cin = Cin; p.Ho = H; p.Wo = W; p.KW = 3; p.sh = 1; p.sw = 1; p.pt = 1; p.pl = 1;
-    p.pre_tab = tab; p.pre_act = (int)act_pre; p.pre_imgs = N;
-    const int rc = osg_conv3x3_run(ctx, p);
-    if (rc < 0) OSG_FAIL(ctx, "osg_group_norm_conv3x3: convolution shape rejected");
-    return rc;
-}
-
-}  // extern "C"
 
 // Shape gate + tile/split choice.  Model (cycles, calibrated like choose_v2 in osg_gemm.hip): a (slab, tap) unit costs
 // max(MFMA, bytes / 23 B/clk) with bytes = the weight tile + 1/9 of the patch; whole rounds of tiles over the CUs.
@@ -529,6 +429,8 @@ std::vector<std::pair<double, std::pair<int, int>>> osg_conv3x3_rank(const osg_c
             double cost = rounds * (sl * 9.0 * (std::max(mfma, tload) + 250.0) + 6000.0);
             if (s > 1) cost += 9000.0 + (double)p.M * p.N * s * 4.0 / 2000.0;
             out.push_back({cost, {bn, s}});
+            // (measured candidates only) the same split finished inside the kernel by the last arriver of each tile: splits + 1000
+            if (ctx->autotune && s >= 2 && s <= 4 && osg_mm::splitk_fold_mode() != 0) out.push_back({cost * 1.0005, {bn, s + 1000}});
         }
     }
     std::stable_sort(out.begin(), out.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
@@ -536,29 +438,29 @@ std::vector<std::pair<double, std::pair<int, int>>> osg_conv3x3_rank(const osg_c
 }
 
 // launch one configuration (reduce kernel included); p must have passed osg_conv3x3_prepare
-int osg_conv3x3_launch(osg_ctx* ctx, GemmParams p, int bn, int s, int nl) {
+int osg_conv3x3_launch(osg_ctx* ctx, GemmParams p, int bn, int s, int nl, int fold) {
     const int slabs = p.Cin / 64;
     if (s < 1) s = 1;
     const int sl = (slabs + s - 1) / s;
     p.splits = (slabs + sl - 1) / sl;
     p.k_per_split = sl * 64;
     p.tickets = nullptr;
+    p.fold_acc = 0;
+    p.xcd_local = 0;
     if (p.splits > 1) {
         size_t need = (size_t)p.splits * p.M * p.N * sizeof(float);
+        if (fold) need = std::max(need, osg_mm::splitk_fold_route(ctx, p, (long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn), 128, bn));
         if (osg_ensure_workspace(ctx, need)) return 1;
         p.partial = (float*)ctx->ws;
-        const long n_tiles = (long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
-        osg_mm::splitk_route(ctx, p, n_tiles);
     }
     p.n_major = (double)p.N * p.K * 2.0 > (double)p.a_bytes_l;
     int rc;
-    if (p.pre_tab) nl = 4;
     if (p.W == 64) rc = launch3_bn<64>(ctx, p, bn, nl);
     else if (p.W == 32) rc = launch3_bn<32>(ctx, p, bn, nl);
     else if (p.W == 16) rc = launch3_bn<16>(ctx, p, bn, nl);
     else rc = launch3_bn<8>(ctx, p, bn, nl);
     if (rc) return rc;
-    if (p.splits > 1 && !p.tickets) return launch_splitk_reduce(ctx, p, 1);
+    if (p.splits > 1 && !p.fold_acc) return launch_splitk_reduce(ctx, p, 1);
     return 0;
 }
 
@@ -566,10 +468,11 @@ int osg_conv3x3_run(osg_ctx* ctx, GemmParams& p) {
     if (osg_conv3x3_prepare(ctx, p)) return -1;
     auto ranked = osg_conv3x3_rank(ctx, p);
     int best_bn = 128, best_s = 1;
-    if (!ranked.empty()) { best_bn = ranked[0].second.first; best_s = ranked[0].second.second; }
+    if (!ranked.empty()) { best_bn = ranked[0].second.first; best_s = ranked[0].second.second % 1000; }
     if (const char* e = getenv("OSG_CONV3X3_BN")) best_bn = atoi(e);
     if (const char* e = getenv("OSG_CONV3X3_SPLITS")) best_s = atoi(e);
     int nl = 4;
     if (const char* e = getenv("OSG_CONV3X3_NL")) nl = atoi(e) == 8 ? 8 : 4;
-    return osg_conv3x3_launch(ctx, p, best_bn, best_s, nl);
+    const int fold = getenv("OSG_CONV3X3_FOLD") ? atoi(getenv("OSG_CONV3X3_FOLD")) : 0;   // (tests / probes)
+    return osg_conv3x3_launch(ctx, p, best_bn, best_s, nl, fold);
 }

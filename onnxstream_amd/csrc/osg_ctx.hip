@@ -28,20 +28,40 @@ static void load_locked() {
         // a row that names no launchable configuration is dropped (the launchers would silently fall back to another tile, or divide by
         // splits == 0); the device ordinal is not part of the identity of a shape -- one table serves every rank of a node
         const int tile = c.cfg & 7, ks2 = c.cfg & 8;   /* bit 3 of cfg: KS = 2 (64x64 with 2 / 4 stages, 128x64 with 2) */
-        const bool ok = c.family == 0 ? (c.cfg >= 0 && tile <= 3 && (c.cfg & ~15) == 0 && (!ks2 || (tile == 2 && (c.nst == 2 || c.nst == 4)) || (tile == 1 && c.nst == 2)) && (c.nst == 2 || c.nst == 4 || (c.nst == 6 && tile >= 1) || (c.nst == 8 && tile == 2))   /* = the instantiations of launch_v2_choice (osg_gemm.hip): no 128x128 6-stage ring */ && c.splits >= 1 && c.splits <= 64)
-                                      : (c.family == 1 && (c.bn == 80 || c.bn == 128 || c.bn == 160) && c.splits >= 1 && c.splits <= 64 && (c.nst == 0 || c.nst == 4 || c.nst == 8));   /* nst of a halo-convolution row = its loader waves */
+        const bool ok = c.family == 0 ? (c.cfg >= 0 && tile <= 3 && (c.cfg & ~31) == 0 && (!(c.cfg & 16) || (!ks2 && tile != 0 && c.splits >= 2 && c.splits <= 4))   /* bit 4: split-K folded in the kernel */ && (!ks2 || (tile == 2 && (c.nst == 2 || c.nst == 4)) || (tile == 1 && c.nst == 2)) && (c.nst == 2 || c.nst == 4 || (c.nst == 6 && tile >= 1) || (c.nst == 8 && tile == 2))   /* = the instantiations of launch_v2_choice (osg_gemm.hip): no 128x128 6-stage ring */ && c.splits >= 1 && c.splits <= 64)
+                                      : (c.family == 1 && (c.cfg == 0 || (c.cfg == 16 && c.splits >= 2 && c.splits <= 4)) && (c.bn == 80 || c.bn == 128 || c.bn == 160) && c.splits >= 1 && c.splits <= 64 && (c.nst == 0 || c.nst == 4 || c.nst == 8));   /* nst of a halo-convolution row = its loader waves */
         k.device = 0;
         if (ok && k.M > 0 && k.N > 0 && k.K > 0 && k.batch > 0) g_table[k] = c;
     }
     fclose(f);
 }
+static int g_misses = 0;
 bool lookup(const Key& k, Choice* out) {
     std::lock_guard<std::mutex> lk(g_mu);
     load_locked();
     auto it = g_table.find(k);
-    if (it == g_table.end()) return false;
+    if (it == g_table.end()) {
+        // a miss: the caller times the candidates now (and stores the winner) -- or, frozen, runs the cost model's first candidate.  Counted (osg_tune_misses)
+        // and named once per shape under OSG_TUNE_LOG_MISSES=1, so that a shipped table can be completed.
+        g_misses++;
+        static const bool log = getenv("OSG_TUNE_LOG_MISSES") != nullptr;
+        if (log) fprintf(stderr, "[tune] miss: kind %d M %d N %d K %d batch %d H %d W %d Cin %d KW %d stride %dx%d flags %d%s\n", k.kind, k.M, k.N, k.K, k.batch, k.H, k.W, k.Cin, k.KW, k.sh,
+                         k.sw, k.flags, frozen() ? " (frozen: cost-model choice, not timed)" : "");
+        return false;
+    }
     *out = it->second;
     return true;
+}
+int misses() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_misses;
+}
+// frozen tables: remember the untimed choice of a missed shape for the rest of the process (in memory only: us = -1), so that eager launches of that shape do
+// not rank the candidates again and the miss is counted once
+void remember(const Key& k, const Choice& c) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    load_locked();
+    g_table.emplace(k, c);
 }
 void store(const Key& k, const Choice& c) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -56,6 +76,8 @@ void store(const Key& k, const Choice& c) {
     }
 }
 }  // namespace osg_tune
+
+extern "C" int osg_tune_misses(void) { return osg_tune::misses(); }
 
 #include <dlfcn.h>
 namespace {
@@ -118,7 +140,7 @@ int xcd_check(osg_ctx* c) {
     if (c->xcd_err && *(volatile int*)c->xcd_err) {
         *c->xcd_err = 0;
         c->xcd_rr = false;   // (later plans fall back to the reduce launch)
-        OSG_FAIL(c, "XCD-local split-K: a workgroup ran on another XCD than workgroup-index mod 8 says (results of this pass are invalid); set OSG_SPLITK_TICKET=0");
+        OSG_FAIL(c, "XCD-local split-K: a workgroup ran on another XCD than workgroup-index mod 8 says (results of this pass are invalid); set OSG_SPLITK_FOLD=2");
     }
     return 0;
 }
@@ -153,9 +175,6 @@ int osg_init(int device, osg_ctx** out) {
               hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->copy2, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_copy2, hipEventDisableTiming) == hipSuccess &&
-              hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming) == hipSuccess &&
               hipEventCreate(&c->ev_t0) == hipSuccess && hipEventCreate(&c->ev_t1) == hipSuccess &&
               hipEventCreate(&c->ev_a0) == hipSuccess && hipEventCreate(&c->ev_a1) == hipSuccess;
@@ -190,13 +209,7 @@ void osg_destroy(osg_ctx* c) {
     if (c->evict) hipFree(c->evict);
     if (c->ws) hipFree(c->ws);
     if (c->ws2) hipFree(c->ws2);
-    if (c->ws_s) hipFree(c->ws_s);
-    if (c->ws2_s) hipFree(c->ws2_s);
-    if (c->ev_fork) hipEventDestroy(c->ev_fork);
-    if (c->ev_join) hipEventDestroy(c->ev_join);
-    if (c->side) hipStreamDestroy(c->side);
     if (c->ev_copy) hipEventDestroy(c->ev_copy);
-    for (auto& e : c->blk_cache) hipFree(e.second.copy);
     if (c->ev_copy2) hipEventDestroy(c->ev_copy2);
     if (c->copy2) hipStreamDestroy(c->copy2);
     if (c->ev_t0) hipEventDestroy(c->ev_t0);
@@ -231,10 +244,6 @@ int osg_malloc(osg_ctx* c, size_t bytes, void** dptr) {
 
 int osg_free(osg_ctx* c, void* dptr) {
     if (!dptr) return 0;
-    {
-        auto it = c->blk_cache.find(dptr);      // (a freed weight takes its blocked copy with it)
-        if (it != c->blk_cache.end()) { hipFree(it->second.copy); c->blk_cache.erase(it); }
-    }
     OSG_HIP(c, hipFree(dptr));
     return 0;
 }
@@ -350,40 +359,7 @@ int osg_sync(osg_ctx* c) {
     OSG_HIP(c, hipStreamSynchronize(c->copy));
     OSG_HIP(c, hipStreamSynchronize(c->copy2));
     OSG_HIP(c, hipStreamSynchronize(c->compute));
-    OSG_HIP(c, hipStreamSynchronize(c->side));
     return xcd_check(c);
-}
-
-// ---- side branch: independent work (a resnet's 1x1 shortcut convolution, projections of the text context) runs on a second stream
-// beside the main chain; inside a capture the fork/join events become parallel branches of the hipGraph.
-int osg_side_begin(osg_ctx* c) {
-    if (c->in_side) OSG_FAIL(c, "osg_side_begin: a side section is already open");
-    OSG_HIP(c, hipEventRecord(c->ev_fork, c->compute));
-    OSG_HIP(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    std::swap(c->compute, c->side);
-    std::swap(c->ws, c->ws_s); std::swap(c->ws_bytes, c->ws_s_bytes);
-    std::swap(c->ws2, c->ws2_s); std::swap(c->ws2_bytes, c->ws2_s_bytes);
-    c->in_side = true;
-    c->side_dirty = true;
-    return 0;
-}
-
-int osg_side_end(osg_ctx* c) {
-    if (!c->in_side) OSG_FAIL(c, "osg_side_end: no side section is open");
-    std::swap(c->compute, c->side);
-    std::swap(c->ws, c->ws_s); std::swap(c->ws_bytes, c->ws_s_bytes);
-    std::swap(c->ws2, c->ws2_s); std::swap(c->ws2_bytes, c->ws2_s_bytes);
-    c->in_side = false;
-    return 0;
-}
-
-int osg_side_join(osg_ctx* c) {
-    if (c->in_side) OSG_FAIL(c, "osg_side_join: close the side section first");
-    if (!c->side_dirty) return 0;
-    OSG_HIP(c, hipEventRecord(c->ev_join, c->side));
-    OSG_HIP(c, hipStreamWaitEvent(c->compute, c->ev_join, 0));
-    c->side_dirty = false;
-    return 0;
 }
 
 int osg_graph_begin(osg_ctx* c) {
@@ -400,8 +376,6 @@ int osg_graph_begin(osg_ctx* c) {
 
 int osg_graph_end(osg_ctx* c, osg_graph** out) {
     if (!c->capturing) OSG_FAIL(c, "not capturing");
-    if (c->in_side) osg_side_end(c);
-    if (osg_side_join(c)) return 1;     // every forked branch must be back before the capture ends
     c->capturing = false;
     hipGraph_t g = nullptr;
     OSG_HIP(c, hipStreamEndCapture(c->compute, &g));

@@ -318,12 +318,10 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
         }
     }
     int b_base[B_LD];
-    const int b_kmul = p.b_blk ? 32 : 2;            // bytes of weight offset per k element walked (blocked: a 64-deep tile is the next 2-KiB block)
 #pragma unroll
     for (int j = 0; j < B_LD; j++) {
         const int n = n0 + (j * 4 + wave) * 8 + rsub;
-        if (p.b_blk) b_base[j] = n < p.N ? (int)((long)(n >> 4) * (p.K >> 6) * 2048 + (n & 15) * 128 + gch * 16) : (int)OOB;
-        else b_base[j] = n < p.N ? (int)(((long)n * p.K + gch * 8) * 2) : (int)OOB;
+        b_base[j] = n < p.N ? (int)(((long)n * p.K + gch * 8) * 2) : (int)OOB;
     }
 
     // running position of the NEXT tile to issue (conv: decomposed into tap + channel offset, updated incrementally)
@@ -360,28 +358,9 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
         }
 #pragma unroll
         for (int j = 0; j < B_LD; j++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(Bs + (j * 4 + wave) * 1024), 16, (unsigned)b_base[j] | kill, ik * b_kmul, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(Bs + (j * 4 + wave) * 1024), 16, (unsigned)b_base[j] | kill, ik * 2, 0, 0);
         ik += 64 * KS;
     };
-
-    // ---- the NEXT contraction's weights (osg_set_weight_prefetch): this workgroup touches its share of their cache lines -- one dword per 64 bytes, DMA'ed
-    // into the LDS slot this wave's first real tile load overwrites (vector-memory operations of a wave complete in order) -- so that the next launch finds
-    // them in the memory-side cache instead of HBM.  Older than every tile load: the counted waits of the loop cover them.
-    if (p.pf_bytes && loads) {
-        __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)p.pf_ptr, 0, p.pf_bytes, 0x00020000);
-        const unsigned segs = p.pf_bytes >> 6;                                  // 64-byte segments
-        const unsigned per = (segs + total - 1) / total;                        // ... per workgroup
-        const unsigned nthr = (SPEC ? 4 : (KS == 2 ? 8 : 4)) * 64;
-        const unsigned t = (SPEC ? (wave8 - 4) : wave8) * 64 + lane;
-        char* dst = smem2 + grp * GSTAGE + wave * 1024;
-        for (unsigned i = t; i < per; i += nthr) {
-            const unsigned sg = blockIdx.x * per + i;
-            const unsigned off = sg < segs ? sg << 6 : OOB;
-            if (p.pf_aux == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_ptr)dst, 4, off, 0, 0, 2);          // nt: streaming in the L2
-            else if (p.pf_aux == 17) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_ptr)dst, 4, off, 0, 0, 17);   // sc0 sc1: system scope
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_ptr)dst, 4, off, 0, 0, 0);
-        }
-    }
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -498,13 +477,19 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
         __builtin_amdgcn_s_barrier();           // every wave is done with the ring: its first bytes become the waves' staging areas
         stat_lds = reinterpret_cast<float*>(smem2) + wave * (WN * 2);
     }
+    if constexpr (KS == 1 && !SPEC && LN == 0 && MODE == 0) {
+        if (p.splits > 1 && p.fold_acc) {
+            // split-K, folded by the last workgroup to arrive at the tile (osg_gemm_common.h splitk_fold_acc): it then runs the fused epilogue of an unsplit launch
+            if (!splitk_fold_acc<TM, TN>(p, acc, (zb * p.mt + m_tile) * p.nt + n_tile, zs, reinterpret_cast<int*>(smem2), tid)) return;
+            EpiOps<TM, TN, CONV, false> none;
+            none.have = false;
+            gemm_epilogue_fast<TM, TN, CONV, false>(p, acc, m0, n0, wm0, wn0, lane, zb, none, nullptr);
+            return;
+        }
+    }
     gemm_epilogue<TM, TN, CONV, EPRE>(p, acc, m0, n0, wm0, wn0, lane, zb, zb * p.splits + zs, epre, stat_lds);
     kdbg_stamp(p, 5);
     if (p.kdbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); kdbg_stamp(p, 6); }
-
-    // ---- split-K: the last k-slice block to arrive at this tile folds the slabs (osg_gemm_common.h splitk_finish): no reduce launch
-    if (p.splits > 1 && p.tickets)
-        splitk_finish<BM, BN>(p, m0, n0, (zb * p.mt + m_tile) * p.nt + n_tile, zb, zs, reinterpret_cast<int*>(smem2), tid, 256);
 }
 
 template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0, int LN = 0, int NCH = 5, int KS = 1>
@@ -521,20 +506,11 @@ int launch_v2(osg_ctx* ctx, GemmParams& p, int batch) {
     p.mt = (p.M + BM - 1) / BM;
     p.nt = (p.N + BN - 1) / BN;
     p.tiles_total = p.mt * p.nt * batch;
-    if (KS == 2) { p.tickets = nullptr; p.xcd_local = 0; }   // (the in-kernel split-K fold is a 256-thread protocol: KS = 2 launches use the reduce launch)
-    if (p.xcd_local && (!p.tickets || SPEC)) p.xcd_local = 0;
+    if (KS == 2 || SPEC || LN != 0 || MODE != 0) { p.fold_acc = 0; p.xcd_local = 0; }   // (the in-kernel split-K fold is the plain kernel's: a 256-thread protocol)
+    if (!p.fold_acc) p.xcd_local = 0;
     dim3 grid((unsigned)(p.xcd_local ? (p.tiles_total + 7) / 8 * 8 * p.splits : p.tiles_total * p.splits));
     p.no_epre = osg_mm::no_epi_prefetch();
     p.kdbg = kdbg_buffer(ctx, grid.x);
-    if (apply_blocked_weight(ctx, p, batch)) return 1;
-    p.pf_bytes = 0;
-    if (ctx->pending_pf && !ctx->tuning && MODE == 0) {     // (one launch serves it: the first kernel of the step that can)
-        static const int aux = getenv("OSG_PREFETCH_AUX") ? atoi(getenv("OSG_PREFETCH_AUX")) : 0;
-        p.pf_ptr = ctx->pending_pf;
-        p.pf_bytes = (unsigned)std::min<size_t>(ctx->pending_pf_bytes, 0x7fffffffu);
-        p.pf_aux = aux;
-        ctx->pending_pf = nullptr;
-    }
     const osg_mm::StatSink sinks_in[2] = {p.sink[0], p.sink[1]};     // (p is the caller's: a reduce launch that follows still wants them)
     if (p.sink[0].table || p.sink[1].table) {
         // GroupNorm statistics from this launch's epilogue (StatSink): only the real launch of a pass (not the tuner's repetitions), one k-slice, the compact
@@ -680,78 +656,11 @@ int launch_v3(osg_ctx* ctx, GemmParams& p) {
     return 0;
 }
 
-// ---- first-layer convolution (tiny Cin, e.g. conv_in 4 -> 320): K = KH*KW*Cin is a few dozen, far below one MFMA k-tile, so it
-// runs on the vector ALUs: the OHWI filter bank sits in LDS as [K][Cout], a thread owns 8 output channels of one pixel.
-__global__ __launch_bounds__(256) void conv_small_cin_kernel(GemmParams p, int KH, int pix_per_block) {
-    extern __shared__ __attribute__((aligned(16))) f16 wsm[];   // [K][N]
-    const int K = p.K, N = p.N;
-    for (int n = threadIdx.x; n < N; n += 256)
-        for (int k = 0; k < K; k++) wsm[k * N + n] = p.Bt[(long)n * K + k];
-    __syncthreads();
-    const int tc = N / 8;
-    const int pl_ = threadIdx.x / tc, cc = threadIdx.x - pl_ * tc;
-    if (pl_ >= pix_per_block) return;
-    const int hw = p.Ho * p.Wo;
-    for (int it = 0; it < 4; it++) {
-    const int m = (blockIdx.x * 4 + it) * pix_per_block + pl_;
-    if (m >= p.M) return;
-    const int n_img = m / hw, r2 = m - n_img * hw, ho = r2 / p.Wo, wo = r2 - ho * p.Wo;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const f16* xin = p.A + (long)n_img * p.H * p.W * p.Cin;
-    if (KH == 3 && p.KW == 3 && p.Cin == 4) {
-        // the SD conv_in shape: fetch the 3x3x4 patch with nine independent 8-byte loads, then 36 x 8 FMAs
-        f16x4 patch[9];
-#pragma unroll
-        for (int t = 0; t < 9; t++) {
-            const int hi = ho * p.sh - p.pt + t / 3, wi = wo * p.sw - p.pl + t % 3;
-            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            patch[t] = ok ? *reinterpret_cast<const f16x4*>(xin + ((long)hi * p.W + wi) * 4) : f16x4{0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int t = 0; t < 9; t++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const float xv = (float)patch[t][c];
-                const f16x8 wv = *reinterpret_cast<const f16x8*>(wsm + (t * 4 + c) * N + cc * 8);
-#pragma unroll
-                for (int e = 0; e < 8; e++) acc[e] += xv * (float)wv[e];
-            }
-    } else {
-    int k = 0;
-    for (int kh = 0; kh < KH; kh++) {
-        const int hi = ho * p.sh - p.pt + kh;
-        for (int kw = 0; kw < p.KW; kw++) {
-            const int wi = wo * p.sw - p.pl + kw;
-            const bool ok = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            for (int c = 0; c < p.Cin; c++, k++) {
-                const float xv = ok ? (float)xin[((long)hi * p.W + wi) * p.Cin + c] : 0.f;
-                const f16x8 wv = *reinterpret_cast<const f16x8*>(wsm + k * N + cc * 8);
-#pragma unroll
-                for (int e = 0; e < 8; e++) acc[e] += xv * (float)wv[e];
-            }
-        }
-    }
-    }
-    f16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-        float v = acc[e];
-        const int n = cc * 8 + e;
-        if (p.bias) v += p.bias_f32 ? ((const float*)p.bias)[n] : (float)((const f16*)p.bias)[n];
-        if (p.rowbias) v += (float)p.rowbias[(long)(m / p.rb_rows) * p.rb_ld + n];
-        if (p.residual) v += (float)p.residual[(long)m * N + n];
-        o[e] = (f16)osg_apply_act(v, p.act);
-    }
-    *reinterpret_cast<f16x8*>(p.C + (long)m * (p.ldc ? p.ldc : (long)N) + cc * 8) = o;
-    if (p.C2) *reinterpret_cast<f16x8*>(p.C2 + (long)m * p.ldc2 + cc * 8) = o;
-    }
-}
-
-// The SD / SDXL conv_in and the VAE decoder's first convolution (3x3, Cin = 4: K = 36) on the matrix cores: the vector kernel above spends 288 FMAs + 288
+// The SD / SDXL conv_in and the VAE decoder's first convolution (3x3, Cin = 4: K = 36) on the matrix cores: the vector kernel this replaced (round 4) spent 288 FMAs + 288
 // f16 -> f32 conversions per (pixel, 8 channels) and took 31 us for 0.2 GFLOP at 2 x 64 x 64 -> 320 (profiles/r04_breakdown_tail_v4_fastbox.txt), a
 // twentieth of a pass's convolution time for a ten-thousandth of its work.  Here K is padded to 64 (two v_mfma_f32_16x16x32_f16 steps, the second one holds tap
 // 8 and zeros): the filter bank sits in LDS as [Cout][64 + 8] with the padding zeroed, a lane builds its A fragment -- pixel l & 15, taps 2g and 2g + 1 -- from
-// three 8-byte loads, and each wave walks every other 16-channel tile of its 16 pixels.  Same epilogue operands as conv_small_cin_kernel.
+// three 8-byte loads, and each wave walks every other 16-channel tile of its 16 pixels.  Bias, per-image bias, residual, activation and the second destination in the epilogue.
 __global__ __launch_bounds__(256) void conv_cin4_mfma_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char cin4_lds[];
     constexpr int WLD = 144;                         // bytes per filter row in LDS: 64 halves + 8 of padding (conflict-free 16-byte fragment reads)
@@ -920,7 +829,7 @@ int launch_cfg(osg_ctx* ctx, const GemmParams& p, int batch) {
 // and bounds every configuration (a 128x128x64 k-tile moves 32 KiB for 515 MFMA cycles), so the model is: k-tile time =
 // max(MFMA, bytes / 23) (+ ~450 exposed cycles when a block is alone on its CU), whole rounds of tiles over the CU slots,
 // a fixed fill + epilogue per round, and the extra pass of a split-K reduce.
-struct V2Choice { int cfg, nst, splits, ks = 1; };   // ks = 2: two wave groups on alternating k-tiles (gemm2_kernel KS)
+struct V2Choice { int cfg, nst, splits, ks = 1, fold = 0; };   // ks = 2: two wave groups on alternating k-tiles (gemm2_kernel KS); fold: split-K finished by splitk_fold_acc (no reduce launch)
 static const int kV2BM[4] = {128, 128, 64, 64}, kV2BN[4] = {128, 64, 64, 128};   // (the 64x128 tile: measured candidate only)
 // every legal (tile, stages, splits) with its modelled cost in cycles, cheapest first
 static std::vector<std::pair<double, V2Choice>> rank_v2(const osg_ctx* ctx, int M, int N, int K, int batch, bool allow_split) {
@@ -951,6 +860,8 @@ static std::vector<std::pair<double, V2Choice>> rank_v2(const osg_ctx* ctx, int 
                 // KS = 2 (measured candidates only): the 64x64 tile with a 2- or 4-stage ring, the 128x64 tile with 2 stages (what the 160 KiB hold), >= 2 k-tiles per slice
                 static const bool no_ks2 = getenv("OSG_TUNE_NO_KS2") != nullptr;   // (A/B runs)
                 if (ctx->autotune && !no_ks2 && kts >= 2 && ((c == 2 && (nst == 2 || nst == 4)) || (c == 1 && nst == 2))) out.push_back({cost * 0.999, V2Choice{c, nst, s, 2}});
+                // (measured candidates only) 2 .. 4 slices folded by the last arriver of each tile instead of a reduce launch: the tiles of at most 8 accumulator quads per lane
+                if (ctx->autotune && s >= 2 && s <= 4 && c != 0 && osg_mm::splitk_fold_mode() != 0) out.push_back({cost * 1.0005, V2Choice{c, nst, s, 1, 1}});
             }
         }
     std::stable_sort(out.begin(), out.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
@@ -980,14 +891,18 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
     p.splits = (ktiles + kt_per - 1) / kt_per;
     p.k_per_split = kt_per * 64;
     p.tickets = nullptr;
+    p.fold_acc = 0;
+    p.xcd_local = 0;
     if (p.splits > 1) {
         size_t need = (size_t)batch * p.splits * p.M * p.N * sizeof(float);
+        if (ch.fold && ch.ks == 1 && ch.cfg != 0) {
+            // finished inside the kernel by the last k-slice workgroup of each tile (osg_gemm_common.h splitk_fold_acc); the launch falls back to the reduce
+            // launch where the fold does not apply
+            const long n_tiles = (long)batch * ((p.M + kV2BM[ch.cfg] - 1) / kV2BM[ch.cfg]) * ((p.N + kV2BN[ch.cfg] - 1) / kV2BN[ch.cfg]);
+            need = std::max(need, osg_mm::splitk_fold_route(ctx, p, n_tiles, kV2BM[ch.cfg], kV2BN[ch.cfg]));
+        }
         if (osg_ensure_workspace(ctx, need)) return 1;
         p.partial = (float*)ctx->ws;
-        const long n_tiles = (long)batch * ((p.M + kV2BM[ch.cfg] - 1) / kV2BM[ch.cfg]) * ((p.N + kV2BN[ch.cfg] - 1) / kV2BN[ch.cfg]);
-        // in-kernel last-arriver reduction over write-through slabs (round 1's version published the slabs with plain stores + an
-        // agent-scope release, ~6 us per block); correct and bit-identical, but still loses to the separate reduce launch => OSG_SPLITK_TICKET=1 to try it
-        osg_mm::splitk_route(ctx, p, n_tiles);
     }
     // split the operand with more unique bytes across the XCDs (each private L2 then streams its slice from HBM once)
     const double a_unique = CONV ? (double)p.a_bytes : (double)p.M * p.K * 2.0;
@@ -1049,7 +964,7 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
     else if (ch.cfg == 3) rc = ch.nst == 6 ? launch_v2<64, 128, 6, CONV>(ctx, p, batch) : ch.nst == 4 ? launch_v2<64, 128, 4, CONV>(ctx, p, batch) : launch_v2<64, 128, 2, CONV>(ctx, p, batch);
     else rc = ch.nst == 8 ? launch_v2<64, 64, 8, CONV>(ctx, p, batch) : ch.nst == 6 ? launch_v2<64, 64, 6, CONV>(ctx, p, batch) : ch.nst == 4 ? launch_v2<64, 64, 4, CONV>(ctx, p, batch) : launch_v2<64, 64, 2, CONV>(ctx, p, batch);
     if (rc) return rc;
-    if (p.splits > 1 && !p.tickets) return launch_splitk_reduce(ctx, p, batch);
+    if (p.splits > 1 && !p.fold_acc) return launch_splitk_reduce(ctx, p, batch);
     return 0;
 }
 
@@ -1057,14 +972,14 @@ template <bool CONV>
 int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced) {
     const bool allow_split = p.act != OSG_ACT_GEGLU && !p.ln_c1 && !p.rs_out;   // GEGLU pairing / folded LayerNorm / row statistics live in the tile epilogue
     V2Choice ch;
-    const bool env_forced = getenv("OSG_GEMM_CFG") || getenv("OSG_GEMM_SPLITS") || getenv("OSG_GEMM_NST") || getenv("OSG_GEMM_DBG") || getenv("OSG_GEMM_KS");
+    const bool env_forced = getenv("OSG_GEMM_CFG") || getenv("OSG_GEMM_SPLITS") || getenv("OSG_GEMM_NST") || getenv("OSG_GEMM_DBG") || getenv("OSG_GEMM_KS") || getenv("OSG_GEMM_FOLD");
     if (forced) {
         ch = *forced;
     } else if (ctx->autotune && !env_forced) {
         const osg_tune::Key key = tune_key(ctx, CONV ? 2 : 0, p, batch);
         osg_tune::Choice tc;
         if (osg_tune::lookup(key, &tc)) {
-            ch = {tc.cfg & 7, tc.nst, tc.splits, (tc.cfg & 8) ? 2 : 1};
+            ch = {tc.cfg & 7, tc.nst, tc.splits, (tc.cfg & 8) ? 2 : 1, (tc.cfg & 16) ? 1 : 0};
         } else {
             auto ranked = rank_v2(ctx, p.M, p.N, p.K, batch, allow_split);
             ch = ranked.empty() ? V2Choice{0, 4, 1} : ranked[0].second;
@@ -1074,12 +989,13 @@ int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced) {
                     const float us = osg_tune::time_us(ctx, [&] { return launch_v2_choice<CONV>(ctx, p, batch, cand.second); });
                     static const bool dump = getenv("OSG_TUNE_DUMP") != nullptr;
                     if (dump) fprintf(stderr, "[tune] %s M=%d N=%d K=%d flags=%d: tile %dx%d nst=%d splits=%d ks=%d -> %.2f us (model %.0f)\n", CONV ? "conv" : "gemm", p.M, p.N, p.K, key.flags,
-                                      kV2BM[cand.second.cfg], kV2BN[cand.second.cfg], cand.second.nst, cand.second.splits, cand.second.ks, us, cand.first);
+                                      kV2BM[cand.second.cfg], kV2BN[cand.second.cfg], cand.second.nst, cand.second.splits, cand.second.ks + 10 * cand.second.fold, us, cand.first);
                     if (us >= 0.f && (best < 0.f || us < best)) { best = us; ch = cand.second; }
                 }
                 if (best < 0.f) OSG_FAIL(ctx, "osg_gemm: autotune could not time any configuration");
-                osg_tune::store(key, osg_tune::Choice{0, ch.cfg | (ch.ks == 2 ? 8 : 0), ch.nst, ch.splits, 0, best});
-            }
+                osg_tune::store(key, osg_tune::Choice{0, ch.cfg | (ch.ks == 2 ? 8 : 0) | (ch.fold ? 16 : 0), ch.nst, ch.splits, 0, best});
+            } else if (osg_tune::frozen())
+                osg_tune::remember(key, osg_tune::Choice{0, ch.cfg | (ch.ks == 2 ? 8 : 0) | (ch.fold ? 16 : 0), ch.nst, ch.splits, 0, -1.f});
         }
     } else {
         ch = choose_v2(ctx, p.M, p.N, p.K, batch);
@@ -1088,6 +1004,7 @@ int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced) {
         if (!allow_split) ch.splits = 1;
         if (const char* e = getenv("OSG_GEMM_NST")) ch.nst = atoi(e);
         if (const char* e = getenv("OSG_GEMM_KS")) ch.ks = atoi(e) == 2 ? 2 : 1;
+        if (const char* e = getenv("OSG_GEMM_FOLD")) ch.fold = atoi(e) != 0;   // (tests / probes: finish a forced split inside the kernel)
     }
     return launch_v2_choice<CONV>(ctx, p, batch, ch);
 }
@@ -1168,48 +1085,6 @@ __global__ __launch_bounds__(256) void transpose_kn_nk_kernel(const f16* __restr
 
 }  // namespace
 
-// [N][K] -> [N/16][K/64][16][64] (rows past N zero): one thread per 16-byte chunk
-__global__ __launch_bounds__(256) void block_weights_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int N, int K) {
-    const long chunks = (long)((N + 15) / 16 * 16) * (K >> 3);
-    const long c = (long)blockIdx.x * 256 + threadIdx.x;
-    if (c >= chunks) return;
-    // destination chunk c -> (block row nb, block column kb, row r, chunk q)
-    const int q = (int)(c & 7), r = (int)((c >> 3) & 15);
-    const long blk = c >> 7;
-    const int kbn = K >> 6, kb = (int)(blk % kbn), nb = (int)(blk / kbn);
-    const int n = nb * 16 + r;
-    uint4 v = {0, 0, 0, 0};
-    if (n < N) v = src[((long)n * K + kb * 64) / 8 + q];
-    dst[c] = v;
-}
-
-int osg_mm::apply_blocked_weight(osg_ctx* ctx, GemmParams& p, int batch) {
-    if (p.b_blk) return 0;      // (already swapped in: the tuner re-launches with the same parameter block)
-    if (!ctx->blk_hint || ctx->blk_hint != (const void*)p.Bt || batch != 1 || p.K % 64 || ((uintptr_t)p.Bt & 15)) return 0;
-    auto it = ctx->blk_cache.find(p.Bt);
-    if (it != ctx->blk_cache.end() && (it->second.n != p.N || it->second.k != p.K)) {
-        hipFree(it->second.copy);
-        ctx->blk_cache.erase(it);
-        it = ctx->blk_cache.end();
-    }
-    const long n16 = (p.N + 15) / 16 * 16;
-    const size_t bytes = (size_t)n16 * p.K * 2;
-    if (bytes >= 0x7fffffffu) return 0;
-    if (it == ctx->blk_cache.end()) {
-        if (ctx->capturing) OSG_FAIL(ctx, "blocked weights: first use of a weight inside a graph capture");
-        void* d = nullptr;
-        OSG_HIP(ctx, hipMalloc(&d, bytes));
-        const long chunks = n16 * (p.K >> 3);
-        hipLaunchKernelGGL(block_weights_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, ctx->compute, (const uint4*)p.Bt, (uint4*)d, p.N, p.K);
-        OSG_LAUNCH_CHECK(ctx);
-        it = ctx->blk_cache.emplace((const void*)p.Bt, osg_ctx::BlkCopy{d, p.N, p.K}).first;
-    }
-    p.Bt = (const f16*)it->second.copy;
-    p.b_blk = 1;
-    p.b_bytes = (unsigned)bytes;
-    return 0;
-}
-
 // the reduce launch of a split-K contraction whose output feeds StatSinks (the slabs hold no finished values for the tile epilogues to add up): a workgroup
 // owns 128 rows x 64 columns -- thread = (4 columns, one of 16 row lanes), 8 rows each -- finishes them like splitk_reduce4_kernel and adds the per-group sums
 // of what it stored to the sinks.  The bits of C are those of the flat kernel (same additions in the same order per element).
@@ -1284,7 +1159,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* _
             float S = 0.f, Q = 0.f;
             for (int cc = a; cc < b; cc++)
                 for (int pp = 0; pp < 16; pp++) { S += st[pp][cc][0]; Q += st[pp][cc][1]; }
-            stat_add(per_xcd, reinterpret_cast<unsigned long long*>(sk[k].table), (long)imgs * sk[k].groups * 2, ((long)n_img * sk[k].groups + g) * 2, S, Q);
+            stat_add(per_xcd, reinterpret_cast<unsigned long long*>(sk[k].table), (long)imgs * sk[k].groups * 2, ((long)n_img * sk[k].groups + g) * 2, S, Q, stat_q_scale((long)hw * sk[k].cpg));
         }
     }
 }
@@ -1418,17 +1293,6 @@ int osg_conv2d_nhwc_rb(osg_ctx* ctx, osg_dtype dtype, const void* x, const void*
                              pb, pr, act);
 }
 
-int osg_set_blocked_weight_hint(osg_ctx* ctx, const void* weights) {
-    ctx->blk_hint = weights;
-    return 0;
-}
-
-int osg_set_weight_prefetch(osg_ctx* ctx, const void* weights, size_t bytes) {
-    ctx->pending_pf = bytes ? weights : nullptr;
-    ctx->pending_pf_bytes = bytes;
-    return 0;
-}
-
 int osg_set_stat_sinks(osg_ctx* ctx, void* table0, int groups0, int cpg0, int ch_off0, void* table1, int groups1, int cpg1, int ch_off1, int rows_per_image) {
     if ((table0 && (groups0 <= 0 || cpg0 <= 0 || ch_off0 < 0)) || (table1 && (groups1 <= 0 || cpg1 <= 0 || ch_off1 < 0)) || rows_per_image <= 0)
         OSG_FAIL(ctx, "osg_set_stat_sinks: invalid argument");
@@ -1480,8 +1344,7 @@ int osg_conv2d_nhwc_v(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* 
 
 static int conv2d_route(osg_ctx* ctx, GemmParams& p, int N, int Cin, int Cout, int KH, int KW, int sh, int sw, int pt, int pl, int pb, int pr) {
     (void)N;
-    static const bool cin4_off = getenv("OSG_CONV_CIN4_VALU") != nullptr;     // (A/B: the vector kernel)
-    if (!cin4_off && Cin == 4 && KH == 3 && KW == 3 && Cout % 16 == 0 && (size_t)Cout * (144 + 4) <= 160 * 1024 && (p.ldc % 4) == 0 && (p.ldc2 % 4) == 0 &&
+    if (Cin == 4 && KH == 3 && KW == 3 && Cout % 16 == 0 && (size_t)Cout * (144 + 4) <= 160 * 1024 && (p.ldc % 4) == 0 && (p.ldc2 % 4) == 0 &&
         (!p.rowbias || p.rb_ld % 4 == 0)) {
         const size_t smem = (size_t)Cout * (144 + 4);
         static size_t attr_smem = 0;
@@ -1490,12 +1353,6 @@ static int conv2d_route(osg_ctx* ctx, GemmParams& p, int N, int Cin, int Cout, i
             attr_smem = smem;
         }
         hipLaunchKernelGGL(conv_cin4_mfma_kernel, dim3((p.M + 31) / 32), dim3(256), smem, ctx->compute, p);
-        OSG_LAUNCH_CHECK(ctx);
-        return 0;
-    }
-    if (Cin < 8 && Cout % 8 == 0 && Cout / 8 <= 256 && (size_t)p.K * Cout * 2 <= 64 * 1024) {
-        const int ppb = 256 / (Cout / 8);
-        hipLaunchKernelGGL(conv_small_cin_kernel, dim3((p.M + 4 * ppb - 1) / (4 * ppb)), dim3(256), (size_t)p.K * Cout * 2, ctx->compute, p, KH, ppb);
         OSG_LAUNCH_CHECK(ctx);
         return 0;
     }
@@ -1516,7 +1373,7 @@ static int conv2d_route(osg_ctx* ctx, GemmParams& p, int N, int Cin, int Cout, i
             osg_tune::Choice tc;
             if (!osg_tune::lookup(key, &tc)) {
                 auto r3 = osg_conv3x3_rank(ctx, p);
-                tc = osg_tune::Choice{1, 0, 0, r3.empty() ? 1 : r3[0].second.second, r3.empty() ? 128 : r3[0].second.first, -1.f};
+                tc = osg_tune::Choice{1, 0, 0, r3.empty() ? 1 : r3[0].second.second % 1000, r3.empty() ? 128 : r3[0].second.first, -1.f};
                 if (!ctx->capturing && tune_safe(p) && !osg_tune::frozen()) {
                     float best = -1.f;
                     static const bool dump3 = getenv("OSG_TUNE_DUMP") != nullptr;
@@ -1524,23 +1381,26 @@ static int conv2d_route(osg_ctx* ctx, GemmParams& p, int N, int Cin, int Cout, i
                         for (int nl : {4, 8}) {   // (nst of a conv3x3 row = loader waves of the halo kernel)
                             static const bool no8 = getenv("OSG_TUNE_NO_NL8") != nullptr;   // (A/B runs)
                             if (nl == 8 && no8) continue;
-                            const float us = osg_tune::time_us(ctx, [&] { return osg_conv3x3_launch(ctx, p, c.second.first, c.second.second, nl); });
+                            const int fold3 = c.second.second >= 1000;   // (osg_conv3x3_rank: splits + 1000 = the same split, folded in the kernel)
+                            const int s3 = c.second.second % 1000;
+                            const float us = osg_tune::time_us(ctx, [&] { return osg_conv3x3_launch(ctx, p, c.second.first, s3, nl, fold3); });
                             if (dump3) fprintf(stderr, "[tune] conv3x3 N*H*W=%d Cin=%d Cout=%d W=%d: halo bn=%d splits=%d loaders=%d -> %.2f us\n", p.M, p.Cin, p.N, p.W, c.second.first, c.second.second, nl, us);
-                            if (us >= 0.f && (best < 0.f || us < best)) { best = us; tc = osg_tune::Choice{1, 0, nl, c.second.second, c.second.first, us}; }
+                            if (us >= 0.f && (best < 0.f || us < best)) { best = us; tc = osg_tune::Choice{1, fold3 ? 16 : 0, nl, s3, c.second.first, us}; }
                         }
                     auto r2 = rank_v2(ctx, p.M, p.N, p.K, 1, true);
                     if (r2.size() > 6) r2.resize(6);
                     for (auto& c : r2) {
                         const V2Choice ch = c.second;
                         const float us = osg_tune::time_us(ctx, [&] { return run_gemm<true>(ctx, p, 1, &ch); });
-                        if (us >= 0.f && (best < 0.f || us < best)) { best = us; tc = osg_tune::Choice{0, ch.cfg | (ch.ks == 2 ? 8 : 0), ch.nst, ch.splits, 0, us}; }
+                        if (us >= 0.f && (best < 0.f || us < best)) { best = us; tc = osg_tune::Choice{0, ch.cfg | (ch.ks == 2 ? 8 : 0) | (ch.fold ? 16 : 0), ch.nst, ch.splits, 0, us}; }
                     }
                     if (best < 0.f) OSG_FAIL(ctx, "osg_conv2d_nhwc: autotune could not time any configuration");
                     osg_tune::store(key, tc);
-                }
+                } else if (osg_tune::frozen())
+                    osg_tune::remember(key, tc);
             }
-            if (tc.family == 1) return osg_conv3x3_launch(ctx, p, tc.bn, tc.splits, tc.nst == 8 ? 8 : 4);
-            const V2Choice ch{tc.cfg & 7, tc.nst, tc.splits, (tc.cfg & 8) ? 2 : 1};
+            if (tc.family == 1) return osg_conv3x3_launch(ctx, p, tc.bn, tc.splits, tc.nst == 8 ? 8 : 4, (tc.cfg & 16) ? 1 : 0);
+            const V2Choice ch{tc.cfg & 7, tc.nst, tc.splits, (tc.cfg & 8) ? 2 : 1, (tc.cfg & 16) ? 1 : 0};
             return run_gemm<true>(ctx, p, 1, &ch);
         }
     }

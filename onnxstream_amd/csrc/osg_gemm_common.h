@@ -7,7 +7,7 @@
 namespace osg_mm {
 
 // GroupNorm statistics from the PRODUCER's epilogue (round 3).  A convolution whose output a GroupNorm reads adds, per (image, group), the sum and the sum of
-// squares of the f16 values it stores to a table the normalisation then only has to read: int64 FIXED-POINT sums (kStatSX / kStatSQ fractional bits) --
+// squares of the f16 values it stores to a table the normalisation then only has to read: int64 FIXED-POINT sums (kStatSX / stat_q_scale fractional bits) --
 // integer additions commute, so the atomics of the workgroups give the same bits whatever order they arrive in (fp32 atomics would make the pass
 // non-deterministic).  A wave reduces its tile's columns over its rows (DPP butterfly over the 16 lanes that hold one column quad), stages the channel sums in
 // LDS, and one lane per GROUP the wave's columns touch adds them up and issues the two atomics.
@@ -24,8 +24,19 @@ struct StatSink {
 };
 constexpr int kStatCopies = 8;
 constexpr float kStatSX = 1048576.f;   // 2^20: |sum x| of a group up to 2^43
-constexpr float kStatSQ = 1048576.f;   // 2^20 (round 4; 2^8 before: a wave's partial sum of squares of a SMALL-magnitude tensor -- 64 rows x 4 channels of |x| ~ 1e-3 -- rounded to 0,
-                                       // advisor): sum x^2 of a group up to 2^43 = an rms of 2 900 over the 2^20 elements of the VAE decoder's largest group
+// The sum of squares is scaled by 2^e with e chosen from the group's size (elements per image and group = rows x channels per group; writers and readers derive it
+// from the same two numbers): e = 36 - ceil(log2(elements)), clamped to [10, 20].  Round 4 used 2^20 for every tensor: the int64 sum wrapped at sum x^2 >= 2^43,
+// i.e. at an rms of 1 450 over the 2^22 elements of the VAE decoder's largest groups, silently (advisor, round 4); 2^8 before that rounded the partial sums of a
+// small-magnitude tensor (|x| ~ 1e-3) to zero (advisor, round 3).  With the size-dependent scale the sum holds any group whose rms stays below ~11 500 (2^27 / 2^e
+// per element on average; f16 itself ends at 65 504), and the rounding of the per-wave partials -- at most half a unit each -- averages out over the
+// elements / 256 partials of a group: a group of 2^22 elements of |x| ~ 1e-3 keeps its variance to ~0.1 %.
+__host__ __device__ inline int stat_q_shift(long elems) {
+    int lg = 0;
+    while ((1L << lg) < elems) lg++;
+    const int e = 36 - lg;
+    return e < 10 ? 10 : (e > 20 ? 20 : e);
+}
+__host__ __device__ inline float stat_q_scale(long elems) { return (float)(1L << stat_q_shift(elems)); }
 
 struct GemmParams {
     const f16* A;
@@ -48,16 +59,13 @@ struct GemmParams {
     unsigned a_bytes, b_bytes;   // buffer-descriptor extents of one batch item of A / Bt
     long a_bytes_l;              // conv: byte size of the whole NHWC input (host side, before the 2 GiB check)
     int mt, nt, n_major;         // tile grid and the order tiles are walked inside an XCD's contiguous chunk
-    int* tickets;                // split-K arrival counters (one per output tile), zero between launches
-    int fold_wait;               // splitk_finish: bound of the wait for the sibling slices, in 10 ns ticks of the wall clock
-    // XCD-local split-K: the k-slices of a tile are consecutive workgroups of ONE XCD (xcd_local_map), so the slabs are exchanged through that XCD's
+    int* tickets;                // split-K arrival / publication counters (two per output tile, splitk_fold_acc), zero between launches
+    // XCD-local split-K (splitk_fold_acc): the k-slices of a tile are consecutive workgroups of ONE XCD (xcd_local_map), so the slabs are exchanged through that XCD's
     // L2 -- plain stores, L1-bypassing loads, no trip to memory.  xcc_map / xcd_err: see osg_ctx; tiles_total = batch * mt * nt.
     int xcd_local;
     unsigned xcc_map;
     int* xcd_err;
     int tiles_total;
-    const float* pre_tab;        // osg_conv3x3.hip PRE variant: per-image affine table [n][2][Cin] (ca, cb) of a fused GroupNorm on the INPUT
-    int pre_act, pre_imgs;       //   activation applied after the affine (OSG_ACT_SILU), number of images
     float w_scale;               // W8 kernels (osg_gemm_w8.hip): Bt holds uint8 codes, w = (q - w_zp) * w_scale
     int w_zp;
     const float* ln_c1;          // osg_gemm_ln: LayerNorm over K folded into this GEMM -- c1[n] = sum_k W'[n][k]; bias holds c2 (f32)
@@ -78,14 +86,9 @@ struct GemmParams {
     StatSink sink[2];            // (see StatSink) [0]: of C, [1]: of C2; table NULL = none
     int sink_hw;                 // output rows per image (a multiple of the tile height: a wave's rows lie in one image)
     int sink_imgs, sink_per_xcd; // images of the pass (the stride between table copies = sink_imgs * groups * 2), see StatSink
-    // weight prefetch (round 3, osg_set_weight_prefetch): the NEXT contraction's weights, pulled towards the memory-side cache by this launch's workgroups
-    // before they start on their own tiles (HBM is idle 96 % of a pass; a layer's weights are cold every time)
-    const void* pf_ptr;
-    unsigned pf_bytes;
-    int pf_aux;
-    // blocked weights (round 3, osg_set_blocked_weight_hint): Bt is laid out [N/16][K/64][16][64] -- every (16 rows x 64 k) block 2 KiB contiguous, so a wave-level tile
-    // load (8 rows x 128 B) is ONE 1-KiB burst instead of eight 128-byte pieces K*2 bytes apart (DRAM page locality: tools/dram_pattern_probe.hip)
-    int b_blk;
+    // round 5: split-K folded by the LAST workgroup to arrive at a tile, in ACCUMULATOR layout (splitk_fold_acc below): 1 = on.  partial then holds
+    // [tile][slice][TM * TN][256] f32x4 (a lane's accumulator tile = one 16-byte element: 1-KiB bursts per wave-instruction), tickets two words per tile.
+    int fold_acc;
 };
 __device__ __forceinline__ void kdbg_stamp(const GemmParams& p, int slot) {
     if (p.kdbg && threadIdx.x == 0) p.kdbg[(long)blockIdx.x * 8 + slot] = wall_clock64();
@@ -191,8 +194,8 @@ __device__ __forceinline__ void epi_prefetch(const GemmParams& p, EpiOps<TM, TN,
 // instructions for a 2 x 5 tile (tools/kernel_phase_probe.py: 4.2 us of a 22 us convolution were spent walking it).  Same loads, same additions in
 // the same order, same rounding: identical bits.
 // one (image, group) cell of a StatSink table += (S, Q): into the copy of this workgroup's XCD, executed in its L2 -- or copy 0, device scope
-__device__ __forceinline__ void stat_add(int per_xcd, unsigned long long* table, long copy_stride, long cell, float S, float Q) {
-    const unsigned long long vs = (unsigned long long)__float2ll_rn(S * kStatSX), vq = (unsigned long long)__float2ll_rn(Q * kStatSQ);
+__device__ __forceinline__ void stat_add(int per_xcd, unsigned long long* table, long copy_stride, long cell, float S, float Q, float qscale) {
+    const unsigned long long vs = (unsigned long long)__float2ll_rn(S * kStatSX), vq = (unsigned long long)__float2ll_rn(Q * qscale);
     if (per_xcd) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -255,7 +258,8 @@ __device__ __forceinline__ void gemm_colstats(const GemmParams& p, const f16x4 (
             const int a = max(g * sk.cpg, c_lo) - c_lo, b = min((g + 1) * sk.cpg, c_hi) - c_lo;
             float S = 0.f, Q = 0.f;
             for (int c = a; c < b; c++) { S += st[c * 2]; Q += st[c * 2 + 1]; }
-            stat_add(p.sink_per_xcd, reinterpret_cast<unsigned long long*>(sk.table), (long)p.sink_imgs * sk.groups * 2, ((long)n_img * sk.groups + g) * 2, S, Q);
+            stat_add(p.sink_per_xcd, reinterpret_cast<unsigned long long*>(sk.table), (long)p.sink_imgs * sk.groups * 2, ((long)n_img * sk.groups + g) * 2, S, Q,
+                     stat_q_scale((long)p.sink_hw * sk.cpg));
         }
     }
 }
@@ -470,13 +474,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
                 const int n = n0 + wn0 + j * 16 + (lane >> 4) * 4;
                 if (n >= N) continue;
                 if ((N & 3) == 0) {
-                    if (p.tickets && !p.xcd_local) {
-                        // write-through (sc1): the slab goes past this XCD's L2 to memory, so the folding blocks of the tile -- maybe on
-                        // another XCD -- can read it with sc1 loads after the ticket, no release / acquire fence on either side
-                        const float* dst = P + (long)m * N + n;
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(acc[i][j]) : "memory");
-                    } else   // (XCD-local: the L1 is write-through, the store is in the shared L2 once vmcnt says so)
-                        *reinterpret_cast<f32x4*>(P + (long)m * N + n) = acc[i][j];
+                    *reinterpret_cast<f32x4*>(P + (long)m * N + n) = acc[i][j];
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; r++)
@@ -528,86 +526,88 @@ __device__ __forceinline__ void gemm_epilogue_geglu(const GemmParams& p, f32x4 (
     }
 }
 
-// ---- split-K without a reduce launch: the k-slice blocks of an output tile fold the f32 slabs THEMSELVES, each a 1/splits share of the tile, once
-// all of them have published.  Slabs are published write-through (sc1 stores, see gemm_epilogue), every wave drains its stores (vmcnt(0)) before
-// the block's relaxed agent-scope arrival; the folding blocks read the slabs with sc1 loads (they bypass L1 / L2 and revalidate against memory):
-// the hand-off needs neither the release fence (an L2 write-back of freshly dirtied slabs, ~6 us per block) nor the acquire.
-//
-// One 32-bit word per tile: bits 0-4 arrivals, bit 5 CLOSED, bits 8-23 abandoned shares, bits 24-28 departures.
-//   * a block that arrives LAST (arrivals == splits - 1 before it) closes the word and folds its own share plus every abandoned one;
-//   * any other block waits -- BOUNDED, ~5 us of wall clock -- for the arrivals to reach `splits` and then folds its own share.  If the wait runs
-//     out (a sibling is not resident: the grid is larger than the GPU, or another stream holds the CUs) it abandons its share (fetch_or of its
-//     bit) and leaves; when that fetch_or finds the word already CLOSED everyone HAS arrived and it folds its share after all.
-//   No block ever waits without a bound, so there is no residency requirement and no deadlock; the slow case degrades to "the last arriver folds
-//   what is left" (round 2's first version, measured slower than the reduce launch because ONE block walked splits x tile through its 8-deep
-//   load queue).  The per-element order of the additions (slice 0, 1, 2, ...) is the reduce launch's: both routes give the same bits.
-//   The last block to leave (departures == splits - 1 before it) zeroes the word for the next launch.
-// Call with every thread of the block that ran gemm_epilogue (nthr of them, tid = 0 .. nthr-1); zs = this block's k-slice.
-template <int VB, int SB, int VPR, bool LOCAL>
-__device__ __forceinline__ void splitk_fold_share(const GemmParams& p, const float* __restrict__ P0, f16* __restrict__ C, const f16* __restrict__ R, long MN, int m0,
-                                                  int n0, int vbeg, int vend, int tid, int nthr) {
-    for (int vb = vbeg + tid; vb < vend; vb += VB * nthr) {
-        const float* src[VB];
-        f32x4 acc[VB];
+// ---- round 5: split-K without a reduce launch AND without a second pass over row-major slabs.  Every k-slice workgroup of a tile takes a ticket; all but the last
+// publish their accumulators exactly as the lanes hold them ([TM * TN][256 threads] f32x4: each wave-instruction stores / loads 1 KiB contiguous) and leave;
+// the last arriver waits for those publications (their authors HAVE arrived, so they are running and need nobody: the wait is bounded by their store drain),
+// adds the slices in slice order with its own accumulators at its own position -- the same sum whoever comes last: bit-reproducible -- and runs the unchanged
+// FUSED epilogue (bias, per-image bias, residual, activation, second destination) on the result.  Against the reduce launch: no launch boundary (~5 us in the
+// captured pass), half the slab traffic at two slices, and no f32 row-major slab written and re-read through 64-byte pieces.  XCD-local form (p.xcd_local): the
+// slices of a tile run on one XCD (xcd_local_map) and the slabs / counters live in that XCD's L2 (plain stores, sc0 loads, L2-scope atomics); otherwise
+// write-through stores, sc1 loads and agent-scope atomics through memory.  Returns true in the workgroup that holds the complete sum.
+// flag: one int of LDS; call with all 256 threads of the 4 math waves (tid 0..255) after the k loop.
+template <int TM, int TN>
+__device__ __forceinline__ bool splitk_fold_acc(const GemmParams& p, f32x4 (&acc)[TM][TN], int tile_id, int zs, int* flag, int tid) {
+    constexpr int NV = TM * TN;
+    const bool local = p.xcd_local != 0;
+    f32x4* __restrict__ slab = reinterpret_cast<f32x4*>(p.partial) + ((long)tile_id * p.splits) * (NV * 256) + tid;
+    unsigned* w = reinterpret_cast<unsigned*>(p.tickets) + 2 * tile_id;   // [0] arrivals, [1] publications
+    if (tid == 0) {
+        const unsigned t = local ? __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = (int)t;
+    }
+    __syncthreads();
+    const bool is_last = *flag == p.splits - 1;
+    if (!is_last) {
+        f32x4* dst = slab + (long)zs * (NV * 256);
 #pragma unroll
-        for (int i = 0; i < VB; i++) {
-            const int v = min(vb + i * nthr, vend - 1), r = v / VPR;   // clamped: loads are unconditional, stores are not
-            src[i] = P0 + (long)min(m0 + r, p.M - 1) * p.N + min(n0 + (v - r * VPR) * 4, p.N - 4);
-            acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        for (int s0 = 0; s0 < p.splits; s0 += SB) {
-            f32x4 part[VB][SB];
+        for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int u = 0; u < SB; u++) {
-                const long so = (long)min(s0 + u, p.splits - 1) * MN;
-#pragma unroll
-                for (int i = 0; i < VB; i++) {
-                    const float* a = src[i] + so;
-                    if (LOCAL) asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(part[i][u]) : "v"(a) : "memory");   // past the L1, hit in the XCD's L2
-                    else asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[i][u]) : "v"(a) : "memory");
-                }
+            for (int j = 0; j < TN; j++) {
+                if (local) dst[(i * TN + j) * 256] = acc[i][j];
+                else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + (i * TN + j) * 256), "v"(acc[i][j]) : "memory");
             }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            if (local) __hip_atomic_fetch_add(w + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_fetch_add(w + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return false;
+    }
+    if (tid == 0) {
+        const unsigned want = (unsigned)p.splits - 1;
+        for (;;) {
+            const unsigned got = local ? __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (got == want) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        // both words back to zero for the next launch (nobody else touches them again: every other slice has published and left)
+        if (local) { __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_store(w + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        else { __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(w + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    }
+    __syncthreads();
+    f32x4 sum[TM][TN];
+    for (int s = 0; s < p.splits; s++) {
+        if (s == zs) {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) sum[i][j] = s == 0 ? acc[i][j] : sum[i][j] + acc[i][j];
+        } else {
+            const f32x4* src = slab + (long)s * (NV * 256);
+            f32x4 part[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    if (local) asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(part[i][j]) : "v"(src + (i * TN + j) * 256) : "memory");
+                    else asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[i][j]) : "v"(src + (i * TN + j) * 256) : "memory");
+                }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int u = 0; u < SB; u++)
+            for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int i = 0; i < VB; i++) {
-                    asm volatile("" : "+v"(part[i][u]));
-                    if (s0 + u < p.splits) acc[i] += part[i][u];
+                for (int j = 0; j < TN; j++) {
+                    asm volatile("" : "+v"(part[i][j]));
+                    sum[i][j] = s == 0 ? part[i][j] : sum[i][j] + part[i][j];
                 }
-        }
-#pragma unroll
-        for (int i = 0; i < VB; i++) {
-            const int v = vb + i * nthr;
-            if (v >= vend) continue;
-            const int r = v / VPR, m = m0 + r, n = n0 + (v - r * VPR) * 4;
-            if (m >= p.M || n >= p.N) continue;
-            f32x4 sum = acc[i];
-            if (p.bias) {
-                if (p.bias_f32) sum += *reinterpret_cast<const f32x4*>((const float*)p.bias + n);
-                else {
-                    f16x4 bv = *reinterpret_cast<const f16x4*>((const f16*)p.bias + n);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) sum[e] += (float)bv[e];
-                }
-            }
-            if (p.rowbias) {
-                f16x4 rb = *reinterpret_cast<const f16x4*>(p.rowbias + (long)(m / p.rb_rows) * p.rb_ld + n);
-#pragma unroll
-                for (int e = 0; e < 4; e++) sum[e] += (float)rb[e];
-            }
-            if (R) {
-                f16x4 rv = *reinterpret_cast<const f16x4*>(R + (long)m * p.N + n);
-#pragma unroll
-                for (int e = 0; e < 4; e++) sum[e] += (float)rv[e];
-            }
-            f16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; e++) o[e] = (f16)osg_apply_act(sum[e], p.act);
-            *reinterpret_cast<f16x4*>(C + (long)m * (p.ldc ? p.ldc : (long)p.N) + n) = o;
-            if (p.C2) *reinterpret_cast<f16x4*>(p.C2 + (long)m * p.ldc2 + n) = o;
         }
     }
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = sum[i][j];
+    return true;
 }
 
 // XCD-local launches: flat workgroup index -> (tile, k-slice) with the slices of a tile on consecutive workgroups of ONE XCD.  The grid is
@@ -627,101 +627,30 @@ __device__ __forceinline__ bool xcd_local_map(const GemmParams& p, int* tile, in
     return *tile < p.tiles_total;
 }
 
-template <int BM, int BN>
-__device__ __forceinline__ void splitk_finish(const GemmParams& p, int m0, int n0, int tile_id, int zb, int zs, int* flag, int tid, int nthr) {
-    constexpr unsigned CNT = 0x1fu, CLOSED = 0x20u;
-    constexpr int MASK_SH = 8, DONE_SH = 24;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        unsigned* w = reinterpret_cast<unsigned*>(p.tickets) + tile_id;
-        const unsigned mine = 1u << zs;
-        unsigned shares;
-        unsigned old = __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((old & CNT) == (unsigned)p.splits - 1) {
-            old = __hip_atomic_fetch_or(w, CLOSED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            shares = ((old >> MASK_SH) & 0xffffu) | mine;
-        } else {
-            const unsigned long long t0 = wall_clock64();   // constant 100 MHz
-            bool all;
-            do {
-                all = (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & CNT) == (unsigned)p.splits;
-                if (!all) __builtin_amdgcn_s_sleep(2);
-            } while (!all && wall_clock64() - t0 < (unsigned long long)p.fold_wait);
-            if (all) shares = mine;
-            else {
-                old = __hip_atomic_fetch_or(w, mine << MASK_SH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                shares = (old & CLOSED) ? mine : 0u;
-            }
-        }
-        old = __hip_atomic_fetch_add(w, 1u << DONE_SH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // this block is done with the word
-        if ((old >> DONE_SH) == (unsigned)p.splits - 1) __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        *flag = (int)shares;
-    }
-    __syncthreads();
-    unsigned shares = (unsigned)*flag;
-    if (!shares) return;
-    constexpr int VPR = BN / 4, NV = BM * VPR;
-    const long MN = (long)p.M * p.N;
-    const float* __restrict__ P0 = p.partial + (long)zb * p.splits * MN;
-    f16* __restrict__ C = p.C + zb * p.strideC;
-    const f16* __restrict__ R = p.residual ? p.residual + zb * p.strideC : nullptr;
-    const int chunk = (NV + p.splits - 1) / p.splits;
-    while (shares) {
-        const int z = __builtin_ctz(shares);
-        shares &= shares - 1;
-        const int vbeg = z * chunk, vend = min(NV, vbeg + chunk);
-        if (vbeg >= vend) continue;
-        // 8 slab loads in flight per thread (32 VGPRs: the fold must not raise the register count of the kernel it rides in), shaped by the slice
-        // count (any shape is correct for any count); a share is tile / splits, so that is one round trip for the 64-wide tiles, two for 128 x 128
-        if (p.xcd_local) {
-            if (p.splits <= 2) splitk_fold_share<4, 2, VPR, true>(p, P0, C, R, MN, m0, n0, vbeg, vend, tid, nthr);
-            else if (p.splits <= 4) splitk_fold_share<2, 4, VPR, true>(p, P0, C, R, MN, m0, n0, vbeg, vend, tid, nthr);
-            else splitk_fold_share<1, 8, VPR, true>(p, P0, C, R, MN, m0, n0, vbeg, vend, tid, nthr);
-        } else {
-            if (p.splits <= 2) splitk_fold_share<4, 2, VPR, false>(p, P0, C, R, MN, m0, n0, vbeg, vend, tid, nthr);
-            else if (p.splits <= 4) splitk_fold_share<2, 4, VPR, false>(p, P0, C, R, MN, m0, n0, vbeg, vend, tid, nthr);
-            else splitk_fold_share<1, 8, VPR, false>(p, P0, C, R, MN, m0, n0, vbeg, vend, tid, nthr);
-        }
-    }
-}
-
 int launch_splitk_reduce(osg_ctx* ctx, const GemmParams& p, int batch);   // osg_gemm.hip
-// blocked copy of a resident [N][K] f16 weight the planner vouched for (osg_set_blocked_weight_hint); sets p.Bt / p.b_blk / p.b_bytes.  osg_gemm.hip
-int apply_blocked_weight(osg_ctx* ctx, GemmParams& p, int batch);
 // the statistics a StatSink asks for, from the stored output (rows ldc apart) -- for the launches whose epilogue does not serve sinks (osg_norm.hip)
 int launch_colstats(osg_ctx* ctx, const f16* C, long ldc, int M, int N, int rows_per_image, const StatSink* sinks);
 long long* kdbg_buffer(osg_ctx* ctx, long workgroups);   // osg_ctx.hip: NULL unless OSG_KDBG is set
 inline int no_epi_prefetch() { static const int v = getenv("OSG_NO_EPI_PREFETCH") ? 1 : 0; return v; }
-// OSG_SPLITK_TICKET=1: fold the slabs in the kernel (splitk_finish) instead of with a reduce launch; read per launch (a captured plan keeps what it was
-// captured with)
-inline int splitk_fold_wait() {   // OSG_SPLITK_WAIT: dev knob (0 = nobody waits: the last arriver folds the whole tile)
-    const char* e = getenv("OSG_SPLITK_WAIT");
-    return e ? atoi(e) : 500;
+// OSG_SPLITK_FOLD (round 5; read per call): 0 = never; 1 (default) = splitk_fold_acc where it applies, XCD-local when the dispatcher calibration holds; 2 = through memory
+inline int splitk_fold_mode() {
+    const char* e = getenv("OSG_SPLITK_FOLD");
+    return e ? atoi(e) : 1;
 }
-// = 0: reduce launch; 1: in-kernel fold over write-through slabs (any XCD); 2: in-kernel fold, XCD-local (needs ctx->xcd_rr, else behaves as 0)
-inline int splitk_ticket_mode() {
-    const char* e = getenv("OSG_SPLITK_TICKET");
-    return e ? atoi(e) : 0;
+// a launch of n_tiles output tiles x p.splits k-slices whose tiles are bm x bn: can it finish with splitk_fold_acc?  Sets tickets / fold_acc / xcd_local and returns the
+// slab bytes the launch needs (0: no)
+inline size_t splitk_fold_route(osg_ctx* ctx, GemmParams& p, long n_tiles, int bm, int bn) {
+    p.fold_acc = 0;
+    const int mode = splitk_fold_mode();
+    if (mode == 0 || p.splits < 2 || p.splits > 4 || !ctx->tickets || 2 * n_tiles + 16 > osg_ctx::kTickets / 2) return 0;
+    if ((p.N & 3) != 0 || ((p.ldc | p.ldc2) & 3) != 0 || p.act == OSG_ACT_GEGLU || p.ln_c1 || p.rs_out) return 0;   // the compact fused epilogue only
+    if (p.sink[0].table || p.sink[1].table) return 0;   // (GroupNorm statistics of a split launch come from the reduce launch)
+    p.fold_acc = 1;
+    p.tickets = ctx->tickets;                            // (the lower half of the counters; the upper one belongs to the GroupNorm clusters, osg_norm.hip)
+    p.xcd_local = mode == 1 && ctx->xcd_rr ? 1 : 0;
+    if (p.xcd_local) { p.xcc_map = ctx->xcc_map; p.xcd_err = ctx->xcd_err_dev; }
+    return (size_t)n_tiles * p.splits * bm * bn * sizeof(float);
 }
-// sets p.tickets / p.xcd_local / ... for a split launch of n_tiles output tiles
-inline void splitk_route(osg_ctx* ctx, GemmParams& p, long n_tiles) {
-    p.tickets = nullptr;
-    p.xcd_local = 0;
-    const int mode = splitk_ticket_mode();
-    static const int max_m = getenv("OSG_SPLITK_TICKET_MAXM") ? atoi(getenv("OSG_SPLITK_TICKET_MAXM")) : (1 << 30);   // (only launches of at most this many rows fold in the kernel)
-    if (p.M > max_m) return;
-    if (mode == 0 || p.splits < 2 || p.N % 4 != 0 || p.splits > 16 || !ctx->tickets || n_tiles + 8 > osg_ctx::kTickets / 2) return;
-    if (mode == 2 && !ctx->xcd_rr) return;
-    p.tickets = ctx->tickets;
-    p.fold_wait = splitk_fold_wait();
-    if (mode == 2) {
-        p.xcd_local = 1;
-        p.xcc_map = ctx->xcc_map;
-        p.xcd_err = ctx->xcd_err_dev;
-    }
-}
-
 }  // namespace osg_mm
 
 // osg_conv3x3.hip: halo-reuse 3x3 / stride 1 / pad 1 convolution.  Returns -1 when the shape is not one it takes.
@@ -729,5 +658,5 @@ int osg_conv3x3_run(osg_ctx* ctx, osg_mm::GemmParams& p);
 // the same in pieces, for the measured configuration choice (osg_tune.h): shape gate, ranked (BN, splits) candidates, one launch
 int osg_conv3x3_prepare(osg_ctx* ctx, osg_mm::GemmParams& p);
 std::vector<std::pair<double, std::pair<int, int>>> osg_conv3x3_rank(const osg_ctx* ctx, const osg_mm::GemmParams& p);
-int osg_conv3x3_launch(osg_ctx* ctx, osg_mm::GemmParams p, int bn, int splits, int loader_waves = 4);
+int osg_conv3x3_launch(osg_ctx* ctx, osg_mm::GemmParams p, int bn, int splits, int loader_waves = 4, int fold = 0);   // fold: a 2 .. 4-way split finished by splitk_fold_acc
 int osg_conv3x3_supported(int N, int H, int W, int Cin, int Cout);

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
             for (int k = 0; k < osg_mm::kStatCopies; k++) { ts += tb[k * copy_stride + g * 2]; tq += tb[k * copy_stride + g * 2 + 1]; }
             const double mean = (double)ts * (1.0 / (double)osg_mm::kStatSX) * icnt;
-            const double q = (double)tq * (1.0 / (double)osg_mm::kStatSQ);
+            const double q = (double)tq * (1.0 / (double)osg_mm::stat_q_scale((long)HW * cpg));
             const float var = fmaxf((float)(q * icnt - mean * mean), 0.f);
             stat[g * 2 + 0] = (float)mean;
             stat[g * 2 + 1] = 1.0f / sqrtf(var + eps);
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void gn_apply_stats_kernel(const f16* __restri
 #pragma unroll
             for (int k = 0; k < osg_mm::kStatCopies; k++) { ts += tb[k * copy_stride + g * 2]; tq += tb[k * copy_stride + g * 2 + 1]; }
             const double mean = (double)ts * (1.0 / (double)osg_mm::kStatSX) * icnt;
-            const double q = (double)tq * (1.0 / (double)osg_mm::kStatSQ);
+            const double q = (double)tq * (1.0 / (double)osg_mm::stat_q_scale((long)HW * cpg));
             const float var = fmaxf((float)(q * icnt - mean * mean), 0.f);
             stat[g * 2 + 0] = (float)mean;
             stat[g * 2 + 1] = 1.0f / sqrtf(var + eps);
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const f16* __restrict__ C
             float S = 0.f, Q = 0.f;
             for (int cc = a; cc < b; cc++)
                 for (int pp = 0; pp < 4; pp++) { S += st[pp][cc][0]; Q += st[pp][cc][1]; }
-            osg_mm::stat_add(per_xcd, reinterpret_cast<unsigned long long*>(sk[k].table), (long)imgs * sk[k].groups * 2, ((long)n_img * sk[k].groups + g) * 2, S, Q);
+            osg_mm::stat_add(per_xcd, reinterpret_cast<unsigned long long*>(sk[k].table), (long)imgs * sk[k].groups * 2, ((long)n_img * sk[k].groups + g) * 2, S, Q, osg_mm::stat_q_scale((long)hw * sk[k].cpg));
         }
     }
 }
@@ -775,27 +775,6 @@ int osg_instance_norm(osg_ctx* ctx, osg_dtype dtype, const void* x, const float*
 
 }  // extern "C"
 
-// GroupNorm statistics -> per-image affine table tab[n][2][C] (ca = rstd*gamma, cb = beta - mean*rstd*gamma) in the context's second
-// scratch buffer (the first one holds split-K slabs of the convolution that consumes the table).  Used by osg_group_norm_conv3x3.
-int osg_gn_table(osg_ctx* ctx, const void* x, const void* gamma, const void* beta, int N, long HW, int C, int G, float eps, float** tab_out) {
-    if (G <= 0 || C % G || C % 8) OSG_FAIL(ctx, "osg_group_norm: C must be a multiple of groups and of 8");
-    const int cols = C / 8 < 256 ? C / 8 : 256;
-    const int Rr = 256 / cols;
-    int S = (int)(HW / ((long)Rr * 8));
-    if (S > 64) S = 64;
-    if (S < 1) S = 1;
-    const size_t part_bytes = ((size_t)N * G * S * 2 * sizeof(float) + 255) & ~(size_t)255;
-    if (osg_ensure_workspace2(ctx, part_bytes + (size_t)N * 2 * C * sizeof(float))) return 1;
-    float* part = (float*)ctx->ws2;
-    float* tab = (float*)((char*)ctx->ws2 + part_bytes);
-    hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(S, N), dim3(256), (G * 2 + 2 * 256 * 8) * sizeof(float), ctx->compute, (const f16*)x, part, HW, C, G, S);
-    OSG_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(gn_finalize_kernel<f16>, dim3(N), dim3(256), G * 2 * sizeof(float), ctx->compute, part, (const f16*)gamma, (const f16*)beta,
-                       tab, HW, C, G, S, eps);
-    OSG_LAUNCH_CHECK(ctx);
-    *tab_out = tab;
-    return 0;
-}
 
 extern "C" {
 

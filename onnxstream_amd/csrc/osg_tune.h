@@ -36,6 +36,8 @@ bool lookup(const Key& k, Choice* out);
 // a multi-GPU job run with: every rank seeds the same shipped table and plans on its own, identically, without waiting for rank 0 to measure anything.
 inline bool frozen() { static const bool v = getenv("OSG_TUNE_FROZEN") && atoi(getenv("OSG_TUNE_FROZEN")) != 0; return v; }
 void store(const Key& k, const Choice& c);
+void remember(const Key& k, const Choice& c);   // in memory only (the untimed choice of a shape a frozen table does not hold)
+int misses();                                   // lookups that found nothing, since the process started
 
 // microseconds per launch of f() (which enqueues the whole operation, reduce kernel included, and returns 0 on success); < 0 on failure
 // cold timing (default; OSG_TUNE_COLD=0 switches it off): every timed launch starts with L2 / MALL evicted (a 384 MiB fill on the same stream before the first event) -- inside

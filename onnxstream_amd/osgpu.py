@@ -21,15 +21,15 @@ UN = dict(sigmoid=0, erf=1, sqrt=2, sin=3, cos=4, neg=5, pow=6, silu=7, gelu_erf
 BIN = dict(add=0, sub=1, mul=2, div=3)
 
 EXPORTS = [
-    "osg_device_count", "osg_init", "osg_destroy", "osg_last_error", "osg_device_name", "osg_stream", "osg_set_autotune",
+    "osg_device_count", "osg_init", "osg_destroy", "osg_last_error", "osg_device_name", "osg_stream", "osg_set_autotune", "osg_tune_misses",
     "osg_malloc", "osg_free", "osg_upload", "osg_upload_sync", "osg_host_register", "osg_host_unregister", "osg_upload_pinned", "osg_upload_pinned_async", "osg_copy_fence", "osg_download", "osg_copy", "osg_memset", "osg_sync",
-    "osg_graph_begin", "osg_graph_end", "osg_graph_launch", "osg_graph_destroy", "osg_side_begin", "osg_side_end", "osg_side_join", "osg_timer_start", "osg_timer_stop",
+    "osg_graph_begin", "osg_graph_end", "osg_graph_launch", "osg_graph_destroy", "osg_timer_start", "osg_timer_stop",
     "osg_conv2d_nhwc", "osg_conv2d_nhwc_rb", "osg_conv2d_nhwc_v", "osg_gemm", "osg_gemm_ln", "osg_gemm_rowstats", "osg_gemm_w8", "osg_conv2d_nhwc_w8", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided", "osg_sdpa", "osg_rms_norm", "osg_rope",
-    "osg_instance_norm", "osg_group_norm_nhwc", "osg_group_norm_conv3x3_supported", "osg_group_norm_conv3x3", "osg_layer_norm", "osg_reduce_mean_last", "osg_softmax_last",
+    "osg_instance_norm", "osg_group_norm_nhwc", "osg_layer_norm", "osg_reduce_mean_last", "osg_softmax_last",
     "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_concat2", "osg_resize_nearest", "osg_gather_rows",
     "osg_maxpool_nhwc", "osg_convert", "osg_sampler_prepare", "osg_sampler_cfg_euler_a",
-    "osg_range_push", "osg_range_pop", "osg_marker_record", "osg_copy_wait_marker", "osg_timer_mark", "osg_timer_between", "osg_set_stat_sinks", "osg_set_weight_prefetch", "osg_set_blocked_weight_hint", "osg_group_norm_stats_nhwc", "osg_qu8_conv2d_nhwc", "osg_qu8_conv2d_nhwc_t", "osg_qu8_conv_tap_sums", "osg_qu8_gemm", "osg_qu8_lut", "osg_qu8_binary", "osg_qu8_instance_norm", "osg_qu8_instance_norm_nhwc", "osg_qu8_affine_act", "osg_qu8_norm_affine_act_nhwc", "osg_qu8_softmax_last", "osg_kdbg_read",
-    "osg_tblock_tail_supported", "osg_tblock_tail", "osg_tblock_kv_pack_elems", "osg_tblock_kv_pack_jobs", "osg_tblock_pack_weight", "osg_qattn_supported", "osg_qattn", "osg_linear_small_supported", "osg_linear_small_rowstats_supported", "osg_linear_small",
+    "osg_range_push", "osg_range_pop", "osg_marker_record", "osg_copy_wait_marker", "osg_timer_mark", "osg_timer_between", "osg_set_stat_sinks", "osg_group_norm_stats_nhwc", "osg_qu8_conv2d_nhwc", "osg_qu8_conv2d_nhwc_t", "osg_qu8_conv_tap_sums", "osg_qu8_gemm", "osg_qu8_lut", "osg_qu8_binary", "osg_qu8_instance_norm", "osg_qu8_instance_norm_nhwc", "osg_qu8_affine_act", "osg_qu8_norm_affine_act_nhwc", "osg_qu8_softmax_last", "osg_kdbg_read",
+    "osg_tblock_tail_supported", "osg_tblock_tail", "osg_tblock_kv_pack_elems", "osg_tblock_kv_pack_jobs", "osg_tblock_pack_weight", "osg_qattn_supported", "osg_qattn",
 ]
 
 
@@ -98,8 +98,6 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_rope.argtypes = [vp, ci, vp, vp, vp, vp, cl, cl, ci]
     lib.osg_instance_norm.argtypes = [vp, ci, vp, vp, vp, vp, ci, cl, ci, cf]
     lib.osg_group_norm_nhwc.argtypes = [vp, ci, vp, vp, vp, vp, ci, cl, ci, ci, cf, ci]
-    lib.osg_group_norm_conv3x3_supported.argtypes = [ci] * 5
-    lib.osg_group_norm_conv3x3.argtypes = [vp, vp, vp, vp, ci, cf, ci, vp, vp, ci, vp, cl, vp, vp, ci, ci, ci, ci, ci]
     lib.osg_layer_norm.argtypes = [vp, ci, vp, vp, vp, vp, cl, ci, cf]
     lib.osg_reduce_mean_last.argtypes = [vp, ci, vp, vp, cl, cl]
     lib.osg_softmax_last.argtypes = [vp, ci, vp, vp, cl, cl]
@@ -117,8 +115,6 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_gemm_rowstats.argtypes = [vp, vp, vp, vp, ci, vp, vp, ci, ci, ci, ci, vp]
     lib.osg_sampler_prepare.argtypes = [vp, vp, vp, vp, ci, cl, cf, cf, cl]
     lib.osg_sampler_cfg_euler_a.argtypes = [vp, vp, vp, vp, ci, cl, cf, cf, cf, cf, cf, cf]
-    lib.osg_set_blocked_weight_hint.argtypes = [vp, vp]
-    lib.osg_set_weight_prefetch.argtypes = [vp, vp, ctypes.c_size_t]
     lib.osg_set_stat_sinks.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci, ci, ci]
     lib.osg_group_norm_stats_nhwc.argtypes = [vp, vp, vp, vp, vp, ci, ctypes.c_long, ci, ci, cf, ci, vp]
     lib.osg_qu8_conv2d_nhwc.argtypes = [vp, vp, cf, ci, vp, cf, ci, vp, cf, ci, vp] + [ci] * 13
@@ -140,9 +136,6 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_tblock_kv_pack_elems.restype = ctypes.c_size_t
     lib.osg_tblock_kv_pack_jobs.argtypes = [vp, vp, cl, ci, ci, ci, ci, vp, vp]
     lib.osg_tblock_pack_weight.argtypes = [vp, vp, ci, ci, vp]
-    lib.osg_linear_small_supported.argtypes = [ci] * 4
-    lib.osg_linear_small_rowstats_supported.argtypes = [ci] * 3
-    lib.osg_linear_small.argtypes = [vp, vp, cl, vp, vp, vp, cl, vp, vp, cf, vp, cl, vp, cl, ci, ci, ci, vp]
     return lib
 
 
@@ -345,16 +338,6 @@ class Gpu:
         self._ck(self.lib.osg_copy(self.ctx, kp.ptr, dst.ptr, n * 2))
         self._ck(self.lib.osg_copy(self.ctx, vtp.ptr, dst.ptr + n * 2, n * 2))
         return kp, vtp
-
-    def linear_small(self, x: DevBuf, w_kn8: DevBuf, bias: Optional[DevBuf] = None, residual: Optional[DevBuf] = None, gamma: Optional[DevBuf] = None,
-                     beta: Optional[DevBuf] = None, eps: float = 1e-5, out2: Optional[DevBuf] = None, out2_col: int = 0, rowstats: Optional[DevBuf] = None):
-        """osg_linear_small: x [M, K], w_kn8 [K/8, N, 8] (tblock_pack_weight of the [N, K] weight) -> y [M, N]; optional LayerNorm of x, second destination"""
-        m, k = x.shape
-        n = w_kn8.shape[1]
-        y = self.empty((m, n), x.dtype)
-        y2, ld2 = (out2.ptr + out2_col * 2, out2.shape[-1]) if out2 is not None else (None, 0)
-        self._ck(self.lib.osg_linear_small(self.ctx, x.ptr, k, w_kn8.ptr, self._p(bias), self._p(residual), n, self._p(gamma), self._p(beta), eps, y.ptr, n, y2, ld2, m, n, k, self._p(rowstats)))
-        return y
 
     TBLOCK_WEIGHTS = ("wo1", "wq2", "wo2", "w1", "w2", "wpo")
 

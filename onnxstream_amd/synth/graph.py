@@ -178,6 +178,18 @@ class GraphBuilder:
                        {"dilations": "1,1", "group": "1", "kernel_shape": f"{k},{k}",
                         "pads": f"{pad},{pad},{pad},{pad}", "strides": f"{stride},{stride}"})
 
+    def conv1d(self, name, x: T, cout: int, k: int = 3, stride: int = 1, pad: Optional[int] = None, bias: bool = True) -> T:
+        """Conv over [N, C, L] as the ONNX exporter writes it: one-element dilations / kernel_shape / strides, two pads (the reference lifts it to 2-D,
+        src/onnxstream.cpp:4521-4544)."""
+        n, cin, length = x.shape
+        pad = (k // 2) if pad is None else pad
+        wt = self.weight(f"{name}.weight", self.randn((cout, cin, k, 1), 1.0 / np.sqrt(cin * k)), conv=True)   # (model.txt names a Conv1D's filter bank as [O, I, k, 1]: get_tensor_data :2681 wants four dims)
+        ins = [x, wt]
+        if bias:
+            ins.append(self.weight(f"{name}.bias", self.randn((cout,), 0.02), allow_quant=False, q8_exempt=True))
+        lo = (length + 2 * pad - k) // stride + 1
+        return self.op(name, "Conv", ins, (n, cout, lo), {"dilations": "1", "group": "1", "kernel_shape": f"{k}", "pads": f"{pad},{pad}", "strides": f"{stride}"})
+
     def matmul_w(self, name, x: T, n_out: int, std: Optional[float] = None) -> T:
         k = x.shape[-1]
         std = std if std is not None else (1.0 / np.sqrt(k))

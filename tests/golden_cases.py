@@ -180,8 +180,16 @@ def shape_gather_chain(g):
     return {"x": _rn(20, (1, 6, 32))}
 
 
+def conv1d_pair(g):   # Conv1D lifted to 2-D (reference src/onnxstream.cpp:4521-4544): stride 1, SiLU, stride 2 -- 64 channels (the direct-to-LDS kernel) and a ragged count
+    # (an op between the two: the reference cannot feed a Conv1D's 3-D NHWC result straight into another Conv -- :2917-2920 lifts unspecified-layout inputs only)
+    x = g.input("x", (1, 64, 40))
+    h = g.silu("/act", g.conv1d("/c1", x, 24, 3))
+    g.silu("/act2", g.conv1d("/c2", h, 32, 3, stride=2))   # (nor hand a 3-D NHWC tensor out as a graph output, :8250-8253)
+    return {"x": _rn(21, (1, 64, 40))}
+
+
 CASES = [conv3x3, conv3x3_stride2, conv1x1_nobias, conv_in_4ch, conv_ragged, linear_bias, gemm_temb, group_norm_silu, layer_norm,
-         self_attention, cross_attention, geglu_ff, resnet_block, transformer_block, upsample_concat, time_embedding, shape_gather_chain]
+         self_attention, cross_attention, geglu_ff, resnet_block, transformer_block, upsample_concat, time_embedding, shape_gather_chain, conv1d_pair]
 # longer chains at real widths (15 rounding points deep): held to the whole-net bound of tests/test_golden.py, not the single-pattern one
 CHAINS = [transformer_block_320, transformer_block_640, transformer_block_1280]
 # whole (miniature) networks: SD1.5-shaped and SDXL-shaped UNets, the VAE decoder (single 32-wide attention head + 3 resolutions)

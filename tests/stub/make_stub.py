@@ -29,29 +29,9 @@ SPECIAL = {
     "osg_graph_end": "{ (void)ctx; *out = (osg_graph*)calloc(1, 16); return 0; }",
     "osg_graph_destroy": "{ free(g); }",
     "osg_timer_stop": "{ (void)ctx; if (ms) *ms = 0.0f; return 0; }",
-    "osg_group_norm_conv3x3_supported": "{ (void)N; (void)H; (void)W; (void)Cin; (void)Cout; return 0; }",
     # (shape predicates and sizes the PLANNER branches on: the real library's answers, so the CPU tests see the plan a GPU box would build)
     "osg_tblock_tail_supported": "{ return C == 320 && heads == 8 && M > 0 && M % 32 == 0 && rows_per_img % 32 == 0 && Tk >= 1 && Tk <= 80; }",
     "osg_qattn_supported": "{ return ((C == 640 && (heads == 8 || heads == 10)) || (C == 1280 && (heads == 8 || heads == 20))) && (long)(M / 32) * heads <= 512 && M > 0 && M % 32 == 0 && rows_per_img % 32 == 0 && Tk >= 1 && Tk <= 80; }",
-    "osg_linear_small_supported": """{
-    (void)layer_norm;
-    if (M <= 0 || N <= 0 || K <= 0 || K % 320 || K > 2560) return 0;
-    for (int cfg = 0; cfg < 6; cfg++) {
-        const int bm = cfg <= 1 ? 64 : (cfg == 2 || cfg == 4) ? 32 : 16, bn = (cfg == 0 || cfg >= 4) ? 64 : 128;
-        if ((cfg <= 1 && K > 640) || ((cfg == 2 || cfg == 4) && K > 1280)) continue;
-        if (M % bm == 0 && N % bn == 0 && (long)bm * K * 2 <= 80 * 1024) return 1;
-    }
-    return 0;
-}""",
-    "osg_linear_small_rowstats_supported": """{
-    if (M <= 0 || N <= 0 || K <= 0 || K % 320 || K > 2560) return 0;
-    for (int cfg = 0; cfg < 4; cfg++) {
-        const int bm = cfg <= 1 ? 64 : cfg == 2 ? 32 : 16, bn = cfg == 0 ? 64 : 128;
-        if ((cfg <= 1 && K > 640) || (cfg == 2 && K > 1280)) continue;
-        if (M % bm == 0 && N % bn == 0 && (long)bm * K * 2 <= 80 * 1024) return 1;
-    }
-    return 0;
-}""",
     "osg_tblock_kv_pack_elems": "{ return (size_t)imgs * heads * 80 * (size_t)((D + 15) / 16 * 16); }",
     # ---- DATA MOVEMENT and dtype conversion are real (plain C restatements of the entry points' documented semantics, include/osgpu.h): a graph made
     # of zero-FLOP ops then carries real values end to end on a CPU, which lets tests/test_movement_cpu.py check what the PLANNER hands these entry
