@@ -138,8 +138,10 @@ void calibrate_xcd(osg_ctx* c) {
 
 int xcd_check(osg_ctx* c) {
     if (c->xcd_err && *(volatile int*)c->xcd_err) {
+        const int what = *(volatile int*)c->xcd_err;
         *c->xcd_err = 0;
-        c->xcd_rr = false;   // (later plans fall back to the reduce launch)
+        c->xcd_rr = false;   // (later plans exchange the slabs through memory)
+        if (what == 2) OSG_FAIL(c, "split-K fold: a k-slice workgroup did not publish its partial sums within 2 ms (results of this pass are invalid); set OSG_SPLITK_FOLD=0");
         OSG_FAIL(c, "XCD-local split-K: a workgroup ran on another XCD than workgroup-index mod 8 says (results of this pass are invalid); set OSG_SPLITK_FOLD=2");
     }
     return 0;

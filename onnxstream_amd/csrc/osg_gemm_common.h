@@ -532,19 +532,19 @@ __device__ __forceinline__ void gemm_epilogue_geglu(const GemmParams& p, f32x4 (
 // adds the slices in slice order with its own accumulators at its own position -- the same sum whoever comes last: bit-reproducible -- and runs the unchanged
 // FUSED epilogue (bias, per-image bias, residual, activation, second destination) on the result.  Against the reduce launch: no launch boundary (~5 us in the
 // captured pass), half the slab traffic at two slices, and no f32 row-major slab written and re-read through 64-byte pieces.  XCD-local form (p.xcd_local): the
-// slices of a tile run on one XCD (xcd_local_map) and the slabs / counters live in that XCD's L2 (plain stores, sc0 loads, L2-scope atomics); otherwise
-// write-through stores, sc1 loads and agent-scope atomics through memory.  Returns true in the workgroup that holds the complete sum.
+// slices of a tile run on one XCD (xcd_local_map) and the slabs / counters live in that XCD's L2 (plain stores, sc0 loads); otherwise
+// write-through stores and sc1 loads through memory; the counters are agent-scope atomics in both forms.  Returns true in the workgroup that holds the complete sum.
 // flag: one int of LDS; call with all 256 threads of the 4 math waves (tid 0..255) after the k loop.
 template <int TM, int TN>
 __device__ __forceinline__ bool splitk_fold_acc(const GemmParams& p, f32x4 (&acc)[TM][TN], int tile_id, int zs, int* flag, int tid) {
     constexpr int NV = TM * TN;
     const bool local = p.xcd_local != 0;
     f32x4* __restrict__ slab = reinterpret_cast<f32x4*>(p.partial) + ((long)tile_id * p.splits) * (NV * 256) + tid;
+    // the two counters of a tile are agent-scope words in BOTH forms (as the counters of round 2's XCD-local fold were): an L2-scope load in the wait loop below
+    // may be served by the CU's L1 for ever -- the first version of this function hung there
     unsigned* w = reinterpret_cast<unsigned*>(p.tickets) + 2 * tile_id;   // [0] arrivals, [1] publications
-    if (tid == 0) {
-        const unsigned t = local ? __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = (int)t;
-    }
+    __syncthreads();                                                       // (every wave is done reading the LDS ring: `flag` lives in its first bytes)
+    if (tid == 0) *flag = (int)__hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const bool is_last = *flag == p.splits - 1;
     if (!is_last) {
@@ -553,27 +553,30 @@ __device__ __forceinline__ bool splitk_fold_acc(const GemmParams& p, f32x4 (&acc
         for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int j = 0; j < TN; j++) {
-                if (local) dst[(i * TN + j) * 256] = acc[i][j];
+                if (local) dst[(i * TN + j) * 256] = acc[i][j];       // (the L1 is write-through: in the XCD's L2 once vmcnt says so)
                 else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + (i * TN + j) * 256), "v"(acc[i][j]) : "memory");
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) {
-            if (local) __hip_atomic_fetch_add(w + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else __hip_atomic_fetch_add(w + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid == 0) __hip_atomic_fetch_add(w + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
     }
     if (tid == 0) {
+        // the publishers HAVE arrived (they took their tickets before this workgroup did), so they are running and need nobody -- still, the wait is bounded
+        // (2 ms of the 100 MHz wall clock): should a publication never come, the pass is marked invalid (the host-mapped flag osg_sync / osg_download check)
+        // instead of hanging the device
         const unsigned want = (unsigned)p.splits - 1;
-        for (;;) {
-            const unsigned got = local ? __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (got == want) break;
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+            if (wall_clock64() - t0 > 200000ull) {
+                if (p.xcd_err) __hip_atomic_store(p.xcd_err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
             __builtin_amdgcn_s_sleep(1);
         }
         // both words back to zero for the next launch (nobody else touches them again: every other slice has published and left)
-        if (local) { __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_store(w + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-        else { __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(w + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(w + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     f32x4 sum[TM][TN];
@@ -648,7 +651,8 @@ inline size_t splitk_fold_route(osg_ctx* ctx, GemmParams& p, long n_tiles, int b
     p.fold_acc = 1;
     p.tickets = ctx->tickets;                            // (the lower half of the counters; the upper one belongs to the GroupNorm clusters, osg_norm.hip)
     p.xcd_local = mode == 1 && ctx->xcd_rr ? 1 : 0;
-    if (p.xcd_local) { p.xcc_map = ctx->xcc_map; p.xcd_err = ctx->xcd_err_dev; }
+    p.xcd_err = ctx->xcd_err_dev;       // (both forms: the bounded wait of the last arriver reports through it)
+    if (p.xcd_local) p.xcc_map = ctx->xcc_map;
     return (size_t)n_tiles * p.splits * bm * bn * sizeof(float);
 }
 }  // namespace osg_mm

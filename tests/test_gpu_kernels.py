@@ -262,6 +262,7 @@ def test_conv3x3_halo_kernel(gpu, N, H, Cin, Cout, bn, splits, monkeypatch):
     assert rel_max(got, want) <= 1e-3
 
 
+@pytest.mark.timeout(180, method="thread")   # (a protocol error would spin on the device: bound it)
 @pytest.mark.parametrize("mode", ["1", "2"])
 @pytest.mark.parametrize("M,N,K,splits,cfg,batch", [(512, 1280, 5120, 4, 2, 1), (128, 1280, 1280, 4, 2, 1), (2048, 320, 1280, 2, 1, 1), (300, 100, 2048, 3, 1, 1),
                                                     (64, 640, 10240, 4, 2, 1), (77, 320, 2048, 3, 3, 2), (16384, 320, 1280, 2, 2, 1), (512, 1280, 5120, 8, 2, 1)])
@@ -287,6 +288,7 @@ def test_splitk_fold_in_the_kernel_equals_the_reduce_launch(gpu, M, N, K, splits
         assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
 
 
+@pytest.mark.timeout(180, method="thread")
 @pytest.mark.parametrize("N,H,Cin,Cout,bn,splits", [(1, 64, 128, 160, 160, 2), (2, 32, 192, 128, 128, 3), (2, 16, 1280, 320, 80, 4), (1, 8, 2560, 1280, 80, 4),
                                                     (3, 8, 192, 128, 128, 3), (2, 16, 1280, 320, 80, 10)])
 @pytest.mark.parametrize("mode", ["1", "2"])

@@ -27,7 +27,7 @@ for name in gc.all_case_names():
             alt[name] = h16
             line += f" | host ref16 vs fixture {np.abs(h16 - r16).max() / mx:.3e} host noise {np.abs(h16 - r32).max() / mx:.3e} ref32 same {np.array_equal(h32, r32)}"
         for fusion in (0, 1, 2):
-            for extra in ({}, {"hip_fuse_ln_gemm": 1}) if fusion == 2 else ({},):
+            for extra in ({}, {"hip_fuse_ln_gemm": 0}) if fusion == 2 else ({},):
                 m = Model(b.LIB_HOST, 0, "ram+nocache")
                 m.read_file(d + "model.txt")
                 m._set_option("hip_fusion_level", fusion)
@@ -43,7 +43,7 @@ for name in gc.all_case_names():
                 e16 = np.abs(got - r16).max() / mx
                 e32 = np.abs(got - r32).max() / mx
                 ea = np.abs(got - alt[name]).max() / mx if name in alt else float("nan")
-                line += f" | f{fusion}{'+ln' if extra else ''}: e16 {e16:.2e} e16host {ea:.2e} e32 {e32:.2e}"
+                line += f" | f{fusion}{'-lnfold' if extra else ''}: e16 {e16:.2e} e16host {ea:.2e} e32 {e32:.2e}"
     print(line, flush=True)
 if alt and len(sys.argv) > 1:
     np.savez_compressed(sys.argv[1], **alt)

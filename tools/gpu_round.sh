@@ -73,5 +73,19 @@ attn)   # attention: kernel tests + golden chains, then the probe with the round
 abenv1)   # like abenv, one round only
   n=0; for e in "${ARGS[@]}"; do n=$((n + 1))
     env $e timeout 600 python bench.py --cpu-passes 0 --windows 2 > ${T}_abenv1_${n}.json 2> ${T}_abenv1_${n}.err; line ${T}_abenv1_${n}.json "[$e]"; done ;;
+ktests)   # the kernel-level GPU tests
+  timeout 1200 python -m pytest tests/test_gpu_kernels.py tests/test_tblock_tail.py tests/test_qattn.py tests/test_sdpa.py -m gpu -x -q > ${T}_kernel_tests.log 2>&1; tail -6 ${T}_kernel_tests.log ;;
+gtable)   # error table of every golden case under the deterministic plans + the reference's fp16 output on this host
+  timeout 900 python tools/golden_table.py ${T}_ref16_host.npz > ${T}_golden_table.txt 2> ${T}_golden_table.err; tail -8 ${T}_golden_table.txt ;;
+retune)   # retune "<tag>" "<env>": the headline bench from an EMPTY tune table under <env>; the table it measured -> gpurun_out (then SDXL / 4 prompts appended by `extend`)
+  tag=${ARGS[0]}; rm -f /tmp/osg_tune_$tag.txt
+  env ${ARGS[1]} OSG_TUNE_CACHE=/tmp/osg_tune_$tag.txt timeout 900 python bench.py --cpu-passes 0 --windows 3 > ${T}_retune_$tag.json 2> ${T}_retune_$tag.err; line ${T}_retune_$tag.json "[retune $tag: ${ARGS[1]}]"
+  env ${ARGS[1]} OSG_TUNE_CACHE=/tmp/osg_tune_$tag.txt timeout 900 python bench.py --cpu-passes 0 --windows 3 > ${T}_retune_${tag}_2.json 2> ${T}_retune_${tag}_2.err; line ${T}_retune_${tag}_2.json "[seeded from it: $tag]"
+  cp /tmp/osg_tune_$tag.txt ${T}_tune_$tag.txt; wc -l ${T}_tune_$tag.txt; ARGS=("${ARGS[@]:2}") ;;
+extend)   # extend "<tag>": SDXL, the W8A16 / 4-prompt variants run on the table of `retune <tag>`, appending the shapes they add
+  tag=${ARGS[0]}; export OSG_TUNE_CACHE=/tmp/osg_tune_$tag.txt
+  timeout 900 python bench.py --config SDXL --steps-per-image 10 --steps 20 --warmup 2 --cpu-passes 0 --windows 2 > ${T}_bench_sdxl.json 2> ${T}_bench_sdxl.err; line ${T}_bench_sdxl.json "SDXL 1024x1024 10-step"
+  timeout 600 python bench.py --prompts-per-gpu 4 --cpu-passes 0 --windows 2 > ${T}_bench_p4.json 2> ${T}_bench_p4.err; line ${T}_bench_p4.json "4 prompts per GPU"
+  cp /tmp/osg_tune_$tag.txt ${T}_tune_${tag}_extended.txt; wc -l ${T}_tune_${tag}_extended.txt; unset OSG_TUNE_CACHE; ARGS=("${ARGS[@]:1}") ;;
 *) echo "unknown recipe $R" ;;
 esac; done
