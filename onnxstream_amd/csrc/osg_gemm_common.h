@@ -635,7 +635,7 @@ int launch_splitk_reduce(osg_ctx* ctx, const GemmParams& p, int batch);   // osg
 int launch_colstats(osg_ctx* ctx, const f16* C, long ldc, int M, int N, int rows_per_image, const StatSink* sinks);
 long long* kdbg_buffer(osg_ctx* ctx, long workgroups);   // osg_ctx.hip: NULL unless OSG_KDBG is set
 inline int no_epi_prefetch() { static const int v = getenv("OSG_NO_EPI_PREFETCH") ? 1 : 0; return v; }
-// OSG_SPLITK_FOLD (round 5; read per call): 0 = never; 1 (default) = splitk_fold_acc where it applies, XCD-local when the dispatcher calibration holds; 2 = through memory
+// OSG_SPLITK_FOLD (round 5; read per call): 0 = never; 1 (default) / 2 = splitk_fold_acc where it applies, slabs through memory; 3 = XCD-local slabs (isolated launches only)
 inline int splitk_fold_mode() {
     const char* e = getenv("OSG_SPLITK_FOLD");
     return e ? atoi(e) : 1;
@@ -650,7 +650,10 @@ inline size_t splitk_fold_route(osg_ctx* ctx, GemmParams& p, long n_tiles, int b
     if (p.sink[0].table || p.sink[1].table) return 0;   // (GroupNorm statistics of a split launch come from the reduce launch)
     p.fold_acc = 1;
     p.tickets = ctx->tickets;                            // (the lower half of the counters; the upper one belongs to the GroupNorm clusters, osg_norm.hip)
-    p.xcd_local = mode == 1 && ctx->xcd_rr ? 1 : 0;
+    // (the XCD-local form -- slices of a tile on one XCD, slabs through its L2 -- needs workgroup b of EVERY launch on XCD b mod 8; that holds for an isolated
+    // launch (the calibration probe, the kernel tests) but not inside a pass: the dispatcher carries on round-robin from wherever the previous kernel stopped, and
+    // the per-workgroup XCC_ID check failed the first captured pass, profiles/r05_fold_xcd_local_fails_in_the_pass.txt.  OSG_SPLITK_FOLD=3 keeps it for probes.)
+    p.xcd_local = mode == 3 && ctx->xcd_rr ? 1 : 0;
     p.xcd_err = ctx->xcd_err_dev;       // (both forms: the bounded wait of the last arriver reports through it)
     if (p.xcd_local) p.xcc_map = ctx->xcc_map;
     return (size_t)n_tiles * p.splits * bm * bn * sizeof(float);

@@ -1031,7 +1031,11 @@ int osg_qattn_supported(int M, int rows_per_img, int C, int heads, int Tk) {
     const bool shape = (C == 640 && (heads == 8 || heads == 10)) || (C == 1280 && (heads == 8 || heads == 20));
     // one workgroup per (32 rows, head) re-reads the rows and a head's weight slice: it pays while the launch is a handful of workgroups per CU (SD 1.5's 32x32 level:
     // 512); at SDXL's sizes (2 560 / 1 280 workgroups) the tiled GEMM + the attention launch are faster (profiles/r04_sdxl_qattn_ab.txt: 32.6 against 30.5 ms per step)
-    static const bool any_size = getenv("OSG_QATTN_ANY_SIZE") != nullptr;     // dev knob (tools/qattn_repro.py)
+#ifdef OSG_DEV_PROBES   // (tools/qattn_repro.py, tools/sdxl_repro.py: compiled out of the product library -- an environment variable must not change production routing; advisor, round 4)
+    static const bool any_size = getenv("OSG_QATTN_ANY_SIZE") != nullptr;
+#else
+    constexpr bool any_size = false;
+#endif
     if (!any_size && (long)(M / 32) * heads > 512) return 0;
     return shape && M > 0 && M % 32 == 0 && rows_per_img % 32 == 0 && Tk >= 1 && Tk <= 80;
 }

@@ -23,6 +23,7 @@ EXCEPTIONS: dict = {
     "vae_tiny@f0": (1.10, 1.037, "err32 1.81e-3 vs drift 1.745e-3: one rounding point per graph op, 3 resolutions of GroupNorm + attention"),
     "unet_tiny_w8@f0": (1.55, 1.457, "err32 6.67e-3 vs drift 4.58e-3: the W8A16 miniature UNet at one kernel per graph op"),
     "unet_tiny_w8@f2": (1.05, 1.0002, "err32 4.580e-3 vs drift 4.579e-3"),
+    "yolov8n scores": (1.25, 1.183, "err32 9.14e-3 vs drift 7.73e-3 (class scores in [0, 1] behind a sigmoid; fusion 0 and 2 alike; profiles/r05_parity_table.txt)"),
     "unet_tiny@tuned": (1.10, 1.017, "a timing-dependent plan: err32 seen between 4.6e-3 and 6.3e-3 across runs against a drift of 6.195e-3 (round 2)"),
 }
 

@@ -114,6 +114,41 @@ def test_sd15_unet_tuned_plan_reference_parity(sd15_dir, tmp_path):
     _triangulated(got, sd15_dir, sd_unet.unet_inputs(sd_unet.SD15, 42), "SD1.5 UNet full size, tuned plan (shipped table)")
 
 
+def test_shipped_tune_table_covers_the_headline_plan(sd15_dir, tmp_path):
+    """N = 1 and N > 1 must time the SAME plan (round 5): the ranks of an N > 1 job seed the shipped table onnxstream_amd/tune/mi355x.txt and run OSG_TUNE_FROZEN = 1 --
+    a shape the table does not hold would take the cost model's first candidate there and be measured live at N = 1.  So: the full-size SD 1.5 UNet (cond + uncond,
+    as bench.py pushes them) and the SD VAE decoder planned under the frozen shipped table leave osg_tune_misses() at 0."""
+    import shutil
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    table = str(tmp_path / "tune.txt")
+    shutil.copy(os.path.join(repo, "onnxstream_amd", "tune", "mi355x.txt"), table)
+    vae = _vae_dir("sd_vae")
+    code = ("import sys, ctypes, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_fullsize as t; from onnxstream_amd import build as b; "
+            "from onnxstream_amd.bindings import Model; from onnxstream_amd.synth import sd_unet, sd_vae; "
+            "a, c = sd_unet.unet_inputs(sd_unet.SD15, 42), sd_unet.unet_inputs(sd_unet.SD15, 43); "
+            "t._run(b.LIB_HOST, sys.argv[1], [a, c], runs=1, options=(('hip_autotune', 1),)); "
+            "m = Model(b.LIB_HOST, 0, 'ram+nocache'); m.read_file(sys.argv[2] + 'model.txt'); m._set_option('hip_autotune', 1); "
+            "[m.add_tensor(k, v) for k, v in sd_vae.vae_inputs(sd_vae.SD_VAE).items()]; m.set_use_fp16_arithmetic(True); m.set_fuse_ops_in_attention(True); m.run(); m.close(); "
+            "n = ctypes.CDLL(b.LIB_GPU).osg_tune_misses(); print('tune table misses:', n); sys.exit(3 if n else 0)" % (repo, os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code, sd15_dir, vae], env=dict(os.environ, OSG_TUNE_CACHE=table, OSG_TUNE_FROZEN="1", OSG_TUNE_LOG_MISSES="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, "the shipped tune table does not hold every shape of the SD 1.5 UNet + VAE plan (or the run failed): see the [tune] miss lines above"
+
+
+@pytest.fixture(scope="module")
+def sd15_w8_dir():
+    d = os.path.join(os.environ.get("OSA_SYNTH_DIR", "/tmp/onnxstream_amd_synth"), "sd15_w8") + "/"
+    if not os.path.exists(d + ".complete"):
+        os.makedirs(d, exist_ok=True)
+        sd_unet.build_unet(DirSink(d), sd_unet.SD15, quant_weights=True)
+        open(d + ".complete", "w").write("ok")
+    return d
+
+
+@pytest.mark.parametrize("resident", [0, 1])
 def test_sd15_unet_w8a16_reference_parity_full_size(sd15_w8_dir, resident):
     """BASELINE config 3's UNet half at full size: uint8 weights with per-tensor (scale, zero point) in model.txt, fp16 activations.  The reference
     dequantises at load (get_tensor_data, src/onnxstream.cpp:2887-2891, dequantize :3353) -- so does the default plan; hip_w8_resident keeps the CODES in

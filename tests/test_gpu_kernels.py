@@ -263,13 +263,13 @@ def test_conv3x3_halo_kernel(gpu, N, H, Cin, Cout, bn, splits, monkeypatch):
 
 
 @pytest.mark.timeout(180, method="thread")   # (a protocol error would spin on the device: bound it)
-@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("mode", ["1", "3"])
 @pytest.mark.parametrize("M,N,K,splits,cfg,batch", [(512, 1280, 5120, 4, 2, 1), (128, 1280, 1280, 4, 2, 1), (2048, 320, 1280, 2, 1, 1), (300, 100, 2048, 3, 1, 1),
                                                     (64, 640, 10240, 4, 2, 1), (77, 320, 2048, 3, 3, 2), (16384, 320, 1280, 2, 2, 1), (512, 1280, 5120, 8, 2, 1)])
 def test_splitk_fold_in_the_kernel_equals_the_reduce_launch(gpu, M, N, K, splits, cfg, batch, mode, monkeypatch):
     """Round 5: split-K finished by the LAST k-slice workgroup to arrive at each tile (osg_gemm_common.h splitk_fold_acc: the others publish their accumulators in
-    lane layout, the last one adds the slices in slice order and runs the fused epilogue) gives the bits of the separate reduce launch -- OSG_SPLITK_FOLD = 1: the
-    slices of a tile on one XCD, slabs and counters in its L2; 2: through memory -- on every tile the fold takes, 2 .. 4 slices, ragged M / N, bias + residual, the
+    lane layout, the last one adds the slices in slice order and runs the fused epilogue) gives the bits of the separate reduce launch -- OSG_SPLITK_FOLD = 1: slabs
+    through memory (what a pass runs); 3: the slices of a tile on one XCD, slabs in its L2 (holds for isolated launches only) -- on every tile the fold takes, 2 .. 4 slices, ragged M / N, bias + residual, the
     batched form, and again on the next launches (the tile words are left zeroed); one case has more workgroups than the GPU holds at once (nobody waits for a
     workgroup that has not arrived); 8 slices: the launch falls back to the reduce launch."""
     monkeypatch.setenv("OSG_GEMM_SPLITS", str(splits))
@@ -291,7 +291,7 @@ def test_splitk_fold_in_the_kernel_equals_the_reduce_launch(gpu, M, N, K, splits
 @pytest.mark.timeout(180, method="thread")
 @pytest.mark.parametrize("N,H,Cin,Cout,bn,splits", [(1, 64, 128, 160, 160, 2), (2, 32, 192, 128, 128, 3), (2, 16, 1280, 320, 80, 4), (1, 8, 2560, 1280, 80, 4),
                                                     (3, 8, 192, 128, 128, 3), (2, 16, 1280, 320, 80, 10)])
-@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("mode", ["1", "3"])
 def test_conv3x3_splitk_fold_in_the_kernel_equals_the_reduce_launch(gpu, N, H, Cin, Cout, bn, splits, mode, monkeypatch):
     monkeypatch.setenv("OSG_CONV3X3_BN", str(bn))
     monkeypatch.setenv("OSG_CONV3X3_SPLITS", str(splits))
@@ -413,7 +413,7 @@ def test_group_norm_statistics_from_the_producing_convolution(gpu, N, H, W, Cin,
         # the scale of the sums of squares follows the group's size (osg_gemm_common.h stat_q_shift): 2^(36 - ceil(log2(elements))) clamped to [2^10, 2^20]
         qs = lambda elems: 2.0 ** min(20, max(10, 36 - int(np.ceil(np.log2(elems)))))
         q0, q1 = qs(H * W * (Cout // G)), qs(H * W * (Cw // Gw))
-        assert (tab0 >= 0).all() and (tab1[..., 1] >= 0).all()
+        assert (tab0[..., 1] >= 0).all() and (tab1[..., 1] >= 0).all()          # (a wrapped int64 sum of squares shows up negative)
         assert np.allclose(tab0[..., 0] / 2.0 ** 20, yg.sum((1, 3)), rtol=1e-5, atol=2e-2 * max(sc, 1))
         assert np.allclose(tab0[..., 1] / q0, (yg * yg).sum((1, 3)), rtol=1e-4 if sc < 1 else 1e-5, atol=2.0 * sc * sc)
         # the slot's share of the concatenated tensor's groups (the other columns are not this launch's business)

@@ -68,7 +68,7 @@ def test_hip_backend_on_the_real_yolov8n_graph(fusion):
     """f16 arithmetic on the device (the fp32 weights are rounded to f16 at load exactly as the reference's get_tensor_data does under
     m_use_fp16_arithmetic, src/onnxstream.cpp:2885-2909).  Output rows 0-3 are box coordinates in pixels (max 639), rows 4-83 class
     scores in [0,1]; both must be on the reference's fp16 output (<= 1e-3 of the row group's max) or as close to the fp32 output as the
-    reference's own fp16 path (1.5 x drift + 1e-3).  Full [1,84,8400] output against the oracle run on the spot where it travelled; the
+    reference's own fp16 path (the rule of tests/parity.py; the class scores are a named exception at 1.18 x drift).  Full [1,84,8400] output against the oracle run on the spot where it travelled; the
     committed subsample otherwise."""
     if not have_model:
         pytest.skip("oracle/_ref/yolov8n_fp32 not present (built by `make -C oracle ref` where /root/reference exists)")
@@ -96,4 +96,4 @@ def test_hip_backend_on_the_real_yolov8n_graph(fusion):
         g, a, c = got[:, sl], r16[:, sl], r32[:, sl]
         mx = float(np.abs(c).max())
         err16, err32, noise = float(np.abs(g - a).max()) / mx, float(np.abs(g - c).max()) / mx, float(np.abs(a - c).max()) / mx
-        parity.check(f"yolov8n fusion {fusion} ({n_launch} launches) {name}", err16, err32, noise)
+        parity.check(f"yolov8n fusion {fusion} ({n_launch} launches) {name}", err16, err32, noise, key=f"yolov8n {name}")

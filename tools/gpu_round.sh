@@ -87,5 +87,25 @@ extend)   # extend "<tag>": SDXL, the W8A16 / 4-prompt variants run on the table
   timeout 900 python bench.py --config SDXL --steps-per-image 10 --steps 20 --warmup 2 --cpu-passes 0 --windows 2 > ${T}_bench_sdxl.json 2> ${T}_bench_sdxl.err; line ${T}_bench_sdxl.json "SDXL 1024x1024 10-step"
   timeout 600 python bench.py --prompts-per-gpu 4 --cpu-passes 0 --windows 2 > ${T}_bench_p4.json 2> ${T}_bench_p4.err; line ${T}_bench_p4.json "4 prompts per GPU"
   cp /tmp/osg_tune_$tag.txt ${T}_tune_${tag}_extended.txt; wc -l ${T}_tune_${tag}_extended.txt; unset OSG_TUNE_CACHE; ARGS=("${ARGS[@]:1}") ;;
+foldcheck)   # the in-kernel split-K fold: its kernel tests (bounded), then -- only if they pass -- the headline bench retuned with the fold among the candidates
+  timeout 240 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "splitk_fold or output_views or statistics_from" > ${T}_fold_tests.log 2>&1; rc=$?; tail -4 ${T}_fold_tests.log
+  if [ $rc -eq 0 ]; then
+    rm -f /tmp/osg_tune_fold.txt
+    OSG_SPLITK_FOLD=1 OSG_TUNE_CACHE=/tmp/osg_tune_fold.txt timeout 300 python bench.py --cpu-passes 0 --windows 3 > ${T}_retune_fold.json 2> ${T}_retune_fold.err; line ${T}_retune_fold.json "[retune fold]"
+    OSG_SPLITK_FOLD=1 OSG_TUNE_CACHE=/tmp/osg_tune_fold.txt timeout 200 python bench.py --cpu-passes 0 --windows 3 > ${T}_retune_fold_2.json 2> ${T}_retune_fold_2.err; line ${T}_retune_fold_2.json "[seeded from it: fold]"
+    cp /tmp/osg_tune_fold.txt ${T}_tune_fold.txt; wc -l ${T}_tune_fold.txt; grep -c " 1[0-9] [0-9]* [0-9]* [0-9]* [0-9.]*$\| 2[0-9] [0-9]* [0-9]* [0-9]* [0-9.]*$" ${T}_tune_fold.txt
+  else echo "fold tests failed: no retune"; fi ;;
+paritytable)   # every test that uses the triangulated rule, without -x: the table of margins (tests/parity.py prints one line per case)
+  timeout 600 python -m pytest tests/test_golden.py tests/test_fullsize.py tests/test_real_graph.py -m gpu -q -s -k "whole_nets or chains or full_size or yolov8 or streamed or w8 or measured or sd15" > ${T}_parity_table.log 2>&1
+  grep "leg (\|passed\|failed\|FAILED\|Error" ${T}_parity_table.log | cut -c1-260 ;;
+foldab)   # the headline bench retuned with the in-kernel split-K fold among the candidates, then alternating 2x against the table measured WITHOUT it (gpurun_out/r05_tune_nofold.txt)
+  rm -f /tmp/osg_tune_fold.txt
+  OSG_SPLITK_FOLD=1 OSG_TUNE_CACHE=/tmp/osg_tune_fold.txt timeout 300 python bench.py --cpu-passes 0 --windows 3 > ${T}_retune_fold.json 2> ${T}_retune_fold.err; line ${T}_retune_fold.json "[retune fold]"
+  cp /tmp/osg_tune_fold.txt ${T}_tune_fold.txt; wc -l ${T}_tune_fold.txt; echo "rows with the fold bit:"; awk '{ if (int($15 / 16) % 2 == 1) n++ } END { print n + 0 }' ${T}_tune_fold.txt
+  cp tools/tune_nofold_r05.txt /tmp/osg_tune_nofold.txt
+  for i in 1 2; do
+    OSG_SPLITK_FOLD=0 OSG_TUNE_CACHE=/tmp/osg_tune_nofold.txt timeout 200 python bench.py --cpu-passes 0 --windows 3 > ${T}_foldab_A_$i.json 2> ${T}_foldab_A_$i.err; line ${T}_foldab_A_$i.json "A [reduce launches]"
+    OSG_SPLITK_FOLD=1 OSG_TUNE_CACHE=/tmp/osg_tune_fold.txt timeout 200 python bench.py --cpu-passes 0 --windows 3 > ${T}_foldab_B_$i.json 2> ${T}_foldab_B_$i.err; line ${T}_foldab_B_$i.json "B [fold among the candidates]"
+  done ;;
 *) echo "unknown recipe $R" ;;
 esac; done
