@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -542,7 +543,7 @@ def main():
         sys.path.insert(0, os.path.join(REPO, "tools"))
         import src_hash
         tree = src_hash.src_sha1(REPO)
-        for cand in sorted((f for f in os.listdir(os.path.join(REPO, "profiles")) if f.startswith("r04_pmc") and f.endswith(".json")), reverse=True):
+        for cand in sorted((f for f in os.listdir(os.path.join(REPO, "profiles")) if re.match(r"r\d\d_pmc.*\.json$", f)), reverse=True):   # (newest round first; the src_sha1 test below picks the file of THIS tree)
             try:
                 hdr = json.load(open(os.path.join(REPO, "profiles", cand)))
             except Exception:

@@ -107,5 +107,12 @@ foldab)   # the headline bench retuned with the in-kernel split-K fold among the
     OSG_SPLITK_FOLD=0 OSG_TUNE_CACHE=/tmp/osg_tune_nofold.txt timeout 200 python bench.py --cpu-passes 0 --windows 3 > ${T}_foldab_A_$i.json 2> ${T}_foldab_A_$i.err; line ${T}_foldab_A_$i.json "A [reduce launches]"
     OSG_SPLITK_FOLD=1 OSG_TUNE_CACHE=/tmp/osg_tune_fold.txt timeout 200 python bench.py --cpu-passes 0 --windows 3 > ${T}_foldab_B_$i.json 2> ${T}_foldab_B_$i.err; line ${T}_foldab_B_$i.json "B [fold among the candidates]"
   done ;;
+gnprof)   # GroupNorm per instantiation: the in-graph timeline with the statistics coming from the producing convolutions (hip_gn_stats 1) -- the default plan's is `prof`
+  export OSG_TUNE_CACHE=/tmp/osg_tune_cache_gn.txt; cp onnxstream_amd/tune/mi355x.txt $OSG_TUNE_CACHE
+  rm -rf /tmp/prof_gn
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_gn -o gn -- python bench.py --gn-stats 1 --steps 20 --warmup 2 --cpu-passes 0 --profile-reps 1 --windows 0 > ${T}_rocprof_gn.log 2>&1
+  echo "rocprofv3 (gn stats on) exit $?"
+  for f in $(find /tmp/prof_gn -name "*kernel_stats.csv"); do cp $f ${T}_gn_stats_on_kernel_stats.csv; done
+  python tools/graph_trace.py $(find /tmp/prof_gn -name "*kernel_trace.csv" | head -1) > ${T}_gn_stats_on_graph_timeline.txt 2>&1; head -26 ${T}_gn_stats_on_graph_timeline.txt; unset OSG_TUNE_CACHE ;;
 *) echo "unknown recipe $R" ;;
 esac; done
