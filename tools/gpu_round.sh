@@ -114,5 +114,15 @@ gnprof)   # GroupNorm per instantiation: the in-graph timeline with the statisti
   echo "rocprofv3 (gn stats on) exit $?"
   for f in $(find /tmp/prof_gn -name "*kernel_stats.csv"); do cp $f ${T}_gn_stats_on_kernel_stats.csv; done
   python tools/graph_trace.py $(find /tmp/prof_gn -name "*kernel_trace.csv" | head -1) > ${T}_gn_stats_on_graph_timeline.txt 2>&1; head -26 ${T}_gn_stats_on_graph_timeline.txt; unset OSG_TUNE_CACHE ;;
+r4vs5)   # the round-4 kernels' equivalent (attention v1, reduce launches only, the table tuned without the fold) against this tree's default, alternating 2x on one box; then SDXL with attention v1 / v2
+  cp tools/tune_nofold_r05.txt /tmp/osg_tune_nofold.txt; cp onnxstream_amd/tune/mi355x.txt /tmp/osg_tune_fold.txt
+  for i in 1 2; do
+    OSG_ATTN_V1=1 OSG_SPLITK_FOLD=0 OSG_TUNE_CACHE=/tmp/osg_tune_nofold.txt timeout 200 python bench.py --cpu-passes 0 --windows 3 > ${T}_r4vs5_A_$i.json 2> ${T}_r4vs5_A_$i.err; line ${T}_r4vs5_A_$i.json "A [attention v1, reduce launches]"
+    OSG_TUNE_CACHE=/tmp/osg_tune_fold.txt timeout 200 python bench.py --cpu-passes 0 --windows 3 > ${T}_r4vs5_B_$i.json 2> ${T}_r4vs5_B_$i.err; line ${T}_r4vs5_B_$i.json "B [round 5 default]"
+  done
+  rm -f /tmp/osg_tune_sdxl.txt; cp onnxstream_amd/tune/mi355x.txt /tmp/osg_tune_sdxl.txt
+  for v in 0 1 0 1; do
+    OSG_ATTN_V1=$v OSG_TUNE_CACHE=/tmp/osg_tune_sdxl.txt timeout 400 python bench.py --config SDXL --steps-per-image 10 --steps 20 --warmup 2 --cpu-passes 0 --windows 2 > ${T}_sdxl_attn_v1_$v.json 2> ${T}_sdxl_attn_v1_$v.err; line ${T}_sdxl_attn_v1_$v.json "SDXL [OSG_ATTN_V1=$v]"
+  done ;;
 *) echo "unknown recipe $R" ;;
 esac; done
