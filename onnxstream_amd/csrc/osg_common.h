@@ -36,12 +36,7 @@ struct osg_ctx {
     size_t ws2_bytes = 0;
     static constexpr long kTickets = 1 << 16;
     int* tickets = nullptr;             // split-K arrival counters (zeroed once; the last arriver of a tile resets its counter)
-    // XCD-local split-K (osg_gemm_common.h splitk_finish, OSG_SPLITK_TICKET=2): workgroup i of a launch runs on XCD  xcc_of[i % 8]  -- calibrated by a probe
-    // launch in osg_init (xcd_rr = the probe saw exactly that, 8 distinct XCDs); every block of such a launch re-checks it and raises *xcd_err (pinned,
-    // host-mapped; read back by osg_sync / osg_download) if the dispatcher ever does otherwise
-    bool xcd_rr = false;
     bool xcd_ids8 = false;              // the device has exactly 8 XCDs whose XCC_ID are 0..7 (StatSink tables: one copy per XCD, L2-scope atomics)
-    unsigned xcc_map = 0;               // 4 bits per residue of the workgroup index mod 8
     int* xcd_err = nullptr;             // host pointer
     int* xcd_err_dev = nullptr;         // the same word as the device sees it
     bool capturing = false;

@@ -100,12 +100,7 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
         L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
     int m_tile, n_tile, zs;
-    if (p.xcd_local) {
-        int t;
-        if (!xcd_local_map(p, &t, &zs)) return;
-        if (p.n_major) { n_tile = t / p.mt; m_tile = t - n_tile * p.mt; }
-        else { m_tile = t / p.nt; n_tile = t - m_tile * p.nt; }
-    } else if (p.n_major) {
+    if (p.n_major) {
         n_tile = L / (p.splits * p.mt); L -= n_tile * p.splits * p.mt;
         zs = L / p.mt; m_tile = L - zs * p.mt;
     } else {
@@ -333,18 +328,16 @@ int launch3(osg_ctx* ctx, GemmParams& p) {
     }
     p.mt = (p.M + 127) / 128;
     p.nt = (p.N + BN - 1) / BN;
-    p.tiles_total = p.mt * p.nt;
     if (MODE != 0) p.fold_acc = 0;
-    if (!p.fold_acc) p.xcd_local = 0;
     p.no_epre = osg_mm::no_epi_prefetch();
-    p.kdbg = kdbg_buffer(ctx, (long)(p.xcd_local ? (p.tiles_total + 7) / 8 * 8 * p.splits : p.tiles_total * p.splits));
+    p.kdbg = kdbg_buffer(ctx, (long)p.mt * p.nt * p.splits);
     const osg_mm::StatSink sinks_in[2] = {p.sink[0], p.sink[1]};
     if (p.sink[0].table || p.sink[1].table) {   // (see launch_v2 in osg_gemm.hip)
         const bool ok = !ctx->tuning && p.splits == 1 && MODE == 0 && (p.N & 3) == 0 && ((p.ldc | p.ldc2) & 3) == 0 && p.sink_hw > 0 && p.sink_hw % 128 == 0 && p.M % p.sink_hw == 0;
         if (ok) { ctx->sink_fused = true; p.sink_imgs = p.M / p.sink_hw; p.sink_per_xcd = ctx->xcd_ids8 ? 1 : 0; }
         else p.sink[0].table = p.sink[1].table = nullptr;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.xcd_local ? (p.tiles_total + 7) / 8 * 8 * p.splits : p.tiles_total * p.splits)), dim3(256 + 64 * NLW), smem, ctx->compute, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.mt * p.nt * p.splits)), dim3(256 + 64 * NLW), smem, ctx->compute, p);
     p.sink[0] = sinks_in[0]; p.sink[1] = sinks_in[1];
     OSG_LAUNCH_CHECK(ctx);
     return 0;
@@ -352,17 +345,6 @@ int launch3(osg_ctx* ctx, GemmParams& p) {
 
 template <int W_>
 int launch3_bn(osg_ctx* ctx, GemmParams& p, int bn, int nl) {
-    if (W_ == 64 && bn == 80) {   // experiments (tools/gemm_probe.py): 1 = loads + barriers only, 2 = no global loads (compute on stale LDS)
-        const char* e = getenv("OSG_CONV3X3_DBG");
-        const int dbg = e ? atoi(e) : 0;
-        if (dbg == 1) return launch3<64, 80, 4, 1, 1>(ctx, p);
-        if (dbg == 2) return launch3<64, 80, 4, 1, 2>(ctx, p);
-        if (dbg == 3) return launch3<64, 80, 4, 1, 3>(ctx, p);
-        if (dbg == 4) return launch3<64, 80, 4, 1, 4>(ctx, p);
-        if (dbg == 5) return launch3<64, 80, 4, 1, 5>(ctx, p);
-        if (dbg == 6) return launch3<64, 80, 4, 1, 6>(ctx, p);
-        if (dbg == 7) return launch3<64, 80, 4, 1, 7>(ctx, p);
-    }
     if (nl == 8) {   // 8 loader waves (768 threads): a measured candidate only (osg_tune.h) -- the same arithmetic, twice the DMA issue slots
         // (where the wider stages leave the LDS ring too short -- W = 8 with BN = 160 -- the 4-loader kernel runs instead)
         if (bn == 80) { if constexpr (Geo<W_, 80, 8>::OK) return launch3<W_, 80, 4, 1, 0, 8>(ctx, p); }
@@ -446,7 +428,6 @@ int osg_conv3x3_launch(osg_ctx* ctx, GemmParams p, int bn, int s, int nl, int fo
     p.k_per_split = sl * 64;
     p.tickets = nullptr;
     p.fold_acc = 0;
-    p.xcd_local = 0;
     if (p.splits > 1) {
         size_t need = (size_t)p.splits * p.M * p.N * sizeof(float);
         if (fold) need = std::max(need, osg_mm::splitk_fold_route(ctx, p, (long)((p.M + 127) / 128) * ((p.N + bn - 1) / bn), 128, bn));

@@ -95,7 +95,7 @@ struct Roctx {
 Roctx& roctx() { static Roctx r; return r; }
 }  // namespace
 
-// ---- XCD-local split-K support (osg_common.h: xcd_rr / xcc_map / xcd_err) -----------------------------------------------------------------------------
+// ---- which XCDs does this device have (osg_common.h: xcd_ids8), and the host-mapped error flag of the in-kernel split-K fold (xcd_err) ------------------------
 namespace {
 __global__ void xcc_probe_kernel(int* out) {
     unsigned v;
@@ -103,8 +103,8 @@ __global__ void xcc_probe_kernel(int* out) {
     if (threadIdx.x == 0) out[blockIdx.x] = (int)(v & 15u);
 }
 
-// does workgroup i of a launch land on XCD (i mod 8)?  (the dispatcher's documented round robin; true on an MI355X in SPX mode.)  Anything else --
-// another partition mode, fewer XCDs, a failed probe -- leaves xcd_rr false and the XCD-local route unused.
+// does an isolated launch spread its workgroups round-robin over exactly 8 XCDs whose XCC_ID are 0..7?  (true on an MI355X in SPX mode: the GroupNorm statistics
+// tables then keep one copy per XCD, osg_gemm_common.h StatSink.)  Anything else -- another partition mode, fewer XCDs, a failed probe -- leaves xcd_ids8 false.
 void calibrate_xcd(osg_ctx* c) {
     constexpr int kBlocks = 256;
     int* d = nullptr;
@@ -129,9 +129,6 @@ void calibrate_xcd(osg_ctx* c) {
         fprintf(stderr, "  -> round robin over 8 XCDs: %s\n", ok ? "yes" : "no");
     }
     if (!ok) return;
-    c->xcc_map = 0;
-    for (int i = 0; i < 8; i++) c->xcc_map |= (unsigned)(h[i] & 15) << (4 * i);
-    c->xcd_rr = true;
     c->xcd_ids8 = true;                 // (8 distinct XCC_IDs ...
     for (int i = 0; i < 8; i++) c->xcd_ids8 = c->xcd_ids8 && h[i] >= 0 && h[i] < 8;   // ... all of them in 0..7: the per-XCD statistics tables index by XCC_ID)
 }
@@ -140,9 +137,8 @@ int xcd_check(osg_ctx* c) {
     if (c->xcd_err && *(volatile int*)c->xcd_err) {
         const int what = *(volatile int*)c->xcd_err;
         *c->xcd_err = 0;
-        c->xcd_rr = false;   // (later plans exchange the slabs through memory)
         if (what == 2) OSG_FAIL(c, "split-K fold: a k-slice workgroup did not publish its partial sums within 2 ms (results of this pass are invalid); set OSG_SPLITK_FOLD=0");
-        OSG_FAIL(c, "XCD-local split-K: a workgroup ran on another XCD than workgroup-index mod 8 says (results of this pass are invalid); set OSG_SPLITK_FOLD=2");
+        OSG_FAIL(c, "split-K fold: the device raised its error flag (results of this pass are invalid); set OSG_SPLITK_FOLD=0");
     }
     return 0;
 }

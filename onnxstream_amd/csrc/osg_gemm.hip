@@ -268,14 +268,7 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
     }
     const int per_batch = p.mt * p.nt * p.splits;
     int zb, m_tile, n_tile, zs;
-    if (p.xcd_local) {
-        int t;
-        if (!xcd_local_map(p, &t, &zs)) return;
-        zb = t / (p.mt * p.nt);
-        const int rem = t - zb * p.mt * p.nt;
-        if (p.n_major) { n_tile = rem / p.mt; m_tile = rem - n_tile * p.mt; }
-        else { m_tile = rem / p.nt; n_tile = rem - m_tile * p.nt; }
-    } else {
+    {
         zb = L / per_batch;
         int rem = L - zb * per_batch;
         if (p.n_major) {
@@ -505,10 +498,8 @@ int launch_v2(osg_ctx* ctx, GemmParams& p, int batch) {
     }
     p.mt = (p.M + BM - 1) / BM;
     p.nt = (p.N + BN - 1) / BN;
-    p.tiles_total = p.mt * p.nt * batch;
-    if (KS == 2 || SPEC || LN != 0 || MODE != 0) { p.fold_acc = 0; p.xcd_local = 0; }   // (the in-kernel split-K fold is the plain kernel's: a 256-thread protocol)
-    if (!p.fold_acc) p.xcd_local = 0;
-    dim3 grid((unsigned)(p.xcd_local ? (p.tiles_total + 7) / 8 * 8 * p.splits : p.tiles_total * p.splits));
+    if (KS == 2 || SPEC || LN != 0 || MODE != 0) p.fold_acc = 0;   // (the in-kernel split-K fold is the plain kernel's: a 256-thread protocol)
+    dim3 grid((unsigned)(p.mt * p.nt * batch * p.splits));
     p.no_epre = osg_mm::no_epi_prefetch();
     p.kdbg = kdbg_buffer(ctx, grid.x);
     const osg_mm::StatSink sinks_in[2] = {p.sink[0], p.sink[1]};     // (p is the caller's: a reduce launch that follows still wants them)
@@ -522,136 +513,6 @@ int launch_v2(osg_ctx* ctx, GemmParams& p, int batch) {
     }
     hipLaunchKernelGGL(kern, grid, dim3((SPEC || KS == 2) ? 512 : 256), smem, ctx->compute, p);
     p.sink[0] = sinks_in[0]; p.sink[1] = sinks_in[1];
-    OSG_LAUNCH_CHECK(ctx);
-    return 0;
-}
-
-// =====================================================================================================================
-// v3 (experiment, plain GEMM only): producer/consumer wave specialization with REGISTER-staged loads.  4 loader waves fetch
-// the 128x64 A and B tiles with ordinary buffer_load_dwordx4 (3 tiles deep in VGPRs), then ds_write_b128 them into a 2-stage
-// swizzled LDS image; 4 math waves do ds_read + MFMA only.  Question it answers: is the ~23 B/clk/CU ceiling of the
-// `buffer_load ... lds` path a property of the LDS-DMA or of the CU's vector memory path?
-template <int RT>
-__global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
-    constexpr int BM = 128, BN = 128, ROWB = 128;
-    constexpr int A_BYTES = BM * ROWB, STAGE = 2 * A_BYTES;
-    constexpr int LD = 8;                        // 16-byte loads per loader lane per tile (4 for A + 4 for B)
-    constexpr int TM = 4, TN = 4;
-    extern __shared__ __attribute__((aligned(16))) char smem4[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wave8 >= 4;
-    const int wave = wave8 & 3;
-    int L;
-    {
-        const int total = gridDim.x, bid = blockIdx.x, x = bid & 7, i = bid >> 3, q = total >> 3, r = total & 7;
-        L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-    }
-    const int m_tile = L / p.nt, n_tile = L - m_tile * p.nt;
-    const int m0 = m_tile * BM, n0 = n_tile * BN;
-    const int nkt = p.K >> 6;
-    if (loader) {
-        __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
-        __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)p.Bt, 0, p.b_bytes, 0x00020000);
-        const int rsub = lane >> 3, ch = lane & 7;
-        unsigned voff[LD];
-        int lds_off[LD];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int row = (j * 4 + wave) * 8 + rsub;
-            const int m = m0 + row, n = n0 + row;
-            voff[j] = m < p.M ? (unsigned)(((long)m * p.lda + ch * 8) * 2) : 0x80000000u;
-            voff[4 + j] = n < p.N ? (unsigned)(((long)n * p.K + ch * 8) * 2) : 0x80000000u;
-            lds_off[j] = row * ROWB + ((ch ^ (row & 7)) << 4);
-            lds_off[4 + j] = A_BYTES + row * ROWB + ((ch ^ (row & 7)) << 4);
-        }
-        typedef int v4i __attribute__((ext_vector_type(4)));
-        v4i regs[RT][LD];
-        auto issue = [&](v4i (&r)[LD], int kt) {
-            const unsigned kill = kt < nkt ? 0u : 0x80000000u;
-#pragma unroll
-            for (int j = 0; j < LD; j++)
-                r[j] = __builtin_amdgcn_raw_buffer_load_b128(j < 4 ? rsA : rsB, voff[j] | kill, kt * 128, 0);
-        };
-        auto commit = [&](v4i (&r)[LD], int stage) {
-#pragma unroll
-            for (int j = 0; j < LD; j++) *reinterpret_cast<v4i*>(smem4 + stage * STAGE + lds_off[j]) = r[j];
-        };
-        static_assert(RT == 3, "register ring depth");
-        issue(regs[0], 0);
-        issue(regs[1], 1);
-        issue(regs[2], 2);
-        // tile 0 -> stage 0 before the first barrier
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LD) : "memory");
-        commit(regs[0], 0);
-        issue(regs[0], 3);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                    // barrier #0: tile 0 visible
-        for (int kt = 0; kt < nkt; kt += 3) {            // unrolled by the ring depth so register sets are static
-            // iteration for tile kt (math computes kt): stage tile kt+1
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LD) : "memory");
-            commit(regs[1], (kt + 1) & 1);
-            issue(regs[1], kt + 4);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (kt + 1 >= nkt) break;
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LD) : "memory");
-            commit(regs[2], (kt + 2) & 1);
-            issue(regs[2], kt + 5);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (kt + 2 >= nkt) break;
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LD) : "memory");
-            commit(regs[0], (kt + 3) & 1);
-            issue(regs[0], kt + 6);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-    }
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15;
-    const int fsw = (((lane >> 4) ^ (frow & 7)) << 4);
-    const int a_rd = (wm0 + frow) * ROWB + fsw;
-    const int b_rd = A_BYTES + (wn0 + frow) * ROWB + fsw;
-    __builtin_amdgcn_s_barrier();                        // barrier #0
-    for (int kt = 0; kt < nkt; kt++) {
-        const char* St = smem4 + (kt & 1) * STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            f16x8 a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; i++) a[i] = *reinterpret_cast<const f16x8*>(St + ((a_rd + i * 16 * ROWB) ^ (ks << 6)));
-#pragma unroll
-            for (int j = 0; j < TN; j++) b[j] = *reinterpret_cast<const f16x8*>(St + ((b_rd + j * 16 * ROWB) ^ (ks << 6)));
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_s_barrier();                    // tile kt consumed; tile kt+1 staged
-    }
-    gemm_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0, lane, 0, 0);
-}
-
-int launch_v3(osg_ctx* ctx, GemmParams& p) {
-    constexpr size_t smem = 2 * 2 * 128 * 128;
-    auto kern = gemm3_kernel<3>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
-    }
-    p.mt = (p.M + 127) / 128;
-    p.nt = (p.N + 127) / 128;
-    p.splits = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.mt * p.nt)), dim3(512), smem, ctx->compute, p);
     OSG_LAUNCH_CHECK(ctx);
     return 0;
 }
@@ -892,7 +753,6 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
     p.k_per_split = kt_per * 64;
     p.tickets = nullptr;
     p.fold_acc = 0;
-    p.xcd_local = 0;
     if (p.splits > 1) {
         size_t need = (size_t)batch * p.splits * p.M * p.N * sizeof(float);
         if (ch.fold && ch.ks == 1 && ch.cfg != 0) {
@@ -953,13 +813,7 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
             return rc;
         }
     }
-    static const int dbg = getenv("OSG_GEMM_DBG") ? atoi(getenv("OSG_GEMM_DBG")) : 0;   // experiments (tools/gemm_probe.py)
-    if (dbg == 7) return launch_v2<128, 128, 4, CONV, 0, 1>(ctx, p, batch) || (p.splits > 1 ? launch_splitk_reduce(ctx, p, batch) : 0);   // specialized waves
-    if (dbg == 6 && !CONV && batch == 1) return launch_v3(ctx, p);          // register-staged specialized loaders (experiment)
-    if (dbg == 1) rc = launch_v2<128, 128, 4, CONV, 1>(ctx, p, batch);        // loads only
-    else if (dbg == 2) rc = launch_v2<128, 128, 3, CONV>(ctx, p, batch);
-    else if (dbg == 5) rc = launch_v2<128, 128, 2, CONV>(ctx, p, batch);
-    else if (ch.cfg == 0) rc = ch.nst == 4 ? launch_v2<128, 128, 4, CONV>(ctx, p, batch) : launch_v2<128, 128, 2, CONV>(ctx, p, batch);
+    if (ch.cfg == 0) rc = ch.nst == 4 ? launch_v2<128, 128, 4, CONV>(ctx, p, batch) : launch_v2<128, 128, 2, CONV>(ctx, p, batch);
     else if (ch.cfg == 1) rc = ch.nst == 6 ? launch_v2<128, 64, 6, CONV>(ctx, p, batch) : ch.nst == 4 ? launch_v2<128, 64, 4, CONV>(ctx, p, batch) : launch_v2<128, 64, 2, CONV>(ctx, p, batch);
     else if (ch.cfg == 3) rc = ch.nst == 6 ? launch_v2<64, 128, 6, CONV>(ctx, p, batch) : ch.nst == 4 ? launch_v2<64, 128, 4, CONV>(ctx, p, batch) : launch_v2<64, 128, 2, CONV>(ctx, p, batch);
     else rc = ch.nst == 8 ? launch_v2<64, 64, 8, CONV>(ctx, p, batch) : ch.nst == 6 ? launch_v2<64, 64, 6, CONV>(ctx, p, batch) : ch.nst == 4 ? launch_v2<64, 64, 4, CONV>(ctx, p, batch) : launch_v2<64, 64, 2, CONV>(ctx, p, batch);
@@ -972,7 +826,7 @@ template <bool CONV>
 int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced) {
     const bool allow_split = p.act != OSG_ACT_GEGLU && !p.ln_c1 && !p.rs_out;   // GEGLU pairing / folded LayerNorm / row statistics live in the tile epilogue
     V2Choice ch;
-    const bool env_forced = getenv("OSG_GEMM_CFG") || getenv("OSG_GEMM_SPLITS") || getenv("OSG_GEMM_NST") || getenv("OSG_GEMM_DBG") || getenv("OSG_GEMM_KS") || getenv("OSG_GEMM_FOLD");
+    const bool env_forced = getenv("OSG_GEMM_CFG") || getenv("OSG_GEMM_SPLITS") || getenv("OSG_GEMM_NST") || getenv("OSG_GEMM_KS") || getenv("OSG_GEMM_FOLD");
     if (forced) {
         ch = *forced;
     } else if (ctx->autotune && !env_forced) {
@@ -1363,7 +1217,7 @@ static int conv2d_route(osg_ctx* ctx, GemmParams& p, int N, int Cin, int Cout, i
     }
     if (KH == 3) {
         const bool env_forced = getenv("OSG_CONV3X3_BN") || getenv("OSG_CONV3X3_SPLITS") || getenv("OSG_CONV3X3_DBG") || getenv("OSG_GEMM_CFG") ||
-                                getenv("OSG_GEMM_SPLITS") || getenv("OSG_GEMM_NST") || getenv("OSG_GEMM_DBG");
+                                getenv("OSG_GEMM_SPLITS") || getenv("OSG_GEMM_NST");
         if (!ctx->autotune || env_forced) {
             int rc3 = osg_conv3x3_run(ctx, p);
             if (rc3 >= 0) return rc3;

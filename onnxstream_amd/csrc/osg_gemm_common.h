@@ -60,12 +60,7 @@ struct GemmParams {
     long a_bytes_l;              // conv: byte size of the whole NHWC input (host side, before the 2 GiB check)
     int mt, nt, n_major;         // tile grid and the order tiles are walked inside an XCD's contiguous chunk
     int* tickets;                // split-K arrival / publication counters (two per output tile, splitk_fold_acc), zero between launches
-    // XCD-local split-K (splitk_fold_acc): the k-slices of a tile are consecutive workgroups of ONE XCD (xcd_local_map), so the slabs are exchanged through that XCD's
-    // L2 -- plain stores, L1-bypassing loads, no trip to memory.  xcc_map / xcd_err: see osg_ctx; tiles_total = batch * mt * nt.
-    int xcd_local;
-    unsigned xcc_map;
-    int* xcd_err;
-    int tiles_total;
+    int* xcd_err;                // host-mapped flag the bounded wait of splitk_fold_acc raises (osg_ctx; checked by osg_sync / osg_download)
     float w_scale;               // W8 kernels (osg_gemm_w8.hip): Bt holds uint8 codes, w = (q - w_zp) * w_scale
     int w_zp;
     const float* ln_c1;          // osg_gemm_ln: LayerNorm over K folded into this GEMM -- c1[n] = sum_k W'[n][k]; bias holds c2 (f32)
@@ -531,14 +526,13 @@ __device__ __forceinline__ void gemm_epilogue_geglu(const GemmParams& p, f32x4 (
 // the last arriver waits for those publications (their authors HAVE arrived, so they are running and need nobody: the wait is bounded by their store drain),
 // adds the slices in slice order with its own accumulators at its own position -- the same sum whoever comes last: bit-reproducible -- and runs the unchanged
 // FUSED epilogue (bias, per-image bias, residual, activation, second destination) on the result.  Against the reduce launch: no launch boundary (~5 us in the
-// captured pass), half the slab traffic at two slices, and no f32 row-major slab written and re-read through 64-byte pieces.  XCD-local form (p.xcd_local): the
-// slices of a tile run on one XCD (xcd_local_map) and the slabs / counters live in that XCD's L2 (plain stores, sc0 loads); otherwise
-// write-through stores and sc1 loads through memory; the counters are agent-scope atomics in both forms.  Returns true in the workgroup that holds the complete sum.
+// captured pass), half the slab traffic at two slices, and no f32 row-major slab written and re-read through 64-byte pieces.  Slabs travel through memory
+// (write-through stores, sc1 loads: the slices of a tile run on whatever XCDs the dispatcher picks), the counters are agent-scope atomics.  Returns true in the
+// workgroup that holds the complete sum.
 // flag: one int of LDS; call with all 256 threads of the 4 math waves (tid 0..255) after the k loop.
 template <int TM, int TN>
 __device__ __forceinline__ bool splitk_fold_acc(const GemmParams& p, f32x4 (&acc)[TM][TN], int tile_id, int zs, int* flag, int tid) {
     constexpr int NV = TM * TN;
-    const bool local = p.xcd_local != 0;
     f32x4* __restrict__ slab = reinterpret_cast<f32x4*>(p.partial) + ((long)tile_id * p.splits) * (NV * 256) + tid;
     // the two counters of a tile are agent-scope words in BOTH forms (as the counters of round 2's XCD-local fold were): an L2-scope load in the wait loop below
     // may be served by the CU's L1 for ever -- the first version of this function hung there
@@ -553,8 +547,7 @@ __device__ __forceinline__ bool splitk_fold_acc(const GemmParams& p, f32x4 (&acc
         for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int j = 0; j < TN; j++) {
-                if (local) dst[(i * TN + j) * 256] = acc[i][j];       // (the L1 is write-through: in the XCD's L2 once vmcnt says so)
-                else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + (i * TN + j) * 256), "v"(acc[i][j]) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + (i * TN + j) * 256), "v"(acc[i][j]) : "memory");   // write-through: past the XCD's L2
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -593,8 +586,7 @@ __device__ __forceinline__ bool splitk_fold_acc(const GemmParams& p, f32x4 (&acc
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) {
-                    if (local) asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(part[i][j]) : "v"(src + (i * TN + j) * 256) : "memory");
-                    else asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[i][j]) : "v"(src + (i * TN + j) * 256) : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[i][j]) : "v"(src + (i * TN + j) * 256) : "memory");
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -613,34 +605,17 @@ __device__ __forceinline__ bool splitk_fold_acc(const GemmParams& p, f32x4 (&acc
     return true;
 }
 
-// XCD-local launches: flat workgroup index -> (tile, k-slice) with the slices of a tile on consecutive workgroups of ONE XCD.  The grid is
-// 8 * ceil(tiles / 8) * splits workgroups; workgroup b runs on XCD x = b % 8 and is the (b / 8)-th of that XCD, which owns the tiles
-// x * ceil(tiles / 8) ... (slices innermost).  Returns false for the padding workgroups past the last tile.  Every workgroup also checks the dispatcher assumption the scheme
-// rests on (its own XCC_ID against the calibrated map) and raises the host-visible flag if it does not hold.
-__device__ __forceinline__ bool xcd_local_map(const GemmParams& p, int* tile, int* zs) {
-    const int b = blockIdx.x, x = b & 7, i = b >> 3;
-    if (threadIdx.x == 0) {
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        if ((xcc & 15u) != ((p.xcc_map >> (4 * x)) & 15u)) __hip_atomic_store(p.xcd_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    const int tg = i / p.splits;
-    *zs = i - tg * p.splits;
-    *tile = x * ((p.tiles_total + 7) >> 3) + tg;   // a CONTIGUOUS run of tiles per XCD: its L2 streams one slice of the operand the tile order walks
-    return *tile < p.tiles_total;
-}
-
 int launch_splitk_reduce(osg_ctx* ctx, const GemmParams& p, int batch);   // osg_gemm.hip
 // the statistics a StatSink asks for, from the stored output (rows ldc apart) -- for the launches whose epilogue does not serve sinks (osg_norm.hip)
 int launch_colstats(osg_ctx* ctx, const f16* C, long ldc, int M, int N, int rows_per_image, const StatSink* sinks);
 long long* kdbg_buffer(osg_ctx* ctx, long workgroups);   // osg_ctx.hip: NULL unless OSG_KDBG is set
 inline int no_epi_prefetch() { static const int v = getenv("OSG_NO_EPI_PREFETCH") ? 1 : 0; return v; }
-// OSG_SPLITK_FOLD (round 5; read per call): 0 = never; 1 (default) / 2 = splitk_fold_acc where it applies, slabs through memory; 3 = XCD-local slabs (isolated launches only)
+// OSG_SPLITK_FOLD (round 5; read per call): 0 = never; 1 (default) = splitk_fold_acc where it applies
 inline int splitk_fold_mode() {
     const char* e = getenv("OSG_SPLITK_FOLD");
     return e ? atoi(e) : 1;
 }
-// a launch of n_tiles output tiles x p.splits k-slices whose tiles are bm x bn: can it finish with splitk_fold_acc?  Sets tickets / fold_acc / xcd_local and returns the
+// a launch of n_tiles output tiles x p.splits k-slices whose tiles are bm x bn: can it finish with splitk_fold_acc?  Sets tickets / fold_acc and returns the
 // slab bytes the launch needs (0: no)
 inline size_t splitk_fold_route(osg_ctx* ctx, GemmParams& p, long n_tiles, int bm, int bn) {
     p.fold_acc = 0;
@@ -650,12 +625,10 @@ inline size_t splitk_fold_route(osg_ctx* ctx, GemmParams& p, long n_tiles, int b
     if (p.sink[0].table || p.sink[1].table) return 0;   // (GroupNorm statistics of a split launch come from the reduce launch)
     p.fold_acc = 1;
     p.tickets = ctx->tickets;                            // (the lower half of the counters; the upper one belongs to the GroupNorm clusters, osg_norm.hip)
-    // (the XCD-local form -- slices of a tile on one XCD, slabs through its L2 -- needs workgroup b of EVERY launch on XCD b mod 8; that holds for an isolated
-    // launch (the calibration probe, the kernel tests) but not inside a pass: the dispatcher carries on round-robin from wherever the previous kernel stopped, and
-    // the per-workgroup XCC_ID check failed the first captured pass, profiles/r05_fold_xcd_local_fails_in_the_pass.txt.  OSG_SPLITK_FOLD=3 keeps it for probes.)
-    p.xcd_local = mode == 3 && ctx->xcd_rr ? 1 : 0;
-    p.xcd_err = ctx->xcd_err_dev;       // (both forms: the bounded wait of the last arriver reports through it)
-    if (p.xcd_local) p.xcc_map = ctx->xcc_map;
+    // (an XCD-local form -- slices of a tile on one XCD, slabs through its L2 -- needs workgroup b of EVERY launch on XCD b mod 8; that holds for an isolated launch
+    // but not inside a pass: the dispatcher carries on round-robin from wherever the previous kernel stopped, and the per-workgroup XCC_ID check failed the first
+    // captured pass, profiles/r05_fold_xcd_local_fails_in_the_pass.txt.  Removed.)
+    p.xcd_err = ctx->xcd_err_dev;       // (the bounded wait of the last arriver reports through it)
     return (size_t)n_tiles * p.splits * bm * bn * sizeof(float);
 }
 }  // namespace osg_mm

@@ -124,5 +124,8 @@ r4vs5)   # the round-4 kernels' equivalent (attention v1, reduce launches only, 
   for v in 0 1 0 1; do
     OSG_ATTN_V1=$v OSG_TUNE_CACHE=/tmp/osg_tune_sdxl.txt timeout 400 python bench.py --config SDXL --steps-per-image 10 --steps 20 --warmup 2 --cpu-passes 0 --windows 2 > ${T}_sdxl_attn_v1_$v.json 2> ${T}_sdxl_attn_v1_$v.err; line ${T}_sdxl_attn_v1_$v.json "SDXL [OSG_ATTN_V1=$v]"
   done ;;
+frozen)   # N = 1 as the ranks of an N > 1 job run (shipped table, OSG_TUNE_FROZEN=1): the same plan, the same time, 0 misses
+  timeout 400 python bench.py --frozen-table --cpu-passes 0 --windows 3 > ${T}_bench_frozen.json 2> ${T}_bench_frozen.err; line ${T}_bench_frozen.json "[--frozen-table]"
+  python -c "import json; c=json.load(open('${T}_bench_frozen.json'))['config']; print('tune_table_frozen', c['tune_table_frozen'], 'tune_table_misses', c['tune_table_misses'])" ;;
 *) echo "unknown recipe $R" ;;
 esac; done
