@@ -127,5 +127,13 @@ r4vs5)   # the round-4 kernels' equivalent (attention v1, reduce launches only, 
 frozen)   # N = 1 as the ranks of an N > 1 job run (shipped table, OSG_TUNE_FROZEN=1): the same plan, the same time, 0 misses
   timeout 400 python bench.py --frozen-table --cpu-passes 0 --windows 3 > ${T}_bench_frozen.json 2> ${T}_bench_frozen.err; line ${T}_bench_frozen.json "[--frozen-table]"
   python -c "import json; c=json.load(open('${T}_bench_frozen.json'))['config']; print('tune_table_frozen', c['tune_table_frozen'], 'tune_table_misses', c['tune_table_misses'])" ;;
+sdxlprof)   # SDXL 1024x1024: the in-graph timeline of one replayed pass (rocprofv3 --kernel-trace of the bench command)
+  export OSG_TUNE_CACHE=/tmp/osg_tune_cache_sdxl.txt; [ -s $OSG_TUNE_CACHE ] || cp onnxstream_amd/tune/mi355x.txt $OSG_TUNE_CACHE
+  timeout 600 python bench.py --config SDXL --steps-per-image 10 --steps 20 --warmup 2 --cpu-passes 0 --windows 2 > ${T}_bench_sdxl_tune.json 2> ${T}_bench_sdxl_tune.err; line ${T}_bench_sdxl_tune.json "SDXL (tuning run)"
+  rm -rf /tmp/prof_sdxl
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_sdxl -o sdxl -- python bench.py --config SDXL --steps-per-image 10 --steps 20 --warmup 2 --cpu-passes 0 --profile-reps 1 --windows 0 > ${T}_rocprof_sdxl.log 2>&1
+  echo "rocprofv3 (SDXL) exit $?"
+  for f in $(find /tmp/prof_sdxl -name "*kernel_stats.csv"); do cp $f ${T}_sdxl_rocprofv3_kernel_stats.csv; done
+  python tools/graph_trace.py $(find /tmp/prof_sdxl -name "*kernel_trace.csv" | head -1) > ${T}_sdxl_graph_timeline.txt 2>&1; head -30 ${T}_sdxl_graph_timeline.txt; unset OSG_TUNE_CACHE ;;
 *) echo "unknown recipe $R" ;;
 esac; done
