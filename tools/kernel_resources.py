@@ -43,9 +43,9 @@ def code_objects(blob: bytes):
 
 
 def waves_per_simd(vgpr: int, agpr: int) -> int:
-    # gfx950: 512 unified registers per lane per SIMD, allocated in blocks of 8; accumulation registers start at an aligned offset after the VGPRs
-    v = (vgpr + 7) // 8 * 8
-    total = v + (agpr + 7) // 8 * 8 if agpr else v
+    # gfx950: 512 unified registers per lane per SIMD, allocated in blocks of 8.  The metadata's .vgpr_count is the UNIFIED total (architectural VGPRs, rounded up,
+    # plus the accumulation registers the compiler used beyond 256); .agpr_count is the part of it that is AGPRs.
+    total = (vgpr + 7) // 8 * 8
     return max(1, min(8, 512 // max(total, 1)))
 
 
@@ -85,6 +85,7 @@ def main():
     rows.sort(key=lambda r: (not hot.search(r["pretty"]), r["pretty"]))
     print(f"# {os.path.basename(a.lib)}: {len(rows)} gfx950 kernels; dynamic LDS (the contraction rings, attention) is not in the static figure")
     print(f"# kernels with scratch: {sum(1 for r in rows if r['scratch'])}; with register spills: {sum(1 for r in rows if r['vspill'] or r['sspill'])}")
+    print("# vgpr = unified total (agpr = the part of it that is accumulation registers)")
     print("# vgpr agpr sgpr  lds_static scratch vspill sspill waves/SIMD(regs)  max_wg  kernel")
     for r in rows:
         if not a.all and not hot.search(r["pretty"]):
