@@ -1,6 +1,6 @@
 #!/bin/bash
 # Dev tool (CPU): the host library under AddressSanitizer + UBSan, driven through the no-op stub of libosgpu -- planner, providers, streaming ring
-# bookkeeping, fusion passes, plan-time evaluation, the LLM flow's per-call re-plans.  Clean at the end of round 2 (75 tests + tools run).
+# bookkeeping, fusion passes, plan-time evaluation, the LLM flow's per-call re-plans.  Clean at the end of round 2 (75 tests + tools run) and on the final tree of round 5 (131 tests, profiles/r05_asan_host.txt).
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p /tmp/asan
