@@ -19,4 +19,4 @@ for (T, h, D) in [(4096, 8, 40), (1024, 8, 80), (256, 8, 160)]:
     fn(); fn(); g.sync(); g.timer_start()
     for _ in range(20): fn()
     ms = g.timer_stop() / 20
-    print(f"[NW={os.environ.get('OSG_ATTN_NW','auto')}] attn T={T} h={B*h} D={D}: {ms*1e3:7.1f} us {4.0*B*h*T*T*D/ms/1e9:7.1f} TF/s")
+    print(f"[V1={os.environ.get('OSG_ATTN_V1','0')}] attn T={T} h={B*h} D={D}: {ms*1e3:7.1f} us {4.0*B*h*T*T*D/ms/1e9:7.1f} TF/s")
