@@ -2659,6 +2659,9 @@ struct Lowering {
         // Conv1D (reference :4521-4544): run as the 2-D convolution over [N, C, L, 1] -- dilations / kernel_shape gain a 1, pads [b, e] become [b, 0, e, 0], the
         // stride is repeated -- and the [N, O, Lo, 1] result is handed on as [N, O, Lo]
         const bool is1d = V(x).shape.size() == 3;
+        // (the reference keys the lift on dilations.size() == 1, :4521; here the input's rank decides and a dilations attribute that disagrees with it is refused)
+        for (auto& a : op.m_attributes)
+            if (a.first == "dilations") need(op, (dil.size() == 1) == is1d, "invalid dilations attribute value.");
         if (is1d) {
             need(op, !has_res && !has_ib, "Conv1D with fused epilogue inputs not implemented on the HIP backend.");
             bool have_pads = false, have_strides = false, have_dil = false;
@@ -4535,6 +4538,15 @@ void Plan::run_steps(size_t begin, size_t end) {
             ~Range() { if (on) b.api.osg_range_pop(); }
         } range(be, roctx_on, s.what.c_str());
         s.run();
+        // measurement aid (round 6): OSG_PROBE_EXTRA_TRIVIAL=<k> puts k trivial launches (a 4-element convert on a private buffer) behind EVERY
+        // step of the pass -- eager, captured and replayed alike: (replayed pass time with k) - (without) over k x steps = what a trivial node costs INSIDE this pass
+        static const int extra_trivial = std::getenv("OSG_PROBE_EXTRA_TRIVIAL") ? atoi(std::getenv("OSG_PROBE_EXTRA_TRIVIAL")) : 0;
+        if (extra_trivial > 0) {
+            static void* probe = nullptr;          // (first used in the eager first pass: never allocated inside a capture; a process-lifetime 4 KiB)
+            if (!probe) be.check(be.api.osg_malloc(be.ctx, 4096, &probe), "osg_malloc");
+            for (int k = 0; k < extra_trivial; k++)
+                be.check(be.api.osg_convert(be.ctx, OSG_F32, OSG_F16, probe, (char*)probe + 2048, 4, 1.0f, 0), "osg_convert");
+        }
         // OSG_PLAN_TRACE=1 (debugging aid, eager passes only): name every step on stderr and wait for it -- a device fault then points at its launch
         static const bool trace = std::getenv("OSG_PLAN_TRACE") != nullptr;
         if (trace && !in_capture) {

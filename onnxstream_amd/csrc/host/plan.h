@@ -277,7 +277,7 @@ struct Plan {
     char* gn_stats = nullptr;      // the pass's statistics block: one [N][G][2] int64 table per such GroupNorm, zeroed at the start of every pass
     size_t gn_stats_bytes = 0;
     void zero_gn_stats();
-    void run_steps(size_t begin = 0, size_t end = (size_t)-1);   // steps [begin, end) honouring the side-stream marks
+    void run_steps(size_t begin = 0, size_t end = (size_t)-1);   // steps [begin, end)
     // uint8 plans: steps [0, dyn_end) read values quantised per run (a pushed input and what merely re-arranges its codes): they run eagerly every
     // pass with the parameters of that pass, the steps after them only see range-data parameters and are captured like any other plan
     size_t dyn_end = 0;

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(AttnParams p, int nqb) {
     constexpr int NT = 4, NS = 2;               // 16-key score tiles / 32-deep P V steps per 64-key tile
     constexpr int NINST = 2 * RSC;              // 1-KiB DMA pieces per tile: K's RSC, then V's RSC
     constexpr int MAXP = NINST / 4;             // ... per wave (RSC is even: the same count for every wave)
-    static_assert(NST >= 3 && MAXP * (NST - 2) <= 63, "three stages at least (the tile being read, the next one, one in flight); vmcnt is a 6-bit counter");
+    static_assert((NST == 3 || NST == 4) && MAXP * (NST - 2) <= 63, "three or four stages (the tile being read, the next one, one or two in flight: sync_issue's tail guard `kt + 2 >= ntiles` covers no deeper ring); vmcnt is a 6-bit counter");
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) char asmem[];
     typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -606,11 +606,10 @@ int launch_attn2(osg_ctx* ctx, const AttnParams& p, int batch) {
     const bool qt2 = p.Tq >= 1024 && force_qt != 1 && (blocks128 >= 2L * ctx->num_cu || force_qt == 2);
     auto k1 = attn2_kernel<D, 1, NST>;
     auto k2 = attn2_kernel<D, 2, NST>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_mask = 0;   // (per device: hipFuncSetAttribute is, and a process may hold several)
+    if (osg_first_on_device(attr_mask)) {
         OSG_HIP(ctx, hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         OSG_HIP(ctx, hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
     }
     const int nqb = qt2 ? (p.Tq + 127) / 128 : (p.Tq + 63) / 64;
     dim3 grid((unsigned)((long)nqb * batch * p.heads));

@@ -51,6 +51,15 @@ struct osg_ctx {
     int num_cu = 256;
 };
 
+// memo "this kernel's attributes are set" per DEVICE (advisor, round 5: a static bool left the large-LDS opt-in unset on a second device of the process)
+inline bool osg_first_on_device(unsigned long long& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    if ((mask >> dev) & 1ull) return false;
+    mask |= 1ull << dev;
+    return true;
+}
+
 struct osg_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;

@@ -321,10 +321,9 @@ int launch3(osg_ctx* ctx, GemmParams& p) {
     static_assert(smem <= 160 * 1024, "LDS budget");
     static_assert(Geo<W_, BN, NLW>::OK, "pipeline depth out of range");
     auto kern = conv3x3_kernel<W_, BN, WGM, WGN, MODE, NLW>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_mask = 0;   // (per device: hipFuncSetAttribute is, and a process may hold several)
+    if (osg_first_on_device(attr_mask)) {
         OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
     }
     p.mt = (p.M + 127) / 128;
     p.nt = (p.N + BN - 1) / BN;

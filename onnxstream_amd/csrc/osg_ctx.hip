@@ -6,6 +6,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <set>
 
 namespace osg_tune {
 static std::mutex g_mu;
@@ -35,7 +36,7 @@ static void load_locked() {
     }
     fclose(f);
 }
-static int g_misses = 0;
+static std::set<Key> g_missed;   // DISTINCT shapes that missed (a shape that cannot be timed -- during capture, or when it consumes its own output -- misses on every launch)
 bool lookup(const Key& k, Choice* out) {
     std::lock_guard<std::mutex> lk(g_mu);
     load_locked();
@@ -43,9 +44,9 @@ bool lookup(const Key& k, Choice* out) {
     if (it == g_table.end()) {
         // a miss: the caller times the candidates now (and stores the winner) -- or, frozen, runs the cost model's first candidate.  Counted (osg_tune_misses)
         // and named once per shape under OSG_TUNE_LOG_MISSES=1, so that a shipped table can be completed.
-        g_misses++;
+        const bool first = g_missed.insert(k).second;
         static const bool log = getenv("OSG_TUNE_LOG_MISSES") != nullptr;
-        if (log) fprintf(stderr, "[tune] miss: kind %d M %d N %d K %d batch %d H %d W %d Cin %d KW %d stride %dx%d flags %d%s\n", k.kind, k.M, k.N, k.K, k.batch, k.H, k.W, k.Cin, k.KW, k.sh,
+        if (log && first) fprintf(stderr, "[tune] miss: kind %d M %d N %d K %d batch %d H %d W %d Cin %d KW %d stride %dx%d flags %d%s\n", k.kind, k.M, k.N, k.K, k.batch, k.H, k.W, k.Cin, k.KW, k.sh,
                          k.sw, k.flags, frozen() ? " (frozen: cost-model choice, not timed)" : "");
         return false;
     }
@@ -54,7 +55,7 @@ bool lookup(const Key& k, Choice* out) {
 }
 int misses() {
     std::lock_guard<std::mutex> lk(g_mu);
-    return g_misses;
+    return (int)g_missed.size();
 }
 // frozen tables: remember the untimed choice of a missed shape for the rest of the process (in memory only: us = -1), so that eager launches of that shape do
 // not rank the candidates again and the miss is counted once
@@ -137,7 +138,10 @@ int xcd_check(osg_ctx* c) {
     if (c->xcd_err && *(volatile int*)c->xcd_err) {
         const int what = *(volatile int*)c->xcd_err;
         *c->xcd_err = 0;
-        if (what == 2) OSG_FAIL(c, "split-K fold: a k-slice workgroup did not publish its partial sums within 2 ms (results of this pass are invalid); set OSG_SPLITK_FOLD=0");
+        // the last arriver that gave up left its tile's two counters as they stood (a late publication may still have bumped one): every counter back to zero, behind
+        // everything the stream holds -- the captured graph stays valid (the counters are data), only this pass's results are lost
+        if (c->tickets && hipMemsetAsync(c->tickets, 0, osg_ctx::kTickets * sizeof(int), c->compute) == hipSuccess) hipStreamSynchronize(c->compute);
+        if (what == 2) OSG_FAIL(c, "split-K fold: a k-slice workgroup did not publish its partial sums within 20 ms (results of this pass are invalid); set OSG_SPLITK_FOLD=0");
         OSG_FAIL(c, "split-K fold: the device raised its error flag (results of this pass are invalid); set OSG_SPLITK_FOLD=0");
     }
     return 0;

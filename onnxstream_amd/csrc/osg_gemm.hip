@@ -491,10 +491,9 @@ int launch_v2(osg_ctx* ctx, GemmParams& p, int batch) {
     static_assert(smem <= 160 * 1024, "LDS budget");
     static_assert(KS == 1 || (size_t)4 * ((BM / 32) * (BN / 32) + 1) * 1024 <= smem, "KS = 2: the accumulator hand-over must fit the ring");
     auto kern = gemm2_kernel<BM, BN, NST, CONV, MODE, SPEC, LN, NCH, KS>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_mask = 0;   // (per device: hipFuncSetAttribute is, and a process may hold several)
+    if (osg_first_on_device(attr_mask)) {
         OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
     }
     p.mt = (p.M + BM - 1) / BM;
     p.nt = (p.N + BN - 1) / BN;
@@ -674,10 +673,9 @@ int launch_cfg(osg_ctx* ctx, const GemmParams& p, int batch) {
     constexpr int LDS = BK + 8;
     size_t smem = (size_t)2 * (BM + BN) * LDS * sizeof(f16);
     auto kern = gemm_kernel<BM, BN, BK, CONV, VEC>;
-    static bool attr_set = false;
-    if (!attr_set && smem > 48 * 1024) {
+    static unsigned long long attr_mask = 0;   // (per device: hipFuncSetAttribute is, and a process may hold several)
+    if (osg_first_on_device(attr_mask) && smem > 48 * 1024) {
         OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
     }
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, batch * p.splits);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, ctx->compute, p);

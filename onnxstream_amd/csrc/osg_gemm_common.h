@@ -556,20 +556,26 @@ __device__ __forceinline__ bool splitk_fold_acc(const GemmParams& p, f32x4 (&acc
     }
     if (tid == 0) {
         // the publishers HAVE arrived (they took their tickets before this workgroup did), so they are running and need nobody -- still, the wait is bounded
-        // (2 ms of the 100 MHz wall clock): should a publication never come, the pass is marked invalid (the host-mapped flag osg_sync / osg_download check)
-        // instead of hanging the device
+        // (20 ms of the 100 MHz wall clock, which keeps counting while a wave is descheduled: long enough for queue pre-emption / two processes time-slicing one
+        // GPU): should a publication never come, the pass is marked invalid (the host-mapped flag osg_sync / osg_download check) instead of hanging the device
         const unsigned want = (unsigned)p.splits - 1;
         const unsigned long long t0 = wall_clock64();
+        bool complete = true;
         while (__hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-            if (wall_clock64() - t0 > 200000ull) {
+            if (wall_clock64() - t0 > 2000000ull) {
                 if (p.xcd_err) __hip_atomic_store(p.xcd_err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                complete = false;
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
         }
-        // both words back to zero for the next launch (nobody else touches them again: every other slice has published and left)
-        __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(w + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // both words back to zero for the next launch (nobody else touches them again: every other slice has published and left).  NOT after a timeout (advisor,
+        // round 5): a late publisher would bump the zeroed word and every later launch of this tile would fold early -- the host zeroes ALL counters when it sees
+        // the flag (osg_ctx.hip xcd_check), behind everything the stream holds
+        if (complete) {
+            __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(w + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     __syncthreads();
     f32x4 sum[TM][TN];

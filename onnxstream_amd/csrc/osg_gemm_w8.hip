@@ -215,10 +215,9 @@ template <int BN, bool CONV>
 int launch_w8(osg_ctx* ctx, GemmParams& p) {
     constexpr size_t smem = (size_t)4 * (128 + BN) * 128;
     auto kern = gemm_w8_kernel<BN, CONV>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_mask = 0;   // (per device: hipFuncSetAttribute is, and a process may hold several)
+    if (osg_first_on_device(attr_mask)) {
         OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
     }
     p.mt = (p.M + 127) / 128;
     p.nt = (p.N + BN - 1) / BN;

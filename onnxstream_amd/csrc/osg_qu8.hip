@@ -459,10 +459,9 @@ int launch_q8v2(osg_ctx* ctx, Q8Params& p, int batch) {
     constexpr size_t smem = (size_t)NST * (BM + BN) * 128;
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = q8_gemm2_kernel<BM, BN, NST, CONV, WGM, DBG>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_mask = 0;   // (per device: hipFuncSetAttribute is, and a process may hold several)
+    if (osg_first_on_device(attr_mask)) {
         OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set = true;
     }
     p.mt = (p.M + BM - 1) / BM;
     p.nt = (p.N + BN - 1) / BN;

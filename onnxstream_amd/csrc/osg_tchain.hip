@@ -1006,16 +1006,15 @@ int osg_tblock_tail(osg_ctx* ctx, const osg_tblock_tail_args* a) {
     // eight more workgroups pull the weights into the eight L2s -- where the launch leaves CUs free for them (64-row blocks at M = 8 192); beside one row block per CU
     // they cost more than they bring (32-row blocks, 256 + 8 workgroups: 76.7 against 71.2 us per launch, profiles/r04_tblock_tail_rows_probe.txt)
     const int npf = nblk >= 64 && nblk + pfw <= ctx->num_cu ? pfw : 0;
-    auto launch = [&](auto kern, int smem, bool& attr_set) -> int {
-        if (!attr_set) {
+    auto launch = [&](auto kern, int smem, unsigned long long& attr_mask) -> int {
+        if (osg_first_on_device(attr_mask)) {
             OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            attr_set = true;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)(nblk + npf)), dim3(256), smem, ctx->compute, p);
         return 0;
     };
     constexpr int vec_bytes = (9 * 320 + 8 * 320) * 2;     // the small operands behind the three row-block images
-    static bool attr64 = false, attr32 = false, attr32n3 = false;
+    static unsigned long long attr64 = 0, attr32 = 0, attr32n3 = 0;   // (per-device memos, osg_common.h osg_first_on_device)
     static const bool ns3 = getenv("OSG_TBLOCK_NS") && atoi(getenv("OSG_TBLOCK_NS")) == 3;     // dev knob: two weight tiles ahead (32-row blocks only)
     int rc;
     if (rows == 64) rc = launch(osg_tb::tblock_tail_kernel<4, 320, 40, 5, 2>, 3 * 5 * osg_tb::kTileBytes<4> + vec_bytes, attr64);
@@ -1055,15 +1054,14 @@ int osg_qattn(osg_ctx* ctx, const osg_qattn_args* a) {
     p.out = (f16*)a->out; p.ldo = a->ldo ? a->ldo : a->C;
     p.M = a->M; p.rows_per_img = a->rows_per_img; p.heads = a->heads;
     p.dbg_q = (f16*)a->dbg_q;
-    auto launch = [&](auto kern, int smem, bool& attr_set) -> int {
-        if (!attr_set) {
+    auto launch = [&](auto kern, int smem, unsigned long long& attr_mask) -> int {
+        if (osg_first_on_device(attr_mask)) {
             OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            attr_set = true;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)(a->M / 32), (unsigned)a->heads), dim3(256), smem, ctx->compute, p);
         return 0;
     };
-    static bool attr640 = false, attr1280 = false, attr640x = false, attr1280x = false;
+    static unsigned long long attr640 = 0, attr1280 = 0, attr640x = 0, attr1280x = 0;   // (per-device memos, osg_common.h osg_first_on_device)
     int rc;
     if (a->C == 640 && a->heads == 8) rc = launch(osg_tb::qattn_kernel<640, 80>, 10 * 4096 + 2 * 4096 + 2 * 640 * 2, attr640);
     else if (a->C == 640) rc = launch(osg_tb::qattn_kernel<640, 64>, 10 * 4096 + 1 * 4096 + 2 * 640 * 2, attr640x);
