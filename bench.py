@@ -40,7 +40,7 @@ if REPO not in sys.path:
 STEPS_PER_IMAGE = 20                 # BASELINE.json: 512x512 20-step
 PEAK_F16_TFLOPS = 2500.0             # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-GEMM_KINDS = ("Conv", "Linear", "MatMul", "Gemm", "TBlockTail", "QAttention")   # (QAttention: attn2.to_q + its cross-attention in one launch, osg_qattn; TBlockTail: a transformer block's tail as one launch -- six contractions + the 77-token cross-attention, osg_tchain.hip)
+GEMM_KINDS = ("Conv", "Linear", "MatMul", "Gemm", "TBlockTail")   # (TBlockTail: a transformer block's tail as one launch -- six contractions + the 77-token cross-attention, osg_tchain.hip)
 
 
 def log(*a):
@@ -229,7 +229,6 @@ def main():
     ap.add_argument("--profile-reps", type=int, default=3)
     ap.add_argument("--steps-per-image", type=int, default=0, help="denoising steps per image (default 20; BASELINE config 4 = SDXL uses 10)")
     ap.add_argument("--no-ln-fold", action="store_true", help="standalone LayerNorm launches instead of folding every LayerNorm into the GEMM that consumes it (osg_gemm_ln, default)")
-    ap.add_argument("--no-qattn-fuse", action="store_true", help="LayerNorm-folded attn2.to_q and the cross-attention as two launches (round 3) instead of one osg_qattn launch where it takes the shape (round 4 default)")
     ap.add_argument("--no-tblock-fuse", action="store_true", help="the tail of every transformer block as the seven launches of round 3 instead of one osg_tblock_tail launch where it takes the shape (round 4 default)")
     ap.add_argument("--no-concat-views", action="store_true", help="skip tensors through copy launches (Concat) instead of convolutions storing straight into their Concat slot (round 3 default)")
     ap.add_argument("--gn-stats", type=int, default=None, choices=[0, 1, 2], help="GroupNorm statistics from the producing convolutions' epilogues: 0 never, 1 every eligible GroupNorm, 2 only tensors of >= 8 M elements (the Model's default: pays in the throughput regime, neutral on the SD 1.5 pass, profiles/r03_gn_stats_ab.txt)")
@@ -372,8 +371,6 @@ def main():
         m._set_option("hip_concat_views", 0)
     if args.no_tblock_fuse:
         m._set_option("hip_fuse_tblock", 0)
-    if args.no_qattn_fuse:
-        m._set_option("hip_fuse_qattn", 0)
     if args.gn_stats is not None:
         m._set_option("hip_gn_stats", args.gn_stats)
     L = cfg.latent
@@ -553,8 +550,8 @@ def main():
                 break
         if pmc_src and cfg.name == "sd15" and P == 1 and not args.no_autotune:   # (the counter file describes the tuned batch-2 pass of one prompt)
             tj = json.load(open(os.path.join(REPO, "profiles", pmc_src)))["kernels"]
-            sel = [v for k, v in tj.items() if "gemm2_kernel" in k or "conv3x3_kernel" in k or "conv_small" in k or "gemm_kernel" in k or "splitk_reduce" in k or "tblock_tail" in k or "qattn_kernel" in k or "conv_cin4" in k]
-            nd = sum(v["dispatches"] for k, v in tj.items() if ("gemm2_kernel" in k or "conv3x3_kernel" in k or "conv_small" in k or "gemm_kernel" in k or "tblock_tail" in k or "qattn_kernel" in k or "conv_cin4" in k))
+            sel = [v for k, v in tj.items() if "gemm2_kernel" in k or "conv3x3_kernel" in k or "conv_small" in k or "gemm_kernel" in k or "splitk_reduce" in k or "tblock_tail" in k or "conv_cin4" in k]
+            nd = sum(v["dispatches"] for k, v in tj.items() if ("gemm2_kernel" in k or "conv3x3_kernel" in k or "conv_small" in k or "gemm_kernel" in k or "tblock_tail" in k or "conv_cin4" in k))
             if nd:
                 traffic = (sum(2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0) for v in sel) * 1024.0) / nd
                 busy = sum(v.get("SQ_BUSY_CYCLES", 0.0) for v in sel)
@@ -562,7 +559,7 @@ def main():
                     mfma_util = sum(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for v in sel) / (busy / 32.0 * 1024.0)
                 if g_ms > 0 and g_n:
                     hbm_gbs = traffic / (g_ms * 1e-3 / g_n) / 1e9
-        roofline = {"bound": "mfma", "kernel": "gemm2_kernel + conv3x3_kernel + tblock_tail_kernel + qattn_kernel (implicit-GEMM / halo-reuse Conv, Linear/MatMul/Gemm, fused transformer-block tails, q projection + cross-attention)", "achieved": round(achieved, 2),
+        roofline = {"bound": "mfma", "kernel": "gemm2_kernel + conv3x3_kernel + tblock_tail_kernel (implicit-GEMM / halo-reuse Conv, Linear/MatMul/Gemm, fused transformer-block tails)", "achieved": round(achieved, 2),
                     "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": f"HBM-side bytes per contraction launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of profiles/{pmc_src}, split-K reduce launches folded in; {pmc_note})" if traffic is not None else None,
                     "counters": (f"profiles/{pmc_src}: eager passes of the tuned plan (same tune table as the timed hipGraph run), one counter set per rocprofv3 pass" if traffic is not None

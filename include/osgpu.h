@@ -235,24 +235,6 @@ typedef struct {
 } osg_tblock_tail_args;
 int osg_tblock_tail_supported(int M, int rows_per_img, int C, int heads, int Tk); /* 1 = osg_tblock_tail takes the shape */
 int osg_tblock_tail(osg_ctx* ctx, const osg_tblock_tail_args* a);
-/* Cross-attention with its query projection inside (osg_tchain.hip), for the levels the tail above does not take (C = 640 / 1280; 8 heads, or SDXL's 10 / 20 heads of 64):
- *   out[:, h D .. h D + D) = softmax(scale (LayerNorm(x; gamma, beta, eps) . Wq_h^T + bq_h) k_h^T) v_h        per head h, D = C / heads
- * = the 9-op LayerNorm chain (onnxstream.cpp:5237-5604) + MatMul (:5669-5861) + AttentionFusedOps (:6696-6929) of attn2, one workgroup per (32 rows, head).
- * x [M][C] rows ldx elements apart (0 = C), wq in the kn8 layout of osg_tblock_pack_weight (from [C][C] = [N][K]), bq may be NULL, kp / vtp from
- * osg_tblock_kv_pack(_jobs) with head dim D, out [M][C] rows ldo apart (0 = C).  M = images x rows_per_img, both multiples of 32; Tk <= 80.
- * f16 everywhere, f32 accumulation, q rounded to f16 as the separate launch rounds it.  dbg_q (may be NULL): dense [M][C] dump of q (tests). */
-typedef struct {
-  const void* x; long ldx;
-  const void *gamma, *beta; float eps;
-  const void *wq, *bq;
-  const void *kp, *vtp;
-  float scale; int Tk;
-  void* out; long ldo;
-  int M, rows_per_img, C, heads;
-  void* dbg_q;
-} osg_qattn_args;
-int osg_qattn_supported(int M, int rows_per_img, int C, int heads, int Tk);
-int osg_qattn(osg_ctx* ctx, const osg_qattn_args* a);
 /* A resident [N][K] weight (k contiguous: a MatMul's [K,N] after osg_transpose_kn_to_nk, a 1x1 convolution's OHWI) -> the layout osg_tblock_tail streams:
  * [K/8][N][8], i.e. for every 8-deep k chunk the N rows side by side -- an MFMA fragment request (lane = row, lane group = k chunk) is then four runs of
  * 256 contiguous bytes.  Done once per weight, when it becomes resident.  K % 8 == 0. */

@@ -27,7 +27,7 @@ namespace onnxstream {
     X(osg_copy_2d) X(osg_concat2) X(osg_resize_nearest) X(osg_gather_rows) X(osg_maxpool_nhwc) X(osg_convert) \
     X(osg_sampler_prepare) X(osg_sampler_cfg_euler_a) X(osg_qu8_conv2d_nhwc) X(osg_qu8_conv2d_nhwc_t) X(osg_qu8_conv_tap_sums) X(osg_qu8_gemm) X(osg_qu8_lut) X(osg_qu8_binary) \
     X(osg_qu8_instance_norm) X(osg_qu8_instance_norm_nhwc) X(osg_qu8_affine_act) X(osg_qu8_norm_affine_act_nhwc) X(osg_qu8_softmax_last) X(osg_range_push) X(osg_range_pop) X(osg_marker_record) \
-    X(osg_copy_wait_marker) X(osg_timer_mark) X(osg_timer_between) X(osg_tblock_tail_supported) X(osg_tblock_tail) X(osg_tblock_kv_pack_elems) X(osg_tblock_kv_pack_jobs) X(osg_tblock_pack_weight) X(osg_qattn_supported) X(osg_qattn)
+    X(osg_copy_wait_marker) X(osg_timer_mark) X(osg_timer_between) X(osg_tblock_tail_supported) X(osg_tblock_tail) X(osg_tblock_kv_pack_elems) X(osg_tblock_kv_pack_jobs) X(osg_tblock_pack_weight)
 
 struct OsgApi {
 #define OSG_FN(name) decltype(&::name) name = nullptr;

@@ -236,7 +236,6 @@ void model_set_option(Handle* h, char* name, unsigned int value) {
     else if (n == "hip_fuse_ln_gemm") m.m_hip_fuse_ln_gemm = b;
     else if (n == "hip_concat_views") m.m_hip_concat_views = b;
     else if (n == "hip_fuse_tblock") m.m_hip_fuse_tblock = b;
-    else if (n == "hip_fuse_qattn") m.m_hip_fuse_qattn = b;
     else if (n == "hip_gn_stats") m.m_hip_gn_stats = (int)value;
     else if (n == "hip_stream_weights") m.m_hip_stream_weights = b;
     else if (n == "hip_w8_resident") m.m_hip_w8_resident = b;

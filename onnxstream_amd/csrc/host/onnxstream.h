@@ -563,7 +563,6 @@ public:
     int m_hip_gn_stats = 2;         // fusion level 2: a GroupNorm over what convolutions store reads its statistics from their epilogues (osg_set_stat_sinks) and is one streaming
                                     // launch.  0 off, 1 every eligible GroupNorm, 2 (default) where the tensor has >= 8 M elements: in the throughput regime it pays (f16 VAE decoder
                                     // 4.61 -> 4.08 ms, SDXL UNet -1.1 %), on the SD 1.5 pass -- launches that last as long as one workgroup -- it is neutral (profiles/r03_gn_stats_ab.txt)
-    bool m_hip_fuse_qattn = true;   // fusion level 2: LayerNorm + attn2.to_q + cross-attention as ONE launch where osg_qattn takes the shape (C = 640 / 1280; round 4)
     bool m_hip_fuse_tblock = true;  // fusion level 2: the row-local tail of a transformer block (attn1.to_out .. ff.net.2 [.. proj_out]) as ONE launch where osg_tblock_tail takes the shape (round 4)
     bool m_hip_concat_views = true; // fusion level 2: convolutions store skip tensors straight into their Concat slot (osg_conv2d_nhwc_v), no copy launch
     bool m_hip_autotune = false;   // true: the first (eager) pass TIMES the legal tile / split-K configurations of every GEMM / convolution shape

@@ -104,7 +104,6 @@ Plan::Plan(Model& model, HipBackend& backend, ConstPool& cpool, size_t batch) : 
     fuse_ln_gemm = m.m_hip_fuse_ln_gemm;
     concat_views = m.m_hip_concat_views;
     fuse_tblock = m.m_hip_fuse_tblock;
-    fuse_qattn = m.m_hip_fuse_qattn;
     gn_stats_req = m.m_hip_gn_stats;
     gn_stats_min_elems = m.m_hip_gn_stats == 2 ? (8L << 20) : 0;
     gn_stats_on = m.m_hip_gn_stats != 0 && !stream_weights && m.m_hip_fusion_level >= 2 && !m.m_use_uint8_arithmetic && !m.m_range_data_calibrate;
@@ -129,7 +128,7 @@ bool Plan::compatible(Model& mm, size_t batch) const {
     const bool want_stream = mm.m_hip_stream_weights || mm.m_cuda_options.m_vram_to_use > 0;
     if ((long)batch != N) return no("batch size");
     if (mm.m_use_fp16_arithmetic != fp16 || mm.m_use_uint8_arithmetic != u8 || mm.m_use_uint8_qdq != u8_qdq) return no("arithmetic type");
-    if (mm.m_hip_fusion_level != fusion_req || mm.m_hip_fuse_ln_gemm != fuse_ln_gemm || mm.m_hip_concat_views != concat_views || mm.m_hip_fuse_tblock != fuse_tblock || mm.m_hip_fuse_qattn != fuse_qattn || mm.m_hip_gn_stats != gn_stats_req ||
+    if (mm.m_hip_fusion_level != fusion_req || mm.m_hip_fuse_ln_gemm != fuse_ln_gemm || mm.m_hip_concat_views != concat_views || mm.m_hip_fuse_tblock != fuse_tblock || mm.m_hip_gn_stats != gn_stats_req ||
         mm.m_fuse_ops_in_attention != fuse_attn || mm.m_use_scaled_dp_attn_op != sdp_attn || mm.m_hip_autotune != autotune)
         return no("fusion / tuning options");
     if (want_stream != stream_weights || (size_t)mm.m_cuda_options.m_vram_to_use != vram_budget ||
@@ -760,7 +759,6 @@ struct Lowering {
             if (has_type("Conv")) { index_graph(); fuse_conv_act(); }
             if (has_type("osg.GEGLU")) { index_graph(); fuse_linear_geglu(); }
             if (has_type("osg.Attention") && has_type("osg.LayerNorm")) { index_graph(); fuse_tblock_tail(); }
-            if (has_type("osg.Attention") && has_type("osg.LayerNorm")) { index_graph(); fuse_qattn(); }   // (after the residual / GEGLU fusions: it matches their results)
             if (has_type("osg.SiLU")) { index_graph(); cse_silu(); }
             if (has_type("osg.SiLU") && has_type("Gemm")) { index_graph(); fuse_gemm_act(); }   // (after the CSE: the 22 SiLUs behind the time embedding are one by now)
             if (has_type("Conv")) { index_graph(); fuse_image_bias(); }
@@ -1389,47 +1387,6 @@ struct Lowering {
             for (int k2 : {lo1, ln2, lq, (int)i, lo2, ln3, l1, l2, rsh, trp})
                 if (k2 >= 0 && k2 != last) dead[k2] = 1;
             ops()[last] = std::move(f);
-        }
-    }
-
-    // LayerNorm -> attn2.to_q -> cross-attention ==> osg.QAttention (one launch, osg_qattn / osg_tchain.hip), for the blocks fuse_tblock_tail leaves alone
-    // (C = 640 / 1280): osg.LayerNorm(x1) -> osg.Linear(Wq [, bq]) = q -> osg.Attention(q, k, v), k / v projections of the text context
-    void fuse_qattn() {
-        if (P.stream_weights || !m.m_hip_fuse_qattn || P.w8_resident) return;
-        for (size_t i = 0; i < ops().size(); i++) {
-            if (!is((int)i, "osg.Attention")) continue;
-            const Operation& at = ops()[i];
-            if (at.m_input.size() != 3 || at.m_output.size() != 1) continue;
-            const Tensor q = at.m_input[0], kt = at.m_input[1], vt = at.m_input[2];
-            if (q.m_name == kt.m_name || q.m_name == vt.m_name) continue;
-            const int lq = prod_of(q);
-            if (!is(lq, "osg.Linear") || use_count(q.m_name) != 1 || attr(ops()[lq], "osg_residual") || attr(ops()[lq], "osg_geglu") || attr(ops()[lq], "osg_act")) continue;
-            const Operation& LQ = ops()[lq];
-            if (LQ.m_input.size() < 2 || LQ.m_input.size() > 3) continue;
-            const int ln = prod_of(LQ.m_input[0]);
-            if (!is(ln, "osg.LayerNorm") || use_count(LQ.m_input[0].m_name) != 1) continue;
-            const Operation& LN = ops()[ln];
-            const Tensor x1 = LN.m_input[0];
-            const auto& xs = x1.m_shape;
-            if (!act(x1) || xs.size() != 3 || xs[0] != 1 || q.m_shape != xs) continue;
-            const long T = (long)xs[1], C = (long)xs[2];
-            const Val* w = cval(LQ.m_input[1]);
-            if (!w || w->dtype != OSG_F16 || w->shape != Shape{C, C}) continue;
-            auto vok = [&](const Tensor& t) { const Val* b = cval(t); return b && b->dtype == OSG_F16 && b->numel() == C; };
-            if (!vok(LN.m_input[1]) || !vok(LN.m_input[2])) continue;
-            const bool has_b = LQ.m_input.size() == 3 && !LQ.m_input[2].m_name.empty();
-            if (has_b && !vok(LQ.m_input[2])) continue;
-            if (kt.m_shape.size() != 3 || kt.m_shape[0] != 1 || (long)kt.m_shape[2] != C || vt.m_shape != kt.m_shape) continue;
-            const long heads = std::stol(*attr(at, "heads")), Tk = (long)kt.m_shape[1];
-            if (!be.api.osg_qattn_supported((int)(T * N), (int)T, (int)C, (int)heads, (int)Tk)) continue;
-            Operation f;
-            f.m_name = at.m_name + "_QAttention";
-            f.m_type = "osg.QAttention";
-            f.m_input = {x1, LN.m_input[1], LN.m_input[2], LQ.m_input[1], has_b ? LQ.m_input[2] : Tensor(), kt, vt};
-            f.m_attributes = {{"heads", *attr(at, "heads")}, {"scale", *attr(at, "scale")}, {"eps", *attr(LN, "epsilon")}};
-            f.m_output = {at.m_output[0]};
-            dead[ln] = dead[lq] = 1;
-            ops()[i] = std::move(f);
         }
     }
 
@@ -2560,7 +2517,6 @@ struct Lowering {
         if (t == "osg.GEGLU") return lower_geglu(op);
         if (t == "osg.Attention") return lower_attention(op);
         if (t == "osg.TBlockTail") return lower_tblock_tail(op);
-        if (t == "osg.QAttention") return lower_qattn(op);
         if (t == "AttentionFusedOps") return lower_attention_fused_ops(op);
         if (t == "ScaledDotProductAttention") return lower_sdpa(op);
         if (t == "Expand") return lower_expand(op);
@@ -3485,7 +3441,7 @@ struct Lowering {
     // K / V of cross-attentions that are column views of ONE merged projection of the text context (plan_linear_groups: 32 -> 1) are re-packed by ONE
     // launch for every osg.TBlockTail of the graph that shares the merged output and the head count with `op`
     // (input positions of k / v in the fused ops that read packs)
-    static int kv_input(const Operation& o) { return o.m_type == "osg.TBlockTail" ? 8 : o.m_type == "osg.QAttention" ? 5 : -1; }
+    static int kv_input(const Operation& o) { return o.m_type == "osg.TBlockTail" ? 8 : -1; }
     void prepack_kv(const Operation& op, int k, int v, long heads, long Tk) {
         struct Job { std::string name; long kcol, vcol, D; };
         const int ki0 = kv_input(op);
@@ -3618,49 +3574,6 @@ struct Lowering {
         });
         P.steps.back().flops = 2.0 * M * C * C * (proj ? 4 : 3) + 2.0 * M * C * 2 * F + 2.0 * M * F * C + 4.0 * nb * heads * T * Tk * (C / heads);
         if (proj) conv_producers[P.root_of(y)] = ConvProducer{P.steps.size() - 1, co, y};
-    }
-
-    // ---- osg.QAttention (fuse_qattn): LayerNorm + q projection + cross-attention, one launch of osg_qattn; K / V from the packs of prepack_kv --------------
-    void lower_qattn(const Operation& op) {
-        need(op, op.m_input.size() == 7 && op.m_output.size() == 1, "wrong number of inputs.");
-        const long heads = std::stol(*attr(op, "heads"));
-        const float scale = std::stof(*attr(op, "scale")), eps = std::stof(*attr(op, "eps"));
-        const int x = P.ensure_plain(in_val(op.m_input[0]));
-        const int g = in_val(op.m_input[1]), b = in_val(op.m_input[2]);
-        const int wq = weight_kn8(weight_nk(in_val(op.m_input[3])));
-        const int bq = op.m_input[4].m_name.empty() ? -1 : in_val(op.m_input[4]);
-        const int k = in_val_raw(op.m_input[5]), v = in_val_raw(op.m_input[6]);
-        const Shape xs = V(x).shape;
-        need(op, xs.size() == 3 && xs[0] == 1 && V(x).ld == 0, "invalid shape of input.");
-        const long T = xs[1], C = xs[2], Tk = V(k).shape[1], nb = B(x), M = T * nb;
-        need(op, V(k).batched == V(x).batched && V(v).batched == V(x).batched, "q/k/v batching mismatch.");
-        need(op, be.api.osg_qattn_supported((int)M, (int)T, (int)C, (int)heads, (int)Tk) == 1, "shape not taken by osg_qattn.");
-        for (int t : {g, b}) need(op, V(t).dtype == OSG_F16 && V(t).numel() == C, "invalid LayerNorm operands.");
-        if (!kv_packs.count(op.m_name)) prepack_kv(op, k, v, heads, Tk);
-        const auto [pack, koff] = kv_packs.at(op.m_name);
-        const size_t each = be.api.osg_tblock_kv_pack_elems((int)nb, (int)heads, (int)(C / heads));
-        const int y = out_val(op, xs, Lay::plain, V(x).batched);
-        std::vector<int> reads = {x, g, b, wq, pack};
-        if (bq >= 0) reads.push_back(bq);
-        const std::string what = "QAttention " + op.m_name;
-        P.add_step(what, reads, {y}, [=, this] {
-            osg_qattn_args a{};
-            a.x = P.ptr(x); a.ldx = C;
-            a.gamma = P.ptr(g); a.beta = P.ptr(b); a.eps = eps;
-            a.wq = P.ptr(wq); a.bq = bq >= 0 ? P.ptr(bq) : nullptr;
-            a.kp = (const char*)P.ptr(pack) + koff * 2;
-            a.vtp = (const char*)a.kp + each * 2;
-            a.scale = scale; a.Tk = (int)Tk;
-            a.out = P.ptr(y); a.ldo = C;
-            a.M = (int)M; a.rows_per_img = (int)T; a.C = (int)C; a.heads = (int)heads;
-            {   // (workgroups of different heads read the same rows of x while others already store their columns of the output: the two must not share memory)
-                const char *xb = (const char*)a.x, *yb = (const char*)a.out, *pb = (const char*)P.ptr(pack);
-                const size_t nbytes = (size_t)M * C * 2, pbytes = P.val_bytes(pack);
-                if ((xb < yb + nbytes && yb < xb + nbytes) || (pb < yb + nbytes && yb < pb + pbytes)) throw std::runtime_error(what + ": output overlaps an operand (arena packing)");
-            }
-            be.check(be.api.osg_qattn(be.ctx, &a), what.c_str());
-        });
-        P.steps.back().flops = 2.0 * M * C * C + 4.0 * nb * heads * T * Tk * (C / heads);
     }
 
     // ScaledDotProductAttention (reference :7767-7882): q [B,Hq,T,D], k [B,Hkv,S,D], mask [T,S] | [1,1,T,S], v [B,Hkv,S,Dv] -> [B,Hq,T,Dv]

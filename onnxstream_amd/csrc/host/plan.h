@@ -269,7 +269,6 @@ struct Plan {
     bool fuse_ln_gemm = false;
     bool concat_views = true;     // m_hip_concat_views
     bool fuse_tblock = true;      // m_hip_fuse_tblock
-    bool fuse_qattn = true;       // m_hip_fuse_qattn
     bool in_flight = false;       // a pass of this plan may still be running on the device (set while execute() / replay() are between enqueue and wait)
     bool gn_stats_on = false;
     int gn_stats_req = 2;          // m_hip_gn_stats as requested (0 off, 1 all eligible, 2 large tensors only)

@@ -28,9 +28,20 @@ static void load_locked() {
                   &k.sh, &k.sw, &k.flags, &c.family, &c.cfg, &c.nst, &c.splits, &c.bn, &c.us) == 19) {
         // a row that names no launchable configuration is dropped (the launchers would silently fall back to another tile, or divide by
         // splits == 0); the device ordinal is not part of the identity of a shape -- one table serves every rank of a node
-        const int tile = c.cfg & 7, ks2 = c.cfg & 8;   /* bit 3 of cfg: KS = 2 (64x64 with 2 / 4 stages, 128x64 with 2) */
-        const bool ok = c.family == 0 ? (c.cfg >= 0 && tile <= 3 && (c.cfg & ~31) == 0 && (!(c.cfg & 16) || (!ks2 && tile != 0 && c.splits >= 2 && c.splits <= 4))   /* bit 4: split-K folded in the kernel */ && (!ks2 || (tile == 2 && (c.nst == 2 || c.nst == 4)) || (tile == 1 && c.nst == 2)) && (c.nst == 2 || c.nst == 4 || (c.nst == 6 && tile >= 1) || (c.nst == 8 && tile == 2))   /* = the instantiations of launch_v2_choice (osg_gemm.hip): no 128x128 6-stage ring */ && c.splits >= 1 && c.splits <= 64)
-                                      : (c.family == 1 && (c.cfg == 0 || (c.cfg == 16 && c.splits >= 2 && c.splits <= 4)) && (c.bn == 80 || c.bn == 128 || c.bn == 160) && c.splits >= 1 && c.splits <= 64 && (c.nst == 0 || c.nst == 4 || c.nst == 8));   /* nst of a halo-convolution row = its loader waves */
+        const int tile = c.cfg & 7, ks2 = c.cfg & 8, fold = c.cfg & 16, spec = c.cfg & 32;   /* bit 3 of cfg: KS = 2 (64x64 with 2 / 4 stages, 128x64 with 2); bit 4: split-K folded in the kernel; bit 5: four loader waves */
+        bool ok;
+        if (c.family == 0) {
+            ok = c.cfg >= 0 && (c.cfg & ~63) == 0 && c.splits >= 1 && c.splits <= 64;
+            ok = ok && (!spec || ((tile == 0 || tile == 4) && c.nst == 4 && !ks2 && !fold && c.splits == 1));
+            ok = ok && (!fold || (!ks2 && tile != 0 && tile != 4 && tile != 7 && c.splits >= 2 && c.splits <= 4));
+            ok = ok && (!ks2 || (tile == 2 && (c.nst == 2 || c.nst == 4)) || (tile == 1 && c.nst == 2));
+            // = the instantiations of launch_v2_choice (osg_gemm.hip): no 128x128 6-stage ring; tiles 4 .. 7 (round 6, osg_gemm_wide.hip): rings of 2 / 4, 6 for 64x80
+            if (tile <= 3) ok = ok && (c.nst == 2 || c.nst == 4 || (c.nst == 6 && tile >= 1) || (c.nst == 8 && tile == 2));
+            else ok = ok && (c.nst == 2 || c.nst == 4 || (c.nst == 6 && tile == 6));
+        } else {
+            ok = c.family == 1 && (c.cfg == 0 || (c.cfg == 16 && c.splits >= 2 && c.splits <= 4)) && (c.bn == 80 || c.bn == 128 || c.bn == 160) && c.splits >= 1 && c.splits <= 64 &&
+                 (c.nst == 0 || c.nst == 4 || c.nst == 8);   /* nst of a halo-convolution row = its loader waves */
+        }
         k.device = 0;
         if (ok && k.M > 0 && k.N > 0 && k.K > 0 && k.batch > 0) g_table[k] = c;
     }

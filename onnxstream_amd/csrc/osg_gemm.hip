@@ -213,308 +213,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     gemm_epilogue<TM, TN>(p, acc, m0, n0, wm0, wn0, lane, zb, (int)blockIdx.z);
 }
 
-// =====================================================================================================================
-// v2: direct-to-LDS pipelined kernel (the hot one).  Requirements: K % 64 == 0 (conv: Cin % 64 == 0), 16-byte aligned rows.
-//   * both operands stream HBM/L2 -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR staging, no ds_write pass); the
-//     buffer descriptor's bounds check zero-fills M/N tails AND the convolution halo (out-of-image taps get an
-//     out-of-range offset), so the inner loop has no predication at all.
-//   * BK = 64: one tile row = 128 B = 8 x 16-B chunks; chunk c of row r lives at slot c ^ (r & 7) (XOR swizzle applied
-//     on the per-lane SOURCE address, LDS image stays lane-linear as the DMA requires) => conflict-free ds_read_b128.
-//   * NST-deep LDS ring, counted `s_waitcnt vmcnt(N)` (never 0 in the loop), ONE raw s_barrier per k-tile; one workgroup
-//     per CU owns up to 128 KiB of the 160 KiB LDS: with grids of ~1 tile per CU the latency hiding has to come from the
-//     depth of the ring, not from co-resident blocks.
-//   * XCD-aware tile walk: the 1-D grid is remapped so each of the 8 XCDs (private L2) gets a CONTIGUOUS run of tiles,
-//     ordered so that the operand with more unique bytes is split across XCDs and read from HBM once.
-// SPEC = 1: 512 threads -- waves 4..7 only issue the DMA loads, waves 0..3 only do ds_read + MFMA + epilogue (see osg_conv3x3.hip)
-// LN = 1: LayerNorm over K folded in, row statistics accumulated beside the MFMAs; LN = 2: ... row statistics emitted by the producer of A
-// (rs_in), prefetched into registers before the first tile is requested and combined right before the epilogue
-// KS = 2 (round 3): 512 threads = TWO groups of four waves, each group a complete copy of the 2x2 wave layout with its own LDS tiles; group g takes the
-// k-tiles g, g + 2, g + 4, ... and the two partial accumulators are added through LDS before the (unchanged) epilogue, which group 0 runs.  A launch of
-// the UNet pass lasts as long as one workgroup, and a workgroup's k loop is bound by what ONE wave per SIMD can issue per k-tile (4 x 1 KiB DMA requests
-// at ~100+ cycles each, 8 ds_read, 8 MFMA: ~700 cycles for 136 cycles of matrix work at 64 x 64); with two waves per SIMD on different k-tiles the loop
-// has half the steps and the SIMD always has a second instruction stream to issue from.  The fp32 sum is (even tiles) + (odd tiles): same value class as
-// a 2-way split-K, not the bits of the KS = 1 kernel.
-template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0, int LN = 0, int NCH = 5, int KS = 1>
-__global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(GemmParams p) {
-    static_assert(KS == 1 || (KS == 2 && !SPEC && MODE == 0 && LN != 1), "KS = 2: plain kernel only (row statistics come from the producer, LN = 2, or not at all)");
-    constexpr int ROWB = 128;                       // bytes per tile row (BK = 64 halves)
-    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, GSTAGE = A_BYTES + B_BYTES, STAGE = KS * GSTAGE;
-    constexpr int A_LD = BM / 32, B_LD = BN / 32;   // 1-KiB wave-loads per wave per k-tile
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-    constexpr int INFLIGHT = (NST - 2) * (A_LD + B_LD);
-    constexpr unsigned OOB = 0x80000000u;
-    static_assert(INFLIGHT <= 63, "vmcnt is a 6-bit counter");
-
-    extern __shared__ __attribute__((aligned(16))) char smem2[];
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-
-    kdbg_stamp(p, 0);
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = SPEC && wave8 >= 4, math = !SPEC || wave8 < 4;
-    const bool loads = !SPEC || loader;
-    const int wave = wave8 & 3;
-    const int grp = KS == 2 ? (wave8 >> 2) : 0;     // k-tile parity this wave works on
-    const int wm0 = (wave >> 1) * WM;
-    const int wn0 = (wave & 1) * WN;
-
-    // ---- XCD-aware bijective remap of the flat grid -------------------------------------------------------------------
-    const int total = gridDim.x;
-    int L;
-    {
-        const int bid = blockIdx.x, x = bid & 7, i = bid >> 3, q = total >> 3, r = total & 7;
-        L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-    }
-    const int per_batch = p.mt * p.nt * p.splits;
-    int zb, m_tile, n_tile, zs;
-    {
-        zb = L / per_batch;
-        int rem = L - zb * per_batch;
-        if (p.n_major) {
-            n_tile = rem / (p.splits * p.mt); rem -= n_tile * p.splits * p.mt;
-            zs = rem / p.mt; m_tile = rem - zs * p.mt;
-        } else {
-            m_tile = rem / (p.splits * p.nt); rem -= m_tile * p.splits * p.nt;
-            zs = rem / p.nt; n_tile = rem - zs * p.nt;
-        }
-    }
-    const int m0 = m_tile * BM, n0 = n_tile * BN;
-    const int kbeg = zs * p.k_per_split;
-    const int kend = min(p.K, kbeg + p.k_per_split);
-    const int nkt = (kend - kbeg) >> 6;
-    const int nsteps = (nkt + KS - 1) / KS;         // (KS = 2: group 1 may run one dummy, zero-filled tile at the end)
-
-    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long)zb * p.strideA), 0, p.a_bytes, 0x00020000);
-    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Bt + (long)zb * p.strideB), 0, p.b_bytes, 0x00020000);
-
-    // ---- per-lane source addressing (constant over the k loop) -------------------------------------------------------------
-    const int rsub = lane >> 3;                     // row inside the 8-row group one wave-load covers
-    const int gch = (lane & 7) ^ rsub;              // global chunk this lane fetches into LDS slot (lane & 7)
-    int a_base[A_LD];                               // byte offset (conv: of tap (0,0); may be negative)
-    int a_hi0[A_LD], a_wi0[A_LD];
-#pragma unroll
-    for (int j = 0; j < A_LD; j++) {
-        const int m = m0 + (j * 4 + wave) * 8 + rsub;
-        if (CONV) {
-            const int mm = m < p.M ? m : 0;
-            const int hw = p.Ho * p.Wo;
-            const int n_img = mm / hw;
-            const int r2 = mm - n_img * hw;
-            const int ho = r2 / p.Wo, wo = r2 - ho * p.Wo;
-            a_hi0[j] = m < p.M ? ho * p.sh - p.pt : -0x40000000;
-            a_wi0[j] = wo * p.sw - p.pl;
-            a_base[j] = (((n_img * p.H + (ho * p.sh - p.pt)) * p.W + (wo * p.sw - p.pl)) * p.Cin + gch * 8) * 2;
-        } else {
-            a_base[j] = m < p.M ? (int)(((long)m * p.lda + gch * 8) * 2) : (int)OOB;
-            a_hi0[j] = a_wi0[j] = 0;
-        }
-    }
-    int b_base[B_LD];
-#pragma unroll
-    for (int j = 0; j < B_LD; j++) {
-        const int n = n0 + (j * 4 + wave) * 8 + rsub;
-        b_base[j] = n < p.N ? (int)(((long)n * p.K + gch * 8) * 2) : (int)OOB;
-    }
-
-    // running position of the NEXT tile to issue (conv: decomposed into tap + channel offset, updated incrementally)
-    int ik = kbeg + 64 * grp, i_c0 = 0, i_kh = 0, i_kw = 0;
-    if (CONV) {
-        const int cell = ik / p.Cin;
-        i_c0 = ik - cell * p.Cin;
-        i_kh = cell / p.KW;
-        i_kw = cell - i_kh * p.KW;
-    }
-    auto issue_tile = [&](int stage) {
-        char* As = smem2 + stage * STAGE + grp * GSTAGE;
-        char* Bs = As + A_BYTES;
-        const bool live = ik < kend;
-        const unsigned kill = live ? 0u : OOB;      // past the last k-tile: dummy (zero-filling) loads keep vmcnt uniform
-        if (CONV) {
-            const int tap_off = ((i_kh * p.W + i_kw) * p.Cin + i_c0) * 2;
-#pragma unroll
-            for (int j = 0; j < A_LD; j++) {
-                const int hi = a_hi0[j] + i_kh, wi = a_wi0[j] + i_kw;
-                const bool ok = live && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                const unsigned off = ok ? (unsigned)(a_base[j] + tap_off) : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(As + (j * 4 + wave) * 1024), 16, off, 0, 0, 0);
-            }
-#pragma unroll
-            for (int adv = 0; adv < KS; adv++) {
-                i_c0 += 64;
-                if (i_c0 >= p.Cin) { i_c0 = 0; if (++i_kw == p.KW) { i_kw = 0; ++i_kh; } }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < A_LD; j++)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(As + (j * 4 + wave) * 1024), 16, (unsigned)a_base[j] | kill, ik * 2, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < B_LD; j++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(Bs + (j * 4 + wave) * 1024), 16, (unsigned)b_base[j] | kill, ik * 2, 0, 0);
-        ik += 64 * KS;
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // fragment read addressing: row = lane & 15, k-chunk = (lane >> 4) (+4 for the second 32-deep half)
-    const int frow = lane & 15;
-    const int fsw = (((lane >> 4) ^ (frow & 7)) << 4);
-    const int a_rd = (wm0 + frow) * ROWB + fsw;
-    const int b_rd = A_BYTES + (wn0 + frow) * ROWB + fsw;
-
-    // LN == 2: the producer's partial row statistics, [M][rs_np][2] floats = rs_np/2 16-byte chunks per row.  Lane l of a wave owns row
-    // (l & 15) + 16 ((l >> 4) % TM) of the wave's rows and requests ALL chunks of that row -- BEFORE the first tile (vector-memory
-    // results return in order: they are home by the time tile 0 is, at no extra wait).  NCH = chunks per row (template: K <= 64 NCH).
-    f32x4 pst[LN == 2 ? NCH : 1];
-    if constexpr (LN == 2) {
-        const int m = min(m0 + wm0 + (lane & 15) + 16 * ((lane >> 4) % TM), p.M - 1);
-        const float* src = p.rs_in + (long)m * p.rs_np * 2;
-        const int nch = p.rs_np >> 1;
-#pragma unroll
-        for (int c = 0; c < NCH; c++)   // unconditional, clamped (a predicated load makes the compiler wait for it on the spot); masked when consumed
-            pst[c] = *reinterpret_cast<const f32x4*>(src + 4 * min(c, nch - 1));
-        asm volatile("" ::: "memory");
-    }
-
-    // epilogue operands of this wave's outputs: requested now, home by the end of the k loop (osg_gemm_common.h epi_prefetch).  They are OLDER than
-    // every tile load in the wave's in-order vector-memory queue, so the counted waits of the loop cover them.
-    constexpr bool EPRE = TM * TN <= 8;    // (64x64 / 128x64 / 64x128 tiles; the 128x128 tile keeps its on-demand loads: no registers to spare)
-    EpiOps<TM, TN, CONV, EPRE> epre;
-    epre.have = false;
-    if (math && !p.ln_c1 && grp == 0) epi_prefetch<TM, TN, CONV, EPRE>(p, epre, m0, n0, wm0, wn0, lane, zb);
-    if (loads) {
-#pragma unroll
-        for (int s2 = 0; s2 < NST - 1; s2++) issue_tile(s2);
-    }
-    kdbg_stamp(p, 1);
-
-    float ls[TM], lq[TM];          // LN: running row sums / sums of squares of this lane's rows (see ln_accumulate)
-#pragma unroll
-    for (int i = 0; i < TM; i++) ls[i] = lq[i] = 0.f;
-
-    int cur = 0, nxt = NST - 1;
-    for (int kt = 0; kt < nsteps; kt++) {
-        if (loads) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");   // my share of tile kt has landed
-        __builtin_amdgcn_s_barrier();                                      // everyone's has; tile kt-1's buffer is free
-        if (kt == 0) kdbg_stamp(p, 2);
-        if (loads) issue_tile(nxt);
-        const char* St = smem2 + cur * STAGE + grp * GSTAGE;
-        // (round 3: a pinned order -- half 0's MFMAs with half 1's fragment reads between them, half 1's with the next tile's DMA requests -- was measured
-        // against hipcc's own "all reads + requests, wait, all MFMAs": no difference in the k loop of any shape, profiles/r03_interleave_ab.txt; not kept)
-        if (math)
-#pragma unroll
-        for (int ks = 0; ks < (MODE == 1 ? 0 : 2); ks++) {
-            f16x8 a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; i++) a[i] = *reinterpret_cast<const f16x8*>(St + ((a_rd + i * 16 * ROWB) ^ (ks << 6)));
-#pragma unroll
-            for (int j = 0; j < TN; j++) b[j] = *reinterpret_cast<const f16x8*>(St + ((b_rd + j * 16 * ROWB) ^ (ks << 6)));
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j], a[i], acc[i][j], 0, 0, 0);
-            if constexpr (LN == 1) ln_accumulate<TM>(a, ls, lq);
-        }
-        cur = cur + 1 == NST ? 0 : cur + 1;
-        nxt = nxt + 1 == NST ? 0 : nxt + 1;
-    }
-    kdbg_stamp(p, 3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the dummy tail loads before the LDS is released
-    if (loader) return;
-    if constexpr (KS == 2) {
-        // group 1 hands its partial accumulators (and, LN = 1, its partial row sums) to group 0 through the LDS the ring no longer needs
-        __builtin_amdgcn_s_barrier();                    // every wave is done reading tiles, no DMA is in flight
-        f32x4* red = reinterpret_cast<f32x4*>(smem2) + (wave * (TM * TN + 1)) * 64 + lane;
-        if (grp == 1) {
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++) red[(i * TN + j) * 64] = acc[i][j];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (a bare s_barrier does not wait for the LDS writes above: osg_tchain.hip lds_barrier)
-        __builtin_amdgcn_s_barrier();
-        if (grp == 1) return;
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++) acc[i][j] += red[(i * TN + j) * 64];
-    }
-    if constexpr (LN == 2) {
-        const int nch = p.rs_np >> 1;
-        float S = 0.f, Q = 0.f;
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            // (the empty asm pins the additions AFTER the k loop: hoisted, they would wait for the prefetch before the first tile request)
-            asm volatile("" : "+v"(pst[c]));
-            if (c < nch) { S += pst[c][0] + pst[c][2]; Q += pst[c][1] + pst[c][3]; }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; i++) {   // row (lane & 15) + 16 i lives in lane (lane & 15) + 16 i
-            ls[i] = __shfl(S, (lane & 15) + 16 * i, 64);
-            lq[i] = __shfl(Q, (lane & 15) + 16 * i, 64);
-        }
-    }
-    if constexpr (LN != 0) ln_apply<TM, TN, LN == 1>(p, acc, ls, lq, n0, wn0, lane);
-    if (p.act == OSG_ACT_GEGLU) {
-        if constexpr (TN % 2 == 0) gemm_epilogue_geglu<TM, TN>(p, acc, m0, n0, wm0, wn0, lane, zb);
-        return;
-    }
-    kdbg_stamp(p, 4);
-    float* stat_lds = nullptr;
-    if (p.sink[0].table || p.sink[1].table) {   // (launch_v2 leaves the sinks set only where this epilogue can serve them: one k-slice, 4-aligned shapes)
-        __builtin_amdgcn_s_barrier();           // every wave is done with the ring: its first bytes become the waves' staging areas
-        stat_lds = reinterpret_cast<float*>(smem2) + wave * (WN * 2);
-    }
-    if constexpr (KS == 1 && !SPEC && LN == 0 && MODE == 0) {
-        if (p.splits > 1 && p.fold_acc) {
-            // split-K, folded by the last workgroup to arrive at the tile (osg_gemm_common.h splitk_fold_acc): it then runs the fused epilogue of an unsplit launch
-            if (!splitk_fold_acc<TM, TN>(p, acc, (zb * p.mt + m_tile) * p.nt + n_tile, zs, reinterpret_cast<int*>(smem2), tid)) return;
-            EpiOps<TM, TN, CONV, false> none;
-            none.have = false;
-            gemm_epilogue_fast<TM, TN, CONV, false>(p, acc, m0, n0, wm0, wn0, lane, zb, none, nullptr);
-            return;
-        }
-    }
-    gemm_epilogue<TM, TN, CONV, EPRE>(p, acc, m0, n0, wm0, wn0, lane, zb, zb * p.splits + zs, epre, stat_lds);
-    kdbg_stamp(p, 5);
-    if (p.kdbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); kdbg_stamp(p, 6); }
-}
-
-template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0, int LN = 0, int NCH = 5, int KS = 1>
-int launch_v2(osg_ctx* ctx, GemmParams& p, int batch) {
-    constexpr size_t smem = (size_t)NST * KS * (BM + BN) * 128;
-    static_assert(smem <= 160 * 1024, "LDS budget");
-    static_assert(KS == 1 || (size_t)4 * ((BM / 32) * (BN / 32) + 1) * 1024 <= smem, "KS = 2: the accumulator hand-over must fit the ring");
-    auto kern = gemm2_kernel<BM, BN, NST, CONV, MODE, SPEC, LN, NCH, KS>;
-    static unsigned long long attr_mask = 0;   // (per device: hipFuncSetAttribute is, and a process may hold several)
-    if (osg_first_on_device(attr_mask)) {
-        OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    }
-    p.mt = (p.M + BM - 1) / BM;
-    p.nt = (p.N + BN - 1) / BN;
-    if (KS == 2 || SPEC || LN != 0 || MODE != 0) p.fold_acc = 0;   // (the in-kernel split-K fold is the plain kernel's: a 256-thread protocol)
-    dim3 grid((unsigned)(p.mt * p.nt * batch * p.splits));
-    p.no_epre = osg_mm::no_epi_prefetch();
-    p.kdbg = kdbg_buffer(ctx, grid.x);
-    const osg_mm::StatSink sinks_in[2] = {p.sink[0], p.sink[1]};     // (p is the caller's: a reduce launch that follows still wants them)
-    if (p.sink[0].table || p.sink[1].table) {
-        // GroupNorm statistics from this launch's epilogue (StatSink): only the real launch of a pass (not the tuner's repetitions), one k-slice, the compact
-        // epilogue, whole tiles inside one image; otherwise the caller's follow-up launch computes them (osg_conv2d_nhwc_v)
-        const bool ok = !ctx->tuning && p.splits == 1 && batch == 1 && MODE == 0 && LN == 0 && !SPEC && p.act != OSG_ACT_GEGLU && (p.N & 3) == 0 && ((p.ldc | p.ldc2) & 3) == 0 &&
-                        p.sink_hw > 0 && p.sink_hw % BM == 0 && p.M % p.sink_hw == 0;
-        if (ok) { ctx->sink_fused = true; p.sink_imgs = p.M / p.sink_hw; p.sink_per_xcd = ctx->xcd_ids8 ? 1 : 0; }
-        else p.sink[0].table = p.sink[1].table = nullptr;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3((SPEC || KS == 2) ? 512 : 256), smem, ctx->compute, p);
-    p.sink[0] = sinks_in[0]; p.sink[1] = sinks_in[1];
-    OSG_LAUNCH_CHECK(ctx);
-    return 0;
-}
+}  // namespace
+#include "osg_gemm2.h"
+namespace {
 
 // The SD / SDXL conv_in and the VAE decoder's first convolution (3x3, Cin = 4: K = 36) on the matrix cores: the vector kernel this replaced (round 4) spent 288 FMAs + 288
 // f16 -> f32 conversions per (pixel, 8 channels) and took 31 us for 0.2 GFLOP at 2 x 64 x 64 -> 320 (profiles/r04_breakdown_tail_v4_fastbox.txt), a
@@ -688,22 +389,29 @@ int launch_cfg(osg_ctx* ctx, const GemmParams& p, int batch) {
 // and bounds every configuration (a 128x128x64 k-tile moves 32 KiB for 515 MFMA cycles), so the model is: k-tile time =
 // max(MFMA, bytes / 23) (+ ~450 exposed cycles when a block is alone on its CU), whole rounds of tiles over the CU slots,
 // a fixed fill + epilogue per round, and the extra pass of a split-K reduce.
-struct V2Choice { int cfg, nst, splits, ks = 1, fold = 0; };   // ks = 2: two wave groups on alternating k-tiles (gemm2_kernel KS); fold: split-K finished by splitk_fold_acc (no reduce launch)
-static const int kV2BM[4] = {128, 128, 64, 64}, kV2BN[4] = {128, 64, 64, 128};   // (the 64x128 tile: measured candidate only)
+struct V2Choice { int cfg, nst, splits, ks = 1, fold = 0, spec = 0; };   // ks = 2: two wave groups on alternating k-tiles (gemm2_kernel KS); fold: split-K finished by splitk_fold_acc (no reduce launch); spec: 4 loader waves beside the 4 math waves (gemm2_kernel SPEC; round 6: the 128x128 and 128x160 tiles with a 4-stage ring)
+static const int kV2BM[8] = {128, 128, 64, 64, 128, 128, 64, 64}, kV2BN[8] = {128, 64, 64, 128, 160, 80, 80, 160};   // (64x128 and the round-6 tiles 4 .. 7 of osg_gemm_wide.hip: measured candidates only)
 // every legal (tile, stages, splits) with its modelled cost in cycles, cheapest first
-static std::vector<std::pair<double, V2Choice>> rank_v2(const osg_ctx* ctx, int M, int N, int K, int batch, bool allow_split) {
+struct V2Form { bool conv = false, ln1 = false, ln2 = false, geglu = false, rowstats = false; };   // what the launch needs of an instantiation (the round-6 tiles hold a subset)
+static std::vector<std::pair<double, V2Choice>> rank_v2(const osg_ctx* ctx, int M, int N, int K, int batch, bool allow_split, V2Form form = V2Form{}) {
     const double cus = ctx->num_cu;
     const int kt = K / 64;
     std::vector<std::pair<double, V2Choice>> out;
-    for (int c = 0; c < (ctx->autotune ? 4 : 3); c++)
+    static const bool no_wide = getenv("OSG_TUNE_NO_WIDE") != nullptr;   // (A/B runs: the candidate set of round 5)
+    for (int c = 0; c < (ctx->autotune ? (no_wide ? 4 : 8) : 3); c++)
         for (int nst = 8; nst >= 2; nst -= 2) {
             // 6 / 8 stages (every tile of a short-K GEMM in flight at once): only as a measured candidate, only where the ring fits the LDS
-            if (nst == 6 && (!ctx->autotune || c == 0)) continue;
-            if (nst == 8 && (!ctx->autotune || c != 2)) continue;
+            if (c < 4) {
+                if (nst == 6 && (!ctx->autotune || c == 0)) continue;
+                if (nst == 8 && (!ctx->autotune || c != 2)) continue;
+            } else if (!osg_mm::wide_tile_has(c, nst, form.conv, form.ln1, form.ln2, form.geglu, form.rowstats)) continue;
+            if (c >= 4 && N % 80 != 0) continue;              // (the 80 / 160-column tiles are for the widths they divide)
+            const int bnp = (kV2BN[c] + 31) / 32 * 32;
             const double tiles = (double)((M + kV2BM[c] - 1) / kV2BM[c]) * ((N + kV2BN[c] - 1) / kV2BN[c]) * batch;
             const double mfma = kV2BM[c] * kV2BN[c] * 128.0 / 4069.0;
             const double tload = (kV2BM[c] + kV2BN[c]) * 128.0 / 23.0;
-            const int smem = nst * (kV2BM[c] + kV2BN[c]) * 128;
+            const int smem = nst * (kV2BM[c] + bnp) * 128;
+            if (smem > 160 * 1024) continue;
             const int bpc = std::min(4, 163840 / smem);
             for (int s = 1; s <= (allow_split ? 16 : 1); s++) {
                 if (s > 1 && (kt / s < (ctx->autotune ? 3 : 8))) break;   // measured choice: let shorter slices compete too
@@ -716,11 +424,15 @@ static std::vector<std::pair<double, V2Choice>> rank_v2(const osg_ctx* ctx, int 
                 double cost = rounds * (kts * tk + 3500.0);
                 if (s > 1) cost += 9000.0 + (double)M * N * batch * s * 4.0 / 2000.0;   // reduce launch (measured ~4-7 us) + slab traffic
                 out.push_back({cost, V2Choice{c, nst, s}});
+                // (measured candidates only, round 6) the one-workgroup-per-CU tiles with their DMA requests issued by four LOADER waves: a wave that issues both
+                // stalls ~70-100 cycles per request (the CU's address path takes 1 KiB per ~17 cycles and the four waves queue on it) with its MFMAs behind them
+                static const bool no_spec = getenv("OSG_TUNE_NO_SPEC") != nullptr;   // (A/B runs)
+                if (ctx->autotune && !no_spec && !no_wide && (c == 0 || c == 4) && nst == 4 && s == 1 && !form.conv && !form.ln1) out.push_back({cost * 0.9995, V2Choice{c, nst, s, 1, 0, 1}});
                 // KS = 2 (measured candidates only): the 64x64 tile with a 2- or 4-stage ring, the 128x64 tile with 2 stages (what the 160 KiB hold), >= 2 k-tiles per slice
                 static const bool no_ks2 = getenv("OSG_TUNE_NO_KS2") != nullptr;   // (A/B runs)
                 if (ctx->autotune && !no_ks2 && kts >= 2 && ((c == 2 && (nst == 2 || nst == 4)) || (c == 1 && nst == 2))) out.push_back({cost * 0.999, V2Choice{c, nst, s, 2}});
-                // (measured candidates only) 2 .. 4 slices folded by the last arriver of each tile instead of a reduce launch: the tiles of at most 8 accumulator quads per lane
-                if (ctx->autotune && s >= 2 && s <= 4 && c != 0 && osg_mm::splitk_fold_mode() != 0) out.push_back({cost * 1.0005, V2Choice{c, nst, s, 1, 1}});
+                // (measured candidates only) 2 .. 4 slices folded by the last arriver of each tile instead of a reduce launch: the tiles of at most 10 accumulator quads per lane
+                if (ctx->autotune && s >= 2 && s <= 4 && c != 0 && c != 4 && c != 7 && osg_mm::splitk_fold_mode() != 0) out.push_back({cost * 1.0005, V2Choice{c, nst, s, 1, 1}});
             }
         }
     std::stable_sort(out.begin(), out.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
@@ -753,7 +465,7 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
     p.fold_acc = 0;
     if (p.splits > 1) {
         size_t need = (size_t)batch * p.splits * p.M * p.N * sizeof(float);
-        if (ch.fold && ch.ks == 1 && ch.cfg != 0) {
+        if (ch.fold && ch.ks == 1 && ch.cfg != 0 && ch.cfg != 4 && ch.cfg != 7) {
             // finished inside the kernel by the last k-slice workgroup of each tile (osg_gemm_common.h splitk_fold_acc); the launch falls back to the reduce
             // launch where the fold does not apply
             const long n_tiles = (long)batch * ((p.M + kV2BM[ch.cfg] - 1) / kV2BM[ch.cfg]) * ((p.N + kV2BN[ch.cfg] - 1) / kV2BN[ch.cfg]);
@@ -766,6 +478,16 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
     const double a_unique = CONV ? (double)p.a_bytes : (double)p.M * p.K * 2.0;
     p.n_major = (double)p.N * p.K * 2.0 > a_unique;
     int rc;
+    if (ch.cfg >= 4) {   // the round-6 tiles (osg_gemm_wide.hip); a form they do not hold falls back to the 64x64 / 128x128 tile of the same ring
+        rc = osg_mm::launch_v2_wide(ctx, p, batch, ch.cfg, ch.nst, CONV, ch.spec);
+        if (rc != -2) {
+            if (rc) return rc;
+            if (p.splits > 1 && !p.fold_acc) return launch_splitk_reduce(ctx, p, batch);
+            return 0;
+        }
+        ch.cfg = kV2BM[ch.cfg] == 128 ? 0 : 2; ch.nst = ch.nst == 2 ? 2 : 4; ch.ks = 1; ch.spec = 0;
+        if (p.fold_acc && ch.cfg == 0) p.fold_acc = 0;
+    }
     if (p.ln_c1 && ch.cfg == 3) ch.cfg = 2;   // (the folded-LayerNorm variants exist for the first three tiles only)
     if (ch.ks == 2 && (ch.cfg == 1 || ch.cfg == 2) && !(p.ln_c1 && !p.rs_in)) {
         // two wave groups on alternating k-tiles: 64x64 (2- or 4-stage ring) and 128x64 (2 stages)
@@ -790,6 +512,18 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
         return 0;
     }
     if constexpr (!CONV) {
+        if (ch.spec && ch.cfg == 0 && ch.nst == 4 && !(p.ln_c1 && !p.rs_in)) {   // 128x128, four loader waves (round 6)
+            p.fold_acc = 0;
+            if (p.ln_c1) {
+                const int nch = p.rs_np >> 1;
+                if (nch <= 5) rc = launch_v2<128, 128, 4, false, 0, 1, 2, 5>(ctx, p, batch);
+                else if (nch <= 10) rc = launch_v2<128, 128, 4, false, 0, 1, 2, 10>(ctx, p, batch);
+                else rc = launch_v2<128, 128, 4, false, 0, 1, 2, 20>(ctx, p, batch);
+            } else rc = launch_v2<128, 128, 4, false, 0, 1>(ctx, p, batch);
+            if (rc) return rc;
+            if (p.splits > 1) return launch_splitk_reduce(ctx, p, batch);
+            return 0;
+        }
         if (p.ln_c1 && p.rs_in) {   // LayerNorm folded into the GEMM, row statistics handed over by the producer of A
             const int nch = p.rs_np >> 1;
 #define OSG_LN2(NCH_)                                                                                                                                \
@@ -824,16 +558,18 @@ template <bool CONV>
 int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced) {
     const bool allow_split = p.act != OSG_ACT_GEGLU && !p.ln_c1 && !p.rs_out;   // GEGLU pairing / folded LayerNorm / row statistics live in the tile epilogue
     V2Choice ch;
-    const bool env_forced = getenv("OSG_GEMM_CFG") || getenv("OSG_GEMM_SPLITS") || getenv("OSG_GEMM_NST") || getenv("OSG_GEMM_KS") || getenv("OSG_GEMM_FOLD");
+    const bool env_forced = getenv("OSG_GEMM_CFG") || getenv("OSG_GEMM_SPLITS") || getenv("OSG_GEMM_NST") || getenv("OSG_GEMM_KS") || getenv("OSG_GEMM_FOLD") || getenv("OSG_GEMM_SPEC");
     if (forced) {
         ch = *forced;
     } else if (ctx->autotune && !env_forced) {
         const osg_tune::Key key = tune_key(ctx, CONV ? 2 : 0, p, batch);
         osg_tune::Choice tc;
         if (osg_tune::lookup(key, &tc)) {
-            ch = {tc.cfg & 7, tc.nst, tc.splits, (tc.cfg & 8) ? 2 : 1, (tc.cfg & 16) ? 1 : 0};
+            ch = {tc.cfg & 7, tc.nst, tc.splits, (tc.cfg & 8) ? 2 : 1, (tc.cfg & 16) ? 1 : 0, (tc.cfg & 32) ? 1 : 0};
         } else {
-            auto ranked = rank_v2(ctx, p.M, p.N, p.K, batch, allow_split);
+            V2Form form;
+            form.conv = CONV; form.ln1 = p.ln_c1 && !p.rs_in; form.ln2 = p.ln_c1 && p.rs_in; form.geglu = p.act == OSG_ACT_GEGLU; form.rowstats = p.rs_out != nullptr;
+            auto ranked = rank_v2(ctx, p.M, p.N, p.K, batch, allow_split, form);
             ch = ranked.empty() ? V2Choice{0, 4, 1} : ranked[0].second;
             if (!ctx->capturing && tune_safe(p) && !ranked.empty() && !osg_tune::frozen()) {
                 float best = -1.f;
@@ -841,13 +577,13 @@ int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced) {
                     const float us = osg_tune::time_us(ctx, [&] { return launch_v2_choice<CONV>(ctx, p, batch, cand.second); });
                     static const bool dump = getenv("OSG_TUNE_DUMP") != nullptr;
                     if (dump) fprintf(stderr, "[tune] %s M=%d N=%d K=%d flags=%d: tile %dx%d nst=%d splits=%d ks=%d -> %.2f us (model %.0f)\n", CONV ? "conv" : "gemm", p.M, p.N, p.K, key.flags,
-                                      kV2BM[cand.second.cfg], kV2BN[cand.second.cfg], cand.second.nst, cand.second.splits, cand.second.ks + 10 * cand.second.fold, us, cand.first);
+                                      kV2BM[cand.second.cfg], kV2BN[cand.second.cfg], cand.second.nst, cand.second.splits, cand.second.ks + 10 * cand.second.fold + 100 * cand.second.spec, us, cand.first);
                     if (us >= 0.f && (best < 0.f || us < best)) { best = us; ch = cand.second; }
                 }
                 if (best < 0.f) OSG_FAIL(ctx, "osg_gemm: autotune could not time any configuration");
-                osg_tune::store(key, osg_tune::Choice{0, ch.cfg | (ch.ks == 2 ? 8 : 0) | (ch.fold ? 16 : 0), ch.nst, ch.splits, 0, best});
+                osg_tune::store(key, osg_tune::Choice{0, ch.cfg | (ch.ks == 2 ? 8 : 0) | (ch.fold ? 16 : 0) | (ch.spec ? 32 : 0), ch.nst, ch.splits, 0, best});
             } else if (osg_tune::frozen())
-                osg_tune::remember(key, osg_tune::Choice{0, ch.cfg | (ch.ks == 2 ? 8 : 0) | (ch.fold ? 16 : 0), ch.nst, ch.splits, 0, -1.f});
+                osg_tune::remember(key, osg_tune::Choice{0, ch.cfg | (ch.ks == 2 ? 8 : 0) | (ch.fold ? 16 : 0) | (ch.spec ? 32 : 0), ch.nst, ch.splits, 0, -1.f});
         }
     } else {
         ch = choose_v2(ctx, p.M, p.N, p.K, batch);
@@ -856,6 +592,7 @@ int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced) {
         if (!allow_split) ch.splits = 1;
         if (const char* e = getenv("OSG_GEMM_NST")) ch.nst = atoi(e);
         if (const char* e = getenv("OSG_GEMM_KS")) ch.ks = atoi(e) == 2 ? 2 : 1;
+        if (const char* e = getenv("OSG_GEMM_SPEC")) ch.spec = atoi(e) != 0;   // (tests / probes: four loader waves, tiles 0 and 4 with a 4-stage ring)
         if (const char* e = getenv("OSG_GEMM_FOLD")) ch.fold = atoi(e) != 0;   // (tests / probes: finish a forced split inside the kernel)
     }
     return launch_v2_choice<CONV>(ctx, p, batch, ch);
@@ -1239,7 +976,9 @@ static int conv2d_route(osg_ctx* ctx, GemmParams& p, int N, int Cin, int Cout, i
                             if (dump3) fprintf(stderr, "[tune] conv3x3 N*H*W=%d Cin=%d Cout=%d W=%d: halo bn=%d splits=%d loaders=%d -> %.2f us\n", p.M, p.Cin, p.N, p.W, c.second.first, c.second.second, nl, us);
                             if (us >= 0.f && (best < 0.f || us < best)) { best = us; tc = osg_tune::Choice{1, fold3 ? 16 : 0, nl, s3, c.second.first, us}; }
                         }
-                    auto r2 = rank_v2(ctx, p.M, p.N, p.K, 1, true);
+                    V2Form form3;
+                    form3.conv = true;
+                    auto r2 = rank_v2(ctx, p.M, p.N, p.K, 1, true, form3);
                     if (r2.size() > 6) r2.resize(6);
                     for (auto& c : r2) {
                         const V2Choice ch = c.second;

@@ -612,6 +612,9 @@ __device__ __forceinline__ bool splitk_fold_acc(const GemmParams& p, f32x4 (&acc
 }
 
 int launch_splitk_reduce(osg_ctx* ctx, const GemmParams& p, int batch);   // osg_gemm.hip
+// osg_gemm_wide.hip (round 6): tiles 4 .. 7 of the direct-to-LDS kernel -- 128 x 160, 128 x 80, 64 x 80, 64 x 160; -2 = no such instantiation
+int launch_v2_wide(osg_ctx* ctx, GemmParams& p, int batch, int tile, int nst, bool conv, int spec = 0);   // spec: four loader waves (tile 4, 4-stage ring)
+bool wide_tile_has(int tile, int nst, bool conv, bool ln1, bool ln2, bool geglu, bool rowstats);
 // the statistics a StatSink asks for, from the stored output (rows ldc apart) -- for the launches whose epilogue does not serve sinks (osg_norm.hip)
 int launch_colstats(osg_ctx* ctx, const f16* C, long ldc, int M, int N, int rows_per_image, const StatSink* sinks);
 long long* kdbg_buffer(osg_ctx* ctx, long workgroups);   // osg_ctx.hip: NULL unless OSG_KDBG is set

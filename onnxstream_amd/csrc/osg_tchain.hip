@@ -29,7 +29,6 @@
 // launches it replaced (profiles/r04_tblock_tail_v1_ab.txt), whatever the prefetch depth.
 // Numerics: f32 accumulation in the order of gemm2_kernel's one-slice form, one RNE rounding per reference op boundary that survives fusion level 2
 // (x1, LN, q, a2, x2, LN, h, x3, y), scores / probabilities in f32 as attn_kernel keeps them.
-// Second kernel of this file: qattn_kernel -- LayerNorm + attn2.to_q + cross-attention of the 640- / 1280-wide blocks, one workgroup per (32 rows, head); see there.
 // Every workgroup barrier of this file is lds_barrier() (s_waitcnt lgkmcnt(0) + s_barrier): a bare s_barrier does not wait for LDS writes on gfx950.
 #include "osg_common.h"
 
@@ -63,7 +62,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 
 // Workgroup barrier behind LDS writes.  A bare s_barrier does not wait for the wave's own outstanding LDS operations (gfx90a and later back off at barriers, so
 // hipcc inserts no s_waitcnt in front of one), and LDS requests of different SIMDs are not served in issue order: without the wait a wave past the barrier can
-// read what another wave has issued but the LDS has not yet written -- seen as run-to-run differences of osg_qattn at 10 heads of 64 on cold operands
+// read what another wave has issued but the LDS has not yet written -- seen as run-to-run differences of round 4's osg_qattn (removed in round 6) at 10 heads of 64 on cold operands
 // (profiles/r04_qattn_lds_barrier_race.txt).  lgkmcnt only: vector-memory requests (weight fragments in flight) are deliberately NOT waited for.
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -261,45 +260,6 @@ __device__ __forceinline__ void ln_rows(const char* X, char* P, const char* gamm
 #pragma unroll
         for (int e = 0; e < 8; e++) o[e] = (f16)((v[i][e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
         *reinterpret_cast<f16x8*>(P + (c >> 3) * kTileBytes<RT> + row * 128 + (((c & 7) ^ (row & 7)) << 4)) = o;
-    }
-}
-
-// the same LayerNorm for wide rows (C = 640 / 1280 in qattn_kernel): three passes over the row in LDS instead of the row's values held in registers
-// (C / 8 floats per lane would crowd out the weight fragments that are in flight at this point); in place
-template <int RT, int C>
-__device__ __forceinline__ void ln_rows_wide(char* X, const char* gamma, const char* beta, float eps, int tid) {
-    constexpr int NCH = C / 8, LPR = 16 / RT, PER = NCH / LPR;
-    static_assert(NCH % LPR == 0 && LPR == 8, "row chunks split over the lanes of a row");
-    const int row = tid / LPR, part = tid % LPR;
-    auto at = [&](int i) __attribute__((always_inline)) { const int c = part + LPR * i; return X + (c >> 3) * kTileBytes<RT> + row * 128 + (((c & 7) ^ (row & 7)) << 4); };
-    float s = 0.f;
-#pragma unroll 5
-    for (int i = 0; i < PER; i++) {
-        const f16x8 t = *reinterpret_cast<const f16x8*>(at(i));
-#pragma unroll
-        for (int e = 0; e < 8; e++) s += (float)t[e];
-    }
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-    const float mean = s / (float)C;
-    float q = 0.f;
-#pragma unroll 5
-    for (int i = 0; i < PER; i++) {
-        const f16x8 t = *reinterpret_cast<const f16x8*>(at(i));
-#pragma unroll
-        for (int e = 0; e < 8; e++) { const float d = (float)t[e] - mean; q += d * d; }
-    }
-    q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
-    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
-#pragma unroll 5
-    for (int i = 0; i < PER; i++) {
-        const int c = part + LPR * i;
-        const f16x8 t = *reinterpret_cast<const f16x8*>(at(i));
-        const f16x8 gm = *reinterpret_cast<const f16x8*>(gamma + c * 16);
-        const f16x8 bt = *reinterpret_cast<const f16x8*>(beta + c * 16);
-        f16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; e++) o[e] = (f16)(((float)t[e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
-        *reinterpret_cast<f16x8*>(at(i)) = o;
     }
 }
 
@@ -746,199 +706,6 @@ __global__ __launch_bounds__(256) void kn8_pack_kernel(const f16x8* __restrict__
 }
 
 
-// ---- cross-attention with its query projection inside (round 4): a2[:, head h] = softmax(scale (LayerNorm(x1) Wq_h^T) k_h^T) v_h -----------------------
-// At C = 640 / 1280 the tail above does not apply (a row block would stream 12 - 50 MB of weights), but the q projection of ONE head is a [rows x C] .
-// [C x D] contraction whose weight slice is 100 - 400 KB: one workgroup = 32 rows x one head.  x1's rows go to LDS once, LayerNorm runs on them in place,
-// the four waves split the contraction over k (each holds its k-steps' weight fragments in registers, requested before the rows arrive), the partial sums
-// meet in LDS, and two waves run the attention of their 16 rows against the K / V packs of osg_tblock_kv_pack.  Replaces two launches of 14 - 19 us and
-// 11 - 14 us (Linear with the LayerNorm fold, Attention) that each waited for one workgroup's worth of latency.
-struct QAttnParams {
-    const f16* x; long ldx;
-    const f16 *gamma, *beta; float eps;
-    const f16 *wq, *bq;
-    const f16 *kp, *vtp;
-    float sc_log2e; int Tk;
-    f16* out; long ldo;
-    int M, rows_per_img, heads;
-    f16* dbg_q;        // [M][C] dump of q (tests), may be NULL
-};
-
-template <int C, int D>
-__global__ __launch_bounds__(256) void qattn_kernel(QAttnParams p) {
-    constexpr int RT = 2, RB = 32, TB = kTileBytes<RT>, KT = C / 64, IMG = KT * TB;
-    constexpr int NT = D / 16;                 // 16-column tiles of q_h
-    constexpr int KSW = C / 32 / 4;            // 32-deep k-steps per wave
-    constexpr int PD = 5;                      // k-steps of weight fragments in flight per wave
-    constexpr int QT = (D + 63) / 64;          // k-tiles of the q image
-    constexpr int TKT = 5, DS = D / 16, TKP = TKT * 16;
-    static_assert(D % 16 == 0 && C % 128 == 0 && KSW % PD == 0 && 4 * RB * D * 4 <= IMG, "shape");
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* const XI = lds;                      // x1 rows -> LayerNorm in place -> (after the contraction) the four waves' partial sums
-    char* const QI = lds + IMG;                // q_h as an [32 x D] image
-    char* const VEC = QI + QT * TB;            // gamma, beta
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, g = lane >> 4;
-    const int h = blockIdx.y;
-    const long row0 = (long)blockIdx.x * RB;
-    const int img = (int)(row0 / p.rows_per_img);
-
-    // this wave's weight fragments: k-steps wave KSW .. + KSW - 1, rows h D + 16 j + l16 of the kn8 weight [C/8][C][8]
-    const __amdgpu_buffer_rsrc_t u_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wq, 0, C * C * 2, 0x00020000);
-    const unsigned lo = (unsigned)((g * C + h * D + l16) * 16);
-    constexpr int KSTEP = 4 * C * 16;          // bytes between 32-deep k-steps
-    f16x8 b[PD][NT];
-    auto request = [&](f16x8 (&bb)[NT], int s) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < NT; j++) bb[j] = ldb(u_w, lo, (wave * KSW + s) * KSTEP + j * 256);
-    };
-
-    // ---- the rows (LDS-DMA, swizzle on the source side) and the LayerNorm vectors FIRST, the first PD k-steps of weight fragments right behind them:
-    // vector-memory results return in order, so "all but the last PD NT requests have landed" = the rows are in LDS -- LayerNorm runs while the weights fly
-    {
-        __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + row0 * p.ldx), 0, (int)((RB - 1) * p.ldx * 2 + C * 2), 0x00020000);
-        const int rsub = lane >> 3, gch = (lane & 7) ^ rsub;
-#pragma unroll
-        for (int kt = 0; kt < KT; kt++) {
-            const int q8 = wave;                                            // 8-row group inside the tile (32 rows = 4 groups = 4 waves)
-            const unsigned off = (unsigned)(((q8 * 8 + rsub) * p.ldx + kt * 64 + gch * 8) * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr)(XI + kt * TB + q8 * 1024), 16, off, 0, 0, 0);
-        }
-        constexpr int NV = (2 * C / 8 + 255) / 256;
-        f16x8 vv[NV];
-#pragma unroll
-        for (int i = 0; i < NV; i++) {
-            const int c = min(tid + i * 256, 2 * C / 8 - 1);
-            vv[i] = *reinterpret_cast<const f16x8*>((c < C / 8 ? p.gamma + c * 8 : p.beta + (c - C / 8) * 8));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        static_for<PD>([&](auto sc) __attribute__((always_inline)) { request(b[decltype(sc)::value], decltype(sc)::value); });
-        __builtin_amdgcn_sched_barrier(0);
-        static_assert(PD * NT <= 63, "vmcnt");
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * NT) : "memory");
-#pragma unroll
-        for (int i = 0; i < NV; i++)
-            if (tid + i * 256 < 2 * C / 8) *reinterpret_cast<f16x8*>(VEC + (tid + i * 256) * 16) = vv[i];
-    }
-    lds_barrier();
-    ln_rows_wide<RT, C>(XI, VEC, VEC + C * 2, p.eps, tid);
-    lds_barrier();
-
-    // ---- partial q_h over this wave's k-steps ----------------------------------------------------------------------------------------------
-    f32x4 acc[RT][NT];
-    zero_acc(acc);
-    const int a_rd = l16 * 128 + ((g ^ (l16 & 7)) << 4);
-    static_for<KSW>([&](auto sc) __attribute__((always_inline)) {
-        constexpr int s = decltype(sc)::value;
-        const int ks = wave * KSW + s;                                      // global k-step: k-tile ks >> 1, half ks & 1
-        const char* At = XI + (ks >> 1) * TB;
-        f16x8 a[RT];
-#pragma unroll
-        for (int i = 0; i < RT; i++) a[i] = *reinterpret_cast<const f16x8*>(At + ((a_rd + i * 2048) ^ ((ks & 1) << 6)));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < NT; j++)
-#pragma unroll
-            for (int i = 0; i < RT; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[s % PD][j], a[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (s + PD < KSW) request(b[s % PD], s + PD);
-    });
-
-    // the attention waves' K / V fragments: requested now, they arrive while the partial sums are added up
-    const bool att = wave < RT;
-    f16x4 kf[TKT][DS], vf[DS][TKT];
-    {
-        const long per_head = (long)TKP * D;
-        const f16* kh = p.kp + ((long)img * p.heads + h) * per_head;
-        const f16* vh = p.vtp + ((long)img * p.heads + h) * per_head;
-        if (att) {
-#pragma unroll
-            for (int tt = 0; tt < TKT; tt++)
-#pragma unroll
-                for (int ds = 0; ds < DS; ds++) kf[tt][ds] = *reinterpret_cast<const f16x4*>(kh + (tt * 16 + l16) * D + ds * 16 + g * 4);
-#pragma unroll
-            for (int dt = 0; dt < DS; dt++)
-#pragma unroll
-                for (int tt = 0; tt < TKT; tt++) vf[dt][tt] = *reinterpret_cast<const f16x4*>(vh + (dt * 16 + l16) * TKP + tt * 16 + g * 4);
-        }
-    }
-    lds_barrier();              // every wave is past its last read of the rows
-    {
-        float* PS = reinterpret_cast<float*>(XI) + wave * (RB * D);
-#pragma unroll
-        for (int i = 0; i < RT; i++)
-#pragma unroll
-            for (int j = 0; j < NT; j++) *reinterpret_cast<f32x4*>(PS + (i * 16 + l16) * D + j * 16 + g * 4) = acc[i][j];
-    }
-    lds_barrier();
-    for (int idx = tid; idx < RB * D / 4; idx += 256) {
-        const int m = idx / (D / 4), n = (idx - m * (D / 4)) * 4;
-        const float* ps = reinterpret_cast<const float*>(XI) + m * D + n;
-        f32x4 v = *reinterpret_cast<const f32x4*>(ps);
-#pragma unroll
-        for (int w = 1; w < 4; w++) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(ps + w * (RB * D));
-#pragma unroll
-            for (int r = 0; r < 4; r++) v[r] += t[r];
-        }
-        f16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; r++) o[r] = (f16)(v[r] + (p.bq ? (float)p.bq[h * D + n + r] : 0.f));
-        *reinterpret_cast<f16x4*>(QI + img_off<RT>(m, n)) = o;
-        if (p.dbg_q) *reinterpret_cast<f16x4*>(p.dbg_q + (row0 + m) * C + h * D + n) = o;
-    }
-    lds_barrier();
-    if (!att) return;
-
-    // ---- attention of row tile `wave` (cross_attention's arithmetic) ------------------------------------------------------------------------
-    {
-        const int m = wave * 16 + l16;
-        const float c = p.sc_log2e;
-        f16x4 qf[DS];
-#pragma unroll
-        for (int ds = 0; ds < DS; ds++) qf[ds] = *reinterpret_cast<const f16x4*>(QI + img_off<RT>(m, ds * 16 + g * 4));
-        f32x4 s[TKT];
-#pragma unroll
-        for (int tt = 0; tt < TKT; tt++) {
-            s[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ds = 0; ds < DS; ds++) s[tt] = __builtin_amdgcn_mfma_f32_16x16x16f16(kf[tt][ds], qf[ds], s[tt], 0, 0, 0);
-        }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int tt = 0; tt < TKT; tt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float v = (tt * 16 + g * 4 + r) < p.Tk ? s[tt][r] * c : -INFINITY;
-                s[tt][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-        f16x4 pf[TKT];
-#pragma unroll
-        for (int tt = 0; tt < TKT; tt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float e = __builtin_amdgcn_exp2f(s[tt][r] - mx);
-                sum += e;
-                pf[tt][r] = (f16)e;
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int dt = 0; dt < DS; dt++) {
-            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int tt = 0; tt < TKT; tt++) o = __builtin_amdgcn_mfma_f32_16x16x16f16(vf[dt][tt], pf[tt], o, 0, 0, 0);
-            f16x4 ov;
-#pragma unroll
-            for (int r = 0; r < 4; r++) ov[r] = (f16)(o[r] * inv);
-            *reinterpret_cast<f16x4*>(p.out + (row0 + m) * p.ldo + h * D + dt * 16 + g * 4) = ov;
-        }
-    }
-}
-
 }   // namespace osg_tb
 
 extern "C" {
@@ -1020,53 +787,6 @@ int osg_tblock_tail(osg_ctx* ctx, const osg_tblock_tail_args* a) {
     if (rows == 64) rc = launch(osg_tb::tblock_tail_kernel<4, 320, 40, 5, 2>, 3 * 5 * osg_tb::kTileBytes<4> + vec_bytes, attr64);
     else if (ns3) rc = launch(osg_tb::tblock_tail_kernel<2, 320, 40, 5, 3>, 3 * 5 * osg_tb::kTileBytes<2> + vec_bytes, attr32n3);
     else rc = launch(osg_tb::tblock_tail_kernel<2, 320, 40, 5, 2>, 3 * 5 * osg_tb::kTileBytes<2> + vec_bytes, attr32);
-    if (rc) return rc;
-    OSG_LAUNCH_CHECK(ctx);
-    return 0;
-}
-
-int osg_qattn_supported(int M, int rows_per_img, int C, int heads, int Tk) {
-    // (SD 1.5 / 2.x: 8 heads of 80 / 160; SDXL: 10 / 20 heads of 64)
-    const bool shape = (C == 640 && (heads == 8 || heads == 10)) || (C == 1280 && (heads == 8 || heads == 20));
-    // one workgroup per (32 rows, head) re-reads the rows and a head's weight slice: it pays while the launch is a handful of workgroups per CU (SD 1.5's 32x32 level:
-    // 512); at SDXL's sizes (2 560 / 1 280 workgroups) the tiled GEMM + the attention launch are faster (profiles/r04_sdxl_qattn_ab.txt: 32.6 against 30.5 ms per step)
-#ifdef OSG_DEV_PROBES   // (tools/qattn_repro.py, tools/sdxl_repro.py: compiled out of the product library -- an environment variable must not change production routing; advisor, round 4)
-    static const bool any_size = getenv("OSG_QATTN_ANY_SIZE") != nullptr;
-#else
-    constexpr bool any_size = false;
-#endif
-    if (!any_size && (long)(M / 32) * heads > 512) return 0;
-    return shape && M > 0 && M % 32 == 0 && rows_per_img % 32 == 0 && Tk >= 1 && Tk <= 80;
-}
-
-int osg_qattn(osg_ctx* ctx, const osg_qattn_args* a) {
-    if (!osg_qattn_supported(a->M, a->rows_per_img, a->C, a->heads, a->Tk)) OSG_FAIL(ctx, "osg_qattn: unsupported shape (see osg_qattn_supported)");
-    if (!(a->scale > 0.f)) OSG_FAIL(ctx, "osg_qattn: scale must be > 0");
-    if (!a->x || !a->gamma || !a->beta || !a->wq || !a->kp || !a->vtp || !a->out) OSG_FAIL(ctx, "osg_qattn: missing operand");
-    const long ldx = a->ldx ? a->ldx : a->C;
-    if (ldx % 8 || (ldx * 2 * 31 + a->C * 2) >= (1L << 31)) OSG_FAIL(ctx, "osg_qattn: row pitch of x must be a multiple of 8 elements");
-    osg_tb::QAttnParams p;
-    p.x = (const f16*)a->x; p.ldx = ldx;
-    p.gamma = (const f16*)a->gamma; p.beta = (const f16*)a->beta; p.eps = a->eps;
-    p.wq = (const f16*)a->wq; p.bq = (const f16*)a->bq;
-    p.kp = (const f16*)a->kp; p.vtp = (const f16*)a->vtp;
-    p.sc_log2e = a->scale * 1.4426950408889634f; p.Tk = a->Tk;
-    p.out = (f16*)a->out; p.ldo = a->ldo ? a->ldo : a->C;
-    p.M = a->M; p.rows_per_img = a->rows_per_img; p.heads = a->heads;
-    p.dbg_q = (f16*)a->dbg_q;
-    auto launch = [&](auto kern, int smem, unsigned long long& attr_mask) -> int {
-        if (osg_first_on_device(attr_mask)) {
-            OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        }
-        hipLaunchKernelGGL(kern, dim3((unsigned)(a->M / 32), (unsigned)a->heads), dim3(256), smem, ctx->compute, p);
-        return 0;
-    };
-    static unsigned long long attr640 = 0, attr1280 = 0, attr640x = 0, attr1280x = 0;   // (per-device memos, osg_common.h osg_first_on_device)
-    int rc;
-    if (a->C == 640 && a->heads == 8) rc = launch(osg_tb::qattn_kernel<640, 80>, 10 * 4096 + 2 * 4096 + 2 * 640 * 2, attr640);
-    else if (a->C == 640) rc = launch(osg_tb::qattn_kernel<640, 64>, 10 * 4096 + 1 * 4096 + 2 * 640 * 2, attr640x);
-    else if (a->heads == 8) rc = launch(osg_tb::qattn_kernel<1280, 160>, 20 * 4096 + 3 * 4096 + 2 * 1280 * 2, attr1280);
-    else rc = launch(osg_tb::qattn_kernel<1280, 64>, 20 * 4096 + 1 * 4096 + 2 * 1280 * 2, attr1280x);
     if (rc) return rc;
     OSG_LAUNCH_CHECK(ctx);
     return 0;

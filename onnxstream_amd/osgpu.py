@@ -29,7 +29,7 @@ EXPORTS = [
     "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_concat2", "osg_resize_nearest", "osg_gather_rows",
     "osg_maxpool_nhwc", "osg_convert", "osg_sampler_prepare", "osg_sampler_cfg_euler_a",
     "osg_range_push", "osg_range_pop", "osg_marker_record", "osg_copy_wait_marker", "osg_timer_mark", "osg_timer_between", "osg_set_stat_sinks", "osg_group_norm_stats_nhwc", "osg_qu8_conv2d_nhwc", "osg_qu8_conv2d_nhwc_t", "osg_qu8_conv_tap_sums", "osg_qu8_gemm", "osg_qu8_lut", "osg_qu8_binary", "osg_qu8_instance_norm", "osg_qu8_instance_norm_nhwc", "osg_qu8_affine_act", "osg_qu8_norm_affine_act_nhwc", "osg_qu8_softmax_last", "osg_kdbg_read",
-    "osg_tblock_tail_supported", "osg_tblock_tail", "osg_tblock_kv_pack_elems", "osg_tblock_kv_pack_jobs", "osg_tblock_pack_weight", "osg_qattn_supported", "osg_qattn",
+    "osg_tblock_tail_supported", "osg_tblock_tail", "osg_tblock_kv_pack_elems", "osg_tblock_kv_pack_jobs", "osg_tblock_pack_weight", 
 ]
 
 
@@ -44,13 +44,6 @@ class TBlockTailArgs(ctypes.Structure):
                 ("kp", _vp), ("vtp", _vp), ("scale", _cf), ("Tk", _ci), ("wo2", _vp), ("bo2", _vp), ("g3", _vp), ("be3", _vp), ("eps3", _cf),
                 ("w1", _vp), ("b1", _vp), ("w2", _vp), ("b2", _vp), ("wpo", _vp), ("bpo", _vp), ("xin", _vp), ("out", _vp), ("out2", _vp),
                 ("ldo", _cl), ("ldo2", _cl), ("M", _ci), ("rows_per_img", _ci), ("C", _ci), ("heads", _ci), ("dbg", _vp * 8), ("rows_per_block", _ci)]
-
-
-class QAttnArgs(ctypes.Structure):
-    """osg_qattn_args of include/osgpu.h"""
-    _vp, _cf, _ci, _cl = ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_long
-    _fields_ = [("x", _vp), ("ldx", _cl), ("gamma", _vp), ("beta", _vp), ("eps", _cf), ("wq", _vp), ("bq", _vp), ("kp", _vp), ("vtp", _vp),
-                ("scale", _cf), ("Tk", _ci), ("out", _vp), ("ldo", _cl), ("M", _ci), ("rows_per_img", _ci), ("C", _ci), ("heads", _ci), ("dbg_q", _vp)]
 
 
 def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
@@ -130,8 +123,6 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_qu8_softmax_last.argtypes = [vp, vp, vp, cl, cl, vp]
     lib.osg_tblock_tail_supported.argtypes = [ci] * 5
     lib.osg_tblock_tail.argtypes = [vp, ctypes.POINTER(TBlockTailArgs)]
-    lib.osg_qattn_supported.argtypes = [ci] * 5
-    lib.osg_qattn.argtypes = [vp, ctypes.POINTER(QAttnArgs)]
     lib.osg_tblock_kv_pack_elems.argtypes = [ci, ci, ci]
     lib.osg_tblock_kv_pack_elems.restype = ctypes.c_size_t
     lib.osg_tblock_kv_pack_jobs.argtypes = [vp, vp, cl, ci, ci, ci, ci, vp, vp]
@@ -380,23 +371,6 @@ class Gpu:
             a.dbg[7] = stamps.ptr
         self._ck(self.lib.osg_tblock_tail(self.ctx, ctypes.byref(a)))
         return out, dumps
-
-    def qattn(self, x: DevBuf, gamma: DevBuf, beta: DevBuf, wq_kn8: DevBuf, kp: DevBuf, vtp: DevBuf, tk: int, heads: int, scale: float, rows_per_img: int, eps: float = 1e-5,
-              bq: Optional[DevBuf] = None, debug: bool = False, out: Optional[DevBuf] = None):
-        """osg_qattn: LayerNorm + q projection + cross-attention of one transformer block.  Returns (out, q dump or None)."""
-        m, c = x.shape
-        a = QAttnArgs()
-        a.x, a.ldx, a.gamma, a.beta, a.eps = x.ptr, c, gamma.ptr, beta.ptr, eps
-        a.wq, a.bq = wq_kn8.ptr, bq.ptr if bq is not None else None
-        a.kp, a.vtp, a.scale, a.Tk = kp.ptr, vtp.ptr, scale, tk
-        if out is None:
-            out = self.empty((m, c), x.dtype)
-        a.out, a.ldo = out.ptr, c
-        a.M, a.rows_per_img, a.C, a.heads = m, rows_per_img, c, heads
-        qd = self.empty((m, c), x.dtype) if debug else None
-        a.dbg_q = qd.ptr if qd is not None else None
-        self._ck(self.lib.osg_qattn(self.ctx, ctypes.byref(a)))
-        return out, qd
 
     def rms_norm(self, x: DevBuf, w: DevBuf, eps: float):
         rows, c = int(np.prod(x.shape[:-1])), x.shape[-1]

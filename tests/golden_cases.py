@@ -127,8 +127,7 @@ def transformer_block_320(g):
 
 
 def transformer_block_640(g):
-    """the same at the 32x32 level's widths (640 channels, 8 heads of 80): the shape osg_qattn takes -- LayerNorm + attn2.to_q + cross-attention are ONE launch
-    at fusion level 2 (round 4)"""
+    """the same at the 32x32 level's widths (640 channels, 8 heads of 80): LayerNorm folded into attn2.to_q, then the cross-attention launch, at fusion level 2"""
     cfg = sd_unet.UNetConfig(block_out=(640, 1280), heads=8, ctx_dim=768, ctx_len=77, latent=8, groups=32, name="case640")
     x = g.input("x", (1, 640, 8, 8))
     c = g.input("ctx", (1, 77, 768))
@@ -137,7 +136,7 @@ def transformer_block_640(g):
 
 
 def transformer_block_1280(g):
-    """... and at the 16x16 / 8x8 levels' widths (1280 channels, 8 heads of 160): osg_qattn's second instantiation, the five-deep weight ring"""
+    """... and at the 16x16 / 8x8 levels' widths (1280 channels, 8 heads of 160): the 160-wide heads"""
     cfg = sd_unet.UNetConfig(block_out=(1280, 1280), heads=8, ctx_dim=768, ctx_len=77, latent=8, groups=32, name="case1280")
     x = g.input("x", (1, 1280, 8, 8))
     c = g.input("ctx", (1, 77, 768))

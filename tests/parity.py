@@ -40,7 +40,9 @@ EXCEPTIONS: dict = {
     "unet_tiny@tuned": (1.10, 1.017, "a timing-dependent plan: err32 seen between 4.6e-3 and 6.3e-3 across runs against a drift of 6.195e-3 (round 2)"),
 }
 # case key -> (factor on the host-to-host spread in leg (p), the measured err16 / spread, where it was measured); filled from profiles/r06_parity_table.txt
-SPREAD_EXCEPTIONS: dict = {}
+SPREAD_EXCEPTIONS: dict = {
+    "SDXL UNet full size": (1.30, 1.181, "err16 3.33e-3 to the nearer host (EPYC) vs a spread of 2.82e-3 between Xeon and EPYC; err32 / drift 1.02 (profiles/r06_parity_table.txt)"),
+}
 
 
 def margins(err16: float, err32: float, drift: float, key: str | None = None, spread: float | None = None):

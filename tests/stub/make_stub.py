@@ -31,7 +31,6 @@ SPECIAL = {
     "osg_timer_stop": "{ (void)ctx; if (ms) *ms = 0.0f; return 0; }",
     # (shape predicates and sizes the PLANNER branches on: the real library's answers, so the CPU tests see the plan a GPU box would build)
     "osg_tblock_tail_supported": "{ return C == 320 && heads == 8 && M > 0 && M % 32 == 0 && rows_per_img % 32 == 0 && Tk >= 1 && Tk <= 80; }",
-    "osg_qattn_supported": "{ return ((C == 640 && (heads == 8 || heads == 10)) || (C == 1280 && (heads == 8 || heads == 20))) && (long)(M / 32) * heads <= 512 && M > 0 && M % 32 == 0 && rows_per_img % 32 == 0 && Tk >= 1 && Tk <= 80; }",
     "osg_tblock_kv_pack_elems": "{ return (size_t)imgs * heads * 80 * (size_t)((D + 15) / 16 * 16); }",
     # ---- DATA MOVEMENT and dtype conversion are real (plain C restatements of the entry points' documented semantics, include/osgpu.h): a graph made
     # of zero-FLOP ops then carries real values end to end on a CPU, which lets tests/test_movement_cpu.py check what the PLANNER hands these entry

@@ -136,6 +136,86 @@ def test_gemm_two_wave_groups_on_alternating_k_tiles(gpu, M, N, K, cfg, nst, spl
     assert rel_max(two, one.astype(np.float64)) <= 1e-3
 
 
+@pytest.mark.parametrize("tile", [4, 5, 6, 7])
+@pytest.mark.parametrize("M,N,K,nst,splits,fold", [(2048, 640, 640, 2, 1, 0), (512, 1280, 1280, 4, 1, 0), (8192, 320, 320, 4, 1, 0), (512, 1280, 5120, 4, 2, 0), (512, 1280, 5120, 4, 2, 1),
+                                                 (300, 200, 192, 2, 1, 0), (130, 72, 64, 4, 1, 0), (77, 960, 768, 2, 1, 0), (1000, 2560, 320, 4, 1, 0)])
+def test_gemm_160_and_80_column_tiles_give_the_bits_of_the_64x64_tile(gpu, tile, M, N, K, nst, splits, fold, monkeypatch):
+    """Round 6 (osg_gemm_wide.hip): the 128x160 / 128x80 / 64x80 / 64x160 tiles of gemm2_kernel -- the waves as 4 x 1 (tiles 4 .. 6), a B stage padded to 96 rows
+    for the 80-column tiles (pad rows never requested, never read), ragged M and N (N no multiple of 80 included: the tuner never picks the tiles there, the kernel
+    must still be right), split-K with the reduce launch and folded by the last arriver.  Every output element is the same MFMA sequence whatever the tile (k
+    ascending in steps of 32, f32 accumulate, one rounding), so at the same split of K the result must equal the 64x64 tile's BIT FOR BIT, bias + residual included."""
+    if fold and tile in (4, 7):
+        pytest.skip("the in-kernel fold is not offered for the 160-column tiles (20 accumulator quads per lane)")
+    rng = np.random.default_rng(M + N + K + tile)
+    a, w = rnd(rng, (M, K)), rnd(rng, (K, N), K ** -0.5)
+    bias, res = rnd(rng, (N,), 0.1), rnd(rng, (M, N))
+    da, dw, db, dr = gpu.to_dev(a), gpu.transpose_kn_to_nk(gpu.to_dev(w)), gpu.to_dev(bias), gpu.to_dev(res)
+    monkeypatch.setenv("OSG_GEMM_NST", str(nst)); monkeypatch.setenv("OSG_GEMM_SPLITS", str(splits)); monkeypatch.setenv("OSG_GEMM_KS", "1")
+    monkeypatch.setenv("OSG_GEMM_FOLD", str(fold))
+    monkeypatch.setenv("OSG_GEMM_CFG", "2")
+    base = gpu.gemm(da, dw, db, dr, b_is_nk=True).numpy()
+    monkeypatch.setenv("OSG_GEMM_CFG", str(tile))
+    got = gpu.gemm(da, dw, db, dr, b_is_nk=True).numpy()
+    assert rel_max(base, ref.matmul(a, w, bias, res)) <= 1e-3
+    assert np.array_equal(got, base), (int((got != base).sum()), rel_max(got, base.astype(np.float64)))
+
+
+def test_160_column_tiles_geglu_layer_norm_fold_and_convolution(gpu, monkeypatch):
+    """... the forms osg_gemm_wide.hip holds beside the plain GEMM: the GEGLU epilogue on the 128x160 tile (10 column blocks per wave: value / gate pairs stay inside
+    a wave), the LayerNorm-folding GEMM with handed-over row statistics on the 128x160 and 64x160 tiles, the implicit-GEMM convolution (3x3 stride 2) on tiles
+    4 .. 6 -- each against the 128x64 / 64x64 tile's bits."""
+    rng = np.random.default_rng(606)
+    # GEGLU, plain and LayerNorm-folded (weights in any order: both tiles read the same interleaved matrix)
+    M, K, N = 1024, 640, 5120
+    a, w, b = rnd(rng, (M, K)), rnd(rng, (N, K), K ** -0.5), rnd(rng, (N,), 0.1)
+    da, dw, db = gpu.to_dev(a), gpu.to_dev(w), gpu.to_dev(b)
+    def geglu():
+        y = gpu.empty((M, N // 2), f16)
+        gpu._ck(gpu.lib.osg_gemm(gpu.ctx, 2, da.ptr, dw.ptr, 1, db.ptr, 2, None, y.ptr, M, N, K, 1, 0, 0, 0, 3))
+        return y.numpy()
+    monkeypatch.setenv("OSG_GEMM_NST", "2"); monkeypatch.setenv("OSG_GEMM_SPLITS", "1"); monkeypatch.setenv("OSG_GEMM_KS", "1")
+    monkeypatch.setenv("OSG_GEMM_CFG", "1")
+    base = geglu()
+    monkeypatch.setenv("OSG_GEMM_CFG", "4")
+    assert np.array_equal(geglu(), base)
+    gamma, beta = (1 + rnd(rng, (K,), 0.2).astype(f32)).astype(f16), rnd(rng, (K,), 0.2)
+    eye = gpu.to_dev(np.eye(K, dtype=f16))
+    for act, n_out in ((3, N), (0, 1920)):
+        wk, bk = w[:n_out], b[:n_out]
+        for nst in (2, 4):
+            monkeypatch.setenv("OSG_GEMM_NST", str(nst))
+            monkeypatch.setenv("OSG_GEMM_CFG", "1")
+            xd, rs = gpu.gemm_rowstats(da, eye)
+            base = gpu.gemm_ln(xd, wk, gamma, beta, bk, 1e-5, act=act, rowstats=rs).numpy()
+            for tile in ((4,) if act == 3 else (4, 7)):
+                monkeypatch.setenv("OSG_GEMM_CFG", str(tile))
+                got = gpu.gemm_ln(xd, wk, gamma, beta, bk, 1e-5, act=act, rowstats=rs).numpy()
+                assert np.array_equal(got, base), (tile, act, nst, rel_max(got, base.astype(np.float64)))
+    # a GEMM that also emits its output's partial row statistics (32-column slots): the 128x160 tile serves them (a wave's 160 columns = 5 whole slots from a
+    # multiple of 32), the 80-column tiles and the 2 x 2 form of 64x160 do not and hand the launch back to a round-2 tile
+    monkeypatch.setenv("OSG_GEMM_NST", "4")
+    monkeypatch.setenv("OSG_GEMM_CFG", "2")
+    wq = gpu.to_dev(rnd(rng, (640, K), K ** -0.5))
+    yb, rb = gpu.gemm_rowstats(da, wq)
+    for tile in (4, 5, 6, 7):
+        monkeypatch.setenv("OSG_GEMM_CFG", str(tile))
+        yt, rt = gpu.gemm_rowstats(da, wq)
+        assert np.array_equal(yt.numpy(), yb.numpy()) and np.array_equal(rt.numpy(), rb.numpy()), tile
+    # the downsampling convolution of the 32 x 32 level through the implicit-GEMM kernel
+    x = rnd(rng, (2, 32, 32, 640))
+    wc = rnd(rng, (640, 3, 3, 640), (640 * 9) ** -0.5)
+    bc = rnd(rng, (640,), 0.1)
+    dx, dwc, dbc = gpu.to_dev(x), gpu.to_dev(wc), gpu.to_dev(bc)
+    monkeypatch.setenv("OSG_GEMM_NST", "4")
+    monkeypatch.setenv("OSG_GEMM_CFG", "2")
+    base = gpu.conv2d_nhwc(dx, dwc, dbc, 2, (1, 1, 1, 1)).numpy()
+    assert rel_max(base, ref.conv2d_nhwc(x, wc, bc, (2, 2), (1,) * 4)) <= 1e-3
+    for tile in (4, 5, 6):
+        monkeypatch.setenv("OSG_GEMM_CFG", str(tile))
+        got = gpu.conv2d_nhwc(dx, dwc, dbc, 2, (1, 1, 1, 1)).numpy()
+        assert np.array_equal(got, base), (tile, rel_max(got, base.astype(np.float64)))
+
+
 def test_two_wave_groups_conv_and_folded_layer_norm(gpu, monkeypatch):
     """KS = 2 through the implicit-GEMM convolution (tap / channel position advanced by two k-tiles per step) and through the LayerNorm-folding GEMM with
     handed-over row statistics"""

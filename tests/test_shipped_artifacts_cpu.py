@@ -92,7 +92,7 @@ def test_hot_kernels_do_not_spill_to_scratch():
     by = {}
     for r, n in zip(rows, names):
         by[n.replace("void ", "")] = r
-    hot = [n for n in by if any(k in n for k in ("gemm2_kernel", "attn2_kernel", "attn_kernel", "tblock_tail_kernel", "qattn_kernel", "gn_slab_kernel", "gn_apply",
+    hot = [n for n in by if any(k in n for k in ("gemm2_kernel", "attn2_kernel", "attn_kernel", "tblock_tail_kernel", "gn_slab_kernel", "gn_apply",
                                                   "splitk_reduce", "layer_norm_kernel", "q8_gemm_kernel", "q8_conv"))]
     assert len(hot) > 100
     for n in hot:

@@ -10,7 +10,6 @@
 #   pmc              per-kernel counters of the timed plan, each set in its own --pmc pass (tools/pmc_round4.sh)
 #   tailprobe        osg_tblock_tail: per-launch time (cold / hot weights) + stage stamps for 64- / 32-row blocks, 1 / 2 weight tiles ahead, with / without prefetching workgroups
 #   tailtests        the tail kernel's tests + the golden chains
-#   qattn            osg_qattn: tests, golden chains, probe against the separate launches
 #   abenv "<env A>" "<env B>" ...  bench.py under each environment (X=1 Y=2 strings; use a dummy variable for 'default'), alternating 2x
 mkdir -p gpurun_out; export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-.}
 T=gpurun_out/${ROUND:-r05}; export OSA_REQUIRE_ORACLE=1
@@ -52,18 +51,11 @@ tailprobe)
     ROWS=$1 OSG_TBLOCK_NS=$2 OSG_TBLOCK_PREFETCH=$3 REPS=2 timeout 300 python tools/tblock_tail_probe.py 2>&1 | grep -v "^$"; done > ${T}_tail_probe.log 2>&1; cat ${T}_tail_probe.log ;;
 kerneltests)   # kerneltests "<pytest -k expression>": part of tests/test_gpu_kernels.py
   timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "${ARGS[0]}" > ${T}_kernel_tests.log 2>&1; tail -4 ${T}_kernel_tests.log ;;
-qattn)   # osg_qattn: its tests, the golden chains, the probe
-  timeout 900 python -m pytest tests/test_qattn.py tests/test_golden.py -m gpu -x -q -k "qattn or chains" > ${T}_qattn_tests.log 2>&1; tail -12 ${T}_qattn_tests.log
-  timeout 300 python tools/qattn_probe.py > ${T}_qattn_probe.log 2>&1; cat ${T}_qattn_probe.log ;;
 tailtests)
   timeout 900 python -m pytest tests/test_tblock_tail.py tests/test_golden.py -m gpu -x -q -k "tblock or chains" > ${T}_tail_tests.log 2>&1; tail -4 ${T}_tail_tests.log ;;
 p4rows)   # 4 prompts per GPU (M = 32 768 rows at the 64x64 level): 64- vs 32-row blocks in the tail kernel
   for i in 1 2; do for r in 64 32; do
     OSG_TBLOCK_ROWS=$r timeout 600 python bench.py --prompts-per-gpu 4 --cpu-passes 0 --windows 2 > ${T}_p4rows_${r}_$i.json 2> ${T}_p4rows_${r}_$i.err; line ${T}_p4rows_${r}_$i.json "[4 prompts, $r-row blocks]"; done; done ;;
-sdxlab)   # SDXL: the default plan against --no-qattn-fuse, alternating 2x; then the full-size SDXL parity test
-  for i in 1 2; do for f in "" "--no-qattn-fuse"; do
-    timeout 900 python bench.py --config SDXL --steps-per-image 10 --steps 20 --warmup 2 --cpu-passes 0 --windows 2 $f > ${T}_sdxlab_$i.json 2> ${T}_sdxlab_$i.err; line ${T}_sdxlab_$i.json "SDXL [$f]"; done; done
-  timeout 900 python -m pytest tests/test_fullsize.py -m gpu -x -q -s -k "sdxl" > ${T}_sdxl_fullsize.log 2>&1; tail -4 ${T}_sdxl_fullsize.log ;;
 abenv)   # abenv "<env A>" "<env B>" [more env sets ...]: bench.py under each environment, alternating 2x
   for i in 1 2; do n=0; for e in "${ARGS[@]}"; do n=$((n + 1))
     env $e timeout 600 python bench.py --cpu-passes 0 --windows 2 > ${T}_abenv_${n}_$i.json 2> ${T}_abenv_${n}_$i.err; line ${T}_abenv_${n}_$i.json "[$e]"; done; done ;;
@@ -74,7 +66,7 @@ abenv1)   # like abenv, one round only
   n=0; for e in "${ARGS[@]}"; do n=$((n + 1))
     env $e timeout 600 python bench.py --cpu-passes 0 --windows 2 > ${T}_abenv1_${n}.json 2> ${T}_abenv1_${n}.err; line ${T}_abenv1_${n}.json "[$e]"; done ;;
 ktests)   # the kernel-level GPU tests
-  timeout 1200 python -m pytest tests/test_gpu_kernels.py tests/test_tblock_tail.py tests/test_qattn.py tests/test_sdpa.py -m gpu -x -q > ${T}_kernel_tests.log 2>&1; tail -6 ${T}_kernel_tests.log ;;
+  timeout 1200 python -m pytest tests/test_gpu_kernels.py tests/test_tblock_tail.py tests/test_sdpa.py -m gpu -x -q > ${T}_kernel_tests.log 2>&1; tail -6 ${T}_kernel_tests.log ;;
 gtable)   # error table of every golden case under the deterministic plans + the reference's fp16 output on this host
   timeout 900 python tools/golden_table.py ${T}_ref16_host.npz > ${T}_golden_table.txt 2> ${T}_golden_table.err; tail -8 ${T}_golden_table.txt ;;
 retune)   # retune "<tag>" "<env>": the headline bench from an EMPTY tune table under <env>; the table it measured -> gpurun_out (then SDXL / 4 prompts appended by `extend`)

@@ -81,7 +81,7 @@ def main():
     names = demangle([r["name"] for r in rows])
     for r, n in zip(rows, names):
         r["pretty"] = n.replace("void ", "")
-    hot = re.compile(r"gemm2_kernel|conv3x3_kernel|attn2_kernel|attn_kernel|tblock_tail|qattn_kernel|gn_|splitk_reduce|qu8|lean|layer_norm")
+    hot = re.compile(r"gemm2_kernel|conv3x3_kernel|attn2_kernel|attn_kernel|tblock_tail|gn_|splitk_reduce|qu8|lean|layer_norm")
     rows.sort(key=lambda r: (not hot.search(r["pretty"]), r["pretty"]))
     print(f"# {os.path.basename(a.lib)}: {len(rows)} gfx950 kernels; dynamic LDS (the contraction rings, attention) is not in the static figure")
     print(f"# kernels with scratch: {sum(1 for r in rows if r['scratch'])}; with register spills: {sum(1 for r in rows if r['vspill'] or r['sspill'])}")

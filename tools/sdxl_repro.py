@@ -1,6 +1,6 @@
-"""Dev probe (GPU box): SDXL UNet, cond + uncond, four runs of one Model: md5 of every run's output (run 1 eager, 2.. replayed).  OSG_QATTN_ANY_SIZE=1 forces
-osg_qattn launches at SDXL's sizes (the library declines them: slower than the tiled GEMM + attention there) -- the configuration that exposed the missing
-LDS wait in front of the fused kernels' workgroup barriers (profiles/r04_qattn_lds_barrier_race.txt)."""
+"""Dev probe (GPU box): SDXL UNet, cond + uncond, four runs of one Model: md5 of every run's output (run 1 eager, 2.. replayed) -- the check that exposed the
+missing LDS wait in front of the fused kernels' workgroup barriers in round 4 (profiles/r04_qattn_lds_barrier_race.txt; the kernel it showed up in, osg_qattn, was
+removed in round 6)."""
 import hashlib
 import os
 import sys
@@ -22,7 +22,6 @@ for graph, fuse, lnfold in ((1, 1, 1),):
     m = Model(b.LIB_HOST, 0, "ram+nocache")
     m.read_file(d + "model.txt")
     m._set_option("hip_use_graph", graph)
-    m._set_option("hip_fuse_qattn", fuse)
     m._set_option("hip_fuse_ln_gemm", lnfold)
     sums = []
     first = None
@@ -39,4 +38,4 @@ for graph, fuse, lnfold in ((1, 1, 1),):
         sums.append(hashlib.md5(o.tobytes()).hexdigest()[:8] + f"({int((o != first).sum())} differ, max {float(np.abs(o - first).max()):.2e})")
         m.clear_tensors()
     m.close()
-    print(f"hip_use_graph={graph} hip_fuse_qattn={fuse} hip_fuse_ln_gemm={lnfold}: {sums}", flush=True)
+    print(f"hip_use_graph={graph} hip_fuse_ln_gemm={lnfold}: {sums}", flush=True)
