@@ -65,7 +65,7 @@ def build_host(force=False):
     srcs = sorted(glob.glob(os.path.join(hdir, "*.cpp")))
     if not srcs:
         return None
-    hdrs = sorted(glob.glob(os.path.join(hdir, "*.h"))) + [os.path.join(INC, "osgpu.h")]
+    hdrs = sorted(glob.glob(os.path.join(hdir, "*.h"))) + sorted(glob.glob(os.path.join(hdir, "*.inc"))) + [os.path.join(INC, "osgpu.h")]
     if force or _newer(LIB_HOST, srcs + hdrs):
         _run(["g++", "-std=c++20", "-O2", "-fPIC", "-shared", "-I" + INC, "-I" + hdir, "-o", LIB_HOST] + srcs +
              ["-ldl", "-lpthread"])

@@ -10,6 +10,8 @@
 //   -> eager first pass, then capture into a hipGraph that later passes replay.
 #pragma once
 
+#include <cmath>
+#include <cstdint>
 #include <functional>
 #include <map>
 #include <unordered_map>
@@ -152,6 +154,16 @@ struct ConstPool {
         fused_valid = false; fused_ops.clear(); fused_key.clear(); snap_vals.clear(); snap_weight_bytes = 0; in_names.clear();
     }
 };
+
+// f16 bits -> float (host side: constants, folded weights, the sampler's table); shared by plan.cpp and plan_run.cpp
+inline float half_to_float(uint16_t h) {
+    uint32_t sign = (h >> 15) & 1, exp = (h >> 10) & 0x1f, man = h & 0x3ff;
+    float v;
+    if (exp == 0) v = std::ldexp((float)man, -24);
+    else if (exp == 31) v = man ? NAN : INFINITY;
+    else v = std::ldexp((float)(man | 0x400), (int)exp - 25);
+    return sign ? -v : v;
+}
 
 struct Plan {
     Plan(Model& m, HipBackend& be, ConstPool& pool, size_t batch);

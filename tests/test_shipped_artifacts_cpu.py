@@ -29,15 +29,20 @@ def _rows():
 
 def _launchable(family, cfg, nst, splits, bn):
     """osg_ctx.hip load_locked(), restated: which (family, cfg, nst, splits, bn) name an instantiation the launchers have."""
-    tile, ks2 = cfg & 7, cfg & 8
-    if family == 0:      # gemm2_kernel: cfg = tile | KS2 << 3 | fold << 4
-        if cfg < 0 or tile > 3 or (cfg & ~31):
+    tile, ks2, fold, spec = cfg & 7, cfg & 8, cfg & 16, cfg & 32
+    if family == 0:      # gemm2_kernel: cfg = tile | KS2 << 3 | fold << 4 | four loader waves << 5; tiles 4 .. 7 = the 160 / 80-column tiles
+        if cfg < 0 or (cfg & ~63):
             return False
-        if (cfg & 16) and (ks2 or tile == 0 or not 2 <= splits <= 4):
+        if spec and not (tile in (0, 4) and nst == 4 and not ks2 and not fold and splits == 1):
+            return False
+        if fold and (ks2 or tile in (0, 4, 7) or not 2 <= splits <= 4):
             return False
         if ks2 and not ((tile == 2 and nst in (2, 4)) or (tile == 1 and nst == 2)):
             return False
-        if not (nst in (2, 4) or (nst == 6 and tile >= 1) or (nst == 8 and tile == 2)):
+        if tile <= 3:
+            if not (nst in (2, 4) or (nst == 6 and tile >= 1) or (nst == 8 and tile == 2)):
+                return False
+        elif not (nst in (2, 4) or (nst == 6 and tile == 6)):
             return False
         return 1 <= splits <= 64
     if family == 1:      # conv3x3_kernel: cfg = fold << 4, nst = loader waves
