@@ -313,7 +313,10 @@ __device__ __forceinline__ attn2_hx4 attn2_tr_read(unsigned lds_addr) {
 }
 
 template <int D, int QT, int NST>
-__global__ __launch_bounds__(256) void attn2_kernel(AttnParams p, int nqb) {
+__global__ __launch_bounds__(256) void attn2_kernel(AttnParams pk, int nqb) {
+    const AttnParams p = pk;
+    osg_pin_all(p.q, p.k, p.v, p.o, p.q_tok, p.q_head, p.q_batch, p.k_tok, p.k_head, p.k_batch, p.v_tok, p.v_head, p.v_batch, p.o_tok, p.o_head, p.o_batch, p.heads, p.Tq, p.Tkv,
+                p.scale_log2e, p.mask, p.inv_scale, p.kv_div, nqb, (int)gridDim.x);
     constexpr int DCH = D / 8;                  // 16-byte chunks per K / V row
     constexpr int RSC = DCH + ((6 - DCH % 4) % 4);   // ... of the LDS image: the next count = 2 (mod 4), see the header
     constexpr int ROWB = RSC * 16;              // bytes per row of the LDS image

@@ -130,6 +130,15 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)v; }  // v_cvt_f16_f32: RNE
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 
+// Kernel arguments pulled into scalar registers NOW, in one batch (round 6).  hipcc loads a kernel argument where it is first used: a kernel's prologue then walks
+// 3-7 DEPENDENT round trips to the kernel-argument segment (~0.1-0.4 us each inside a pass, where nothing is warm) before its first vector load -- and a launch of the
+// pass lasts as long as one workgroup.  An INPUT of an empty asm makes the value live at the top, so the loads of all arguments are issued together; the values stay
+// what they were to the optimiser (an in-out operand would hide a pointer's address space: flat loads).
+template <class T>
+__device__ __forceinline__ void osg_pin_one(const T& v) { asm volatile("" ::"s"(v)); }
+template <class... T>
+__device__ __forceinline__ void osg_pin_all(const T&... v) { (osg_pin_one(v), ...); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -96,16 +96,16 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
     // ---- XCD-aware bijective remap of the flat grid (see osg_gemm.hip) ------------------------------------------------
     int L;
     {
-        const int total = gridDim.x, bid = blockIdx.x, x = bid & 7, i = bid >> 3, q = total >> 3, r = total & 7;
+        const int total = p.grid, bid = blockIdx.x, x = bid & 7, i = bid >> 3, q = total >> 3, r = total & 7;   // (p.grid = gridDim.x, without the trip to the hidden arguments)
         L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
     int m_tile, n_tile, zs;
     if (p.n_major) {
         n_tile = L / (p.splits * p.mt); L -= n_tile * p.splits * p.mt;
-        zs = L / p.mt; m_tile = L - zs * p.mt;
+        zs = L / (p.mt); m_tile = L - zs * p.mt;
     } else {
         m_tile = L / (p.splits * p.nt); L -= m_tile * p.splits * p.nt;
-        zs = L / p.nt; n_tile = L - zs * p.nt;
+        zs = L / (p.nt); n_tile = L - zs * p.nt;
     }
     const int m0 = m_tile * 128, n0 = n_tile * BN;
     const int slab_b = zs * (p.k_per_split >> 6);
@@ -311,7 +311,12 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
 }
 
 template <int W_, int BN, int WGM, int WGN, int MODE, int NLW>
-__global__ __launch_bounds__(256 + 64 * NLW) void conv3x3_kernel(GemmParams p) {
+__global__ __launch_bounds__(256 + 64 * NLW) void conv3x3_kernel(GemmParams pk) {
+    // the fields the first DMA requests / the epilogue prefetch depend on, in ONE batch of scalar loads at entry (GemmParams, round 6)
+    GemmParams p = pk;
+    OSG_PIN(p.A); OSG_PIN(p.Bt); OSG_PIN(p.kdbg); OSG_PIN(p.M); OSG_PIN(p.N); OSG_PIN(p.K); OSG_PIN(p.splits); OSG_PIN(p.k_per_split); OSG_PIN(p.a_bytes); OSG_PIN(p.b_bytes);
+    OSG_PIN(p.mt); OSG_PIN(p.nt); OSG_PIN(p.n_major); OSG_PIN(p.grid); OSG_PIN(p.H); OSG_PIN(p.Cin);
+    OSG_PIN(p.bias); OSG_PIN(p.residual); OSG_PIN(p.rowbias); OSG_PIN(p.rb_ld); OSG_PIN(p.rb_rows); OSG_PIN(p.bias_f32); OSG_PIN(p.act); OSG_PIN(p.no_epre);
     conv3x3_body<W_, BN, WGM, WGN, MODE, NLW>(p);
 }
 
@@ -336,7 +341,8 @@ int launch3(osg_ctx* ctx, GemmParams& p) {
         if (ok) { ctx->sink_fused = true; p.sink_imgs = p.M / p.sink_hw; p.sink_per_xcd = ctx->xcd_ids8 ? 1 : 0; }
         else p.sink[0].table = p.sink[1].table = nullptr;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.mt * p.nt * p.splits)), dim3(256 + 64 * NLW), smem, ctx->compute, p);
+    p.grid = p.mt * p.nt * p.splits;
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.grid), dim3(256 + 64 * NLW), smem, ctx->compute, p);
     p.sink[0] = sinks_in[0]; p.sink[1] = sinks_in[1];
     OSG_LAUNCH_CHECK(ctx);
     return 0;

@@ -319,6 +319,7 @@ template <int SB>
 __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const float* __restrict__ partial, f16* __restrict__ C, const void* __restrict__ bias, int bias_f32,
                                                              const f16* __restrict__ residual, long MN, int N, int splits, int batch, long strideC, int act,
                                                              const f16* __restrict__ rowbias, int rb_rows, long rb_ld, long ldc, f16* __restrict__ C2, long ldc2) {
+    osg_pin_all(partial, C, bias, bias_f32, residual, MN, N, splits, batch, strideC, act, rowbias, rb_rows, rb_ld, ldc, C2, ldc2);
     const long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long total = MN * batch;
     if (idx >= total) return;

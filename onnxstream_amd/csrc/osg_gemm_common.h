@@ -4,7 +4,19 @@
 #include <vector>
 #include "osg_common.h"
 
+#include <type_traits>
+#ifndef OSG_EPI_STORE_AUX
+#define OSG_EPI_STORE_AUX -1    // < 0: plain pointer stores with exec masks (rounds 1-5); 0 / 16: buffer stores, plain / sc1 write-through (A/B builds)
+#endif
 namespace osg_mm {
+// compile-time loop: f(std::integral_constant<int, B>{}), ..., f(std::integral_constant<int, E - 1>{}) -- every index a constant expression inside f
+template <int B, int E, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        sfor<B + 1, E>(f);
+    }
+}
 
 // GroupNorm statistics from the PRODUCER's epilogue (round 3).  A convolution whose output a GroupNorm reads adds, per (image, group), the sum and the sum of
 // squares of the f16 values it stores to a table the normalisation then only has to read: int64 FIXED-POINT sums (kStatSX / stat_q_scale fractional bits) --
@@ -39,45 +51,50 @@ __host__ __device__ inline int stat_q_shift(long elems) {
 __host__ __device__ inline float stat_q_scale(long elems) { return (float)(1L << stat_q_shift(elems)); }
 
 struct GemmParams {
+    // ---- round 6: field ORDER = the order a workgroup needs them.  A launch of the pass lasts as long as one workgroup, and a workgroup's first DMA request waited for
+    // ~6 dependent round trips of scalar loads from the kernel-argument segment (hipcc loads a field where it is first used); the kernels now pull the first group in
+    // ONE batch at entry (OSG_PIN in gemm2_kernel), the second group (convolution geometry) and the third (operands of the epilogue prefetch) right behind it.
+    // group 1: tile mapping + the DMA addressing of both operands
     const f16* A;
     const f16* Bt;
-    f16* C;
+    long long* kdbg;             // developer probe (OSG_KDBG=1, tools/kernel_phase_probe.py): per-workgroup phase timestamps, 8 x int64 per workgroup (s_memrealtime, 100 MHz); NULL in normal operation
+    long lda;
+    long strideA, strideB;
+    int M, N, K;
+    int splits, k_per_split;
+    unsigned a_bytes, b_bytes;   // (v2 kernels) buffer-descriptor extents of one batch item of A / Bt
+    int mt, nt, n_major;         // tile grid and the order tiles are walked inside an XCD's contiguous chunk
+    int grid;                    // gemm2_kernel: workgroups of the launch (gridDim.x without the trip to the hidden arguments)
+    // group 2: conv geometry (CONV only)
+    int H, W, Cin, Ho, Wo, KW, sh, sw, pt, pl;
+    // group 3: what the epilogue prefetch reads before the first tile is requested
     const void* bias;
     const f16* residual;
     const f16* rowbias;          // optional [M / rb_rows][rb_ld] per-image channel bias (the resnet time-embedding add)
-    int rb_rows;
     long rb_ld;
-    float* partial;
-    int M, N, K;
-    long lda;
-    long strideA, strideB, strideC;
+    long strideC;
+    const float* ln_c1;          // osg_gemm_ln: LayerNorm over K folded into this GEMM -- c1[n] = sum_k W'[n][k]; bias holds c2 (f32)
+    const float* rs_in;          //   row statistics of A emitted by the GEMM that produced it: [M][K/32][2] (sum, sum of squares) per 32 columns
+    int rb_rows;
     int bias_f32, act;
-    int splits, k_per_split;
-    // conv geometry (CONV only)
-    int H, W, Cin, Ho, Wo, KW, sh, sw, pt, pl;
-    // v2 (direct-to-LDS) kernel only
-    unsigned a_bytes, b_bytes;   // buffer-descriptor extents of one batch item of A / Bt
+    int no_epre;                 // OSG_NO_EPI_PREFETCH=1 (A/B): the epilogue fetches its operands on demand, as before round 3
+    int rs_np;                   //   = N / 32
+    // the rest: epilogue / split-K
+    f16* C;
+    float* partial;
     long a_bytes_l;              // conv: byte size of the whole NHWC input (host side, before the 2 GiB check)
-    int mt, nt, n_major;         // tile grid and the order tiles are walked inside an XCD's contiguous chunk
     int* tickets;                // split-K arrival / publication counters (two per output tile, splitk_fold_acc), zero between launches
     int* xcd_err;                // host-mapped flag the bounded wait of splitk_fold_acc raises (osg_ctx; checked by osg_sync / osg_download)
     float w_scale;               // W8 kernels (osg_gemm_w8.hip): Bt holds uint8 codes, w = (q - w_zp) * w_scale
     int w_zp;
-    const float* ln_c1;          // osg_gemm_ln: LayerNorm over K folded into this GEMM -- c1[n] = sum_k W'[n][k]; bias holds c2 (f32)
     float ln_eps;
-    const float* rs_in;          //   row statistics of A emitted by the GEMM that produced it: [M][K/32][2] (sum, sum of squares) per 32 columns
     float* rs_out;               // osg_gemm_rowstats: this GEMM's epilogue also emits [M][rs_np][2] partial row statistics of its f16 output
-    int rs_np;                   //   = N / 32
     // output VIEWS (round 3: skip tensors written straight into their Concat slot, no copy launch): C rows are `ldc` elements apart (0 = dense, N), and
     // the finished f16 values are stored a second time to C2 (rows ldc2 apart) when it is set -- the dense tensor for the layers that read it as it is,
     // the column slice of the concatenated buffer for the up-block that reads the concatenation.  batch (strideC) launches take no views.
     long ldc;
     f16* C2;
     long ldc2;
-    // developer probe (OSG_KDBG=1, tools/kernel_phase_probe.py): per-workgroup phase timestamps, 8 x int64 per workgroup (s_memrealtime, 100 MHz);
-    // NULL in normal operation
-    long long* kdbg;
-    int no_epre;                 // OSG_NO_EPI_PREFETCH=1 (A/B): the epilogue fetches its operands on demand, as before round 3
     StatSink sink[2];            // (see StatSink) [0]: of C, [1]: of C2; table NULL = none
     int sink_hw;                 // output rows per image (a multiple of the tile height: a wave's rows lie in one image)
     int sink_imgs, sink_per_xcd; // images of the pass (the stride between table copies = sink_imgs * groups * 2), see StatSink
@@ -85,6 +102,9 @@ struct GemmParams {
     // [tile][slice][TM * TN][256] f32x4 (a lane's accumulator tile = one 16-byte element: 1-KiB bursts per wave-instruction), tickets two words per tile.
     int fold_acc;
 };
+// a kernel-argument field pulled into a scalar register NOW: see GemmParams.  (An INPUT of an empty asm: an in-out operand would make the value opaque -- pointers lose
+// their address space and every load through them becomes a flat_load, which counts on lgkmcnt AND vmcnt and breaks the counted waits of the k loop.)
+#define OSG_PIN(x) asm volatile("" ::"s"(x))
 __device__ __forceinline__ void kdbg_stamp(const GemmParams& p, int slot) {
     if (p.kdbg && threadIdx.x == 0) p.kdbg[(long)blockIdx.x * 8 + slot] = wall_clock64();
 }
@@ -366,6 +386,38 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, f32x4 (&
         for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 4; r++) o[i][j][r] = (f16)acc[i][j][r];
+#if OSG_EPI_STORE_AUX >= 0
+    // round 6: the finished tile through a buffer descriptor -- rows / columns outside the matrix get an out-of-range offset and the hardware drops them (no exec-mask
+    // code per store), and the cache policy is a compile-time choice (OSG_EPI_STORE_AUX: 0 plain, 16 = sc1 write-through: nothing left dirty in the L2 for the
+    // end-of-kernel write-back to wait for)
+    {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, 0x80000000u, 0x00020000)   /* (outputs stay below 2 GiB: the planner's own limit on a tensor) */;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int m = mb + i * 16;
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const int n = nb + j * 16;
+                const unsigned off = (m < p.M && n < N) ? (unsigned)(((long)m * ldc + n) * 2) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o[i][j]), rsC, off, 0, OSG_EPI_STORE_AUX);
+            }
+        }
+        if (p.C2) {
+            __amdgpu_buffer_rsrc_t rsC2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.C2, 0, 0x80000000u, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const int m = mb + i * 16;
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    const int n = nb + j * 16;
+                    const unsigned off = (m < p.M && n < N) ? (unsigned)(((long)m * p.ldc2 + n) * 2) : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o[i][j]), rsC2, off, 0, OSG_EPI_STORE_AUX);
+                }
+            }
+        }
+    }
+#else
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int m = mb + i * 16;
@@ -387,6 +439,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, f32x4 (&
             }
         }
     }
+#endif
     if (stat_lds) gemm_colstats<TM, TN>(p, o, m0 + wm0, n0 + wn0, lane, stat_lds);
     if (p.rs_out) {
         // osg_gemm_rowstats: sums over this wave's 32-column slots of every row, of the ROUNDED outputs.  The four 16-lane groups of a row hold

@@ -268,13 +268,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 template <int NV, bool CL>
 __global__ __launch_bounds__(1024) void gn_slab_kernel(const f16* __restrict__ x, const f16* __restrict__ gamma, const f16* __restrict__ beta,
                                                        f16* __restrict__ y, int HW, int C, int cpg, int gb, float eps, int act, int S,
-                                                       double* __restrict__ part, int* __restrict__ cnt, int wait_ticks, long long* __restrict__ kdbg) {
-    auto stamp = [&](int slot) { if (kdbg && threadIdx.x == 0) kdbg[((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + slot] = wall_clock64(); };
+                                                       double* __restrict__ part, int* __restrict__ cnt, int wait_ticks, long long* __restrict__ kdbg, int NT,
+                                                       int gdx, int gdy) {
+    // NT / gdx / gdy = blockDim.x / gridDim.x / gridDim.y as ARGUMENTS (round 6): the implicit ones cost the prologue a vector load with a full drain behind it
+    osg_pin_all(x, gamma, beta, y, HW, C, cpg, gb, eps, act, S, part, cnt, wait_ticks, kdbg, NT, gdx, gdy);
+    auto stamp = [&](int slot) { if (kdbg && threadIdx.x == 0) kdbg[((long)(blockIdx.z * gdy + blockIdx.y) * gdx + blockIdx.x) * 8 + slot] = wall_clock64(); };
     stamp(0);
     __shared__ float red[8][16][2];   // [local group][wave][sum, sumsq]
     __shared__ float stat[8][2];      // [local group][mean, rstd]
     const int HWs = CL ? HW / S : HW;      // rows of this block
-    const int NT = blockDim.x, nw = NT >> 6;
+    const int nw = NT >> 6;
     const int CW = gb * cpg, VR = CW >> 3, RT = NT / VR;
     const int t = threadIdx.x, tr = t / VR, tc = t - tr * VR;
     const bool active = tr < RT;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const f16* __restrict__ x
     if constexpr (CL) {
         typedef double d2 __attribute__((ext_vector_type(2)));
         __shared__ int alone;             // 1: the wait for the peers ran out -- this block computes every partial of its slab itself
-        const long slab = (long)blockIdx.y * gridDim.x + blockIdx.x;
+        const long slab = (long)blockIdx.y * gdx + blockIdx.x;
         double* mine = part + ((slab * gb) * S) * 2;
         int* c2 = cnt + slab * 2;
         d2 own = {0.0, 0.0};              // (threads t < gb) this block's partial of local group t
@@ -823,7 +826,8 @@ int osg_group_norm_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void
         const dim3 grid(G / sp.gb, N), block(sp.nt);
 #define OSG_GN_SLAB(NV_)                                                                                                             \
     hipLaunchKernelGGL((gn_slab_kernel<NV_, false>), grid, block, 0, ctx->compute, (const f16*)x, (const f16*)gamma, (const f16*)beta, (f16*)y, \
-                       (int)HW, C, C / G, sp.gb, eps, (int)act, 1, (double*)nullptr, (int*)nullptr, 0, osg_mm::kdbg_buffer(ctx, (long)grid.x * grid.y))
+                       (int)HW, C, C / G, sp.gb, eps, (int)act, 1, (double*)nullptr, (int*)nullptr, 0, osg_mm::kdbg_buffer(ctx, (long)grid.x * grid.y), \
+                       (int)block.x, (int)grid.x, (int)grid.y)
         switch (sp.nv) {
             case 1: OSG_GN_SLAB(1); break;
             case 2: OSG_GN_SLAB(2); break;
@@ -842,7 +846,8 @@ int osg_group_norm_nhwc(osg_ctx* ctx, osg_dtype dtype, const void* x, const void
         const int gn_wait = getenv("OSG_GN_CLUSTER_WAIT") ? atoi(getenv("OSG_GN_CLUSTER_WAIT")) : 20000;   // 10 ns ticks; 0 = nobody waits (tests: every block goes solo)
 #define OSG_GN_CL(NV_)                                                                                                               \
     hipLaunchKernelGGL((gn_slab_kernel<NV_, true>), grid, block, 0, ctx->compute, (const f16*)x, (const f16*)gamma, (const f16*)beta, (f16*)y, \
-                       (int)HW, C, C / G, cp.gb, eps, (int)act, cp.S, (double*)ctx->ws, cnt, gn_wait, osg_mm::kdbg_buffer(ctx, (long)grid.x * grid.y * grid.z))
+                       (int)HW, C, C / G, cp.gb, eps, (int)act, cp.S, (double*)ctx->ws, cnt, gn_wait, osg_mm::kdbg_buffer(ctx, (long)grid.x * grid.y * grid.z), \
+                       (int)block.x, (int)grid.x, (int)grid.y)
         switch (cp.nv) {
             case 1: OSG_GN_CL(1); break;
             case 2: OSG_GN_CL(2); break;

@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libosgpu.so")
+LIB_PATH = os.environ.get("OSGPU_LIB") or os.path.join(_HERE, "libosgpu.so")   # (OSGPU_LIB: A/B runs against another build, as the host library honours it)
 
 U8, F16, F32, I64 = 1, 2, 3, 4
 _NP2DT = {np.dtype(np.uint8): U8, np.dtype(np.float16): F16, np.dtype(np.float32): F32, np.dtype(np.int64): I64}

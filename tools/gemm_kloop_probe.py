@@ -43,16 +43,16 @@ def phases(launch, wgs, reps=5):
     return med, np.diff(med[:7]), last, float(np.median([m for _, m in rows])) * 1e3
 
 
-def gemm_case(M, N, K, cfg, nst, splits=1, ks=1, spec=0, fold=0, note=""):
+def gemm_case(M, N, K, cfg, nst, splits=1, ks=1, spec=0, fold=0, note="", batch=1):
     A = g.to_dev((rng.standard_normal((M, K)) * 0.5).astype(f16))
     W = g.to_dev((rng.standard_normal((N, K)) * K ** -0.5).astype(f16))
-    Y = g.empty((M, N), f16)
+    Y = g.empty((batch * M, N), f16)
     bias = g.to_dev(np.zeros(N, f16))
     for k, v in (("OSG_GEMM_CFG", cfg), ("OSG_GEMM_NST", nst), ("OSG_GEMM_SPLITS", splits), ("OSG_GEMM_KS", ks), ("OSG_GEMM_SPEC", spec), ("OSG_GEMM_FOLD", fold)):
         os.environ[k] = str(v)
     bm, bn = TILES[cfg]
-    wgs = -(-M // bm) * -(-N // bn) * splits
-    med, seg, last, us = phases(lambda: g._ck(L.osg_gemm(g.ctx, DT16, A.ptr, W.ptr, 1, bias.ptr, DT16, None, Y.ptr, M, N, K, 1, 0, 0, 0, 0)), wgs)
+    wgs = -(-M // bm) * -(-N // bn) * splits * batch
+    med, seg, last, us = phases(lambda: g._ck(L.osg_gemm(g.ctx, DT16, A.ptr, W.ptr, 1, bias.ptr, DT16, None, Y.ptr, M, N, K, batch, 0, 0, M * N, 0)), wgs)
     nkt = max(1, (K // 64 + splits - 1) // splits) // (2 if ks == 2 else 1)
     cyc = seg[2] * 1e3 * GHZ / max(nkt, 1)
     bnp = (bn + 31) // 32 * 32
@@ -66,6 +66,7 @@ def gemm_case(M, N, K, cfg, nst, splits=1, ks=1, spec=0, fold=0, note=""):
 
 
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+pitch = len(sys.argv) > 1 and sys.argv[1] == "pitch"   # round 6: is the k loop's delivery rate a matter of the operands' row pitch (L2 channel / DRAM bank camping)?
 print(f"# {'hot' if os.environ.get('PROBE_HOT') else 'cold'} operands; cycles at {GHZ} GHz nominal; B/clk/CU and matrix-pipe use are of the k loop of the MEDIAN workgroup")
 # (shape, [configs]): the round-5 table's choice first, then the round-6 tiles / rings
 cases = [
@@ -79,6 +80,17 @@ cases = [
     ((512, 1280, 1280), [(2, 4, 1, 1, 0), (2, 4, 1, 2, 0), (6, 4, 1, 1, 0)]),
     ((8192, 320, 320), [(2, 2, 1, 1, 0), (5, 4, 1, 1, 0), (5, 2, 1, 1, 0)]),
 ]
+if len(sys.argv) > 1 and sys.argv[1] == "ideal":
+    # round 6: every workgroup the SAME tile (batch items broadcast from one A and one B): the k loop with an ideal memory system behind it
+    for (M, N, K, cfg, nst) in ((64, 64, 640, 2, 4), (64, 64, 2560, 2, 4), (64, 80, 640, 6, 4), (128, 128, 1280, 0, 4), (128, 128, 1280, 0, 2), (128, 160, 1280, 4, 4), (128, 64, 640, 1, 4), (128, 80, 640, 5, 4)):
+        gemm_case(M, N, K, cfg, nst, note="256 x the same tile", batch=256)
+    g.close()
+    sys.exit(0)
+if pitch:
+    cases = [((M, N, K + dk), cfgs[:2]) for (M, N, K), cfgs in (((512, 10240, 1280), [(4, 4, 1, 1, 0), (0, 4, 1, 1, 0)]), ((2048, 640, 640), [(2, 4, 1, 1, 0), (6, 4, 1, 1, 0)]),
+                                                                ((2048, 640, 2560), [(2, 4, 1, 1, 0), (6, 4, 1, 1, 0)]), ((512, 1280, 1280), [(2, 4, 1, 1, 0), (6, 4, 1, 1, 0)]),
+                                                                ((2048, 1920, 640), [(0, 4, 1, 1, 0), (4, 2, 1, 1, 0)]), ((8192, 320, 320), [(5, 4, 1, 1, 0), (2, 2, 1, 1, 0)]))
+             for dk in (0, 64, 192)]
 for (M, N, K), cfgs in (cases[:3] if quick else cases):
     for cfg, nst, splits, ks, spec in cfgs:
         gemm_case(M, N, K, cfg, nst, splits, ks, spec)

@@ -12,6 +12,54 @@ floor4)
   timeout 300 tools/_build/floor_probe4 9 > ${T}_floor_probe4.txt 2>&1; echo "floor_probe4 exit $?"; cat ${T}_floor_probe4.txt ;;
 ref16)
   timeout 1500 python tools/ref16_fullsize.py epyc gpurun_out ${1:-sd15,sd15_w8,sdxl,vae} > ${T}_ref16_epyc.log 2>&1; echo "ref16 exit $?"; tail -8 ${T}_ref16_epyc.log ;;
+pipeprobe)
+  # the k loop pipelined across its barrier (libosgpu_pipe.so = the library built with -DOSG_GEMM_PIPE=1): kernel tests on it, then the k-loop probe of both builds, alternating
+  OSGPU_LIB=$PWD/onnxstream_amd/libosgpu_pipe.so timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "gemm or conv or 160 or two_wave or splitk" > ${T}_pipe_tests.log 2>&1; echo "pipe kernel tests exit $?"; tail -3 ${T}_pipe_tests.log
+  for rep in 1 2; do
+    timeout 600 python tools/gemm_kloop_probe.py > ${T}_kloop_base_$rep.txt 2>&1
+    OSGPU_LIB=$PWD/onnxstream_amd/libosgpu_pipe.so timeout 600 python tools/gemm_kloop_probe.py > ${T}_kloop_pipe_$rep.txt 2>&1
+  done; tail -3 ${T}_kloop_pipe_2.txt ;;
+libab)
+  # headline bench, alternating: libosgpu.so vs the library named by $1 (default libosgpu_pipe.so); first both on the shipped tune table, then each on a table it tunes itself
+  ALT=$PWD/onnxstream_amd/${1:-libosgpu_pipe.so}
+  pl() { python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1]); c = d["config"]
+    print(sys.argv[2], "ms_per_step", d["ms_per_step"], "windows median", c["windows_ms_per_step"]["median"], "unet dev ms", c["unet_device_ms_per_step"], "misses", c["tune_table_misses"], "absmax", c["latent_absmax"])
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+  }
+  for i in 1 2; do
+    export OSG_TUNE_CACHE=/tmp/tc_a.txt; cp onnxstream_amd/tune/mi355x.txt $OSG_TUNE_CACHE
+    timeout 600 python bench.py --cpu-passes 0 --windows 2 > ${T}_libab_A_$i.json 2> ${T}_libab_A_$i.err; pl ${T}_libab_A_$i.json "A libosgpu.so shipped table"
+    export OSG_TUNE_CACHE=/tmp/tc_b.txt; cp onnxstream_amd/tune/mi355x.txt $OSG_TUNE_CACHE
+    OSGPU_LIB=$ALT timeout 600 python bench.py --cpu-passes 0 --windows 2 > ${T}_libab_B_$i.json 2> ${T}_libab_B_$i.err; pl ${T}_libab_B_$i.json "B $(basename $ALT) shipped table"
+  done
+  export OSG_TUNE_CACHE=/tmp/tc_a2.txt; rm -f $OSG_TUNE_CACHE
+  timeout 900 python bench.py --cpu-passes 0 --windows 2 > ${T}_libab_A_tuned.json 2> ${T}_libab_A_tuned.err; pl ${T}_libab_A_tuned.json "A libosgpu.so own table"
+  export OSG_TUNE_CACHE=/tmp/tc_b2.txt; rm -f $OSG_TUNE_CACHE
+  OSGPU_LIB=$ALT timeout 900 python bench.py --cpu-passes 0 --windows 2 > ${T}_libab_B_tuned.json 2> ${T}_libab_B_tuned.err; pl ${T}_libab_B_tuned.json "B $(basename $ALT) own table"
+  cp /tmp/tc_b2.txt ${T}_tune_alt.txt; cp /tmp/tc_a2.txt ${T}_tune_base.txt
+  export OSG_TUNE_CACHE=/tmp/tc_a2.txt; timeout 600 python bench.py --cpu-passes 0 --windows 2 > ${T}_libab_A_tuned2.json 2> ${T}_libab_A_tuned2.err; pl ${T}_libab_A_tuned2.json "A libosgpu.so own table (again)"
+  export OSG_TUNE_CACHE=/tmp/tc_b2.txt; OSGPU_LIB=$ALT timeout 600 python bench.py --cpu-passes 0 --windows 2 > ${T}_libab_B_tuned2.json 2> ${T}_libab_B_tuned2.err; pl ${T}_libab_B_tuned2.json "B $(basename $ALT) own table (again)"
+  ;;
+libs)
+  # headline bench on the shipped tune table, the libraries named in $@ (files under onnxstream_amd/) alternating, 2 rounds
+  pl2() { python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1]); c = d["config"]
+    print(sys.argv[2], "ms_per_step", d["ms_per_step"], "windows median", c["windows_ms_per_step"]["median"], "unet dev ms", c["unet_device_ms_per_step"], "misses", c["tune_table_misses"], "absmax", c["latent_absmax"])
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+  }
+  for i in 1 2; do for L in "$@"; do
+    export OSG_TUNE_CACHE=/tmp/tc_$L.txt; cp onnxstream_amd/tune/mi355x.txt $OSG_TUNE_CACHE
+    OSGPU_LIB=$PWD/onnxstream_amd/$L timeout 600 python bench.py --cpu-passes 0 --windows 2 > ${T}_libs_${L}_$i.json 2> ${T}_libs_${L}_$i.err; pl2 ${T}_libs_${L}_$i.json "$L"
+  done; done; break ;;
 old)
   bash tools/gpu_round.sh "$@"; break ;;
 *) echo "unknown recipe $R" ;;
