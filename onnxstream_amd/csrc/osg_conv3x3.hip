@@ -301,11 +301,11 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
             if (!splitk_fold_acc<TM, TN>(p, acc, m_tile * p.nt + n_tile, zs, reinterpret_cast<int*>(smem3), tid)) return;
             EpiOps<TM, TN, true, false> none;
             none.have = false;
-            gemm_epilogue_fast<TM, TN, true, false>(p, acc, m0, n0, wm0, wn0, lane, 0, none, nullptr);
+            gemm_epilogue_fast<TM, TN, true, false, false>(p, acc, m0, n0, wm0, wn0, lane, 0, none, nullptr);
             return;
         }
     }
-    gemm_epilogue<TM, TN, true, EPRE>(p, acc, m0, n0, wm0, wn0, lane, 0, zs, epre, stat_lds);
+    gemm_epilogue<TM, TN, true, EPRE, false>(p, acc, m0, n0, wm0, wn0, lane, 0, zs, epre, stat_lds);
     kdbg_stamp(p, 5);
     if (p.kdbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); kdbg_stamp(p, 6); }
 }

@@ -327,14 +327,15 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const float* __rest
     const long e = idx - (long)b * MN;
     const long m = e / N;
     const int n = (int)(e - m * N);
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    f16x4 b16 = {0, 0, 0, 0}, rb = {0, 0, 0, 0}, rv = {0, 0, 0, 0};
-    if (bias) {
-        if (bias_f32) bv = *reinterpret_cast<const f32x4*>((const float*)bias + n);
-        else b16 = *reinterpret_cast<const f16x4*>((const f16*)bias + n);
-    }
-    if (rowbias) rb = *reinterpret_cast<const f16x4*>(rowbias + (m / rb_rows) * rb_ld + n);
-    if (residual) rv = *reinterpret_cast<const f16x4*>(residual + b * strideC + e);
+    // round 6: the epilogue operands by UNCONDITIONAL loads (an absent operand reads the slab instead and is replaced by -0.0, the exact neutral element of the
+    // additions below): loaded inside `if (bias) ...` blocks, every operand cost a wait at the end of its block -- a dependent trip to memory in front of the slab
+    // loads of a launch that lasts ~5 us.  Same additions in the same order => the same bits.
+    const bool has_b32 = bias && bias_f32, has_b16 = bias && !bias_f32;
+    const f16* safe = reinterpret_cast<const f16*>(partial);
+    const f32x4 bv_l = *reinterpret_cast<const f32x4*>(has_b32 ? (const float*)bias + n : partial);
+    const f16x4 b16_l = *reinterpret_cast<const f16x4*>(has_b16 ? (const f16*)bias + n : safe);
+    const f16x4 rb_l = *reinterpret_cast<const f16x4*>(rowbias ? rowbias + (m / (rb_rows > 0 ? rb_rows : 1)) * rb_ld + n : safe);
+    const f16x4 rv_l = *reinterpret_cast<const f16x4*>(residual ? residual + b * strideC + e : safe);
     const float* src = partial + (long)b * splits * MN + e;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     for (int s0 = 0; s0 < splits; s0 += SB) {
@@ -345,20 +346,11 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const float* __rest
         for (int u = 0; u < SB; u++)
             if (s0 + u < splits) v += part[u];
     }
-    if (bias) {
-        if (bias_f32) v += bv;
-        else {
 #pragma unroll
-            for (int r = 0; r < 4; r++) v[r] += (float)b16[r];
-        }
-    }
-    if (rowbias) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) v[r] += (float)rb[r];
-    }
-    if (residual) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) v[r] += (float)rv[r];
+    for (int r = 0; r < 4; r++) {
+        v[r] += bias ? (has_b32 ? bv_l[r] : (float)b16_l[r]) : -0.0f;
+        v[r] += rowbias ? (float)rb_l[r] : -0.0f;
+        v[r] += residual ? (float)rv_l[r] : -0.0f;
     }
     f16x4 o;
 #pragma unroll

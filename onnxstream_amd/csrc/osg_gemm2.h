@@ -444,7 +444,7 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
             return;
         }
     }
-    gemm_epilogue<TM, TN, CONV, EPRE>(p, acc, m0, n0, wm0, wn0, lane, zb, zb * p.splits + zs, epre, stat_lds);
+    gemm_epilogue<TM, TN, CONV, EPRE, !SPEC>(p, acc, m0, n0, wm0, wn0, lane, zb, zb * p.splits + zs, epre, stat_lds);   // (SPEC: 512 threads, 256 registers per lane -- the on-demand operands one block at a time)
     kdbg_stamp(p, 5);
     if (p.kdbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); kdbg_stamp(p, 6); }
 }

@@ -6,7 +6,7 @@
 
 #include <type_traits>
 #ifndef OSG_EPI_STORE_AUX
-#define OSG_EPI_STORE_AUX -1    // < 0: plain pointer stores with exec masks (rounds 1-5); 0 / 16: buffer stores, plain / sc1 write-through (A/B builds)
+#define OSG_EPI_STORE_AUX 0     // < 0: plain pointer stores with exec masks (rounds 1-5); 0 / 16: buffer stores, plain / sc1 write-through (A/B builds: profiles/r06_epilogue_store_ab.txt)
 #endif
 namespace osg_mm {
 // compile-time loop: f(std::integral_constant<int, B>{}), ..., f(std::integral_constant<int, E - 1>{}) -- every index a constant expression inside f
@@ -279,7 +279,7 @@ __device__ __forceinline__ void gemm_colstats(const GemmParams& p, const f16x4 (
     }
 }
 
-template <int TM, int TN, bool RB, bool ON>
+template <int TM, int TN, bool RB, bool ON, bool BATCH = true>
 __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane, int zb,
                                                    const EpiOps<TM, TN, RB, ON>& pre, float* stat_lds = nullptr) {
     // every uniform decision (which operands exist, which activation, a second destination) is taken ONCE, around a whole loop over the wave's tiles --
@@ -329,7 +329,61 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, f32x4 (&
             }
         }
     }
-    if (!done) {   // operands on demand (clamped addresses: the loads are unconditional, the stores below are not)
+    if constexpr (BATCH) if (!done) {
+        // operands on demand (the 128-row tiles: no registers to prefetch into before the k loop).  Round 6: EVERY load first -- unconditional, clamped, an absent operand
+        // reads A instead and enters the sum as -0.0, the exact neutral element -- then the additions in the old order: loaded inside `if (p.bias) ... if (p.rowbias) ...
+        // if (R) ...` each operand was waited for at the end of its block, three dependent trips to memory in a row on the critical path of the launch.  Same bits.
+        // Through buffer descriptors: an absent operand gets an EMPTY descriptor (every load returns 0, no memory traffic), rows / columns outside the matrix are out of
+        // range, and the TN blocks of a row are one address register + immediate offsets.
+        const bool hb32 = p.bias && p.bias_f32, hb16 = p.bias && !p.bias_f32, hrb = p.rowbias != nullptr, hres = R != nullptr;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const unsigned nbytes = (unsigned)N * 2u;
+        __amdgpu_buffer_rsrc_t rsB32 = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, hb32 ? nbytes * 2u : 0u, 0x00020000);
+        __amdgpu_buffer_rsrc_t rsB16 = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, hb16 ? nbytes : 0u, 0x00020000);
+        __amdgpu_buffer_rsrc_t rsRB = __builtin_amdgcn_make_buffer_rsrc((void*)p.rowbias, 0, hrb ? 0x80000000u : 0u, 0x00020000);
+        __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)R, 0, hres ? (unsigned)p.M * nbytes : 0u, 0x00020000);
+        f32x4 b32[TN];
+        f16x4 b16[TN];
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            b32[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB32, (unsigned)nb * 4u + j * 64, 0, 0));
+            b16[j] = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rsB16, (unsigned)nb * 2u + j * 32, 0, 0));
+        }
+        // (tiles of more than 16 blocks per wave -- 128 x 160 -- take the row operands half a 16-row block at a time: 256 architectural registers)
+        constexpr int IB = TM * TN <= 16 ? TM : 1, JB = (TM * TN <= 16 || TN % 2) ? TN : TN / 2;
+        static_assert(TN % JB == 0, "column blocks per chunk");
+#pragma unroll
+        for (int i0 = 0; i0 < TM; i0 += IB)
+#pragma unroll
+            for (int j0 = 0; j0 < TN; j0 += JB) {
+                f16x4 rbv[IB][JB], rsv[IB][JB];
+#pragma unroll
+                for (int ii = 0; ii < IB; ii++) {
+                    const int m = mb + (i0 + ii) * 16;
+                    const unsigned ro = hrb ? (unsigned)(((long)(min(m, p.M - 1) / (p.rb_rows > 0 ? p.rb_rows : 1)) * p.rb_ld + nb) * 2) : 0u;
+                    const unsigned rs = (unsigned)m * nbytes + (unsigned)nb * 2u;
+#pragma unroll
+                    for (int jj = 0; jj < JB; jj++) {
+                        rbv[ii][jj] = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rsRB, ro + (j0 + jj) * 32, 0, 0));
+                        rsv[ii][jj] = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rsR, rs + (j0 + jj) * 32, 0, 0));
+                    }
+                }
+#pragma unroll
+                for (int ii = 0; ii < IB; ii++)
+#pragma unroll
+                    for (int jj = 0; jj < JB; jj++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            float x = acc[i0 + ii][j0 + jj][r];
+                            x += p.bias ? (hb32 ? b32[j0 + jj][r] : (float)b16[j0 + jj][r]) : -0.0f;
+                            x += hrb ? (float)rbv[ii][jj][r] : -0.0f;
+                            x += hres ? (float)rsv[ii][jj][r] : -0.0f;
+                            acc[i0 + ii][j0 + jj][r] = x;
+                        }
+            }
+    }
+    if constexpr (!BATCH) if (!done) {   // (the 512- / 768-thread halo convolution: 256 / 168 registers per lane, no room for the batch) operands on demand (clamped addresses: the loads are unconditional, the stores below are not)
         if (p.bias) {
 #pragma unroll
             for (int j = 0; j < TN; j++) {
@@ -476,13 +530,13 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, f32x4 (&
     }
 }
 
-template <int TM, int TN, bool RB, bool ON>
+template <int TM, int TN, bool RB, bool ON, bool BATCH = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane,
                                               int zb, int zslab, const EpiOps<TM, TN, RB, ON>& pre, float* stat_lds = nullptr) {
     const int N = p.N;
     if (p.splits == 1) {
         if ((N & 3) == 0 && ((p.ldc | p.ldc2) & 3) == 0) {   // every 4-aligned shape: compact code (see gemm_epilogue_fast)
-            gemm_epilogue_fast<TM, TN, RB, ON>(p, acc, m0, n0, wm0, wn0, lane, zb, pre, stat_lds);
+            gemm_epilogue_fast<TM, TN, RB, ON, BATCH>(p, acc, m0, n0, wm0, wn0, lane, zb, pre, stat_lds);
             return;
         }
         // ragged N (conv_out's 3 / 4 channels, odd test shapes): element by element
@@ -550,6 +604,17 @@ __device__ __forceinline__ void gemm_epilogue_geglu(const GemmParams& p, f32x4 (
     static_assert(TN % 2 == 0, "GEGLU epilogue needs value/gate tile pairs");
     const int No = p.N >> 1;
     f16* __restrict__ C = p.C + zb * p.strideC;
+    // round 6: the bias of the wave's TN column blocks by ONE vector load each, all in flight together (rounds 1-5: eight 2-byte loads per output quad, on demand);
+    // unconditional and clamped, an absent bias reads A and enters as -0.0 (the exact neutral element): same sums, same bits
+    const bool hb32 = p.bias && p.bias_f32, hb16 = p.bias && !p.bias_f32;
+    f32x4 b32[TN];
+    f16x4 b16[TN];
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = min(n0 + wn0 + j * 16 + (lane >> 4) * 4, p.N - 4);
+        b32[j] = *reinterpret_cast<const f32x4*>(hb32 ? (const float*)p.bias + n : (const float*)p.A);
+        b16[j] = *reinterpret_cast<const f16x4*>(hb16 ? (const f16*)p.bias + n : p.A);
+    }
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         const int m = m0 + wm0 + i * 16 + (lane & 15);
@@ -562,11 +627,8 @@ __device__ __forceinline__ void gemm_epilogue_geglu(const GemmParams& p, f32x4 (
             f16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float v = acc[i][j][r], g = acc[i][j + 1][r];
-                if (p.bias) {
-                    v += p.bias_f32 ? ((const float*)p.bias)[n + r] : (float)((const f16*)p.bias)[n + r];
-                    g += p.bias_f32 ? ((const float*)p.bias)[n + 16 + r] : (float)((const f16*)p.bias)[n + 16 + r];
-                }
+                const float v = acc[i][j][r] + (p.bias ? (hb32 ? b32[j][r] : (float)b16[j][r]) : -0.0f);
+                const float g = acc[i][j + 1][r] + (p.bias ? (hb32 ? b32[j + 1][r] : (float)b16[j + 1][r]) : -0.0f);
                 o[r] = (f16)(v * osg_gelu_erf(g));
             }
             *reinterpret_cast<f16x4*>(C + (long)m * No + c) = o;
