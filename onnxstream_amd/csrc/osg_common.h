@@ -139,6 +139,26 @@ __device__ __forceinline__ void osg_pin_one(const T& v) { asm volatile("" ::"s"(
 template <class... T>
 __device__ __forceinline__ void osg_pin_all(const T&... v) { (osg_pin_one(v), ...); }
 
+// wave-wide sum on the VALU (round 6, GroupNorm's slab kernel): inside each 16-lane row by DPP (quad butterfly, then row rotations), across the four rows by the gfx950
+// v_permlane16_swap / v_permlane32_swap pair (see osg_attention.hip: lane_swap16 / lane_swap32) -- ~10 VALU instructions where the ds_bpermute chain of wave_sum
+// below is six LDS round trips of ~100 cycles.  Every lane ends up with the total; the additions are a fixed tree (another one than wave_sum's: different last bits).
+template <int CTRL>
+__device__ __forceinline__ float osg_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_valu(float v) {
+    v += osg_dpp<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += osg_dpp<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += osg_dpp<0x124>(v);    // row_ror:4
+    v += osg_dpp<0x128>(v);    // row_ror:8
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    v = a + b;
+    a = v; b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -323,8 +323,8 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const f16* __restrict__ x
     for (int gl = 0; gl < gb; gl++) {
         float s = active ? (g0 == gl ? as : (g0 + 1 == gl ? bs : 0.f)) : 0.f;
         float q = active ? (g0 == gl ? aq : (g0 + 1 == gl ? bq : 0.f)) : 0.f;
-        s = wave_sum(s);
-        q = wave_sum(q);
+        s = wave_sum_valu(s);
+        q = wave_sum_valu(q);
         if (lane == 0) { red[gl][wave][0] = s; red[gl][wave][1] = q; }
     }
     __syncthreads();
@@ -408,8 +408,8 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const f16* __restrict__ x
                     for (int gl = 0; gl < gb; gl++) {
                         float ps = active ? (g0 == gl ? zas : (g0 + 1 == gl ? zbs : 0.f)) : 0.f;
                         float pq2 = active ? (g0 == gl ? zaq : (g0 + 1 == gl ? zbq : 0.f)) : 0.f;
-                        ps = wave_sum(ps);
-                        pq2 = wave_sum(pq2);
+                        ps = wave_sum_valu(ps);
+                        pq2 = wave_sum_valu(pq2);
                         if (lane == 0) { red[gl][wave][0] = ps; red[gl][wave][1] = pq2; }
                     }
                     __syncthreads();
