@@ -675,49 +675,58 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* _
                                                                   const f16* __restrict__ residual, int M, int N, int splits, int act, const f16* __restrict__ rowbias,
                                                                   int rb_rows, long rb_ld, long ldc, f16* __restrict__ C2, long ldc2, StatSink s0, StatSink s1, int hw,
                                                                   int imgs, int per_xcd) {
+    // round 6: a workgroup owns 32 rows x 64 channels (rounds 3-5: 128 rows, eight rows per thread one after the other -- eight dependent trips to memory, 17 us per
+    // launch against the 5 us of splitk_reduce4_kernel).  A thread has TWO rows; every load of both -- all slices, the epilogue operands (unconditional: an absent
+    // operand reads the slab and enters as -0.0, see splitk_reduce4_kernel) -- is in flight before the first addition.  Per element the slices and operands are added in
+    // the old order: the same f16 outputs; the statistics are integer sums of the same rounded values: the same tables.
+    osg_pin_all(partial, C, bias, bias_f32, residual, M, N, splits, act, rowbias, rb_rows, rb_ld, ldc, C2, ldc2, hw, imgs, per_xcd);
+    constexpr int RPT = 2;
     __shared__ float st[16][64][2];
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 64, n = n0 + cq * 4;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 64, n = n0 + cq * 4;
     const long MN = (long)M * N;
     float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq2[4] = {0.f, 0.f, 0.f, 0.f};
     if (n < N) {
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-            if (bias_f32) bv = *reinterpret_cast<const f32x4*>((const float*)bias + n);
-            else {
-                const f16x4 b16 = *reinterpret_cast<const f16x4*>((const f16*)bias + n);
+        const bool has_b32 = bias && bias_f32, has_b16 = bias && !bias_f32;
+        const f16* safe = reinterpret_cast<const f16*>(partial);
+        const f32x4 bv_l = *reinterpret_cast<const f32x4*>(has_b32 ? (const float*)bias + n : partial);
+        const f16x4 b16_l = *reinterpret_cast<const f16x4*>(has_b16 ? (const f16*)bias + n : safe);
+        f32x4 part[RPT][SB];
+        f16x4 rb_l[RPT], rv_l[RPT];
 #pragma unroll
-                for (int r = 0; r < 4; r++) bv[r] = (float)b16[r];
-            }
+        for (int k = 0; k < RPT; k++) {
+            const int m = min(m0 + rl + 16 * k, M - 1);
+            const long e = (long)m * N + n;
+            rb_l[k] = *reinterpret_cast<const f16x4*>(rowbias ? rowbias + (long)(m / (rb_rows > 0 ? rb_rows : 1)) * rb_ld + n : safe);
+            rv_l[k] = *reinterpret_cast<const f16x4*>(residual ? residual + e : safe);
+#pragma unroll
+            for (int u = 0; u < SB; u++) part[k][u] = *reinterpret_cast<const f32x4*>(partial + (long)min(u, splits - 1) * MN + e);
         }
-        for (int k = 0; k < 8; k++) {
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
             const int m = m0 + rl + 16 * k;
             if (m >= M) break;
             const long e = (long)m * N + n;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            for (int z0 = 0; z0 < splits; z0 += SB) {
-                f32x4 part[SB];
 #pragma unroll
-                for (int u = 0; u < SB; u++) part[u] = *reinterpret_cast<const f32x4*>(partial + (long)min(z0 + u, splits - 1) * MN + e);
+            for (int u = 0; u < SB; u++)
+                if (u < splits) v += part[k][u];
+            for (int z0 = SB; z0 < splits; z0 += SB) {     // (more than SB slices: the rest the old way)
+                f32x4 more[SB];
+#pragma unroll
+                for (int u = 0; u < SB; u++) more[u] = *reinterpret_cast<const f32x4*>(partial + (long)min(z0 + u, splits - 1) * MN + e);
 #pragma unroll
                 for (int u = 0; u < SB; u++)
-                    if (z0 + u < splits) v += part[u];
-            }
-            if (bias) v += bv;
-            if (rowbias) {
-                const f16x4 rb = *reinterpret_cast<const f16x4*>(rowbias + (long)(m / rb_rows) * rb_ld + n);
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] += (float)rb[r];
-            }
-            if (residual) {
-                const f16x4 rv = *reinterpret_cast<const f16x4*>(residual + e);
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] += (float)rv[r];
+                    if (z0 + u < splits) v += more[u];
             }
             f16x4 o;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                o[r] = (f16)osg_apply_act(v[r], act);
+                float x = v[r];
+                x += bias ? (has_b32 ? bv_l[r] : (float)b16_l[r]) : -0.0f;
+                x += rowbias ? (float)rb_l[k][r] : -0.0f;
+                x += residual ? (float)rv_l[k][r] : -0.0f;
+                o[r] = (f16)osg_apply_act(x, act);
                 const float f = (float)o[r];
                 cs[r] += f;
                 cq2[r] = fmaf(f, f, cq2[r]);
@@ -752,10 +761,10 @@ int osg_mm::launch_splitk_reduce(osg_ctx* ctx, const GemmParams& p, int batch) {
     const long ldc_ = p.ldc ? p.ldc : (long)p.N;
     static const bool scalar_only = getenv("OSG_SPLITK_REDUCE_SCALAR") != nullptr;   // (A/B)
     if ((p.sink[0].table || p.sink[1].table) && !ctx->tuning && batch == 1 && p.N % 4 == 0 && (ldc_ & 3) == 0 && (p.ldc2 & 3) == 0 && (p.rb_ld & 3) == 0 &&
-        (((uintptr_t)p.C | (uintptr_t)p.C2 | (uintptr_t)p.residual | (uintptr_t)p.rowbias) & 7) == 0 && ((uintptr_t)p.bias & 15) == 0 && p.sink_hw > 0 && p.sink_hw % 128 == 0 &&
+        (((uintptr_t)p.C | (uintptr_t)p.C2 | (uintptr_t)p.residual | (uintptr_t)p.rowbias) & 7) == 0 && ((uintptr_t)p.bias & 15) == 0 && p.sink_hw > 0 && p.sink_hw % 32 == 0 &&
         p.M % p.sink_hw == 0) {
         // (the output feeds GroupNorm statistics sinks: the reduce launch is where the finished values are)
-        const dim3 grid((unsigned)((p.M + 127) / 128), (unsigned)((p.N + 63) / 64));
+        const dim3 grid((unsigned)((p.M + 31) / 32), (unsigned)((p.N + 63) / 64));
         const int imgs = p.M / p.sink_hw, per_xcd = ctx->xcd_ids8 ? 1 : 0;
         if (p.splits <= 4)
             hipLaunchKernelGGL(splitk_reduce_stats_kernel<4>, grid, dim3(256), 0, ctx->compute, p.partial, p.C, p.bias, p.bias_f32, p.residual, p.M, p.N, p.splits, p.act, p.rowbias,

@@ -8,9 +8,6 @@
 #ifndef OSG_GEMM_PIN
 #define OSG_GEMM_PIN 1      // the kernel-argument fields of the prologue pulled in one batch at entry (GemmParams); 0 = as before (A/B)
 #endif
-#ifndef OSG_GEMM_PIPE
-#define OSG_GEMM_PIPE 0     // 1: the k loop pipelined across its barrier (see the kernel); -DOSG_GEMM_PIPE=0/1 builds the two sides of the A/B
-#endif
 
 namespace {
 using namespace osg_mm;
@@ -222,147 +219,12 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
     for (int i = 0; i < TM; i++) ls[i] = lq[i] = 0.f;
 
     int cur = 0, nxt = NST - 1;
-#if OSG_GEMM_PIPE
-    // ---- round 6: the k loop software-pipelined ACROSS its barrier ---------------------------------------------------------------------------------------
-    // One wave per SIMD and one barrier per k-tile: in the loop below every k-tile pays, one after the other, barrier -> DMA requests -> fragment reads (LDS latency) ->
-    // MFMAs, with nobody to issue from meanwhile (670-900 cycles per 64-deep tile of a 64 x 64 block whose MFMAs last 128; hot operands or cold).  Here the MFMAs LAG
-    // the fragment reads: after the barrier of tile j a wave requests tile j + NST - 1, reads the fragments of tile j into the other register set and issues the MFMAs
-    // of tile j - 1 (FULL: a whole tile behind) -- or of the half-tile before (the 128 x 160 tile, whose second register set would not fit) -- in CHUNKS of
-    // {one DMA request, a few fragment reads, a few MFMAs} pinned by sched_barrier, so the matrix pipe runs while the LDS reads and the DMA requests are in flight.
-    // The DMA schedule, the ring and the fp32 summation order are those of the loop below: same bits.
-    constexpr bool FULL = 16 * (TM + TN) + 4 * TM * TN <= ((SPEC || KS == 2) ? 140 : 200);   // (512-thread forms: 256 registers per lane)
-    if constexpr (MODE != 1) {
-        constexpr int NSET = FULL ? 2 : 1;
-        f16x8 fa[NSET][2][TM], fb[NSET][2][TN];
-        constexpr int RH = TM + TN, R_ALL = 2 * RH, FH = TM * TN, F_ALL = 2 * FH, D_ALL = A_LD + B_LD;
-        const char* St = smem2;
-        // fragment read number r of a tile (0 .. R_ALL): half r / RH, then the TM row blocks, then the TN column blocks
-        auto rd1 = [&](auto set, auto r_) {
-            constexpr int S = decltype(set)::value, r = decltype(r_)::value, ks = r / RH, q = r % RH;
-            if constexpr (q < TM) fa[S][ks][q] = *reinterpret_cast<const f16x8*>(St + ((a_rd + q * 16 * ROWB) ^ (ks << 6)));
-            else fb[S][ks][q - TM] = *reinterpret_cast<const f16x8*>(St + ((b_rd + (q - TM) * 16 * ROWB) ^ (ks << 6)));
-        };
-        // MFMA number f of a tile (0 .. F_ALL): half f / FH, block (i, j) = ((f % FH) / TN, (f % FH) % TN) -- the order of the plain loop
-        auto mm1 = [&](auto set, auto f_) {
-            constexpr int S = decltype(set)::value, f = decltype(f_)::value, ks = f / FH, i = (f % FH) / TN, j = (f % FH) % TN;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[S][ks][j], fa[S][ks][i], acc[i][j], 0, 0, 0);
-            if constexpr (LN == 1 && (f % FH) == FH - 1) ln_accumulate<TM>(fa[S][ks], ls, lq);
-        };
-        // the DMA requests of one tile, one at a time (issue_tile, taken apart)
-        char* iAs = nullptr;
-        unsigned ikill = 0;
-        int itap = 0;
-        auto issue_begin = [&](int stage) {
-            iAs = smem2 + stage * STAGE + grp * GSTAGE;
-            ikill = ik < kend ? 0u : OOB;
-            if (CONV) itap = ((i_kh * p.W + i_kw) * p.Cin + i_c0) * 2;
-        };
-        auto issue1 = [&](auto d_) {
-            constexpr int d = decltype(d_)::value;
-            if constexpr (d < A_LD) {
-                if (CONV) {
-                    const int hi = a_hi0[d] + i_kh, wi = a_wi0[d] + i_kw;
-                    const bool ok = !ikill && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                    const unsigned off = ok ? (unsigned)(a_base[d] + itap) : OOB;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(iAs + (d * 4 + wave) * 1024), 16, off, 0, 0, 0);
-                } else {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(iAs + (d * 4 + wave) * 1024), 16, (unsigned)a_base[d] | ikill, ik * 2, 0, 0);
-                }
-            } else {
-                constexpr int j = d - A_LD;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(iAs + A_BYTES + (j * 4 + wave) * 1024), 16, (unsigned)b_base[j] | ikill, ik * 2, 0, 0);
-            }
-        };
-        auto issue_end = [&]() {
-            if (CONV) {
-#pragma unroll
-                for (int adv = 0; adv < KS; adv++) {
-                    i_c0 += 64;
-                    if (i_c0 >= p.Cin) { i_c0 = 0; if (++i_kw == p.KW) { i_kw = 0; ++i_kh; } }
-                }
-            }
-            ik += 64 * KS;
-        };
-        auto head = [&](int kt) {       // tile kt has landed everywhere, the buffer of tile kt - 1 is free
-            if (loads) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // my fragment reads of tile kt - 1 are complete (its buffer is about to be overwritten)
-            __builtin_amdgcn_s_barrier();
-            if (kt == 0) kdbg_stamp(p, 2);
-            St = smem2 + cur * STAGE + grp * GSTAGE;
-            if (loads) issue_begin(nxt);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto advance = [&]() {
-            if (loads) issue_end();
-            cur = cur + 1 == NST ? 0 : cur + 1;
-            nxt = nxt + 1 == NST ? 0 : nxt + 1;
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        using c0 = std::integral_constant<int, 0>;
-        using c1 = std::integral_constant<int, 1>;
-        // NCHUNK chunks: chunk g gets DMA request g (while there are any), the reads [g R / n, (g + 1) R / n) and the MFMAs [g F / n, (g + 1) F / n)
-        constexpr int NCHUNK = D_ALL;
-        if constexpr (FULL) {
-            auto step = [&](int kt, auto set, auto other, auto with_mm) {
-                head(kt);
-                sfor<0, NCHUNK>([&](auto g_) {
-                    constexpr int g = decltype(g_)::value;
-                    if (loads) issue1(g_);
-                    if (math) {
-                        sfor<g * R_ALL / NCHUNK, (g + 1) * R_ALL / NCHUNK>([&](auto r_) { rd1(set, r_); });
-                        if constexpr (decltype(with_mm)::value) sfor<g * F_ALL / NCHUNK, (g + 1) * F_ALL / NCHUNK>([&](auto f_) { mm1(other, f_); });
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                advance();
-            };
-            auto tail = [&](auto set) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (math) sfor<0, F_ALL>([&](auto f_) { mm1(set, f_); });
-            };
-            if (nsteps > 0) {
-                step(0, c0{}, c1{}, c0{});
-                int kt = 1;
-                for (; kt + 1 < nsteps; kt += 2) { step(kt, c1{}, c0{}, c1{}); step(kt + 1, c0{}, c1{}, c1{}); }
-                if (kt < nsteps) { step(kt, c1{}, c0{}, c1{}); tail(c1{}); }
-                else tail(c0{});
-            }
-        } else {
-            // half a tile behind: phase 1 = the DMA requests + the reads of half 0 + the MFMAs of the previous tile's half 1; phase 2 = the reads of half 1 + the MFMAs of half 0
-            auto step = [&](int kt, auto with_mm) {
-                head(kt);
-                sfor<0, NCHUNK>([&](auto g_) {
-                    constexpr int g = decltype(g_)::value;
-                    if (loads) issue1(g_);
-                    if (math) {
-                        sfor<g * RH / NCHUNK, (g + 1) * RH / NCHUNK>([&](auto r_) { rd1(c0{}, r_); });
-                        if constexpr (decltype(with_mm)::value) sfor<FH + g * FH / NCHUNK, FH + (g + 1) * FH / NCHUNK>([&](auto f_) { mm1(c0{}, f_); });
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                constexpr int N2 = RH;
-                sfor<0, N2>([&](auto g_) {
-                    constexpr int g = decltype(g_)::value;
-                    if (math) {
-                        rd1(c0{}, std::integral_constant<int, RH + g>{});
-                        sfor<g * FH / N2, (g + 1) * FH / N2>([&](auto f_) { mm1(c0{}, f_); });
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                advance();
-            };
-            if (nsteps > 0) {
-                step(0, c0{});
-                for (int kt = 1; kt < nsteps; kt++) step(kt, c1{});
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (math) sfor<FH, F_ALL>([&](auto f_) { mm1(c0{}, f_); });
-            }
-        }
-    }
-    for (int kt = 0; MODE == 1 && kt < nsteps; kt++) {
-#else
+    // (round 6, measured and NOT kept: this loop software-pipelined across its barrier -- the MFMAs of tile j - 1 issued between the fragment reads of tile j and the DMA
+    // requests of tile j + NST - 1, a second fragment register set, chunk order pinned with sched_barrier; same DMA schedule and summation order, same bits.  -18 % per
+    // k-tile when every workgroup reads the SAME tile (634 -> 517 cycles at 64 x 64, 1477 -> 1200 at 128 x 128), nothing on cold operands, nothing in the SD 1.5 pass,
+    // +2 % on SDXL and on 4 prompts per GPU: profiles/r06_gemm_kloop_pipelined_*.txt, r06_gemm_kloop_ideal_memory*.txt.  What bounds the loop is the LDS port, shared by
+    // the DMA's writes and the fragment reads: profiles/r06_lds_port_probe.txt.)
     for (int kt = 0; kt < nsteps; kt++) {
-#endif
         if (loads) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");   // my share of tile kt has landed
         __builtin_amdgcn_s_barrier();                                      // everyone's has; tile kt-1's buffer is free
         if (kt == 0) kdbg_stamp(p, 2);

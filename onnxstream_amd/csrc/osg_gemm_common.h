@@ -9,14 +9,6 @@
 #define OSG_EPI_STORE_AUX 0     // < 0: plain pointer stores with exec masks (rounds 1-5); 0 / 16: buffer stores, plain / sc1 write-through (A/B builds: profiles/r06_epilogue_store_ab.txt)
 #endif
 namespace osg_mm {
-// compile-time loop: f(std::integral_constant<int, B>{}), ..., f(std::integral_constant<int, E - 1>{}) -- every index a constant expression inside f
-template <int B, int E, class F>
-__device__ __forceinline__ void sfor(F&& f) {
-    if constexpr (B < E) {
-        f(std::integral_constant<int, B>{});
-        sfor<B + 1, E>(f);
-    }
-}
 
 // GroupNorm statistics from the PRODUCER's epilogue (round 3).  A convolution whose output a GroupNorm reads adds, per (image, group), the sum and the sum of
 // squares of the f16 values it stores to a table the normalisation then only has to read: int64 FIXED-POINT sums (kStatSX / stat_q_scale fractional bits) --

@@ -189,6 +189,7 @@ template <typename T, int FOLD>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ tab, T* __restrict__ y, long HW,
                                                        int C, int act, int slabs, const float* __restrict__ part, const T* __restrict__ gamma,
                                                        const T* __restrict__ beta, int G, int S, float eps) {
+    osg_pin_all(x, tab, y, HW, C, act, slabs, part, gamma, beta, G, S, eps, (int)gridDim.y);
     constexpr int V = 8 / (sizeof(T) / 2);  // f16: 8, f32: 4  (16-byte accesses)
     extern __shared__ float stat[];         // FOLD: [G][2] mean, rstd -- pass 2 folded into every block's prologue (one launch fewer)
     const int n = blockIdx.y, sl = blockIdx.x;
@@ -655,6 +656,7 @@ __global__ __launch_bounds__(256) void softmax_kernel(const T* __restrict__ x, T
 template <int U>
 __global__ __launch_bounds__(256) void gn_apply_stats_kernel(const f16* __restrict__ x, const long long* __restrict__ table, f16* __restrict__ y, long HW, int C, int act,
                                                              const f16* __restrict__ gamma, const f16* __restrict__ beta, int G, float eps) {
+    osg_pin_all(x, table, y, HW, C, act, gamma, beta, G, eps, (int)gridDim.y);
     __shared__ float stat[512];            // [G][2] mean, rstd (G <= 256)
     const int n = blockIdx.y, cv = C >> 3, R = 256 / cv;
     const int tr = threadIdx.x / cv, tc = threadIdx.x - tr * cv;
