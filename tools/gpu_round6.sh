@@ -3,6 +3,8 @@
 # usage: gpu_round6.sh <recipe>[,<recipe>...] [args]     output prefix gpurun_out/r06
 #   floor4      tools/floor_probe4 (built here, travels): what a trivial node costs cold / hot / with its code prefetched
 #   ref16       the reference's fp16 / fp32 outputs of the full-size nets on THIS host's CPU -> gpurun_out/ref16_fullsize_epyc.npz
+#   libab <lib> / libs <lib> ...   whole builds of libosgpu.so (files under onnxstream_amd/, OSGPU_LIB) alternating on the headline bench
+#   pipeprobe / retune / extratrivial   see the recipes
 #   old ...     tools/gpu_round.sh with ROUND=r06
 mkdir -p gpurun_out; export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-.}
 export ROUND=r06; T=gpurun_out/r06; export OSA_REQUIRE_ORACLE=1
@@ -60,6 +62,21 @@ PY
     export OSG_TUNE_CACHE=/tmp/tc_$L.txt; cp onnxstream_amd/tune/mi355x.txt $OSG_TUNE_CACHE
     OSGPU_LIB=$PWD/onnxstream_amd/$L timeout 600 python bench.py --cpu-passes 0 --windows 2 > ${T}_libs_${L}_$i.json 2> ${T}_libs_${L}_$i.err; pl2 ${T}_libs_${L}_$i.json "$L"
   done; done; break ;;
+retune)
+  # the shipped tune table re-measured on this tree: empty table -> headline (its rows first), again (0 misses), then SDXL and 4 prompts per GPU append theirs -> ${T}_tune_extended.txt
+  export OSG_TUNE_CACHE=/tmp/tc_final.txt; rm -f $OSG_TUNE_CACHE
+  timeout 900 python bench.py --cpu-passes 0 --windows 2 > ${T}_retune_headline.json 2> ${T}_retune_headline.err; wc -l $OSG_TUNE_CACHE; cp $OSG_TUNE_CACHE ${T}_tune_headline.txt
+  timeout 900 python bench.py --cpu-passes 0 --windows 2 > ${T}_retune_headline2.json 2> ${T}_retune_headline2.err
+  timeout 900 python bench.py --config SDXL --steps-per-image 10 --steps 20 --warmup 2 --cpu-passes 0 --windows 0 > ${T}_retune_sdxl.json 2> ${T}_retune_sdxl.err; wc -l $OSG_TUNE_CACHE
+  timeout 900 python bench.py --prompts-per-gpu 4 --cpu-passes 0 --windows 0 > ${T}_retune_p4.json 2> ${T}_retune_p4.err; wc -l $OSG_TUNE_CACHE
+  cp $OSG_TUNE_CACHE ${T}_tune_extended.txt ;;
+extratrivial)
+  # what a trivial node costs INSIDE the captured pass: k extra trivial launches behind every plan step (OSG_PROBE_EXTRA_TRIVIAL, plan_run.cpp), unprofiled, alternating twice
+  export OSG_TUNE_CACHE=/tmp/tc_x.txt; cp onnxstream_amd/tune/mi355x.txt $OSG_TUNE_CACHE
+  for i in 1 2; do for k in 0 1 2 4; do
+    OSG_PROBE_EXTRA_TRIVIAL=$k timeout 600 python bench.py --cpu-passes 0 --windows 0 --steps 20 --warmup 3 > ${T}_extra_${k}_$i.json 2> ${T}_extra_${k}_$i.err
+    python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().split('\n')[-1]); print('extra trivial launches per step', sys.argv[2], 'ms_per_step', d['ms_per_step'], 'unet dev ms', d['config']['unet_device_ms_per_step'])" ${T}_extra_${k}_$i.json $k
+  done; done ;;
 old)
   bash tools/gpu_round.sh "$@"; break ;;
 *) echo "unknown recipe $R" ;;
