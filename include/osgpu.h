@@ -158,16 +158,29 @@ int osg_gemm(osg_ctx* ctx, osg_dtype dtype, const void* A, const void* B, int b_
              const void* residual, void* C, int M, int N, int K, int batch, long stride_a, long stride_b, long stride_c,
              osg_act act);
 
-/* W8A16: the same contractions with the weight operand resident as uint8 codes + per-tensor (scale, zero_point); each code is
- * dequantised on chip to  f16((float)((int)q - zero_point) * scale)  -- the value the reference produces when it loads a uint8 weight
- * (get_tensor_data :2887-2891 -> Model::dequantize :3353) -- on its way into the f16 LDS tile the MFMAs read, so the weight stream
- * costs half the HBM/L2 bytes.  Bq_nk is [N,K] (K contiguous), wq_ohwi is [Cout,KH,KW,Cin]; K (Cin) must be a multiple of 64. */
+/* W8A16: the same contractions with the weight operand resident as uint8 codes + (scale, zero_point).  The reference dequantises a uint8
+ * weight when it LOADS it, w = f16((float)((int)q - zero_point) * scale) (get_tensor_data :2887-2891 -> Model::dequantize :3353), and runs the
+ * f16 contraction; here the codes stay uint8 in HBM, stream through L2 and the LDS ring as codes (half the bytes of the weight operand on
+ * every hop) and become halves between the LDS tile and the MFMA: the integer q - zero_point EXACTLY, the scale applied once to the f32
+ * accumulator -- sum_k a[m][k] (q[n][k] - zp[n]) * scale[n].  The result differs from the reference's by the rounding the reference applies
+ * to each dequantised weight (2^-12 relative per term) and is the closer of the two to the f32 contraction.  Same tuned kernels, tiles,
+ * split-K, GEGLU epilogue (pair-interleaved codes), output views and statistics sinks as the f16 entry points.
+ * Bq_nk is [N,K] (K contiguous), wq_ohwi is [Cout,KH,KW,Cin]; K (Cin) must be a multiple of 64, zero_point in 0 .. 255.
+ * _v: per-output-column quantisation parameters as device vectors [N] of float (both or neither; N % 4 == 0; they override the scalars) --
+ * the merged projections concatenate weights quantised one by one --, and for the convolution the output views of osg_conv2d_nhwc_v. */
 int osg_gemm_w8(osg_ctx* ctx, const void* A, const void* Bq_nk, float w_scale, int w_zero_point, const void* bias, osg_dtype bias_dtype,
                 const void* residual, void* C, int M, int N, int K, osg_act act);
 int osg_conv2d_nhwc_w8(osg_ctx* ctx, const void* x, const void* wq_ohwi, float w_scale, int w_zero_point, const void* bias,
                        osg_dtype bias_dtype, const void* image_bias, long image_bias_ld, const void* residual, void* y, int N, int H, int W,
                        int Cin, int Cout, int KH, int KW, int stride_h, int stride_w, int pad_top, int pad_left, int pad_bottom,
                        int pad_right, osg_act act);
+int osg_gemm_w8_v(osg_ctx* ctx, const void* A, const void* Bq_nk, float w_scale, int w_zero_point, const float* w_scale_vec,
+                  const float* w_zero_point_vec, const void* bias, osg_dtype bias_dtype, const void* residual, void* C, int M, int N, int K,
+                  osg_act act);
+int osg_conv2d_nhwc_w8_v(osg_ctx* ctx, const void* x, const void* wq_ohwi, float w_scale, int w_zero_point, const float* w_scale_vec,
+                         const float* w_zero_point_vec, const void* bias, osg_dtype bias_dtype, const void* image_bias, long image_bias_ld,
+                         const void* residual, void* y, long y_ld, void* y2, long y2_ld, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                         int stride_h, int stride_w, int pad_top, int pad_left, int pad_bottom, int pad_right, osg_act act);
 
 /* Re-layout a [K,N] row-major matrix into [N,K] (done once per resident weight). */
 int osg_transpose_kn_to_nk(osg_ctx* ctx, osg_dtype dtype, const void* src_kn, void* dst_nk, int K, int N);

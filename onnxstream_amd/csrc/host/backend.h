@@ -21,7 +21,7 @@ namespace onnxstream {
     X(osg_host_unregister) X(osg_upload_pinned) X(osg_upload_pinned_async) X(osg_copy_fence) X(osg_download) X(osg_copy) X(osg_memset) X(osg_sync) \
     X(osg_graph_begin) X(osg_graph_end) X(osg_graph_launch) X(osg_graph_destroy) \
     X(osg_timer_start) X(osg_timer_stop) X(osg_conv2d_nhwc) X(osg_conv2d_nhwc_rb) X(osg_conv2d_nhwc_v) X(osg_set_stat_sinks) X(osg_group_norm_stats_nhwc) X(osg_gemm) \
-    X(osg_gemm_ln) X(osg_gemm_rowstats) X(osg_gemm_w8) X(osg_conv2d_nhwc_w8) X(osg_transpose_kn_to_nk) X(osg_attention) \
+    X(osg_gemm_ln) X(osg_gemm_rowstats) X(osg_gemm_w8) X(osg_conv2d_nhwc_w8) X(osg_gemm_w8_v) X(osg_conv2d_nhwc_w8_v) X(osg_transpose_kn_to_nk) X(osg_attention) \
     X(osg_attention_strided) X(osg_sdpa) X(osg_rms_norm) X(osg_rope) X(osg_instance_norm) X(osg_group_norm_nhwc) X(osg_layer_norm) \
     X(osg_reduce_mean_last) X(osg_softmax_last) X(osg_unary) X(osg_binary) X(osg_geglu) X(osg_transpose) \
     X(osg_copy_2d) X(osg_concat2) X(osg_resize_nearest) X(osg_gather_rows) X(osg_maxpool_nhwc) X(osg_convert) \

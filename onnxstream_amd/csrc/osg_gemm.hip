@@ -385,7 +385,7 @@ int launch_cfg(osg_ctx* ctx, const GemmParams& p, int batch) {
 struct V2Choice { int cfg, nst, splits, ks = 1, fold = 0, spec = 0; };   // ks = 2: two wave groups on alternating k-tiles (gemm2_kernel KS); fold: split-K finished by splitk_fold_acc (no reduce launch); spec: 4 loader waves beside the 4 math waves (gemm2_kernel SPEC; round 6: the 128x128 and 128x160 tiles with a 4-stage ring)
 static const int kV2BM[8] = {128, 128, 64, 64, 128, 128, 64, 64}, kV2BN[8] = {128, 64, 64, 128, 160, 80, 80, 160};   // (64x128 and the round-6 tiles 4 .. 7 of osg_gemm_wide.hip: measured candidates only)
 // every legal (tile, stages, splits) with its modelled cost in cycles, cheapest first
-struct V2Form { bool conv = false, ln1 = false, ln2 = false, geglu = false, rowstats = false; };   // what the launch needs of an instantiation (the round-6 tiles hold a subset)
+struct V2Form { bool conv = false, ln1 = false, ln2 = false, geglu = false, rowstats = false, w8 = false; };   // what the launch needs of an instantiation (the round-6 tiles hold a subset)
 static std::vector<std::pair<double, V2Choice>> rank_v2(const osg_ctx* ctx, int M, int N, int K, int batch, bool allow_split, V2Form form = V2Form{}) {
     const double cus = ctx->num_cu;
     const int kt = K / 64;
@@ -394,7 +394,10 @@ static std::vector<std::pair<double, V2Choice>> rank_v2(const osg_ctx* ctx, int 
     for (int c = 0; c < (ctx->autotune ? (no_wide ? 4 : 8) : 3); c++)
         for (int nst = 8; nst >= 2; nst -= 2) {
             // 6 / 8 stages (every tile of a short-K GEMM in flight at once): only as a measured candidate, only where the ring fits the LDS
-            if (c < 4) {
+            if (form.w8) {
+                if (!osg_mm::w8_tile_has(c, nst, form.conv) || (form.geglu && c >= 5)) continue;   // (the WQ = 1 instantiations, osg_gemm_w8.hip)
+                if ((nst == 6 || nst == 8) && !ctx->autotune) continue;
+            } else if (c < 4) {
                 if (nst == 6 && (!ctx->autotune || c == 0)) continue;
                 if (nst == 8 && (!ctx->autotune || c != 2)) continue;
             } else if (!osg_mm::wide_tile_has(c, nst, form.conv, form.ln1, form.ln2, form.geglu, form.rowstats)) continue;
@@ -402,8 +405,8 @@ static std::vector<std::pair<double, V2Choice>> rank_v2(const osg_ctx* ctx, int 
             const int bnp = (kV2BN[c] + 31) / 32 * 32;
             const double tiles = (double)((M + kV2BM[c] - 1) / kV2BM[c]) * ((N + kV2BN[c] - 1) / kV2BN[c]) * batch;
             const double mfma = kV2BM[c] * kV2BN[c] * 128.0 / 4069.0;
-            const double tload = (kV2BM[c] + kV2BN[c]) * 128.0 / 23.0;
-            const int smem = nst * (kV2BM[c] + bnp) * 128;
+            const double tload = (kV2BM[c] * 128.0 + kV2BN[c] * (form.w8 ? 64.0 : 128.0)) / 23.0;
+            const int smem = form.w8 ? nst * (kV2BM[c] * 128 + (kV2BN[c] + 63) / 64 * 64 * 64) : nst * (kV2BM[c] + bnp) * 128;
             if (smem > 160 * 1024) continue;
             const int bpc = std::min(4, 163840 / smem);
             for (int s = 1; s <= (allow_split ? 16 : 1); s++) {
@@ -420,10 +423,10 @@ static std::vector<std::pair<double, V2Choice>> rank_v2(const osg_ctx* ctx, int 
                 // (measured candidates only, round 6) the one-workgroup-per-CU tiles with their DMA requests issued by four LOADER waves: a wave that issues both
                 // stalls ~70-100 cycles per request (the CU's address path takes 1 KiB per ~17 cycles and the four waves queue on it) with its MFMAs behind them
                 static const bool no_spec = getenv("OSG_TUNE_NO_SPEC") != nullptr;   // (A/B runs)
-                if (ctx->autotune && !no_spec && !no_wide && (c == 0 || c == 4) && nst == 4 && s == 1 && !form.conv && !form.ln1) out.push_back({cost * 0.9995, V2Choice{c, nst, s, 1, 0, 1}});
+                if (ctx->autotune && !no_spec && !no_wide && !form.w8 && (c == 0 || c == 4) && nst == 4 && s == 1 && !form.conv && !form.ln1) out.push_back({cost * 0.9995, V2Choice{c, nst, s, 1, 0, 1}});
                 // KS = 2 (measured candidates only): the 64x64 tile with a 2- or 4-stage ring, the 128x64 tile with 2 stages (what the 160 KiB hold), >= 2 k-tiles per slice
                 static const bool no_ks2 = getenv("OSG_TUNE_NO_KS2") != nullptr;   // (A/B runs)
-                if (ctx->autotune && !no_ks2 && kts >= 2 && ((c == 2 && (nst == 2 || nst == 4)) || (c == 1 && nst == 2))) out.push_back({cost * 0.999, V2Choice{c, nst, s, 2}});
+                if (ctx->autotune && !no_ks2 && !form.w8 && kts >= 2 && ((c == 2 && (nst == 2 || nst == 4)) || (c == 1 && nst == 2))) out.push_back({cost * 0.999, V2Choice{c, nst, s, 2}});
                 // (measured candidates only) 2 .. 4 slices folded by the last arriver of each tile instead of a reduce launch: the tiles of at most 10 accumulator quads per lane
                 if (ctx->autotune && s >= 2 && s <= 4 && c != 0 && c != 4 && c != 7 && osg_mm::splitk_fold_mode() != 0) out.push_back({cost * 1.0005, V2Choice{c, nst, s, 1, 1}});
             }
@@ -441,7 +444,7 @@ static osg_tune::Key tune_key(const osg_ctx* ctx, int kind, const GemmParams& p,
     k.kind = kind; k.device = 0;   /* (one table for every MI355X of a node: ranks seeded from one file make identical choices) */ k.M = p.M; k.N = p.N; k.K = p.K; k.batch = batch;
     if (kind != 0) { k.H = p.H; k.W = p.W; k.Cin = p.Cin; k.KW = p.KW; k.sh = p.sh; k.sw = p.sw; }
     else k.H = p.lda;
-    k.flags = (int)p.act | (p.residual ? 16 : 0) | (p.rowbias ? 32 : 0) | (p.bias_f32 ? 64 : 0) | (p.ln_c1 ? 128 : 0) | (p.rs_in ? 256 : 0) | (p.rs_out ? 512 : 0);
+    k.flags = (int)p.act | (p.residual ? 16 : 0) | (p.rowbias ? 32 : 0) | (p.bias_f32 ? 64 : 0) | (p.ln_c1 ? 128 : 0) | (p.rs_in ? 256 : 0) | (p.rs_out ? 512 : 0) | (p.w8 ? 1024 : 0);
     return k;
 }
 // a launch may be repeated for timing only when it does not consume its own output
@@ -469,8 +472,21 @@ int launch_v2_choice(osg_ctx* ctx, GemmParams p, int batch, V2Choice ch) {
     }
     // split the operand with more unique bytes across the XCDs (each private L2 then streams its slice from HBM once)
     const double a_unique = CONV ? (double)p.a_bytes : (double)p.M * p.K * 2.0;
-    p.n_major = (double)p.N * p.K * 2.0 > a_unique;
+    p.n_major = (double)p.N * p.K * (p.w8 ? 1.0 : 2.0) > a_unique;
     int rc;
+    if (p.w8) {   // uint8 weight codes: the WQ = 1 instantiations (osg_gemm_w8.hip); a (tile, ring) they do not hold falls back to the 64x64 / 128x128 tile with 4 stages
+        if (ch.fold && (ch.cfg == 0 || ch.cfg == 4 || ch.cfg == 7)) p.fold_acc = 0;
+        rc = osg_mm::launch_v2_w8(ctx, p, batch, ch.cfg, ch.nst, CONV);
+        if (rc == -2) {
+            const int c2 = kV2BM[ch.cfg] == 128 ? 0 : 2;
+            if (c2 == 0) p.fold_acc = 0;
+            rc = osg_mm::launch_v2_w8(ctx, p, batch, c2, 4, CONV);
+        }
+        if (rc == -2) OSG_FAIL(ctx, "osg_gemm_w8: no kernel takes this form with uint8 weight codes");
+        if (rc) return rc;
+        if (p.splits > 1 && !p.fold_acc) return launch_splitk_reduce(ctx, p, batch);
+        return 0;
+    }
     if (ch.cfg >= 4) {   // the round-6 tiles (osg_gemm_wide.hip); a form they do not hold falls back to the 64x64 / 128x128 tile of the same ring
         rc = osg_mm::launch_v2_wide(ctx, p, batch, ch.cfg, ch.nst, CONV, ch.spec);
         if (rc != -2) {
@@ -561,7 +577,7 @@ int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced) {
             ch = {tc.cfg & 7, tc.nst, tc.splits, (tc.cfg & 8) ? 2 : 1, (tc.cfg & 16) ? 1 : 0, (tc.cfg & 32) ? 1 : 0};
         } else {
             V2Form form;
-            form.conv = CONV; form.ln1 = p.ln_c1 && !p.rs_in; form.ln2 = p.ln_c1 && p.rs_in; form.geglu = p.act == OSG_ACT_GEGLU; form.rowstats = p.rs_out != nullptr;
+            form.conv = CONV; form.ln1 = p.ln_c1 && !p.rs_in; form.ln2 = p.ln_c1 && p.rs_in; form.geglu = p.act == OSG_ACT_GEGLU; form.rowstats = p.rs_out != nullptr; form.w8 = p.w8 != 0;
             auto ranked = rank_v2(ctx, p.M, p.N, p.K, batch, allow_split, form);
             ch = ranked.empty() ? V2Choice{0, 4, 1} : ranked[0].second;
             if (!ctx->capturing && tune_safe(p) && !ranked.empty() && !osg_tune::frozen()) {
@@ -579,6 +595,12 @@ int run_gemm_v2(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced) {
                 osg_tune::remember(key, osg_tune::Choice{0, ch.cfg | (ch.ks == 2 ? 8 : 0) | (ch.fold ? 16 : 0) | (ch.spec ? 32 : 0), ch.nst, ch.splits, 0, -1.f});
         }
     } else {
+        if (p.w8) {
+            V2Form form;
+            form.conv = CONV; form.geglu = p.act == OSG_ACT_GEGLU; form.w8 = true;
+            auto r = rank_v2(ctx, p.M, p.N, p.K, batch, allow_split, form);
+            ch = r.empty() ? V2Choice{0, 4, 1} : r[0].second;
+        } else
         ch = choose_v2(ctx, p.M, p.N, p.K, batch);
         if (const char* e = getenv("OSG_GEMM_CFG")) ch.cfg = atoi(e);
         if (const char* e = getenv("OSG_GEMM_SPLITS")) ch.splits = atoi(e);
@@ -598,8 +620,10 @@ int run_gemm(osg_ctx* ctx, GemmParams p, int batch, const V2Choice* forced = nul
         const bool shape_ok = p.K % 64 == 0 && (CONV ? p.Cin % 64 == 0 : p.lda % 8 == 0);
         const bool align_ok = (((uintptr_t)p.A | (uintptr_t)p.Bt) & 15) == 0 && (p.strideA % 8 == 0) && (p.strideB % 8 == 0);
         const double a_ext = CONV ? (double)p.a_bytes_l : ((double)(p.M - 1) * p.lda + p.K) * 2.0;
-        const double b_ext = (double)p.N * p.K * 2.0;
-        if (!force_v1 && shape_ok && align_ok && a_ext < 2147483648.0 && b_ext < 2147483648.0) {
+        const double b_ext = (double)p.N * p.K * (p.w8 ? 1.0 : 2.0);
+        if (p.w8 && !(shape_ok && align_ok && a_ext < 2147483648.0 && b_ext < 2147483648.0))
+            OSG_FAIL(ctx, "osg_gemm_w8 / osg_conv2d_nhwc_w8: K (Cin) must be a multiple of 64, the operands 16-byte aligned and smaller than 2 GiB");
+        if ((!force_v1 || p.w8) && shape_ok && align_ok && a_ext < 2147483648.0 && b_ext < 2147483648.0) {
             p.a_bytes = (unsigned)a_ext;
             p.b_bytes = (unsigned)b_ext;
             return run_gemm_v2<CONV>(ctx, p, batch, forced);
@@ -893,10 +917,66 @@ int osg_set_stat_sinks(osg_ctx* ctx, void* table0, int groups0, int cpg0, int ch
     return 0;
 }
 
+struct W8Quant { int on; float scale; int zp; const float* sc; const float* zv; };   // uint8 weight codes + (scale, zero point): scalars or [N] vectors
+
+static int conv2d_v(osg_ctx* ctx, const W8Quant& q, const void* x, const void* w, const void* bias, osg_dtype bias_dtype,
+                    const void* image_bias, long image_bias_ld, const void* residual, void* y, long y_ld, void* y2, long y2_ld, int N, int H, int W,
+                    int Cin, int Cout, int KH, int KW, int sh, int sw, int pt, int pl, int pb, int pr, osg_act act);
+
 int osg_conv2d_nhwc_v(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* w, const void* bias, osg_dtype bias_dtype,
                       const void* image_bias, long image_bias_ld, const void* residual, void* y, long y_ld, void* y2, long y2_ld, int N, int H, int W,
                       int Cin, int Cout, int KH, int KW, int sh, int sw, int pt, int pl, int pb, int pr, osg_act act) {
     if (dtype != OSG_F16) OSG_FAIL(ctx, "osg_conv2d_nhwc: only f16 arithmetic is implemented on the device");
+    return conv2d_v(ctx, W8Quant{}, x, w, bias, bias_dtype, image_bias, image_bias_ld, residual, y, y_ld, y2, y2_ld, N, H, W, Cin, Cout, KH, KW, sh, sw, pt, pl, pb, pr, act);
+}
+
+static int w8_check(osg_ctx* ctx, const char* who, const W8Quant& q, int N, int K, const void* a, const void* b) {
+    if (K % 64 || ((uintptr_t)a & 15) || ((uintptr_t)b & 15)) { ctx->err = (std::string(who) + ": K (Cin) must be a multiple of 64 and the operands 16-byte aligned"); return 1; }
+    if ((q.sc != nullptr) != (q.zv != nullptr) || (q.sc && ((N & 3) || ((uintptr_t)q.sc & 15)))) { ctx->err = (std::string(who) + ": scale / zero-point vectors come as a pair, N % 4 == 0, 16-byte aligned"); return 1; }
+    if (!q.sc && (q.zp < 0 || q.zp > 255)) { ctx->err = (std::string(who) + ": zero point outside 0 .. 255"); return 1; }
+    return 0;
+}
+
+int osg_gemm_w8_v(osg_ctx* ctx, const void* A, const void* Bq_nk, float w_scale, int w_zero_point, const float* w_scale_vec, const float* w_zero_point_vec,
+                  const void* bias, osg_dtype bias_dtype, const void* residual, void* C, int M, int N, int K, osg_act act) {
+    if (M <= 0 || N <= 0 || K <= 0) OSG_FAIL(ctx, "osg_gemm_w8: invalid shape of inputs");
+    if (bias && bias_dtype != OSG_F16 && bias_dtype != OSG_F32) OSG_FAIL(ctx, "osg_gemm_w8: invalid bias dtype");
+    if (act == OSG_ACT_GEGLU && (residual || N % 32)) OSG_FAIL(ctx, "osg_gemm_w8: the GEGLU epilogue needs a pair-interleaved [N,K] weight, N % 32 == 0, no residual");
+    const W8Quant q{1, w_scale, w_zero_point, w_scale_vec, w_zero_point_vec};
+    if (w8_check(ctx, "osg_gemm_w8", q, N, K, A, Bq_nk)) return 1;
+    GemmParams p{};
+    p.A = (const f16*)A; p.Bt = (const f16*)Bq_nk; p.C = (f16*)C; p.bias = bias; p.residual = (const f16*)residual;
+    p.M = M; p.N = N; p.K = K; p.lda = K;
+    p.bias_f32 = bias_dtype == OSG_F32; p.act = act;
+    p.w8 = 1; p.w_scale = w_scale; p.w_zp = w_zero_point; p.wq_sc = w_scale_vec; p.wq_zp = w_zero_point_vec;
+    return run_gemm<false>(ctx, p, 1);
+}
+
+int osg_gemm_w8(osg_ctx* ctx, const void* A, const void* Bq_nk, float w_scale, int w_zero_point, const void* bias, osg_dtype bias_dtype,
+                const void* residual, void* C, int M, int N, int K, osg_act act) {
+    return osg_gemm_w8_v(ctx, A, Bq_nk, w_scale, w_zero_point, nullptr, nullptr, bias, bias_dtype, residual, C, M, N, K, act);
+}
+
+int osg_conv2d_nhwc_w8_v(osg_ctx* ctx, const void* x, const void* wq_ohwi, float w_scale, int w_zero_point, const float* w_scale_vec, const float* w_zero_point_vec,
+                         const void* bias, osg_dtype bias_dtype, const void* image_bias, long image_bias_ld, const void* residual, void* y, long y_ld, void* y2,
+                         long y2_ld, int N, int H, int W, int Cin, int Cout, int KH, int KW, int sh, int sw, int pt, int pl, int pb, int pr, osg_act act) {
+    const W8Quant q{1, w_scale, w_zero_point, w_scale_vec, w_zero_point_vec};
+    if (w8_check(ctx, "osg_conv2d_nhwc_w8", q, Cout, Cin, x, wq_ohwi)) return 1;
+    return conv2d_v(ctx, q, x, wq_ohwi, bias, bias_dtype, image_bias, image_bias_ld, residual, y, y_ld, y2, y2_ld, N, H, W, Cin, Cout, KH, KW, sh, sw, pt, pl, pb, pr, act);
+}
+
+int osg_conv2d_nhwc_w8(osg_ctx* ctx, const void* x, const void* wq_ohwi, float w_scale, int w_zero_point, const void* bias,
+                       osg_dtype bias_dtype, const void* image_bias, long image_bias_ld, const void* residual, void* y, int N, int H, int W,
+                       int Cin, int Cout, int KH, int KW, int sh, int sw, int pt, int pl, int pb, int pr, osg_act act) {
+    return osg_conv2d_nhwc_w8_v(ctx, x, wq_ohwi, w_scale, w_zero_point, nullptr, nullptr, bias, bias_dtype, image_bias, image_bias_ld, residual, y, 0, nullptr, 0, N, H, W,
+                                Cin, Cout, KH, KW, sh, sw, pt, pl, pb, pr, act);
+}
+
+}  // extern "C"
+
+static int conv2d_v(osg_ctx* ctx, const W8Quant& q, const void* x, const void* w, const void* bias, osg_dtype bias_dtype,
+                    const void* image_bias, long image_bias_ld, const void* residual, void* y, long y_ld, void* y2, long y2_ld, int N, int H, int W,
+                    int Cin, int Cout, int KH, int KW, int sh, int sw, int pt, int pl, int pb, int pr, osg_act act) {
     if (y_ld < 0 || (y_ld && y_ld < Cout) || (y2 && y2_ld < Cout)) OSG_FAIL(ctx, "osg_conv2d_nhwc_v: an output pitch is smaller than Cout");
     if (Cout % 4 == 0 && ((y_ld & 3) || (y2 && (y2_ld & 3)))) OSG_FAIL(ctx, "osg_conv2d_nhwc_v: output pitches must be multiples of 4 elements");
     if ((y_ld && ((uintptr_t)y & 7)) || (y2 && ((uintptr_t)y2 & 7))) OSG_FAIL(ctx, "osg_conv2d_nhwc_v: output views must be 8-byte aligned");
@@ -913,6 +993,7 @@ int osg_conv2d_nhwc_v(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* 
     p.rowbias = (const f16*)image_bias; p.rb_rows = Ho * Wo; p.rb_ld = image_bias_ld;
     p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.KW = KW; p.sh = sh; p.sw = sw; p.pt = pt; p.pl = pl;
     p.ldc = y_ld == Cout ? 0 : y_ld; p.C2 = (f16*)y2; p.ldc2 = y2 ? y2_ld : 0;
+    if (q.on) { p.w8 = 1; p.w_scale = q.scale; p.w_zp = q.zp; p.wq_sc = q.sc; p.wq_zp = q.zv; }
     // GroupNorm statistics of this launch's output (osg_set_stat_sinks): served by the epilogue of the kernel that runs (sink_fused), or by a launch of its own
     bool want_sinks = false;
     for (int k = 0; k < 2; k++) {
@@ -931,11 +1012,9 @@ int osg_conv2d_nhwc_v(osg_ctx* ctx, osg_dtype dtype, const void* x, const void* 
     return osg_mm::launch_colstats(ctx, p.C, p.ldc ? p.ldc : (long)Cout, p.M, Cout, p.sink_hw, p.sink);
 }
 
-}  // extern "C"
-
 static int conv2d_route(osg_ctx* ctx, GemmParams& p, int N, int Cin, int Cout, int KH, int KW, int sh, int sw, int pt, int pl, int pb, int pr) {
     (void)N;
-    if (Cin == 4 && KH == 3 && KW == 3 && Cout % 16 == 0 && (size_t)Cout * (144 + 4) <= 160 * 1024 && (p.ldc % 4) == 0 && (p.ldc2 % 4) == 0 &&
+    if (!p.w8 && Cin == 4 && KH == 3 && KW == 3 && Cout % 16 == 0 && (size_t)Cout * (144 + 4) <= 160 * 1024 && (p.ldc % 4) == 0 && (p.ldc2 % 4) == 0 &&
         (!p.rowbias || p.rb_ld % 4 == 0)) {
         const size_t smem = (size_t)Cout * (144 + 4);
         static size_t attr_smem = 0;
@@ -971,7 +1050,7 @@ static int conv2d_route(osg_ctx* ctx, GemmParams& p, int N, int Cin, int Cout, i
                     for (auto& c : r3)
                         for (int nl : {4, 8}) {   // (nst of a conv3x3 row = loader waves of the halo kernel)
                             static const bool no8 = getenv("OSG_TUNE_NO_NL8") != nullptr;   // (A/B runs)
-                            if (nl == 8 && no8) continue;
+                            if (nl == 8 && (no8 || p.w8)) continue;   // (uint8 weight codes: the 4-loader kernel only)
                             const int fold3 = c.second.second >= 1000;   // (osg_conv3x3_rank: splits + 1000 = the same split, folded in the kernel)
                             const int s3 = c.second.second % 1000;
                             const float us = osg_tune::time_us(ctx, [&] { return osg_conv3x3_launch(ctx, p, c.second.first, s3, nl, fold3); });
@@ -979,7 +1058,7 @@ static int conv2d_route(osg_ctx* ctx, GemmParams& p, int N, int Cin, int Cout, i
                             if (us >= 0.f && (best < 0.f || us < best)) { best = us; tc = osg_tune::Choice{1, fold3 ? 16 : 0, nl, s3, c.second.first, us}; }
                         }
                     V2Form form3;
-                    form3.conv = true;
+                    form3.conv = true; form3.w8 = p.w8 != 0;
                     auto r2 = rank_v2(ctx, p.M, p.N, p.K, 1, true, form3);
                     if (r2.size() > 6) r2.resize(6);
                     for (auto& c : r2) {

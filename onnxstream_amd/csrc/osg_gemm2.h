@@ -41,7 +41,13 @@ using namespace osg_mm;
 // its own request queue, in step with the others at the barrier of every k-tile.  The idea: inside a pass every weight comes from HBM and the rings keep only ~4 MB
 // of UNIQUE bytes in flight over the chip.  Result on cold operands, every hot shape, every tile: the k loop got 15-50 % SLOWER and the first tile arrived 3-5 us
 // later -- the extra requests queue in front of the ring's own, profiles/r06_gemm_kloop_probe_prefetch_wave.txt.)
-template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0, int LN = 0, int NCH = 5, int KS = 1, int WGN = 2>
+// WQ = 1 (round 6, W8A16 with the codes resident: osg_gemm_w8.hip): Bt holds uint8 CODES [N][K].  A B tile row is 64 bytes = 4 x 16-byte chunks, one 1-KiB wave-load
+// covers 16 rows (lane l: row l >> 2, LDS slot l & 3), chunk c of row r lives at slot c ^ ((r >> 2) & 3) -- rows r, r + 4, r + 8, r + 12 share their banks at a 64-byte
+// pitch, the XOR spreads them over the four slots: the 32 lanes of one half of a ds_read_b64 (16 rows x the two 8-byte halves of one chunk) touch every bank
+// exactly once.  A lane's fragment of a 32-deep half is ONE ds_read_b64 (8 codes: k = 32 ks + 8 (lane >> 4) .., the same k the A fragment holds) and 8 VALU
+// operations (osg_gemm_common.h w8_frag); the B stage is half as large, half the DMA requests, half the bytes through the LDS port per k-tile.  The accumulators
+// are scaled once, before any epilogue (w8_scale_acc): split-K slabs, GEGLU, statistics sinks see finished f32 values.  Not with LN (gamma folds into f16 weights).
+template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0, int LN = 0, int NCH = 5, int KS = 1, int WGN = 2, int WQ = 0>
 __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(GemmParams pk) {
     // the fields the first DMA request depends on, in ONE batch of scalar loads (GemmParams); everything below reads the register copy
     GemmParams p = pk;
@@ -53,13 +59,17 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
     }
     OSG_PIN(p.bias); OSG_PIN(p.residual); OSG_PIN(p.rowbias); OSG_PIN(p.rb_ld); OSG_PIN(p.strideC); OSG_PIN(p.ln_c1); OSG_PIN(p.rs_in); OSG_PIN(p.rb_rows);
     OSG_PIN(p.bias_f32); OSG_PIN(p.act); OSG_PIN(p.no_epre); OSG_PIN(p.rs_np);
+    if constexpr (WQ) { OSG_PIN(p.wq_sc); OSG_PIN(p.wq_zp); OSG_PIN(p.w_zp); }
 #endif
     static_assert(KS == 1 || (KS == 2 && !SPEC && MODE == 0 && LN != 1), "KS = 2: plain kernel only (row statistics come from the producer, LN = 2, or not at all)");
     static_assert(WGN == 1 || WGN == 2, "wave grid: 2 x 2 or 4 x 1");
+    static_assert(!WQ || LN == 0, "W8: no folded LayerNorm");
     constexpr int ROWB = 128;                       // bytes per tile row (BK = 64 halves)
-    constexpr int BNP = (BN + 31) / 32 * 32;        // B rows of a stage (padded to whole rounds of the waves' 8-row pieces)
-    constexpr int A_BYTES = BM * ROWB, B_BYTES = BNP * ROWB, GSTAGE = A_BYTES + B_BYTES, STAGE = KS * GSTAGE;
-    constexpr int A_LD = BM / 32, B_LD = BNP / 32;  // 1-KiB wave-loads per wave per k-tile
+    constexpr int ROWB_B = WQ ? 64 : 128;           // ... of the B tile (WQ: 64 codes)
+    constexpr int BRW = WQ ? 16 : 8;                // B rows one 1-KiB wave-load covers
+    constexpr int BNP = (BN + 4 * BRW - 1) / (4 * BRW) * (4 * BRW);   // B rows of a stage (padded to whole rounds of the four waves' pieces)
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BNP * ROWB_B, GSTAGE = A_BYTES + B_BYTES, STAGE = KS * GSTAGE;
+    constexpr int A_LD = BM / 32, B_LD = BNP / (4 * BRW);  // 1-KiB wave-loads per wave per k-tile
     constexpr int WM = BM / (4 / WGN), WN = BN / WGN, TM = WM / 16, TN = WN / 16;
     static_assert(BM % 32 == 0 && WM % 16 == 0 && WN % 16 == 0, "a wave's part of the tile is made of whole 16 x 16 blocks");
     constexpr int INFLIGHT = (NST - 2) * (A_LD + B_LD);
@@ -134,8 +144,13 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
     int b_base[B_LD];
 #pragma unroll
     for (int j = 0; j < B_LD; j++) {
-        const int nl = (j * 4 + wave) * 8 + rsub, n = n0 + nl;
-        b_base[j] = (n < p.N && (BNP == BN || nl < BN)) ? (int)(((long)n * p.K + gch * 8) * 2) : (int)OOB;
+        if constexpr (WQ) {
+            const int nl = (j * 4 + wave) * 16 + (lane >> 2), n = n0 + nl;
+            b_base[j] = (n < p.N && (BNP == BN || nl < BN)) ? (int)((long)n * p.K + (((lane & 3) ^ ((lane >> 4) & 3)) << 4)) : (int)OOB;
+        } else {
+            const int nl = (j * 4 + wave) * 8 + rsub, n = n0 + nl;
+            b_base[j] = (n < p.N && (BNP == BN || nl < BN)) ? (int)(((long)n * p.K + gch * 8) * 2) : (int)OOB;
+        }
     }
 
     // running position of the NEXT tile to issue (conv: decomposed into tap + channel offset, updated incrementally)
@@ -172,7 +187,7 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
         }
 #pragma unroll
         for (int j = 0; j < B_LD; j++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(Bs + (j * 4 + wave) * 1024), 16, (unsigned)b_base[j] | kill, ik * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(Bs + (j * 4 + wave) * 1024), 16, (unsigned)b_base[j] | kill, WQ ? ik : ik * 2, 0, 0);
         ik += 64 * KS;
     };
 
@@ -186,7 +201,8 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
     const int frow = lane & 15;
     const int fsw = (((lane >> 4) ^ (frow & 7)) << 4);
     const int a_rd = (wm0 + frow) * ROWB + fsw;
-    const int b_rd = A_BYTES + (wn0 + frow) * ROWB + fsw;
+    // (WQ: 8 bytes of chunk 2 ks + (lane >> 5), slot = chunk ^ ((row >> 2) & 3); the second 32-deep half is the same address ^ 32)
+    const int b_rd = WQ ? A_BYTES + (wn0 + frow) * ROWB_B + ((((lane >> 5) & 1) ^ ((frow >> 2) & 3)) << 4) + ((lane >> 4) & 1) * 8 : A_BYTES + (wn0 + frow) * ROWB + fsw;
 
     // LN == 2: the producer's partial row statistics, [M][rs_np][2] floats = rs_np/2 16-byte chunks per row.  Lane l of a wave owns row
     // (l & 15) + 16 ((l >> 4) % TM) of the wave's rows and requests ALL chunks of that row -- BEFORE the first tile (vector-memory
@@ -205,6 +221,8 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
     // epilogue operands of this wave's outputs: requested now, home by the end of the k loop (osg_gemm_common.h epi_prefetch).  They are OLDER than
     // every tile load in the wave's in-order vector-memory queue, so the counted waits of the loop cover them.
     constexpr bool EPRE = TM * TN <= 8;    // (64x64 / 128x64 / 64x128 tiles; the 128x128 tile keeps its on-demand loads: no registers to spare)
+    W8Ops<WQ ? TN : 1, true> w8;
+    if constexpr (WQ) { if (math) w8_prefetch<TN, true>(p, w8, n0, wn0, lane); }
     EpiOps<TM, TN, CONV, EPRE> epre;
     epre.have = false;
     if (math && !p.ln_c1 && grp == 0) epi_prefetch<TM, TN, CONV, EPRE>(p, epre, m0, n0, wm0, wn0, lane, zb);
@@ -213,6 +231,7 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
         for (int s2 = 0; s2 < NST - 1; s2++) issue_tile(s2);
     }
     kdbg_stamp(p, 1);
+    if constexpr (WQ) { if (math) w8_finalize<TN, true>(w8); }
 
     float ls[TM], lq[TM];          // LN: running row sums / sums of squares of this lane's rows (see ln_accumulate)
 #pragma unroll
@@ -239,7 +258,10 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
 #pragma unroll
             for (int i = 0; i < TM; i++) a[i] = *reinterpret_cast<const f16x8*>(St + ((a_rd + i * 16 * ROWB) ^ (ks << 6)));
 #pragma unroll
-            for (int j = 0; j < TN; j++) b[j] = *reinterpret_cast<const f16x8*>(St + ((b_rd + j * 16 * ROWB) ^ (ks << 6)));
+            for (int j = 0; j < TN; j++) {
+                if constexpr (WQ) b[j] = w8_frag(*reinterpret_cast<const u32x2v*>(St + ((b_rd + j * 16 * ROWB_B) ^ (ks << 5))), w8.zz[j]);
+                else b[j] = *reinterpret_cast<const f16x8*>(St + ((b_rd + j * 16 * ROWB) ^ (ks << 6)));
+            }
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -252,6 +274,7 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
     kdbg_stamp(p, 3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the dummy tail loads before the LDS is released
     if (loader) return;
+    if constexpr (WQ) w8_scale_acc<TM, TN>(w8, acc);
     if constexpr (KS == 2) {
         // group 1 hands its partial accumulators (and, LN = 1, its partial row sums) to group 0 through the LDS the ring no longer needs
         __builtin_amdgcn_s_barrier();                    // every wave is done reading tiles, no DMA is in flight
@@ -311,12 +334,12 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
     if (p.kdbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); kdbg_stamp(p, 6); }
 }
 
-template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0, int LN = 0, int NCH = 5, int KS = 1, int WGN = 2>
+template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0, int LN = 0, int NCH = 5, int KS = 1, int WGN = 2, int WQ = 0>
 int launch_v2(osg_ctx* ctx, GemmParams& p, int batch) {
-    constexpr size_t smem = (size_t)NST * KS * (BM + (BN + 31) / 32 * 32) * 128;
+    constexpr size_t smem = WQ ? (size_t)NST * KS * (BM * 128 + (BN + 63) / 64 * 64 * 64) : (size_t)NST * KS * (BM + (BN + 31) / 32 * 32) * 128;
     static_assert(smem <= 160 * 1024, "LDS budget");
     static_assert(KS == 1 || (size_t)4 * ((BM / 32) * (BN / 32) + 1) * 1024 <= smem, "KS = 2: the accumulator hand-over must fit the ring");
-    auto kern = gemm2_kernel<BM, BN, NST, CONV, MODE, SPEC, LN, NCH, KS, WGN>;
+    auto kern = gemm2_kernel<BM, BN, NST, CONV, MODE, SPEC, LN, NCH, KS, WGN, WQ>;
     static unsigned long long attr_mask = 0;   // (per device: hipFuncSetAttribute is, and a process may hold several)
     if (osg_first_on_device(attr_mask)) {
         OSG_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

@@ -77,8 +77,11 @@ struct GemmParams {
     long a_bytes_l;              // conv: byte size of the whole NHWC input (host side, before the 2 GiB check)
     int* tickets;                // split-K arrival / publication counters (two per output tile, splitk_fold_acc), zero between launches
     int* xcd_err;                // host-mapped flag the bounded wait of splitk_fold_acc raises (osg_ctx; checked by osg_sync / osg_download)
-    float w_scale;               // W8 kernels (osg_gemm_w8.hip): Bt holds uint8 codes, w = (q - w_zp) * w_scale
+    float w_scale;               // W8 (gemm2_kernel / conv3x3_kernel with WQ = 1, osg_gemm_w8.hip): Bt holds uint8 codes [N][K], w = (q - w_zp) * w_scale
     int w_zp;
+    const float* wq_sc;          //   per-output-column scale / zero point [N] (merged projections: one pair per member); NULL = the scalars above
+    const float* wq_zp;
+    int w8;                      //   host side: the launch takes the WQ = 1 instantiations
     float ln_eps;
     float* rs_out;               // osg_gemm_rowstats: this GEMM's epilogue also emits [M][rs_np][2] partial row statistics of its f16 output
     // output VIEWS (round 3: skip tensors written straight into their Concat slot, no copy launch): C rows are `ldc` elements apart (0 = dense, N), and
@@ -97,6 +100,81 @@ struct GemmParams {
 // a kernel-argument field pulled into a scalar register NOW: see GemmParams.  (An INPUT of an empty asm: an in-out operand would make the value opaque -- pointers lose
 // their address space and every load through them becomes a flat_load, which counts on lgkmcnt AND vmcnt and breaks the counted waits of the k loop.)
 #define OSG_PIN(x) asm volatile("" ::"s"(x))
+
+// ---- W8A16: uint8 weight codes resident in HBM, dequantised between the LDS tile and the MFMA (round 6) ----------------------------------------------------
+// The [BN][64] weight tile travels HBM -> L2 -> LDS as CODES (half the bytes of the f16 tile on every hop, and half the bytes through the LDS port the k loop is
+// bound by); a lane reads the 8 codes of its fragment with one ds_read_b64 and turns them into the 8 halves the MFMA takes with 8 VALU operations:
+//   v_perm_b32 pairs each code with the byte 0x64: the half 0x64cc IS 1024 + c exactly (ulp(1024) = 1 in binary16);
+//   v_pk_add_f16 subtracts 1024 + zero_point: (q - zp), an integer of magnitude <= 255, exact.
+// The MFMA therefore accumulates sum_k a[m][k] * (q[n][k] - zp[n]) in f32 and the tile's accumulators are multiplied by scale[n] ONCE, in f32, before the
+// epilogue (w8_scale_acc).  The reference dequantises when it loads the weight, w = f16((float)(q - zp) * scale) (src/onnxstream.cpp:2887-2891, :3353), i.e. it
+// rounds every weight to f16 first; this path does not round the weights at all: per output it differs from the reference's f16 GEMM on the dequantised
+// weights by the rounding the reference applies to each weight (2^-12 relative per term, independent signs) and is the closer of the two to the f32 result.
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f16x8 w8_frag(u32x2v c, f16x2w zz) {
+    union { unsigned u; f16x2w h; } d0, d1, d2, d3;
+    d0.u = __builtin_amdgcn_perm(0x64646464u, c[0], 0x04010400u);
+    d1.u = __builtin_amdgcn_perm(0x64646464u, c[0], 0x04030402u);
+    d2.u = __builtin_amdgcn_perm(0x64646464u, c[1], 0x04010400u);
+    d3.u = __builtin_amdgcn_perm(0x64646464u, c[1], 0x04030402u);
+    d0.h -= zz; d1.h -= zz; d2.h -= zz; d3.h -= zz;
+    return f16x8{d0.h[0], d0.h[1], d1.h[0], d1.h[1], d2.h[0], d2.h[1], d3.h[0], d3.h[1]};
+}
+// what a lane needs of the quantisation parameters, requested BEFORE the first tile (older than every tile load in the wave's in-order vector-memory queue: home by
+// the time tile 0 is): zz[j] = 1024 + zero point of the weight row its B fragment j holds (row n0 + wn0 + 16 j + (lane & 15)), as a pair of halves; sc[j] = the scales
+// of the 4 consecutive columns n0 + wn0 + 16 j + 4 (lane >> 4) .. + 3 its accumulator registers of column block j are.  Vectors (N % 4 == 0) or the scalars.
+// SC = false (the tiles with no registers to spare): the scales are fetched on demand after the k loop (w8_scale_acc_late).
+template <int TN, bool SC = true>
+struct W8Ops {
+    float zraw[TN];      // as loaded (converted by w8_finalize AFTER the first tiles are requested: a conversion on the spot would wait for the load there)
+    f16x2w zz[TN];
+    f32x4 sc[SC ? TN : 1];
+};
+template <int TN, bool SC>
+__device__ __forceinline__ void w8_prefetch(const GemmParams& p, W8Ops<TN, SC>& w, int n0, int wn0, int lane) {
+    if (p.wq_sc) {
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            w.zraw[j] = p.wq_zp[min(n0 + wn0 + j * 16 + (lane & 15), p.N - 1)];
+            if constexpr (SC) w.sc[j] = *reinterpret_cast<const f32x4*>(p.wq_sc + min(n0 + wn0 + j * 16 + (lane >> 4) * 4, p.N - 4));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            w.zraw[j] = (float)p.w_zp;
+            if constexpr (SC) w.sc[j] = f32x4{p.w_scale, p.w_scale, p.w_scale, p.w_scale};
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+template <int TN, bool SC>
+__device__ __forceinline__ void w8_finalize(W8Ops<TN, SC>& w) {
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const f16 h = (f16)(1024.0f + w.zraw[j]);
+        w.zz[j] = f16x2w{h, h};
+    }
+}
+// acc[m][n] *= scale[n], once, in f32, before the epilogue
+template <int TM, int TN>
+__device__ __forceinline__ void w8_scale_acc(const W8Ops<TN, true>& w, f32x4 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] *= w.sc[j];
+}
+template <int TM, int TN>
+__device__ __forceinline__ void w8_scale_acc_late(const GemmParams& p, f32x4 (&acc)[TM][TN], int n0, int wn0, int lane) {
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        f32x4 s = {p.w_scale, p.w_scale, p.w_scale, p.w_scale};
+        if (p.wq_sc) s = *reinterpret_cast<const f32x4*>(p.wq_sc + min(n0 + wn0 + j * 16 + (lane >> 4) * 4, p.N - 4));
+#pragma unroll
+        for (int i = 0; i < TM; i++) acc[i][j] *= s;
+    }
+}
+
 __device__ __forceinline__ void kdbg_stamp(const GemmParams& p, int slot) {
     if (p.kdbg && threadIdx.x == 0) p.kdbg[(long)blockIdx.x * 8 + slot] = wall_clock64();
 }
@@ -756,3 +834,10 @@ int osg_conv3x3_prepare(osg_ctx* ctx, osg_mm::GemmParams& p);
 std::vector<std::pair<double, std::pair<int, int>>> osg_conv3x3_rank(const osg_ctx* ctx, const osg_mm::GemmParams& p);
 int osg_conv3x3_launch(osg_ctx* ctx, osg_mm::GemmParams p, int bn, int splits, int loader_waves = 4, int fold = 0);   // fold: a 2 .. 4-way split finished by splitk_fold_acc
 int osg_conv3x3_supported(int N, int H, int W, int Cin, int Cout);
+// osg_conv3x3_w8.hip: the WQ = 1 instantiations of the halo kernel (uint8 weight codes, 4 loader waves); p.W in {64, 32, 16, 8}, bn in {80, 128, 160}
+int osg_conv3x3_w8_tile(osg_ctx* ctx, osg_mm::GemmParams& p, int bn);
+namespace osg_mm {
+// osg_gemm_w8.hip: the WQ = 1 instantiations of gemm2_kernel; -2 when the (tile, ring, form) asked for has none (tiles as kV2BM / kV2BN of osg_gemm.hip)
+int launch_v2_w8(osg_ctx* ctx, GemmParams& p, int batch, int tile, int nst, bool conv);
+bool w8_tile_has(int tile, int nst, bool conv);
+}

@@ -24,7 +24,7 @@ EXPORTS = [
     "osg_device_count", "osg_init", "osg_destroy", "osg_last_error", "osg_device_name", "osg_stream", "osg_set_autotune", "osg_tune_misses",
     "osg_malloc", "osg_free", "osg_upload", "osg_upload_sync", "osg_host_register", "osg_host_unregister", "osg_upload_pinned", "osg_upload_pinned_async", "osg_copy_fence", "osg_download", "osg_copy", "osg_memset", "osg_sync",
     "osg_graph_begin", "osg_graph_end", "osg_graph_launch", "osg_graph_destroy", "osg_timer_start", "osg_timer_stop",
-    "osg_conv2d_nhwc", "osg_conv2d_nhwc_rb", "osg_conv2d_nhwc_v", "osg_gemm", "osg_gemm_ln", "osg_gemm_rowstats", "osg_gemm_w8", "osg_conv2d_nhwc_w8", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided", "osg_sdpa", "osg_rms_norm", "osg_rope",
+    "osg_conv2d_nhwc", "osg_conv2d_nhwc_rb", "osg_conv2d_nhwc_v", "osg_gemm", "osg_gemm_ln", "osg_gemm_rowstats", "osg_gemm_w8", "osg_conv2d_nhwc_w8", "osg_gemm_w8_v", "osg_conv2d_nhwc_w8_v", "osg_transpose_kn_to_nk", "osg_attention", "osg_attention_strided", "osg_sdpa", "osg_rms_norm", "osg_rope",
     "osg_instance_norm", "osg_group_norm_nhwc", "osg_layer_norm", "osg_reduce_mean_last", "osg_softmax_last",
     "osg_unary", "osg_binary", "osg_geglu", "osg_transpose", "osg_copy_2d", "osg_concat2", "osg_resize_nearest", "osg_gather_rows",
     "osg_maxpool_nhwc", "osg_convert", "osg_sampler_prepare", "osg_sampler_cfg_euler_a",
@@ -81,6 +81,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.osg_conv2d_nhwc_v.argtypes = [vp, ci, vp, vp, vp, ci, vp, cl, vp, vp, cl, vp, cl] + [ci] * 14
     lib.osg_gemm_w8.argtypes = [vp, vp, vp, cf, ci, vp, ci, vp, vp, ci, ci, ci, ci]
     lib.osg_conv2d_nhwc_w8.argtypes = [vp, vp, vp, cf, ci, vp, ci, vp, cl, vp, vp] + [ci] * 14
+    lib.osg_gemm_w8_v.argtypes = [vp, vp, vp, cf, ci, vp, vp, vp, ci, vp, vp, ci, ci, ci, ci]
+    lib.osg_conv2d_nhwc_w8_v.argtypes = [vp, vp, vp, cf, ci, vp, vp, vp, ci, vp, cl, vp, vp, cl, vp, cl] + [ci] * 14
     lib.osg_gemm.argtypes = [vp, ci, vp, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, cl, cl, cl, ci]
     lib.osg_transpose_kn_to_nk.argtypes = [vp, ci, vp, vp, ci, ci]
     lib.osg_attention.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, cf, ci]

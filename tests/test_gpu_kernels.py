@@ -290,6 +290,123 @@ def test_conv_w8(gpu, N, H, Cin, Cout, k, stride):
     assert rel_max(y.numpy(), want) <= 1e-3
 
 
+def _exact_w8(a, q, scale, zp, bias=None, res=None):
+    """what the resident-codes kernels compute: sum_k a (q - zp) exactly, times scale[n], in float64"""
+    y = (a.astype(np.float64) @ (q.astype(np.float64) - np.asarray(zp, np.float64).reshape(-1, 1)).T) * np.asarray(scale, np.float64).reshape(1, -1)
+    if bias is not None:
+        y = y + bias.astype(np.float64)
+    if res is not None:
+        y = y + res.astype(np.float64)
+    return y
+
+
+def test_w8_fragment_conversion_is_exact(gpu):
+    """every code 0 .. 255 against every zero point class through the byte-permute / packed-subtract conversion (w8_frag): A = identity picks the weight rows
+    out one by one, scale 1 -- the output must be q - zp EXACTLY."""
+    K = N = 256
+    a = np.eye(K, dtype=f16)
+    rng = np.random.default_rng(1)
+    q = np.stack([np.roll(np.arange(256, dtype=np.uint8), r) for r in range(N)])          # every row holds every code
+    da, dq = gpu.to_dev(a), gpu.to_dev(q)
+    for zp in (0, 1, 127, 128, 255):
+        y = gpu.empty((K, N), f16)
+        gpu._ck(gpu.lib.osg_gemm_w8(gpu.ctx, da.ptr, dq.ptr, 1.0, zp, None, 2, None, y.ptr, K, N, K, 0))
+        assert np.array_equal(y.numpy().astype(np.int32), (q.astype(np.int32) - zp).T)
+    # per-column zero points and scales (the merged projections): powers of two keep the product exact
+    zv = rng.integers(0, 256, N).astype(np.float32)
+    sv = (2.0 ** rng.integers(-3, 3, N)).astype(np.float32)
+    y = gpu.empty((K, N), f16)
+    dsz = gpu.to_dev(np.concatenate([sv, zv]))
+    gpu._ck(gpu.lib.osg_gemm_w8_v(gpu.ctx, da.ptr, dq.ptr, 0.0, 0, dsz.ptr, dsz.ptr + 4 * N, None, 2, None, y.ptr, K, N, K, 0))
+    assert np.array_equal(y.numpy().astype(np.float64), ((q.astype(np.float64) - zv[:, None]) * sv[:, None]).T)
+
+
+@pytest.mark.parametrize("M,N,K,cfg,nst,splits", [(300, 200, 128, 0, 2, 1), (8192, 320, 320, 2, 4, 1), (2048, 640, 640, 1, 2, 1), (2048, 640, 640, 3, 4, 1), (512, 1280, 1280, 2, 8, 1),
+                                                  (512, 1280, 5120, 2, 4, 3), (8192, 320, 1280, 4, 4, 1), (2048, 640, 2560, 5, 2, 2), (2048, 640, 640, 6, 6, 1), (512, 1280, 1280, 7, 4, 1),
+                                                  (154, 960, 768, 6, 4, 1), (130, 72, 64, 2, 2, 1), (2, 1280, 320, 2, 4, 1)])
+def test_gemm_w8_every_tile(gpu, M, N, K, cfg, nst, splits, monkeypatch):
+    """the WQ = 1 instantiations of gemm2_kernel, tile by tile (64-byte code rows, 16 rows per wave-load, the 4-slot XOR swizzle, pad rows of the 80 / 160-column
+    tiles, split-K slabs of scaled sums): against the exact contraction in float64, and against the reference's order (dequantise to f16, then the f16 GEMM)."""
+    rng = np.random.default_rng(M + N + K + cfg)
+    a = rnd(rng, (M, K))
+    q, scale, zp, wd = _quant(rng, (N, K), K ** -0.5)
+    bias, res = rnd(rng, (N,), 0.1), rnd(rng, (M, N))
+    monkeypatch.setenv("OSG_GEMM_CFG", str(cfg)); monkeypatch.setenv("OSG_GEMM_NST", str(nst)); monkeypatch.setenv("OSG_GEMM_SPLITS", str(splits))
+    y = gpu.empty((M, N), f16)
+    da, dq, db, dr = gpu.to_dev(a), gpu.to_dev(q), gpu.to_dev(bias), gpu.to_dev(res)
+    gpu._ck(gpu.lib.osg_gemm_w8(gpu.ctx, da.ptr, dq.ptr, scale, zp, db.ptr, 2, dr.ptr, y.ptr, M, N, K, 0))
+    got = y.numpy()
+    assert rel_max(got, _exact_w8(a, q, [scale] * N, [zp] * N, bias, res)) <= 6e-4
+    assert rel_max(got, ref.matmul(a, wd.T, bias, res)) <= 1e-3
+    y2 = gpu.empty((M, N), f16)
+    gpu._ck(gpu.lib.osg_gemm_w8(gpu.ctx, da.ptr, dq.ptr, scale, zp, db.ptr, 2, dr.ptr, y2.ptr, M, N, K, 0))
+    assert np.array_equal(got, y2.numpy())
+
+
+def test_gemm_w8_merged_projection_vectors_and_geglu(gpu):
+    """per-column (scale, zero point) vectors -- three weights quantised one by one, concatenated as codes (the merged Q|K|V projection) -- and the GEGLU epilogue
+    on pair-interleaved codes"""
+    from scipy.special import erf
+    rng = np.random.default_rng(11)
+    M, K = 2048, 640
+    a = rnd(rng, (M, K))
+    parts = [_quant(rng, (n, K), s * K ** -0.5) for n, s in ((640, 1.0), (640, 0.3), (640, 2.0))]
+    q = np.concatenate([p_[0] for p_ in parts])
+    sv = np.concatenate([np.full(p_[0].shape[0], p_[1], np.float32) for p_ in parts])
+    zv = np.concatenate([np.full(p_[0].shape[0], p_[2], np.float32) for p_ in parts])
+    wd = np.concatenate([p_[3] for p_ in parts])
+    N = q.shape[0]
+    bias = rnd(rng, (N,), 0.1)
+    y = gpu.empty((M, N), f16)
+    dsz = gpu.to_dev(np.concatenate([sv, zv]))
+    da, dq, db = gpu.to_dev(a), gpu.to_dev(q), gpu.to_dev(bias)
+    gpu._ck(gpu.lib.osg_gemm_w8_v(gpu.ctx, da.ptr, dq.ptr, 0.0, 0, dsz.ptr, dsz.ptr + 4 * N, db.ptr, 2, None, y.ptr, M, N, K, 0))
+    assert rel_max(y.numpy(), _exact_w8(a, q, sv, zv, bias)) <= 6e-4
+    assert rel_max(y.numpy(), ref.matmul(a, wd.T, bias)) <= 1e-3
+    # GEGLU: value columns 0 .. C-1, gate columns C .. 2C-1, rows interleaved in blocks of 16
+    C = 1280
+    q, scale, zp, wd = _quant(rng, (2 * C, K), K ** -0.5)
+    b = rnd(rng, (2 * C,), 0.1)
+    x = _exact_w8(a, q, [scale] * (2 * C), [zp] * (2 * C), b)
+    v, g = x[:, :C], x[:, C:]
+    want = v * 0.5 * g * (1.0 + erf(g / np.sqrt(2.0)))
+    qi, bi = np.empty_like(q), np.empty_like(b)
+    for k in range(C // 16):
+        qi[32 * k:32 * k + 16] = q[16 * k:16 * k + 16]
+        qi[32 * k + 16:32 * k + 32] = q[C + 16 * k:C + 16 * k + 16]
+        bi[32 * k:32 * k + 16] = b[16 * k:16 * k + 16]
+        bi[32 * k + 16:32 * k + 32] = b[C + 16 * k:C + 16 * k + 16]
+    y = gpu.empty((M, C), f16)
+    dqi, dbi = gpu.to_dev(qi), gpu.to_dev(bi)
+    gpu._ck(gpu.lib.osg_gemm_w8(gpu.ctx, da.ptr, dqi.ptr, scale, zp, dbi.ptr, 2, None, y.ptr, M, 2 * C, K, 3))
+    assert rel_max(y.numpy(), want) <= 1e-3
+
+
+@pytest.mark.parametrize("N,H,Cin,Cout,bn,splits", [(2, 64, 320, 320, 80, 1), (2, 32, 640, 640, 128, 1), (2, 16, 1280, 1280, 160, 2), (2, 8, 1280, 1280, 80, 4),
+                                                    (2, 8, 2560, 1280, 128, 3), (2, 32, 960, 640, 160, 1), (1, 16, 64, 100, 128, 1)])
+def test_conv3x3_w8_halo_kernel(gpu, N, H, Cin, Cout, bn, splits, monkeypatch):
+    """the WQ = 1 instantiations of the halo-reuse 3x3 kernel (every image width, every tile width, split-K over slabs) with bias, per-image bias and residual"""
+    rng = np.random.default_rng(N + H + Cin + Cout)
+    x = rnd(rng, (N, H, H, Cin))
+    q, scale, zp, wd = _quant(rng, (Cout, 3, 3, Cin), (9 * Cin) ** -0.5)
+    bias, res = rnd(rng, (Cout,), 0.1), rnd(rng, (N, H, H, Cout))
+    want = ref.conv2d_nhwc(x, wd, bias, (1, 1), (1,) * 4).astype(np.float64) + res.astype(np.float64)
+    monkeypatch.setenv("OSG_CONV3X3_BN", str(bn)); monkeypatch.setenv("OSG_CONV3X3_SPLITS", str(splits))
+    y = gpu.empty(want.shape, f16)
+    dx, dq, db, dr = gpu.to_dev(x), gpu.to_dev(q), gpu.to_dev(bias), gpu.to_dev(res)
+    gpu._ck(gpu.lib.osg_conv2d_nhwc_w8(gpu.ctx, dx.ptr, dq.ptr, scale, zp, db.ptr, 2, None, 0, dr.ptr, y.ptr, N, H, H, Cin, Cout, 3, 3, 1, 1, 1, 1, 1, 1, 0))
+    assert rel_max(y.numpy(), want) <= 1e-3
+    # the same convolution into a column slice of a wider buffer + a dense second destination (the skip connections' output views)
+    wide = gpu.to_dev(np.zeros((N, H, H, Cout + 64), f16))
+    dense = gpu.empty(want.shape, f16)
+    gpu._ck(gpu.lib.osg_conv2d_nhwc_w8_v(gpu.ctx, dx.ptr, dq.ptr, scale, zp, None, None, db.ptr, 2, None, 0, dr.ptr, dense.ptr, Cout, wide.ptr + 2 * 32, Cout + 64,
+                                          N, H, H, Cin, Cout, 3, 3, 1, 1, 1, 1, 1, 1, 0)) if Cout % 4 == 0 else None
+    if Cout % 4 == 0:
+        assert np.array_equal(dense.numpy(), y.numpy())
+        wv = wide.numpy()
+        assert np.array_equal(wv[..., 32:32 + Cout], y.numpy()) and not wv[..., :32].any() and not wv[..., 32 + Cout:].any()
+
+
 def test_gemm_batched(gpu):
     rng = np.random.default_rng(5)
     a, b = rnd(rng, (8, 256, 160)), rnd(rng, (8, 160, 77), 0.1)

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Dev tool (GPU box), round 6: W8A16 with resident codes through the tuned kernels.  usage: gpu_w8.sh <recipe>[,<recipe>...]   output prefix gpurun_out/r06w8
+#   ktests   the W8 kernel tests + the golden W8 graph      bench   W8A16 dequantised at load vs codes resident, alternating twice, W8 shapes tuned into a copy of the shipped table
+#   parity   full-size SD 1.5 W8A16 against the reference (both modes)      suite   the whole GPU suite
+mkdir -p gpurun_out; export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-.}
+T=gpurun_out/r06w8; export OSA_REQUIRE_ORACLE=1
+pl() { python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1]); c = d["config"]
+    print(sys.argv[2], "ms_per_step", d["ms_per_step"], "windows median", c["windows_ms_per_step"]["median"], "unet dev ms", c["unet_device_ms_per_step"], "launches", c.get("launches_per_step"), "misses", c["tune_table_misses"], "absmax", c["latent_absmax"])
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+}
+IFS=',' read -ra RECIPES <<< "$1"; shift
+for R in "${RECIPES[@]}"; do case $R in
+ktests)
+  timeout 1200 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "w8" > ${T}_kernel_tests.log 2>&1; echo "w8 kernel tests exit $?"; tail -25 ${T}_kernel_tests.log
+  timeout 900 python -m pytest tests/test_golden.py -q -m gpu -k "w8" > ${T}_golden_w8.log 2>&1; echo "golden w8 exit $?"; tail -8 ${T}_golden_w8.log ;;
+bench)
+  export OSG_TUNE_CACHE=/tmp/tc_w8.txt; cp onnxstream_amd/tune/mi355x.txt $OSG_TUNE_CACHE
+  for i in 1 2; do
+    timeout 900 python bench.py --quant-weights --cpu-passes 0 --windows 2 > ${T}_bench_w8a16_$i.json 2> ${T}_bench_w8a16_$i.err; pl ${T}_bench_w8a16_$i.json "W8A16 dequantised at load"
+    timeout 1500 python bench.py --quant-weights --w8-resident --cpu-passes 0 --windows 2 > ${T}_bench_w8res_$i.json 2> ${T}_bench_w8res_$i.err; pl ${T}_bench_w8res_$i.json "W8A16 codes resident"
+  done
+  wc -l $OSG_TUNE_CACHE; cp $OSG_TUNE_CACHE ${T}_tune_with_w8.txt
+  timeout 900 python bench.py --quant-weights --w8-resident --cpu-passes 0 --windows 0 --breakdown ${T}_breakdown_w8res.txt > ${T}_bench_w8res_bd.json 2> ${T}_bench_w8res_bd.err; tail -5 ${T}_bench_w8res_bd.err ;;
+parity)
+  timeout 2400 python -m pytest tests/test_fullsize.py -q -m gpu -k "w8a16" -s > ${T}_fullsize_w8.log 2>&1; echo "fullsize w8 exit $?"; grep -i "err16\|passed\|failed\|error" ${T}_fullsize_w8.log | tail -12 ;;
+suite)
+  timeout 3000 python -m pytest tests -q -m gpu -x > ${T}_pytest_gpu.log 2>&1; echo "gpu suite exit $?"; tail -5 ${T}_pytest_gpu.log ;;
+esac; done
