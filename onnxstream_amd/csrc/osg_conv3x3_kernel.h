@@ -198,7 +198,7 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
         pp0[i] = ti * PPI + ty * PW + tx;
     }
     const int b_rd = WQ ? (wn0 + frow) * 64 + ((((lane >> 5) & 1) ^ ((frow >> 2) & 3)) << 4) + ((lane >> 4) & 1) * 8 : (wn0 + frow) * 128 + ((fq ^ (frow & 7)) << 4);
-    constexpr bool W8SC = TM * TN <= 10;   // (the wider tiles: no registers for 4 TN scales through the k loop)
+    constexpr bool W8SC = false;           // (no registers for 4 TN scales through the k loop; a convolution's weight has ONE scale -- a kernel argument -- unless the caller hands vectors)
     W8Ops<WQ ? TN : 1, W8SC> w8;
     if constexpr (WQ) w8_prefetch<TN, W8SC>(p, w8, n0, wn0, lane);
 
@@ -226,6 +226,29 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
             for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     };
 
+    // WQ: the B fragments in three steps -- codes out of LDS (rb0 / rb1, two halves ahead), codes -> halves (8 VALU operations per fragment, issued between the
+    // MFMAs of the half in front), MFMA: see the loop
+    u32x2v rb0[WQ ? TN : 1], rb1[WQ ? TN : 1];
+    auto read_a = [&](f16x8 (&fa)[TM], const char* pbuf, int tap_off, int ks) {
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int pp = pp0[i] + tap_off;
+            fa[i] = *reinterpret_cast<const f16x8*>(pbuf + ((pp * 128 + ((fq ^ (pp & 7)) << 4)) ^ (ks << 6)));
+        }
+    };
+    auto read_codes = [&](u32x2v (&rb)[WQ ? TN : 1], const char* bbuf, int ks) {
+        if constexpr (WQ) {
+#pragma unroll
+            for (int j = 0; j < TN; j++) rb[j] = *reinterpret_cast<const u32x2v*>(bbuf + ((b_rd + j * 16 * 64) ^ (ks << 5)));
+        }
+    };
+    auto convert = [&](f16x8 (&fb)[TN], const u32x2v (&rb)[WQ ? TN : 1]) {
+        if constexpr (WQ) {
+#pragma unroll
+            for (int j = 0; j < TN; j++) fb[j] = w8_frag(rb[j], w8.zz[j]);
+        }
+    };
+
     // the epilogue's operands (bias, per-image bias, residual) of this wave's outputs: requested now -- the math waves have no other vector-memory
     // traffic -- and home long before the last tap (osg_gemm_common.h epi_prefetch)
     constexpr bool EPRE = TM * TN <= 10 && NLW == 4;   // (the 128x80 tile; the wider tiles and the 768-thread variant have no registers to spare)
@@ -234,7 +257,13 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
     kdbg_stamp(p, 1);
     __builtin_amdgcn_s_barrier();                       // unit 0's weights + the first patch have landed
     kdbg_stamp(p, 2);
-    if constexpr (WQ) w8_finalize<TN, W8SC>(w8);
+    if constexpr (WQ) {
+        w8_finalize<TN, W8SC>(w8);
+        read_a(fa0, patch0, 0, 0);
+        read_codes(rb0, bst0, 0);
+        read_codes(rb1, bst0, 1);
+        convert(fb0, rb0);
+    } else
     read_frags(fa0, fb0, patch0, bst0, 0, 0);
     if (MODE == 4) {
 #pragma unroll
@@ -253,7 +282,35 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
             const char* Bs = bst0 + ust * BST_BYTES;
             // sched_barrier(0) pins the order "issue the NEXT half's ds_reads, then run THIS half's MFMAs": left alone, hipcc sinks
             // the reads next to their uses and re-serialises LDS latency with the matrix pipe
-            if constexpr (MODE == 0 || MODE == 7) {
+            if constexpr (WQ) {
+                // unit u, half 0's MFMAs: A fragments of (u, 1), codes of (u + 1, 0), conversion of (u, 1)'s codes (read one half ago: landed) between them;
+                // half 1's MFMAs: A fragments of (u + 1, 0), codes of (u + 1, 1), conversion of (u + 1, 0)'s.  Units <= u + 1 are resident behind this tap's barrier.
+                constexpr int KV = (8 * TN + TM * TN - 1) / (TM * TN);   // VALU operations per MFMA that spread the conversions over the half
+                const int ustn = ust + 1 == NSTW ? 0 : ust + 1;
+                const char* Bn = bst0 + ustn * BST_BYTES;
+                read_a(fa1, patch, kh * PW + kw, 1);
+                read_codes(rb0, Bn, 0);
+                convert(fb1, rb1);
+                mma(fa0, fb0);
+                static_for<0, TM * TN>([&](auto ic_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if constexpr (decltype(ic_)::value < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, KV, 0);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                ust = ustn;
+                constexpr int tn8 = (t + 1) % 9;
+                read_a(fa0, t == 8 ? patch_next : patch, (tn8 / 3) * PW + tn8 % 3, 0);
+                read_codes(rb1, Bn, 1);
+                convert(fb0, rb0);
+                mma(fa1, fb1);
+                static_for<0, TM * TN>([&](auto ic_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if constexpr (decltype(ic_)::value < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, KV, 0);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (MODE == 0 || MODE == 7) {
                 // round 3 (tools/kernel_phase_probe.py, OSG_CONV3X3_DBG=6 = the old order): the NEXT half's fragment reads interleaved one by one with THIS half's MFMAs (sched_group_barrier) instead of issued in a block
                 // in front of them -- an MFMA occupies the matrix pipe for ~16 cycles in which the wave can issue other instructions
                 read_frags(fa1, fb1, patch, Bs, kh * PW + kw, 1);

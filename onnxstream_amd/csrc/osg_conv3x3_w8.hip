@@ -10,7 +10,12 @@ namespace {
 template <int W_>
 int launch3_w8(osg_ctx* ctx, GemmParams& p, int bn) {
     if (bn == 80) return launch3<W_, 80, 4, 1, 0, 4, 1>(ctx, p);
-    if (bn == 160) return launch3<W_, 160, 2, 2, 0, 4, 1>(ctx, p);
+    if (bn == 160) {
+        // (64-pixel rows with 160 columns: one register short with the code registers of the three-step B pipeline, and 128 tiles for 256 CUs at the only width it
+        // divides, 320 -- the 80-column tile runs instead)
+        if constexpr (W_ == 64) return launch3<W_, 80, 4, 1, 0, 4, 1>(ctx, p);
+        else return launch3<W_, 160, 2, 2, 0, 4, 1>(ctx, p);
+    }
     return launch3<W_, 128, 2, 2, 0, 4, 1>(ctx, p);
 }
 

@@ -109,6 +109,35 @@ def test_every_golden_graph_plans_at_every_fusion_level(stub_backend, name):
     assert counts["f2+ln"] <= counts["f2"]
 
 
+def test_w8_resident_plan_keeps_the_fusions_of_the_f16_plan(stub_backend):
+    """hip_w8_resident (uint8 weight codes resident, dequantised between the LDS tile and the MFMA; round 6: through the tuned kernels): the plan is the f16 plan of the
+    same graph minus the two fusions that need f16 weights -- a LayerNorm folds gamma INTO the weight, the transformer-block tail streams f16 weights into registers --:
+    merged projections concatenate codes and carry per-column (scale, zero point) vectors, the GEGLU rides in the epilogue on pair-interleaved codes, convolutions
+    keep their output views; every contraction whose weight qualifies (K % 64 == 0) runs on codes."""
+    name = "unet_tiny_w8"
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    ins = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    plans = {}
+    with tempfile.TemporaryDirectory() as d:
+        d += "/"
+        gc.emit(gc.by_name(name), DirSink(d))
+        for tag, opts in (("codes", (("hip_w8_resident", 1),)), ("f16", (("hip_fuse_ln_gemm", 0), ("hip_fuse_tblock", 0)))):
+            m, info = _plan(d, ins, opts)
+            steps, vals, arena = _parse(info)
+            _check_arena(steps, vals, arena)
+            plans[tag] = [s["what"] for s in steps]
+            m.close()
+    codes, f16p = plans["codes"], plans["f16"]
+    assert len(codes) == len(f16p)
+    kinds = lambda p: sorted(w.replace(" w8 ", " ").replace("Conv w8", "Conv").split(" ", 1)[0] for w in p)
+    assert kinds(codes) == kinds(f16p)
+    assert any(w.startswith("Linear w8 merged(") for w in codes) and any(w.startswith("Linear+GEGLU w8 ") for w in codes)
+    assert sum(">concat" in w for w in codes) == sum(">concat" in w for w in f16p) > 0
+    n_codes = sum(" w8 " in w or w.startswith("Conv w8") for w in codes)
+    n_contr = sum(w.split(" ", 1)[0].split("+")[0] in ("Conv", "Linear", "Gemm") for w in codes)
+    assert n_codes >= 0.7 * n_contr, (n_codes, n_contr)   # (the miniature's 32-channel level has K % 64 != 0 and stays f16, as conv_in's 4 input channels do everywhere)
+
+
 def test_transformer_chain_plans(stub_backend):
     """The real-width transformer chains (tests/golden_cases.py CHAINS): at fusion level 2 the 320-wide one is proj_in, Q|K|V, self-attention and ONE osg_tblock_tail
     launch, which reads a K / V pack made by one KVPack launch; the 640- / 1280-wide ones keep the launches of round 3 (round 4's osg_qattn -- LayerNorm + attn2.to_q +

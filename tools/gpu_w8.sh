@@ -26,6 +26,31 @@ bench)
   done
   wc -l $OSG_TUNE_CACHE; cp $OSG_TUNE_CACHE ${T}_tune_with_w8.txt
   timeout 900 python bench.py --quant-weights --w8-resident --cpu-passes 0 --windows 0 --breakdown ${T}_breakdown_w8res.txt > ${T}_bench_w8res_bd.json 2> ${T}_bench_w8res_bd.err; tail -5 ${T}_bench_w8res_bd.err ;;
+libab)
+  # W8-resident bench: libosgpu.so vs the library named by $1 (a file under onnxstream_amd/), alternating twice, each on its own copy of the table with W8 rows (tuned in its first run)
+  ALT=$PWD/onnxstream_amd/${1:-libosgpu_w8v1.so}
+  cp onnxstream_amd/tune/mi355x.txt /tmp/tc_A.txt; cp onnxstream_amd/tune/mi355x.txt /tmp/tc_B.txt
+  for i in 1 2 3; do
+    OSG_TUNE_CACHE=/tmp/tc_A.txt timeout 1500 python bench.py --quant-weights --w8-resident --cpu-passes 0 --windows 2 > ${T}_libab_A_$i.json 2> ${T}_libab_A_$i.err; pl ${T}_libab_A_$i.json "A libosgpu.so"
+    OSG_TUNE_CACHE=/tmp/tc_B.txt OSGPU_LIB=$ALT timeout 1500 python bench.py --quant-weights --w8-resident --cpu-passes 0 --windows 2 > ${T}_libab_B_$i.json 2> ${T}_libab_B_$i.err; pl ${T}_libab_B_$i.json "B $(basename $ALT)"
+  done
+  OSG_TUNE_CACHE=/tmp/tc_A.txt timeout 900 python bench.py --quant-weights --cpu-passes 0 --windows 2 > ${T}_libab_w16.json 2> ${T}_libab_w16.err; pl ${T}_libab_w16.json "W8A16 dequantised at load (libosgpu.so)"
+  cp /tmp/tc_A.txt ${T}_tune_with_w8.txt
+  OSG_TUNE_CACHE=/tmp/tc_A.txt timeout 900 python bench.py --quant-weights --w8-resident --cpu-passes 0 --windows 0 --breakdown ${T}_breakdown_w8res.txt > ${T}_bench_w8res_bd.json 2> ${T}_bench_w8res_bd.err ;;
+final)
+  # evidence of the final tree: headline (default bench, W16), W8A16 at load and with codes resident on the SHIPPED table frozen (0 misses expected), alternating twice;
+  # then the rocprofv3 kernel stats + in-graph timeline of the W8-resident plan
+  export OSG_TUNE_CACHE=/tmp/tc_fin.txt; cp onnxstream_amd/tune/mi355x.txt $OSG_TUNE_CACHE
+  timeout 900 python bench.py > ${T}_final_bench.json 2> ${T}_final_bench.err; pl ${T}_final_bench.json "headline (W16A16)"
+  for i in 1 2; do
+    timeout 900 python bench.py --quant-weights --frozen-table --cpu-passes 0 --windows 2 > ${T}_final_bench_w8a16_$i.json 2> ${T}_final_bench_w8a16_$i.err; pl ${T}_final_bench_w8a16_$i.json "W8A16 dequantised at load (frozen shipped table)"
+    timeout 900 python bench.py --quant-weights --w8-resident --frozen-table --cpu-passes 0 --windows 2 > ${T}_final_bench_w8res_$i.json 2> ${T}_final_bench_w8res_$i.err; pl ${T}_final_bench_w8res_$i.json "W8A16 codes resident (frozen shipped table)"
+  done
+  rm -rf /tmp/prof_w8
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_w8 -o w8 -- python bench.py --quant-weights --w8-resident --steps 20 --warmup 2 --cpu-passes 0 --profile-reps 1 --windows 0 > ${T}_rocprof_w8res.log 2>&1
+  echo "rocprofv3 exit $?"
+  for f in $(find /tmp/prof_w8 -name "*kernel_stats.csv"); do cp $f ${T}_w8res_rocprofv3_kernel_stats.csv; done
+  python tools/graph_trace.py $(find /tmp/prof_w8 -name "*kernel_trace.csv" | head -1) > ${T}_w8res_graph_timeline.txt 2>&1; head -16 ${T}_w8res_graph_timeline.txt ;;
 parity)
   timeout 2400 python -m pytest tests/test_fullsize.py -q -m gpu -k "w8a16" -s > ${T}_fullsize_w8.log 2>&1; echo "fullsize w8 exit $?"; grep -i "err16\|passed\|failed\|error" ${T}_fullsize_w8.log | tail -12 ;;
 suite)
