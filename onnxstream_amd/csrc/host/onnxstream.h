@@ -572,9 +572,10 @@ public:
     // Tensor::m_hip_resident) instead of being downloaded into m_data -- the key/value caches of the LLM flow then never cross PCIe
     bool m_hip_resident_outputs = false;
     void hip_fetch_tensor(const std::string& name);   // downloads a device-resident tensor of m_data into its host vector
-    bool m_hip_w8_resident = false;     // true: uint8 weights of Conv/MatMul/Gemm stay uint8 in HBM (half the footprint and weight traffic) and are
-                                        // dequantised on chip by the osg_*_w8 kernels -- same VALUES as the reference's load-time dequantisation
-                                        // (:2887-2891); false (default, currently the faster path: halo conv + merged projections): dequantise once at load
+    bool m_hip_w8_resident = false;     // true: uint8 weights of Conv/MatMul/Gemm (K % 64 == 0) stay uint8 CODES in HBM (half the footprint and weight traffic) and become
+                                        // halves between the LDS tile and the MFMA of the tuned kernels (round 6, osg_gemm_w8.hip: exact q - zp into the MFMA, the scale on
+                                        // the f32 accumulator -- the reference rounds each dequantised weight to f16 first, :2887-2891 / :3353); false (default): dequantise
+                                        // once at load, the reference's order -- the f16 plan with its folded LayerNorms and fused block tails, 8-10 % faster
     bool m_hip_stream_weights = false;  // true: weights are re-streamed through pinned buffers every pass (WeightsProvider mode)
     size_t hip_last_kernel_count() const;
     size_t hip_plans_built() const { return m_plans_built; }   // how many times run() had to (re-)plan since the Model was created

@@ -157,8 +157,9 @@ def sd15_w8_dir():
 @pytest.mark.parametrize("resident", [0, 1])
 def test_sd15_unet_w8a16_reference_parity_full_size(sd15_w8_dir, resident):
     """BASELINE config 3's UNet half at full size: uint8 weights with per-tensor (scale, zero point) in model.txt, fp16 activations.  The reference
-    dequantises at load (get_tensor_data, src/onnxstream.cpp:2887-2891, dequantize :3353) -- so does the default plan; hip_w8_resident keeps the CODES in
-    HBM and dequantises on their way into the MFMA tile (osg_gemm_w8.hip): f16((float)(q - zp) * scale) either way.  Both against the reference on
+    dequantises at load (get_tensor_data, src/onnxstream.cpp:2887-2891, dequantize :3353), w = f16((float)(q - zp) * scale) -- so does the default plan;
+    hip_w8_resident keeps the CODES in HBM and turns them into halves between the LDS tile and the MFMA of the tuned kernels (osg_gemm_w8.hip, round 6): the exact
+    integer q - zp into the MFMA, the scale on the f32 accumulator -- no per-weight rounding, the closer of the two to the fp32 output.  Both against the reference on
     the SAME quantised model directory (missing #2)."""
     from onnxstream_amd import build as b
     a, c = sd_unet.unet_inputs(sd_unet.SD15, 42), sd_unet.unet_inputs(sd_unet.SD15, 43)

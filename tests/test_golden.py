@@ -361,9 +361,10 @@ def test_passes_are_bitwise_reproducible():
 
 @pytest.mark.gpu
 def test_w8_resident_equals_load_time_dequant():
-    """hip_w8_resident (uint8 codes resident, dequantised inside the kernels) vs dequantise-at-load (the reference's order of
-    operations): the dequantised weight VALUES are identical by construction, so the two runs may differ only through tile / split-K
-    choices -- f16 rounding noise -- and both must meet the golden bound."""
+    """hip_w8_resident (uint8 codes resident, dequantised between the LDS tile and the MFMA) vs dequantise-at-load (the reference's order of
+    operations): the resident path feeds the MFMA the exact integers q - zp and scales the f32 accumulator, the other rounds every dequantised
+    weight to f16 first (2^-12 relative per term) -- the two runs differ by that, by the fusions that need f16 weights and by tile / split-K
+    choices: f16 rounding noise; both must meet the golden bound."""
     from onnxstream_amd import build as b
     from onnxstream_amd.bindings import Model
     ins, oname, r16, r32 = load("unet_tiny_w8")
