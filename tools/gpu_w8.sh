@@ -51,6 +51,19 @@ final)
   echo "rocprofv3 exit $?"
   for f in $(find /tmp/prof_w8 -name "*kernel_stats.csv"); do cp $f ${T}_w8res_rocprofv3_kernel_stats.csv; done
   python tools/graph_trace.py $(find /tmp/prof_w8 -name "*kernel_trace.csv" | head -1) > ${T}_w8res_graph_timeline.txt 2>&1; head -16 ${T}_w8res_graph_timeline.txt ;;
+pmc)
+  # per-kernel counters of the W8-resident plan (tools/pmc_round4.sh with PMC_W8=1), seeded from the shipped table
+  export OSG_TUNE_CACHE=/tmp/tc_pmc.txt; cp onnxstream_amd/tune/mi355x.txt $OSG_TUNE_CACHE
+  PMC_W8=1 bash tools/pmc_round4.sh r06_w8res_plan 2>&1 | tail -30 ;;
+lnab)  # (the "folded" leg needs the tree of branch w8-ln-fold; on main both legs run the same plan)
+  # LayerNorm folded into the GEMMs on codes (osg_gemm_ln_w8) vs the standalone LayerNorm launches (--no-ln-fold: the plan of the previous commit), alternating 3x, each on its own table
+  cp onnxstream_amd/tune/mi355x.txt /tmp/tc_A.txt; cp onnxstream_amd/tune/mi355x.txt /tmp/tc_B.txt
+  for i in 1 2 3; do
+    OSG_TUNE_CACHE=/tmp/tc_A.txt timeout 1500 python bench.py --quant-weights --w8-resident --cpu-passes 0 --windows 2 > ${T}_lnab_A_$i.json 2> ${T}_lnab_A_$i.err; pl ${T}_lnab_A_$i.json "A codes resident, LayerNorm folded"
+    OSG_TUNE_CACHE=/tmp/tc_B.txt timeout 1500 python bench.py --quant-weights --w8-resident --no-ln-fold --cpu-passes 0 --windows 2 > ${T}_lnab_B_$i.json 2> ${T}_lnab_B_$i.err; pl ${T}_lnab_B_$i.json "B codes resident, LayerNorm launches"
+  done
+  OSG_TUNE_CACHE=/tmp/tc_A.txt timeout 900 python bench.py --quant-weights --cpu-passes 0 --windows 2 > ${T}_lnab_w16.json 2> ${T}_lnab_w16.err; pl ${T}_lnab_w16.json "W8A16 dequantised at load"
+  cp /tmp/tc_A.txt ${T}_tune_with_w8ln.txt ;;
 parity)
   timeout 2400 python -m pytest tests/test_fullsize.py -q -m gpu -k "w8a16" -s > ${T}_fullsize_w8.log 2>&1; echo "fullsize w8 exit $?"; grep -i "err16\|passed\|failed\|error" ${T}_fullsize_w8.log | tail -12 ;;
 suite)

@@ -9,15 +9,18 @@ from onnxstream_amd.bindings import Model
 from onnxstream_amd.synth import sd_unet
 from onnxstream_amd.synth.graph import DirSink
 cfg = getattr(sd_unet, os.environ.get("PMC_CONFIG", "SD15"))
-d = os.path.join(os.environ.get("OSA_SYNTH_DIR", "/tmp/onnxstream_amd_synth"), cfg.name) + "/"
+w8 = os.environ.get("PMC_W8") == "1"      # W8A16 with the weight codes resident (uint8 weights in model.txt, hip_w8_resident)
+d = os.path.join(os.environ.get("OSA_SYNTH_DIR", "/tmp/onnxstream_amd_synth"), cfg.name + ("_w8" if w8 else "")) + "/"
 if not os.path.exists(d + ".complete"):
     os.makedirs(d, exist_ok=True)
-    sd_unet.build_unet(DirSink(d), cfg)
+    sd_unet.build_unet(DirSink(d), cfg, quant_weights=w8)
     open(d + ".complete", "w").write("ok")
 passes = int(os.environ.get("PMC_PASSES", "2"))
 m = Model(b.LIB_HOST, 0, "ram+nocache")
 m.read_file(d + "model.txt")
 m._set_option("hip_use_graph", 0)
+if w8:
+    m._set_option("hip_w8_resident", 1)
 m._set_option("hip_autotune", int(os.environ.get("PMC_AUTOTUNE", "0")))
 for r in range(passes):
     for s in (42, 43):
