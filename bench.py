@@ -551,7 +551,7 @@ def main():
                 hdr = json.load(open(os.path.join(REPO, "profiles", cand)))
             except Exception:
                 continue
-            if hdr.get("tuned_plan") and "kernels" in hdr and hdr.get("src_sha1") == tree:
+            if hdr.get("tuned_plan") and "kernels" in hdr and hdr.get("src_sha1") == tree and bool(hdr.get("w8_resident")) == bool(args.w8_resident):   # (the W8-resident plan has a counter file of its own)
                 pmc_src, pmc_note = cand, hdr.get("note")
                 break
         if pmc_src and cfg.name == "sd15" and P == 1 and not args.no_autotune:   # (the counter file describes the tuned batch-2 pass of one prompt)

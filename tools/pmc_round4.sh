@@ -36,7 +36,7 @@ for i in (1, 2, 3, 4):
     for (k, c), n in seen.items():
         out[k]["dispatches"] = max(out[k]["dispatches"], n)
 sys.path.insert(0, "tools"); import src_hash, os
-res = {"tuned_plan": True, "src_sha1": src_hash.src_sha1(os.getcwd()), "note": f"sums over {sys.argv[2]} eager SD1.5 batch-2 UNet passes of the TUNED plan (tools/pmc_pass.py, hip_use_graph=0, hip_autotune=1 seeded from the bench run's OSG_TUNE_CACHE table: the tile / ring / split-K choices of the timed hipGraph); FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 "
+res = {"tuned_plan": True, "w8_resident": os.environ.get("PMC_W8") == "1", "src_sha1": src_hash.src_sha1(os.getcwd()), "note": f"sums over {sys.argv[2]} eager SD1.5 batch-2 UNet passes of the TUNED plan (tools/pmc_pass.py, hip_use_graph=0, hip_autotune=1 seeded from the bench run's OSG_TUNE_CACHE table: the tile / ring / split-K choices of the timed hipGraph); FETCH_SIZE/WRITE_SIZE in KiB as rocprofv3 "
                "reports them (gfx950: FETCH_SIZE x2 for wide coalesced reads, MI355X_MICROARCH.md); SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over SIMDs; "
                "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES / 32 shader engines x 256 CUs x 4 SIMDs)", "passes": int(sys.argv[2]), "kernels": {k: dict(v) for k, v in out.items()}}
 json.dump(res, open(f"gpurun_out/pmc_{sys.argv[1]}.json", "w"), indent=1)
