@@ -387,6 +387,7 @@ def main():
     state = {"x": rng.standard_normal(lat_shape, dtype=np.float32) * sig[0], "i": 0, "images": 0, "last": None}
 
     host_loop = args.host_loop
+    trace = [] if os.environ.get("OSA_BENCH_TRACE") else None     # dev: (what, steps, host ms in front of the call, wall ms of the call, device ms) per chunk -> stderr
     from concurrent.futures import ThreadPoolExecutor
     noise_pool, noise_rng = ThreadPoolExecutor(1), np.random.default_rng(99 + rank)
     scal = pipe.loop_scalars(sig)
@@ -410,6 +411,7 @@ def main():
         dev = 0.0
         while k > 0:
             i = state["i"]
+            tr_in = time.perf_counter()
             if args.mode == "replay":
                 m.hip_replay(1)
                 dev += m.hip_last_pass_ms()
@@ -434,9 +436,16 @@ def main():
                 nxt = min(k - n, rem_img) if k > n else rem_img
                 state["noise"] = noise_pool.submit(noise_rng.standard_normal, (nxt,) + lat_shape, np.float32)
                 state["noise"].n = nxt
-                dev += m.hip_sampler_loop(n_names["sample"], n_names["timestep"], n_names["out"], x, noise, *[a[i:i + n] for a in scal], 7.0, clip[i:i + n] if clip is not None else None)
+                tr0 = time.perf_counter()
+                d1 = m.hip_sampler_loop(n_names["sample"], n_names["timestep"], n_names["out"], x, noise, *[a[i:i + n] for a in scal], 7.0, clip[i:i + n] if clip is not None else None)
+                dev += d1
+                if trace is not None:
+                    trace.append(("loop", n, (tr0 - tr_in) * 1e3, (time.perf_counter() - tr0) * 1e3, d1))
             if i + n == STEPS_PER_IMAGE:
+                tr0 = time.perf_counter()
                 x = end_of_image(x)
+                if trace is not None:
+                    trace.append(("end_of_image", 0, 0.0, (time.perf_counter() - tr0) * 1e3, pipe.vae.hip_last_pass_ms() if pipe.vae is not None else 0.0))
             state["x"], state["i"] = x, (i + n) % STEPS_PER_IMAGE
             k -= n
         return dev
@@ -466,6 +475,15 @@ def main():
     # ---- warmup, then EXACTLY K timed steps ---------------------------------------------------------------------------
     run_steps(args.warmup)
     state["i"], state["images"] = 0, 0           # the timed region starts at the first step of an image
+    if not host_loop and args.mode != "replay":
+        # ... with its ancestral noise drawn, as every later chunk finds it (drawn on the worker thread while the chunk before runs): the future the warmup
+        # left behind is for the REST of the warmup's image, its size does not match a chunk starting at step 0 and the main thread would draw inside the timed region
+        n0 = min(args.steps, STEPS_PER_IMAGE)
+        state["noise"] = noise_pool.submit(noise_rng.standard_normal, (n0,) + lat_shape, np.float32)
+        state["noise"].n = n0
+        state["noise"].result()
+    if trace is not None:
+        trace.clear()
     torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
@@ -485,6 +503,9 @@ def main():
         run_steps(STEPS_PER_IMAGE)
         torch.cuda.synchronize()
         win_ms.append((time.perf_counter() - tw0) * 1e3 / STEPS_PER_IMAGE)
+    if trace is not None:
+        for tr in trace:
+            log("[bench trace] %-13s steps %2d  host before %.3f ms  call %.3f ms  device %.3f ms" % tr)
     out = state["last"] if state["last"] is not None else state["x"]
     latent_absmax = float(np.abs(state["x"]).max())
     if not (np.isfinite(np.asarray(out, np.float32)).all() and np.isfinite(latent_absmax)):
