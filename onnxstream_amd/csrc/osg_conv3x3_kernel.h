@@ -353,12 +353,12 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
     if constexpr (WQ) { if constexpr (W8SC) w8_scale_acc<TM, TN>(w8, acc); else w8_scale_acc_late<TM, TN>(p, acc, n0, wn0, lane); }
     kdbg_stamp(p, 4);
     float* stat_lds = nullptr;
-    if (p.sink[0].table || p.sink[1].table) {   // GroupNorm statistics of this launch's output (osg_gemm_common.h StatSink; launch3 decides)
+    if (OSG_UNLIKELY(p.sink[0].table || p.sink[1].table)) {   // GroupNorm statistics of this launch's output (osg_gemm_common.h StatSink; launch3 decides)
         __builtin_amdgcn_s_barrier();           // (the loader waves have left: the four math waves) every one is done with patches and weight stages
         stat_lds = reinterpret_cast<float*>(smem3) + (wave8 & 3) * (WN * 2);
     }
     if constexpr (MODE == 0) {
-        if (p.splits > 1 && p.fold_acc) {
+        if (OSG_UNLIKELY(p.splits > 1 && p.fold_acc)) {
             // split-K over slabs, folded by the last workgroup to arrive at the tile (osg_gemm_common.h splitk_fold_acc; only the 4 math waves are still here:
             // tid 0..255): it then runs the fused epilogue of an unsplit launch
             if (!splitk_fold_acc<TM, TN>(p, acc, m_tile * p.nt + n_tile, zs, reinterpret_cast<int*>(smem3), tid)) return;

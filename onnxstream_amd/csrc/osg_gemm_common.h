@@ -100,6 +100,10 @@ struct GemmParams {
 // a kernel-argument field pulled into a scalar register NOW: see GemmParams.  (An INPUT of an empty asm: an in-out operand would make the value opaque -- pointers lose
 // their address space and every load through them becomes a flat_load, which counts on lgkmcnt AND vmcnt and breaks the counted waits of the k loop.)
 #define OSG_PIN(x) asm volatile("" ::"s"(x))
+// block placement: code a workgroup walks ONCE streams into the CU at ~3 ns per instruction (tools/floor_probe4) and every taken branch over a block it skips restarts the
+// sequential fetch -- the rare side of the epilogue's uniform decisions goes out of line, the common path falls through (round 6: one such hint moved the pass by 0.03 ms)
+#define OSG_LIKELY(x) __builtin_expect(!!(x), 1)
+#define OSG_UNLIKELY(x) __builtin_expect(!!(x), 0)
 
 // ---- W8A16: uint8 weight codes resident in HBM, dequantised between the LDS tile and the MFMA (round 6) ----------------------------------------------------
 // The [BN][64] weight tile travels HBM -> L2 -> LDS as CODES (half the bytes of the f16 tile on every hop, and half the bytes through the LDS port the k loop is
@@ -413,6 +417,32 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, f32x4 (&
         __amdgpu_buffer_rsrc_t rsB16 = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, hb16 ? nbytes : 0u, 0x00020000);
         __amdgpu_buffer_rsrc_t rsRB = __builtin_amdgcn_make_buffer_rsrc((void*)p.rowbias, 0, hrb ? 0x80000000u : 0u, 0x00020000);
         __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)R, 0, hres ? (unsigned)p.M * nbytes : 0u, 0x00020000);
+        // Loads through an EMPTY descriptor are not free (tools/gemm_kloop_probe.py PROBE_NO_BIAS=1: the epilogue phase of a launch with NO operand at all took
+        // 3.9 us on the 128 x 128 tile and 5.4 us on 128 x 160 against 1.95 / 2.44 us for the same stores behind the on-demand form): a launch with neither row
+        // operand -- the merged q / k / v and to_q projections, the feed-forward outputs -- skips the 2 x TM x TN of them behind ONE uniform branch.  Same bits.
+        if (OSG_LIKELY(!hrb && !hres)) {   // (the likely side falls through to the stores: a taken branch at the end of a launch is an instruction-cache miss on its critical path)
+            if (hb32) {
+                f32x4 b32[TN];
+#pragma unroll
+                for (int j = 0; j < TN; j++) b32[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB32, (unsigned)nb * 4u + j * 64, 0, 0));
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc[i][j][r] += b32[j][r];
+            } else if (hb16) {
+                f16x4 b16[TN];
+#pragma unroll
+                for (int j = 0; j < TN; j++) b16[j] = __builtin_bit_cast(f16x4, __builtin_amdgcn_raw_buffer_load_b64(rsB16, (unsigned)nb * 2u + j * 32, 0, 0));
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) acc[i][j][r] += (float)b16[j][r];
+            }
+        } else {
         f32x4 b32[TN];
         f16x4 b16[TN];
 #pragma unroll
@@ -452,6 +482,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, f32x4 (&
                             acc[i0 + ii][j0 + jj][r] = x;
                         }
             }
+        }
     }
     if constexpr (!BATCH) if (!done) {   // (the 512- / 768-thread halo convolution: 256 / 168 registers per lane, no room for the batch) operands on demand (clamped addresses: the loads are unconditional, the stores below are not)
         if (p.bias) {
@@ -494,7 +525,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, f32x4 (&
             }
         }
     }
-    if (p.act != OSG_ACT_NONE) {
+    if (OSG_UNLIKELY(p.act != OSG_ACT_NONE)) {
         const int act = p.act;
 #pragma unroll
         for (int i = 0; i < TM; i++)
@@ -527,7 +558,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, f32x4 (&
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o[i][j]), rsC, off, 0, OSG_EPI_STORE_AUX);
             }
         }
-        if (p.C2) {
+        if (OSG_UNLIKELY(p.C2 != nullptr)) {
             __amdgpu_buffer_rsrc_t rsC2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.C2, 0, 0x80000000u, 0x00020000);
 #pragma unroll
             for (int i = 0; i < TM; i++) {
@@ -564,8 +595,8 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, f32x4 (&
         }
     }
 #endif
-    if (stat_lds) gemm_colstats<TM, TN>(p, o, m0 + wm0, n0 + wn0, lane, stat_lds);
-    if (p.rs_out) {
+    if (OSG_UNLIKELY(stat_lds != nullptr)) gemm_colstats<TM, TN>(p, o, m0 + wm0, n0 + wn0, lane, stat_lds);
+    if (OSG_UNLIKELY(p.rs_out != nullptr)) {
         // osg_gemm_rowstats: sums over this wave's 32-column slots of every row, of the ROUNDED outputs.  The four 16-lane groups of a row hold
         // different columns of the same slot pair: 2-step butterfly, one lane group stores
 #pragma unroll
@@ -604,8 +635,8 @@ template <int TM, int TN, bool RB, bool ON, bool BATCH = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[TM][TN], int m0, int n0, int wm0, int wn0, int lane,
                                               int zb, int zslab, const EpiOps<TM, TN, RB, ON>& pre, float* stat_lds = nullptr) {
     const int N = p.N;
-    if (p.splits == 1) {
-        if ((N & 3) == 0 && ((p.ldc | p.ldc2) & 3) == 0) {   // every 4-aligned shape: compact code (see gemm_epilogue_fast)
+    if (OSG_LIKELY(p.splits == 1)) {
+        if (OSG_LIKELY((N & 3) == 0 && ((p.ldc | p.ldc2) & 3) == 0)) {   // every 4-aligned shape: compact code (see gemm_epilogue_fast)
             gemm_epilogue_fast<TM, TN, RB, ON, BATCH>(p, acc, m0, n0, wm0, wn0, lane, zb, pre, stat_lds);
             return;
         }

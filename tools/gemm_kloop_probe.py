@@ -52,7 +52,8 @@ def gemm_case(M, N, K, cfg, nst, splits=1, ks=1, spec=0, fold=0, note="", batch=
         os.environ[k] = str(v)
     bm, bn = TILES[cfg]
     wgs = -(-M // bm) * -(-N // bn) * splits * batch
-    med, seg, last, us = phases(lambda: g._ck(L.osg_gemm(g.ctx, DT16, A.ptr, W.ptr, 1, bias.ptr, DT16, None, Y.ptr, M, N, K, batch, 0, 0, M * N, 0)), wgs)
+    bptr = None if os.environ.get("PROBE_NO_BIAS") else bias.ptr     # (PROBE_NO_BIAS=1: what the on-demand bias load of the 128-row tiles costs in the epilogue phase)
+    med, seg, last, us = phases(lambda: g._ck(L.osg_gemm(g.ctx, DT16, A.ptr, W.ptr, 1, bptr, DT16, None, Y.ptr, M, N, K, batch, 0, 0, M * N, 0)), wgs)
     nkt = max(1, (K // 64 + splits - 1) // splits) // (2 if ks == 2 else 1)
     cyc = seg[2] * 1e3 * GHZ / max(nkt, 1)
     bnp = (bn + 31) // 32 * 32
