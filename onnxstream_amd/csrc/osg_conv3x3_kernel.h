@@ -370,7 +370,7 @@ __device__ __forceinline__ void conv3x3_body(const GemmParams& p) {
     }
     gemm_epilogue<TM, TN, true, EPRE, false>(p, acc, m0, n0, wm0, wn0, lane, 0, zs, epre, stat_lds);
     kdbg_stamp(p, 5);
-    if (p.kdbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); kdbg_stamp(p, 6); }
+    if (OSG_UNLIKELY(p.kdbg != nullptr)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); kdbg_stamp(p, 6); }
 }
 
 template <int W_, int BN, int WGM, int WGN, int MODE, int NLW, int WQ = 0>

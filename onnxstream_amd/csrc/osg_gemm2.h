@@ -331,7 +331,7 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
     }
     gemm_epilogue<TM, TN, CONV, EPRE, !SPEC>(p, acc, m0, n0, wm0, wn0, lane, zb, zb * p.splits + zs, epre, stat_lds);   // (SPEC: 512 threads, 256 registers per lane -- the on-demand operands one block at a time)
     kdbg_stamp(p, 5);
-    if (p.kdbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); kdbg_stamp(p, 6); }
+    if (OSG_UNLIKELY(p.kdbg != nullptr)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); kdbg_stamp(p, 6); }
 }
 
 template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0, int LN = 0, int NCH = 5, int KS = 1, int WGN = 2, int WQ = 0>

@@ -180,7 +180,7 @@ __device__ __forceinline__ void w8_scale_acc_late(const GemmParams& p, f32x4 (&a
 }
 
 __device__ __forceinline__ void kdbg_stamp(const GemmParams& p, int slot) {
-    if (p.kdbg && threadIdx.x == 0) p.kdbg[(long)blockIdx.x * 8 + slot] = wall_clock64();
+    if (__builtin_expect(p.kdbg != nullptr, 0) && threadIdx.x == 0) p.kdbg[(long)blockIdx.x * 8 + slot] = wall_clock64();   // (out of line: see OSG_LIKELY)
 }
 
 // ---- LayerNorm folded into the consuming GEMM (osg_gemm_ln) ----------------------------------------------------------------
@@ -250,7 +250,7 @@ __device__ __forceinline__ void epi_prefetch(const GemmParams& p, EpiOps<TM, TN,
     const int N = p.N;
     e.have = ON && !p.no_epre && p.splits == 1 && (N & 3) == 0 && p.act != OSG_ACT_GEGLU && N >= 4 && (RB || !p.rowbias);
     if constexpr (!ON) return;
-    if (!e.have) return;
+    if (__builtin_expect(!e.have, 0)) return;
     const f16* __restrict__ R = p.residual ? p.residual + zb * p.strideC : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; j++) {

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const f16* __restrict__ x
                                                        int gdx, int gdy) {
     // NT / gdx / gdy = blockDim.x / gridDim.x / gridDim.y as ARGUMENTS (round 6): the implicit ones cost the prologue a vector load with a full drain behind it
     osg_pin_all(x, gamma, beta, y, HW, C, cpg, gb, eps, act, S, part, cnt, wait_ticks, kdbg, NT, gdx, gdy);
-    auto stamp = [&](int slot) { if (kdbg && threadIdx.x == 0) kdbg[((long)(blockIdx.z * gdy + blockIdx.y) * gdx + blockIdx.x) * 8 + slot] = wall_clock64(); };
+    auto stamp = [&](int slot) { if (__builtin_expect(kdbg != nullptr, 0) && threadIdx.x == 0) kdbg[((long)(blockIdx.z * gdy + blockIdx.y) * gdx + blockIdx.x) * 8 + slot] = wall_clock64(); };
     stamp(0);
     __shared__ float red[8][16][2];   // [local group][wave][sum, sumsq]
     __shared__ float stat[8][2];      // [local group][mean, rstd]
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const f16* __restrict__ x
         stamp(4);
         const bool solo = alone != 0;
         double s = 0, q = 0;
-        if (!solo) {
+        if (__builtin_expect(!solo, 1)) {
             if (t < gb) {
                 for (int s0 = 0; s0 < S; s0 += 4) {
                     d2 pv[4];
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(1024) void gn_slab_kernel(const f16* __restrict__ x
         }
     }
     stamp(6);
-    if (kdbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(7); }
+    if (__builtin_expect(kdbg != nullptr, 0)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(7); }
 }
 
 // launch plan of the slab kernel: groups per block (smallest gb with gb*cpg % 8 == 0), threads, vectors per thread; false => three-pass path
