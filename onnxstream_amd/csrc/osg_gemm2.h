@@ -309,18 +309,18 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
         }
     }
     if constexpr (LN != 0) ln_apply<TM, TN, LN == 1>(p, acc, ls, lq, n0, wn0, lane);
-    if (OSG_UNLIKELY(p.act == OSG_ACT_GEGLU)) {
+    if (OSG_UNLIKELY_IF(!SPEC, p.act == OSG_ACT_GEGLU)) {
         if constexpr (TN % 2 == 0) gemm_epilogue_geglu<TM, TN>(p, acc, m0, n0, wm0, wn0, lane, zb);
         return;
     }
     kdbg_stamp(p, 4);
     float* stat_lds = nullptr;
-    if (OSG_UNLIKELY(p.sink[0].table || p.sink[1].table)) {   // (launch_v2 leaves the sinks set only where this epilogue can serve them: one k-slice, 4-aligned shapes)
+    if (OSG_UNLIKELY_IF(!SPEC, p.sink[0].table || p.sink[1].table)) {   // (launch_v2 leaves the sinks set only where this epilogue can serve them: one k-slice, 4-aligned shapes)
         __builtin_amdgcn_s_barrier();           // every wave is done with the ring: its first bytes become the waves' staging areas
         stat_lds = reinterpret_cast<float*>(smem2) + wave * (WN * 2);
     }
     if constexpr (KS == 1 && !SPEC && LN == 0 && MODE == 0) {
-        if (OSG_UNLIKELY(p.splits > 1 && p.fold_acc)) {
+        if (OSG_UNLIKELY_IF(!SPEC, p.splits > 1 && p.fold_acc)) {
             // split-K, folded by the last workgroup to arrive at the tile (osg_gemm_common.h splitk_fold_acc): it then runs the fused epilogue of an unsplit launch
             if (!splitk_fold_acc<TM, TN>(p, acc, (zb * p.mt + m_tile) * p.nt + n_tile, zs, reinterpret_cast<int*>(smem2), tid)) return;
             EpiOps<TM, TN, CONV, false> none;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__((SPEC || KS == 2) ? 512 : 256) void gemm2_kernel(Ge
     }
     gemm_epilogue<TM, TN, CONV, EPRE, !SPEC>(p, acc, m0, n0, wm0, wn0, lane, zb, zb * p.splits + zs, epre, stat_lds);   // (SPEC: 512 threads, 256 registers per lane -- the on-demand operands one block at a time)
     kdbg_stamp(p, 5);
-    if (OSG_UNLIKELY(p.kdbg != nullptr)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); kdbg_stamp(p, 6); }
+    if (OSG_UNLIKELY_IF(!SPEC, p.kdbg != nullptr)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); kdbg_stamp(p, 6); }
 }
 
 template <int BM, int BN, int NST, bool CONV, int MODE = 0, int SPEC = 0, int LN = 0, int NCH = 5, int KS = 1, int WGN = 2, int WQ = 0>

@@ -104,6 +104,8 @@ struct GemmParams {
 // sequential fetch -- the rare side of the epilogue's uniform decisions goes out of line, the common path falls through (round 6: one such hint moved the pass by 0.03 ms)
 #define OSG_LIKELY(x) __builtin_expect(!!(x), 1)
 #define OSG_UNLIKELY(x) __builtin_expect(!!(x), 0)
+// (h = false: no hint -- the 512- / 768-thread kernels, whose 256 / 168 registers per lane spill under a different block order)
+#define OSG_UNLIKELY_IF(h, x) ((h) ? __builtin_expect(!!(x), 0) : !!(x))
 
 // ---- W8A16: uint8 weight codes resident in HBM, dequantised between the LDS tile and the MFMA (round 6) ----------------------------------------------------
 // The [BN][64] weight tile travels HBM -> L2 -> LDS as CODES (half the bytes of the f16 tile on every hop, and half the bytes through the LDS port the k loop is
@@ -420,7 +422,8 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, f32x4 (&
         // Loads through an EMPTY descriptor are not free (tools/gemm_kloop_probe.py PROBE_NO_BIAS=1: the epilogue phase of a launch with NO operand at all took
         // 3.9 us on the 128 x 128 tile and 5.4 us on 128 x 160 against 1.95 / 2.44 us for the same stores behind the on-demand form): a launch with neither row
         // operand -- the merged q / k / v and to_q projections, the feed-forward outputs -- skips the 2 x TM x TN of them behind ONE uniform branch.  Same bits.
-        if (OSG_LIKELY(!hrb && !hres)) {   // (the likely side falls through to the stores: a taken branch at the end of a launch is an instruction-cache miss on its critical path)
+        // (the 20-block tiles -- 128 x 160 -- keep the one straight form: with a second variant of the epilogue beside it their 256 architectural registers spill)
+        if (TM * TN <= 16 && OSG_LIKELY(!hrb && !hres)) {   // (the likely side falls through to the stores: a taken branch at the end of a launch is an instruction-cache miss on its critical path)
             if (hb32) {
                 f32x4 b32[TN];
 #pragma unroll
@@ -525,7 +528,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, f32x4 (&
             }
         }
     }
-    if (OSG_UNLIKELY(p.act != OSG_ACT_NONE)) {
+    if (OSG_UNLIKELY_IF(BATCH, p.act != OSG_ACT_NONE)) {
         const int act = p.act;
 #pragma unroll
         for (int i = 0; i < TM; i++)
@@ -558,7 +561,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, f32x4 (&
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o[i][j]), rsC, off, 0, OSG_EPI_STORE_AUX);
             }
         }
-        if (OSG_UNLIKELY(p.C2 != nullptr)) {
+        if (OSG_UNLIKELY_IF(BATCH, p.C2 != nullptr)) {
             __amdgpu_buffer_rsrc_t rsC2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.C2, 0, 0x80000000u, 0x00020000);
 #pragma unroll
             for (int i = 0; i < TM; i++) {
@@ -595,8 +598,8 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmParams& p, f32x4 (&
         }
     }
 #endif
-    if (OSG_UNLIKELY(stat_lds != nullptr)) gemm_colstats<TM, TN>(p, o, m0 + wm0, n0 + wn0, lane, stat_lds);
-    if (OSG_UNLIKELY(p.rs_out != nullptr)) {
+    if (OSG_UNLIKELY_IF(BATCH, stat_lds != nullptr)) gemm_colstats<TM, TN>(p, o, m0 + wm0, n0 + wn0, lane, stat_lds);
+    if (OSG_UNLIKELY_IF(BATCH, p.rs_out != nullptr)) {
         // osg_gemm_rowstats: sums over this wave's 32-column slots of every row, of the ROUNDED outputs.  The four 16-lane groups of a row hold
         // different columns of the same slot pair: 2-step butterfly, one lane group stores
 #pragma unroll
